@@ -1,0 +1,56 @@
+// Shared device/host helpers for libpaths_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error convention (include/paths_hip.h): 0 = ok, negative = error, message in thread-local buffer
+#define PATHS_OK 0
+#define PATHS_EINVAL (-1)
+#define PATHS_ELAUNCH (-2)
+#define PATHS_EUNSUPPORTED (-3)
+
+int paths_set_error(int code, const char* fmt, ...);
+
+#define PATHS_REQUIRE(cond, ...)                                     \
+  do {                                                               \
+    if (!(cond)) return paths_set_error(PATHS_EINVAL, __VA_ARGS__);  \
+  } while (0)
+
+#define PATHS_LAUNCH_CHECK(name)                                                              \
+  do {                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                        \
+    if (e_ != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- device math (accurate forms: the selection chain must stay within ~1e-7 of the fp32 CPU path)
+__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- MFMA wrappers.  f32-input MFMA = exact k-ordered fp32 FMA chain (guide §3 "FP32-input MFMA").
+// 32x32x2: A lane l -> A[l&31][l>>5], B lane l -> B[l>>5][l&31]; C: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// 16x16x4: A lane l -> A[l&15][l>>4], B lane l -> B[l>>4][l&15]; C: col=l&15, row=4*(l>>4)+r
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int c32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Is [m0, m0+rows) entirely padding?  Rows are laid out [slide][rows_per_slide]; slide b has
+// num_ims[b] valid rows at its start.  num_ims == nullptr disables skipping.
+__device__ __forceinline__ bool block_all_padding(const int64_t* num_ims, int rows_per_slide, int m0, int rows, int M) {
+  if (num_ims == nullptr) return false;
+  int last = min(m0 + rows, M) - 1;
+  int b0 = m0 / rows_per_slide, b1 = last / rows_per_slide;
+  for (int b = b0; b <= b1; ++b) {
+    int lo = max(m0, b * rows_per_slide);
+    if (lo - b * rows_per_slide < (int)num_ims[b]) return false;
+  }
+  return true;
+}

@@ -1,0 +1,105 @@
+"""Pin the oracle (oracle/paths_oracle.py) against vectors captured from the reference import
+(tools/make_goldens.py).  CPU-only: runs under ``-m "not gpu"``.
+
+Tolerances: the reference's own outputs move by ~1e-7 with thread count / MHA code path
+(SURVEY.md §7 hard part 1, §8c "Version caveat"), so float outputs are compared at 2e-6 and index
+SETS bit-exactly (sequence: identical up to permutations among scores closer than 1e-6).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import paths_oracle as orc
+from tests import helpers as H
+from tests.conftest import load_golden
+
+ATOL = 2e-6
+
+
+def _run_single(name):
+    g, info = load_golden(name)
+    cfg = H.oracle_config(info["cfg_over"])
+    p = H.oracle_params(cfg, info["wseed"])
+    inp = {k: torch.from_numpy(v) for k, v in H.single_level_inputs(info, cfg).items()}
+    with torch.no_grad():
+        out = orc.process_level(p, cfg, info["depth"], inp["fts"], inp["locs"], inp["num_ims"],
+                                inp["ctx_slide"], inp["ctx_patch"])
+    return g, info, out
+
+
+@pytest.mark.parametrize("name", ["g1_level0_b2_k256", "g2_level2_b2_k256"])
+def test_single_level_default(name):
+    g, info, out = _run_single(name)
+    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
+    # padded rows get exactly zero importance (reference utils.py:106-115)
+    for b, n in enumerate(info["num_ims"]):
+        assert (out["importance"][b, n:] == 0).all()
+
+
+@pytest.mark.parametrize("tag", ["pe1d", "nolstm", "concat", "impnone", "subtype"])
+def test_single_level_variants(tag):
+    g, info, out = _run_single(f"g5_{tag}_level1")
+    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])
+def test_single_level_k2048(name):
+    g, info, out = _run_single(name)
+    for k in ("logits", "ctx_slide", "importance"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
+    idx = g["ctx_patch_probe_idx"]
+    np.testing.assert_allclose(out["ctx_patch"].numpy()[tuple(idx.T)], g["ctx_patch_probe"], atol=ATOL, rtol=0)
+    # top-512 of the oracle == top-512 of the reference's importance, as a set
+    n = info["num_ims"][0]
+    a = torch.topk(out["importance"][0, :n], 512).indices.numpy()
+    b = torch.topk(torch.from_numpy(g["importance"][0, :n]), 512).indices.numpy()
+    assert H.set_agreement(a, b)
+
+
+@pytest.mark.parametrize("name", ["g3_recursion_6x7_top5", "g4_recursion_16x16_top64"])
+def test_recursion(name):
+    g, info = load_golden(name)
+    cfg = H.oracle_config(info["cfg_over"], top_k_patches=[info["top_k"]] * 4)
+    p = H.oracle_params(cfg, info["wseed"])
+    slides = H.synthetic_slides(info, cfg)
+    labels = {"survival_bin": torch.from_numpy(g["labels"][:, 0]), "censored": torch.from_numpy(g["labels"][:, 1])}
+    trace = []
+    with torch.no_grad():
+        hazards, loss = orc.inference_end2end(p, cfg, [orc.LazyGrids(s) for s in slides], labels, trace)
+    assert info["min_gap"] >= 2e-6
+    for l, lv in enumerate(trace):
+        np.testing.assert_array_equal(lv["num_ims"].numpy(), g[f"L{l}_num_ims"])
+        if l < cfg.num_levels - 1:
+            for j, ki in enumerate(lv["keep_inds"]):
+                ref_ki = g[f"L{l}_keep_{j}"]
+                assert H.set_agreement(ki.numpy(), ref_ki), (l, j)
+                n = int(lv["num_ims"][j])
+                assert H.sequence_inversions(ki.numpy(), ref_ki, g[f"L{l}_importance"][j, :n]) < 1e-6
+        # same rows in the same order whenever the index sequences agree; always equal as multisets
+        a = np.concatenate([lv["locs"].numpy(), lv["parent_inds"].numpy()[..., None]], -1)
+        b = np.concatenate([g[f"L{l}_locs"], g[f"L{l}_parent_inds"][..., None]], -1)
+        for j in range(a.shape[0]):
+            n = int(lv["num_ims"][j])
+            assert {tuple(r[:2]) for r in a[j, :n]} == {tuple(r[:2]) for r in b[j, :n]}
+        np.testing.assert_allclose(lv["logits"].numpy(), g[f"L{l}_logits"], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(hazards.numpy(), g["hazards"], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(float(loss), float(g["loss"]), atol=5e-6, rtol=0)
+
+
+def test_nll_known_answers():
+    g, _ = load_golden("g7_nll")
+    h, y, c = (torch.from_numpy(g[k]) for k in ("hazards", "y", "c"))
+    np.testing.assert_allclose(float(orc.nll_loss(h, y, c)), float(g["loss"]), rtol=1e-6)
+    for i in range(h.shape[0]):
+        np.testing.assert_allclose(float(orc.nll_loss(h[i:i + 1], y[i:i + 1], c[i:i + 1])), g["per_sample"][i], rtol=1e-6, atol=1e-7)
+
+
+def test_state_dict_surface():
+    """Key names / count of the checkpoint surface (9 881 881 params verified there)."""
+    cfg = H.oracle_config()
+    shapes = orc.state_dict_shapes(cfg)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 9_881_881
+    assert "procs.0.global_agg.transformer.encoder.layers.0.self_attn.in_proj_weight" in shapes
+    assert "lstm.mem_to_out.0.weight" in shapes
