@@ -1,0 +1,119 @@
+/* libpaths_hip.so — C ABI of the MI355X (gfx950) PATHS hot path.
+ *
+ * The reference (zzbuzzard/PATHS) is pure Python/PyTorch and has NO FFI of its own; this header is the
+ * thin boundary the build defines underneath the reference's Python surface.  Each entry
+ * point names the reference code it replaces (file:line relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer unless stated; no torch types;
+ *   - returns 0 on success, a negative code on error (-1 invalid argument, -2 launch failure,
+ *     -3 unsupported configuration); paths_last_error() returns a thread-local message;
+ *   - never allocates, frees or synchronises; launches on the caller's stream (hipStream_t passed as
+ *     void*); no global mutable state, callable from any host thread;
+ *   - all floating-point buffers are fp32, row-major, 16-byte aligned, leading dimensions in elements
+ *     and multiples of 4; integer fields follow the reference's dtypes (int64 locs / num_ims /
+ *     parent_inds);
+ *   - arithmetic: exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), fp32 accumulate.
+ */
+#ifndef PATHS_HIP_H
+#define PATHS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* paths_stream_t; /* hipStream_t */
+
+const char* paths_last_error(void);
+const char* paths_build_info(void);
+int paths_abi_version(void);
+
+/* LSTMCell.forward over depth + residual (reference model/interface.py:31-58, model/paths.py:78-91).
+ *   x [M,D] (ldx), h0/c0 = previous state views (both NULL at depth 0), M = B * rows_per_slide.
+ *   w_gates [3Hc+D, 2D] PACKED: rows [0,3Hc) in groups of 96 = forget|remember|map rows of one block of
+ *   32 memory units, rows [3Hc, 3Hc+D) = out_select_gate; b_gates packed alike; w_mem [D,Hc], b_mem [D].
+ *   state_out [M, D+Hc] <- (h1 | c1)  (= "ctx_patch"), y [M,D] <- x + h1, ws_o [M,D] scratch.
+ *   num_ims != NULL: tiles that contain only padding rows (row index within slide >= num_ims[b]) are skipped. */
+int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
+                    const float* w_gates, const float* b_gates, const float* w_mem, const float* b_mem,
+                    float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o,
+                    int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, paths_stream_t stream);
+
+/* importance MLP + sigmoid + padding mask, importance scaling, proj_in, positional encoding, special token
+ * (reference model/paths.py:95-98,119-124; utils.py:16-23,47-67,106-115; model/aggregator.py:37-65).
+ *   w_ip [256, D] = [importance_mlp.0.weight ; proj_in.weight]; tokens [B, N+1, d]: row 0 = special token.
+ *   pe_mode 2 = "2d" (div_term has d/4 entries, locs [M,2] int64 pixel coords), 1 = "1d" (d/2 entries). */
+int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const float* b1, const float* w2, float b2,
+                          const float* bp, const float* special, const float* div_term, const int64_t* locs,
+                          const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
+                          float* importance, float* tokens, int M, int D, int Hi, int d, int skip_padding,
+                          paths_stream_t stream);
+
+/* Generic out = act(a W^T + b) on the fp32 matrix cores (W rows zero-padded to Npad, a multiple of 128). */
+int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b, float* out, int64_t ldo,
+                     int M, int N, int Npad, int K, int act, paths_stream_t stream);
+
+/* Masked multi-head self-attention, flash style (nn.MultiheadAttention inside nn.TransformerDecoderLayer as
+ * called at reference model/aggregator.py:70-72, key mask utils.py:97-103).
+ *   q,k,v [B,H,T,32] head-major, q pre-scaled by log2(e)/sqrt(32); o [B,T,H*32]; valid keys = num_ims[b]+1. */
+int paths_attention_f32(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims,
+                        int B, int T, int H, int head_dim, paths_stream_t stream);
+
+/* Token-row chain of one post-LN decoder layer with empty memory + the next in_proj (same call site):
+ *   do_post: x_out = norm3(x' + ffn(x')), x' = norm2(norm1(x_in + out_proj(attn)) + cross_attn_bias)
+ *   do_qkv : q,k,v = in_proj(x)  (x = x_out if do_post else x_in) written head-major, q scaled by qscale. */
+int paths_token_layer_f32(const float* x_in, const float* attn, float* x_out,
+                          const float* wo, const float* bo, const float* ln1g, const float* ln1b, const float* cab,
+                          const float* ln2g, const float* ln2b, const float* w1, const float* b1, const float* w2,
+                          const float* b2, const float* ln3g, const float* ln3b, const float* wqkv, const float* bqkv,
+                          float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
+                          int do_post, int do_qkv, int skip_padding, float qscale, float eps, paths_stream_t stream);
+
+/* decoder.norm on token 0, slide-context residual / concat, classifier
+ * (reference model/aggregator.py:75, model/paths.py:130-139). */
+int paths_final_head(const float* x, int64_t slide_stride, const float* lng, const float* lnb,
+                     const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
+                     const float* wcls, const float* bcls, int num_logits, int cls_in,
+                     float* ctx_out, float* logits, int B, int d, float eps, paths_stream_t stream);
+
+/* Stand-alone wavefront-reduction LayerNorm over rows of width 128 (aten::native_layer_norm). */
+int paths_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d,
+                        float eps, paths_stream_t stream);
+
+/* torch.topk(importance[:n], min(n, keep)).indices per slide (reference data_utils/slide.py:294-301).
+ * Order: score descending, ties by index ascending.  keep = -1 keeps every patch in original order. */
+int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, int n_max, int keep,
+               int* keep_idx, int64_t ldk, int* keep_count, paths_stream_t stream);
+
+/* 4-child expansion, bounds + background filter, stable compaction (reference data_utils/slide.py:303-331).
+ *   mask_ptrs[b] -> uint8 [X*Y] tissue mask of the NEXT level (1 = row sum != 0).  status bit0: a slide
+ *   produced zero children (reference fallback slide.py:336-352 needed), bit1: capacity n_next exceeded. */
+int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_count, const int64_t* locs, int64_t n_cur,
+                          int patch_size, const int* next_x, const int* next_y, const int64_t* mask_ptrs, int B,
+                          int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
+                          int* src_cell, int* status, paths_stream_t stream);
+
+/* Gather child features from the next-level grids and parent LSTM state (reference slide.py:318,327-331;
+ * zero padding of data_utils/dataset.py:216-227 when zero_pad != 0). */
+int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,
+                      int64_t ld_state_cur, const int* src_row, int Dp, const int64_t* num_out, int B, int64_t n_next,
+                      float* fts_out, float* state_out, int zero_pad, paths_stream_t stream);
+
+/* Level-0 batch: every grid cell in row-major order (reference data_utils/slide.py:257-269,362-381). */
+int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,
+                       float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, paths_stream_t stream);
+
+/* Tissue mask of a preprocessed grid [cells, D]: 1 iff fp32 row sum != 0 (reference slide.py:324). */
+int paths_tissue_mask(const float* grid, int64_t cells, int D, uint8_t* mask, paths_stream_t stream);
+
+/* Counter-based synthetic grid (paths_amd/synthetic.py). */
+int paths_synth_grid(float* grid, int X, int Y, int D, uint32_t slide_level_key, int level, uint64_t bg_threshold,
+                     paths_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHS_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of ``libpaths_hip.so`` (C ABI in include/paths_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel launch fails this
+module raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (or
+``make -C paths_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpaths_hip.so")
+
+_i64, _i32, _f32, _vp, _u32, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint64
+
+# name -> argtypes (mirrors include/paths_hip.h; tests/test_abi.py checks both against the .so exports)
+SIGNATURES = {
+    "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                        _i32, _i32, _i32, _vp, _i32, _vp],
+    "paths_importance_proj": [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
+                              _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "paths_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
+    "paths_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "paths_token_layer_f32": [_vp] * 21 + [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
+    "paths_final_head": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
+    "paths_layernorm_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "paths_topk": [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "paths_expand_children": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp],
+    "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp],
+    "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
+    "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],
+}
+_PLAIN = {"paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, [])}
+
+_lib: Optional[C.CDLL] = None
+
+
+class PathsHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise PathsHipError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                                "paths_amd has no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, _i32
+        for name, (res, args) in _PLAIN.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = lib
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise PathsHipError(f"{name} failed ({rc}): {lib.paths_last_error().decode()}")
+
+
+def require_cuda(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PathsHipError("paths_amd runs on the GPU only: got a CPU tensor (no CPU fallback)")

@@ -1,0 +1,396 @@
+// fp32-exact tiled GEMM on the CDNA4 f32-input matrix cores (v_mfma_f32_32x32x2_f32) with the fused
+// epilogues of the PATHS selection chain.
+//
+//   C[M, N] = [A0 | A1][M, K0+K1] * Bt[N, K0+K1]^T          (Bt = nn.Linear weight layout, K contiguous)
+//
+// Replaces (reference file:line):
+//   * LSTMCell.forward gates            model/interface.py:49-56   -> EpiLstmC (f,r,m -> c1), EpiLstmO (o gate)
+//   * h1 = o * tanh(Wc c1 + bc), Y=X+h1  model/interface.py:56, model/paths.py:89-91 -> EpiLstmH
+//   * importance MLP + sigmoid + mask   model/paths.py:95, utils.py:106-115 }
+//   * Z = Y*alpha ; proj_in ; 2-D / 1-D positional encoding ; special token   } -> EpiImpProj
+//       model/paths.py:96-98,119-124, model/aggregator.py:37-65, utils.py:16-23,47-67
+//
+// Design (MI355X): 64-lane waves each own WTM x WTN tiles of 32x32 fp32 accumulators; A and Bt k-tiles
+// (BK = 32) are staged global -> registers -> LDS (row stride 36 floats: conflict-free ds_read_b128 for the
+// 16-lane groups of gfx950), double-buffered with one barrier per k-tile and the next tile's global loads
+// in flight under the MFMAs.  The MFMA's two k-slots per step are fed with a PERMUTED k order
+// (lane half h takes k = 8q+4h+e) so that every lane fetches 4 steps of operand with ONE 16-byte LDS read;
+// A and B use the same permutation, the sum over k is unchanged.  The "concat(x, h)" of the reference is
+// never materialised: the k loop walks panel A0 (features) then A1 (previous h state, strided view).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // padded LDS row stride (floats)
+
+struct GemmOperands {
+  const float* A0; int64_t lda0; int K0;
+  const float* A1; int64_t lda1; int K1;
+  const float* Bt; int64_t ldb;   // [Npad rows, K0+K1]
+  int M;
+  const int64_t* num_ims;         // optional padding skip
+  int rows_per_slide;
+};
+
+template <int WTM, int WTN, int WGM, int WGN, class Epi>
+__global__ void __launch_bounds__(64 * WGM * WGN)
+gemm_f32_kernel(GemmOperands g, Epi epi) {
+  constexpr int BM = WTM * 32 * WGM, BN = WTN * 32 * WGN, NT = 64 * WGM * WGN;
+  constexpr int RPP = NT / 8;                 // rows staged per pass (8 threads x float4 = one 32-float row)
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][(BM+BN)*LDK]
+
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M)) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  const float* a0p[PA]; const float* a1p[PA]; const float* bp[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    int row = min(m0 + r0 + p * RPP, g.M - 1);
+    a0p[p] = g.A0 + (int64_t)row * g.lda0 + 4 * c4;
+    a1p[p] = g.A1 ? g.A1 + (int64_t)row * g.lda1 + 4 * c4 : nullptr;
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) bp[p] = g.Bt + (int64_t)(n0 + r0 + p * RPP) * g.ldb + 4 * c4;
+
+  f32x4 ra[PA], rb[PB];
+  auto gload = [&](int kt) {
+    const int k = kt * BK;
+    if (k < g.K0) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a0p[p] + k);
+    } else {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a1p[p] + (k - g.K0));
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(bp[p] + k);
+  };
+  auto swrite = [&](int buf) {
+    float* s = smem + buf * (BM + BN) * LDK;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(s + (r0 + p * RPP) * LDK + 4 * c4) = ra[p];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(s + (BM + r0 + p * RPP) * LDK + 4 * c4) = rb[p];
+  };
+
+  f32x16 acc[WTM][WTN];
+#pragma unroll
+  for (int i = 0; i < WTM; ++i)
+#pragma unroll
+    for (int j = 0; j < WTN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (g.K0 + g.K1) / BK;
+  const int fragoff = (lane & 31) * LDK + 4 * (lane >> 5);
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* sA = smem + buf * (BM + BN) * LDK + (wm * WTM * 32) * LDK + fragoff;
+    const float* sB = smem + buf * (BM + BN) * LDK + (BM + wn * WTN * 32) * LDK + fragoff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a[WTM], b[WTN];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDK + 8 * q);
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LDK + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+          for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+    }
+    if (kt + 1 < nk) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  epi.template run<WTM, WTN, WGM, WGN>(acc, m0 + wm * WTM * 32, n0 + wn * WTN * 32, lane, wm, wn, g.M, smem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  acc[i][j][r] is C[row0 + 32 i + c32_row(r, lane)][col0 + 32 j + (lane & 31)].
+// ------------------------------------------------------------------------------------------------
+
+// c1 = c0 * sigmoid(f) + sigmoid(r) * tanh(m); packed columns per wave = [f(32) | r(32) | m(32)] of one j-block.
+struct EpiLstmC {
+  const float* bias;     // packed like the weight rows
+  const float* c0; int64_t ldc0;   // nullptr at depth 0 (c0 = 0)
+  float* c1; int64_t ldc1;         // state_out + D
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+    static_assert(WTN == 3, "LSTM c epilogue wants f|r|m tiles");
+    const int jj = lane & 31;
+    const int j = (col0 / 96) * 32 + jj;
+    const float bf = bias[col0 + jj], br = bias[col0 + 32 + jj], bm = bias[col0 + 64 + jj];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + c32_row(r, lane);
+        if (row < M) {
+          const float f = sigmoid_acc(acc[i][0][r] + bf);
+          const float rg = sigmoid_acc(acc[i][1][r] + br);
+          const float mp = tanhf(acc[i][2][r] + bm);
+          const float cprev = c0 ? c0[(int64_t)row * ldc0 + j] : 0.f;
+          c1[(int64_t)row * ldc1 + j] = cprev * f + rg * mp;
+        }
+      }
+  }
+};
+
+// o = sigmoid(acc + b)
+struct EpiLstmO {
+  const float* bias; float* o; int64_t ldo; int N;
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int col = col0 + 32 * j + (lane & 31);
+      if (col >= N) continue;
+      const float b = bias[col];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + c32_row(r, lane);
+          if (row < M) o[(int64_t)row * ldo + col] = sigmoid_acc(acc[i][j][r] + b);
+        }
+    }
+  }
+};
+
+// h1 = o * tanh(acc + bc) ; Y = X + h1
+struct EpiLstmH {
+  const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
+  float* h1; int64_t ldh; float* y; int64_t ldy; int N;
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int col = col0 + 32 * j + (lane & 31);
+      if (col >= N) continue;
+      const float b = bias[col];
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + c32_row(r, lane);
+          if (row < M) {
+            const float h = o[(int64_t)row * ldo + col] * tanhf(acc[i][j][r] + b);
+            h1[(int64_t)row * ldh + col] = h;
+            y[(int64_t)row * ldy + col] = x[(int64_t)row * ldx + col] + h;
+          }
+        }
+    }
+  }
+};
+
+// Plain bias epilogue (generic linear; used by the non-LSTM hctx MLP and tests).  act: 0 none, 1 relu.
+struct EpiBias {
+  const float* bias; float* out; int64_t ldo; int N; int act;
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+      const int col = col0 + 32 * j + (lane & 31);
+      if (col >= N) continue;
+      const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + c32_row(r, lane);
+          if (row < M) {
+            float v = acc[i][j][r] + b;
+            if (act == 1) v = fmaxf(v, 0.f);
+            out[(int64_t)row * ldo + col] = v;
+          }
+        }
+    }
+  }
+};
+
+// Packed weight rows = [W1 (Hi=128 rows) ; Wp (d=128 rows)], block covers all 256 columns.
+// Waves with wn == 0 own the importance hidden units, wn == 1 the projected token channels.
+//   alpha = valid ? sigmoid(w2 . relu(acc + b1) + b2) : 0            (importance_mode "mul": token = alpha*acc + bp + PE)
+struct EpiImpProj {
+  const float* b1; const float* w2; float b2;
+  const float* bp;                 // proj_in bias [d]
+  const float* special;            // special token [d]
+  const float* div_term;           // 2d: [d/4] ; 1d: [d/2]   (host: torch.exp(arange * -ln(1e4)/d), utils.py:18,56)
+  const int64_t* locs;             // [M,2] pixel coords (2d mode)
+  const int64_t* num_ims;          // [B]
+  int rows_per_slide;              // N
+  int patch_size;
+  int pe_mode;                     // 2 = "2d", 1 = "1d"
+  int imp_mul;                     // importance_mode == "mul"
+  float* importance;               // [M]
+  float* tokens;                   // [B, N+1, d]
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int wm, int wn, int M, float* smem) const {
+    static_assert(WTM == 1 && WTN == 4 && WGN == 2, "imp/proj epilogue layout");
+    constexpr int d = 128;
+    float* alpha_s = smem;                       // [WGM*32] (main loop is done; LDS is free after its last barrier)
+    if (wn == 0) {
+      float part[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 32 * j + (lane & 31);
+        const float b = b1[col], w = w2[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] += fmaxf(acc[0][j][r] + b, 0.f) * w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = part[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+        const int lrow = c32_row(r, lane);
+        const int row = row0 + lrow;
+        float a = 0.f;
+        if (row < M) {
+          const int b = row / rows_per_slide, idx = row % rows_per_slide;
+          if (idx < (int)num_ims[b]) a = sigmoid_acc(v + b2);
+          if ((lane & 31) == 0) importance[row] = a;
+        }
+        if ((lane & 31) == 0) alpha_s[wm * 32 + lrow] = a;
+      }
+    }
+    __syncthreads();
+    if (wn == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = c32_row(r, lane);
+        const int row = row0 + lrow;
+        if (row >= M) continue;
+        const int b = row / rows_per_slide, idx = row % rows_per_slide;
+        const float a = imp_mul ? alpha_s[wm * 32 + lrow] : 1.f;
+        float px = 0.f, py = 0.f;
+        if (pe_mode == 2) {
+          px = (float)(locs[2 * (int64_t)row] / patch_size);
+          py = (float)(locs[2 * (int64_t)row + 1] / patch_size);
+        } else {
+          px = (float)idx;
+        }
+        float* trow = tokens + ((int64_t)b * (rows_per_slide + 1) + idx + 1) * d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = 32 * j + (lane & 31);
+          float pe;
+          if (pe_mode == 2) {
+            const float pos = (c < d / 2) ? px : py;
+            const float ang = pos * div_term[(c & (d / 2 - 1)) >> 1];
+            pe = (c & 1) ? cosf(ang) : sinf(ang);
+          } else {
+            const float ang = px * div_term[c >> 1];
+            pe = (c & 1) ? cosf(ang) : sinf(ang);
+          }
+          trow[c] = a * acc[0][j][r] + bp[c] + pe;
+          if (idx == 0) tokens[(int64_t)b * (rows_per_slide + 1) * d + c] = special[c];
+        }
+      }
+    }
+  }
+};
+
+template <int WTM, int WTN, int WGM, int WGN, class Epi>
+int launch_gemm(const GemmOperands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
+  constexpr int BM = WTM * 32 * WGM, BN = WTN * 32 * WGN;
+  constexpr size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
+  PATHS_REQUIRE(g.M > 0, "%s: M must be > 0", name);
+  PATHS_REQUIRE(g.K0 > 0 && g.K0 % BK == 0 && g.K1 % BK == 0, "%s: K panels (%d,%d) must be multiples of %d", name, g.K0, g.K1, BK);
+  PATHS_REQUIRE(Npad % BN == 0, "%s: packed N (%d) must be a multiple of %d", name, Npad, BN);
+  PATHS_REQUIRE(g.lda0 % 4 == 0 && g.lda1 % 4 == 0 && g.ldb % 4 == 0, "%s: leading dims must be multiples of 4 floats", name);
+  PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Bt % 16 == 0), "%s: operands must be 16-byte aligned", name);
+  auto kern = gemm_f32_kernel<WTM, WTN, WGM, WGN, Epi>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(Npad / BN, (g.M + BM - 1) / BM);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, stream, g, epi);
+  PATHS_LAUNCH_CHECK(name);
+  return PATHS_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+// Packed LSTM gate weights: rows [0,768) = c-part in 96-row groups [f(32)|r(32)|m(32)] per j-block,
+// rows [768, 768+D) = out_select_gate.  See paths_amd/_pack.py.
+int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
+                    const float* w_gates /*[3Hc+D, 2D] packed*/, const float* b_gates /*[3Hc+D] packed*/,
+                    const float* w_mem /*[D, Hc]*/, const float* b_mem /*[D]*/,
+                    float* state_out /*[M, D+Hc]: h1 | c1*/, int64_t ldso, float* y /*[M,D]*/, int64_t ldy,
+                    float* ws_o /*[M,D] workspace*/,
+                    int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, hipStream_t stream) {
+  PATHS_REQUIRE(D % 128 == 0 && Hc % 64 == 0, "lstm_cell: D (%d) must be a multiple of 128 and Hc (%d) of 64", D, Hc);
+  PATHS_REQUIRE((h0 == nullptr) == (c0 == nullptr), "lstm_cell: h0 and c0 must both be given or both be null");
+  const int Ktot = 2 * D;
+  GemmOperands g{x, ldx, D, h0, ldh0, h0 ? D : 0, w_gates, Ktot, M, num_ims, rows_per_slide};
+  // (1) c-part: N = 3Hc, wave tile 64x96, block 128x192
+  {
+    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso};
+    int rc = launch_gemm<2, 3, 2, 2>(g, 3 * Hc, e, stream, "lstm_cell(c)");
+    if (rc) return rc;
+  }
+  // (2) o gate: N = D
+  {
+    GemmOperands go = g;
+    go.Bt = w_gates + (int64_t)3 * Hc * Ktot;
+    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D};
+    int rc = launch_gemm<2, 2, 2, 2>(go, D, e, stream, "lstm_cell(o)");
+    if (rc) return rc;
+  }
+  // (3) h1 = o * tanh(Wc c1 + bc), Y = X + h1
+  {
+    GemmOperands gh{state_out + D, ldso, Hc, nullptr, 0, 0, w_mem, Hc, M, num_ims, rows_per_slide};
+    EpiLstmH e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D};
+    int rc = launch_gemm<2, 2, 2, 2>(gh, D, e, stream, "lstm_cell(h)");
+    if (rc) return rc;
+  }
+  return PATHS_OK;
+}
+
+int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256, D]: W1 ; Wp*/,
+                          const float* b1, const float* w2, float b2, const float* bp, const float* special,
+                          const float* div_term, const int64_t* locs, const int64_t* num_ims,
+                          int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
+                          float* importance, float* tokens, int M, int D, int Hi, int d, int skip_padding,
+                          hipStream_t stream) {
+  PATHS_REQUIRE(Hi == 128 && d == 128, "importance_proj: this build supports importance_mlp_hidden_dim=128, trans_dim=128 (got %d, %d)", Hi, d);
+  PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj: pe_mode must be 1 (1d) or 2 (2d)");
+  PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj: 2d positional encoding needs locs");
+  PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj: bad slide layout");
+  GemmOperands g{y, ldy, D, nullptr, 0, 0, w_ip, D, M, skip_padding ? num_ims : nullptr, rows_per_slide};
+  EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens};
+  return launch_gemm<1, 4, 2, 2>(g, 256, e, stream, "importance_proj");
+}
+
+// out[M,N] = act(A[M,K] * W[N,K]^T + b).  W rows must be padded (zero rows) to a multiple of 128.
+int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b, float* out, int64_t ldo,
+                     int M, int N, int Npad, int K, int act, hipStream_t stream) {
+  GemmOperands g{a, lda, K, nullptr, 0, 0, w, K, M, nullptr, 0};
+  EpiBias e{b, out, ldo, N, act};
+  return launch_gemm<2, 2, 2, 2>(g, Npad, e, stream, "linear_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+// Device-resident patch selection: importance top-K, 4-child expansion, bounds/background filter, stable
+// compaction and the row gathers that build the next magnification level's batch.
+//
+// Replaces the per-slide host loop of the reference (utils.py:248-260 -> data_utils/slide.py:277-331 and
+// data_utils/dataset.py:206-235): .cpu() sync, torch.topk, torch.cat of 4 child blocks, boolean filters,
+// host-RAM gather of child features, re-padding.  Nothing here synchronises with the host.
+//
+// All of it is HBM-bound integer / copy work: rows are 4 KB (features) and 5 KB (LSTM state) and move as
+// coalesced 16-byte-per-lane copies; the per-slide bookkeeping (sort, scan) lives in LDS.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-K: indices of the `keep` largest scores, ordered by (score descending, index ascending).
+// torch.topk (slide.py:298) leaves tie order unspecified; this rule equals it whenever scores are distinct.
+// ------------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX = 8192;
+
+__global__ void __launch_bounds__(1024)
+topk_kernel(const float* __restrict__ scores, int64_t ld, const int64_t* __restrict__ num_ims, int keep,
+            int* __restrict__ keep_idx, int64_t ldk, int* __restrict__ keep_count) {
+  __shared__ unsigned long long keys[TOPK_MAX];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = (int)num_ims[b];
+  const int count = keep < 0 ? n : min(n, keep);
+  if (tid == 0) keep_count[b] = count;
+  if (keep < 0) {                                     // keep all, original order (slide.py:294 not taken)
+    for (int i = tid; i < n; i += 1024) keep_idx[(int64_t)b * ldk + i] = i;
+    return;
+  }
+  int np = 1;
+  while (np < n) np <<= 1;
+  const float* s = scores + (int64_t)b * ld;
+  for (int i = tid; i < np; i += 1024) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      uint32_t u = __float_as_uint(s[i]);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
+      key = ((unsigned long long)(~u) << 32) | (uint32_t)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= np; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (np >> 1); t += 1024) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], c = keys[hi];
+        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < count; i += 1024) keep_idx[(int64_t)b * ldk + i] = (int)(uint32_t)keys[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// expansion: kept patch (x,y) -> blocks (2x,2y) | (2x,2y+1) | (2x+1,2y) | (2x+1,2y+1), each in top-K
+// order (slide.py:307-315); keep child iff in bounds and tissue (slide.py:320-325); stable compaction.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restrict__ keep_count,
+              const int64_t* __restrict__ locs, int64_t n_cur, int patch_size,
+              const int* __restrict__ next_x, const int* __restrict__ next_y,          // [B] next-level grid dims
+              const int64_t* __restrict__ mask_ptrs,                                     // [B] -> uint8 [X*Y], 1 = tissue
+              int64_t n_next,
+              int64_t* __restrict__ num_out, int64_t* __restrict__ locs_out, int64_t* __restrict__ parent_out,
+              int* __restrict__ src_row, int* __restrict__ src_cell, int* __restrict__ status) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int count = keep_count[b];
+  const int total = 4 * count;
+  const int X = next_x[b], Y = next_y[b];
+  const uint8_t* mask = reinterpret_cast<const uint8_t*>(mask_ptrs[b]);
+  const int per = (total + 1023) / 1024;
+  const int c0 = tid * per, c1 = min(c0 + per, total);
+
+  auto child = [&](int c, int& cx, int& cy, int& i) -> bool {
+    const int blk = c / count;
+    i = c - blk * count;
+    const int prow = keep_idx[(int64_t)b * ldk + i];
+    const int64_t px = locs[((int64_t)b * n_cur + prow) * 2] / patch_size;
+    const int64_t py = locs[((int64_t)b * n_cur + prow) * 2 + 1] / patch_size;
+    const int64_t x = 2 * px + (blk >> 1), y = 2 * py + (blk & 1);
+    cx = (int)x; cy = (int)y;
+    if (x >= X || y >= Y) return false;
+    return mask[(int64_t)x * Y + y] != 0;
+  };
+
+  int mine = 0;
+  for (int c = c0; c < c1; ++c) { int cx, cy, i; mine += child(c, cx, cy, i) ? 1 : 0; }
+  part[tid] = mine;
+  __syncthreads();
+  // inclusive Hillis-Steele scan over 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - mine;
+  const int n_out = part[1023];
+  if (tid == 0) {
+    num_out[b] = n_out;
+    if (n_out == 0) atomicOr(status, 1);               // reference falls back to "all cells" (slide.py:336-352)
+    if (n_out > n_next) atomicOr(status, 2);
+  }
+  if (n_out > n_next) return;
+  for (int c = c0; c < c1; ++c) {
+    int cx, cy, i;
+    if (child(c, cx, cy, i)) {
+      const int64_t o = (int64_t)b * n_next + pos;
+      locs_out[2 * o] = (int64_t)cx * patch_size;
+      locs_out[2 * o + 1] = (int64_t)cy * patch_size;
+      parent_out[o] = i;
+      src_row[o] = keep_idx[(int64_t)b * ldk + i];
+      src_cell[o] = cx * Y + cy;
+      ++pos;
+    }
+  }
+  // padding tail: zero the bookkeeping rows like collate_fn's zero padding (dataset.py:216-218)
+  for (int j = n_out + tid; j < n_next; j += 1024) {
+    const int64_t o = (int64_t)b * n_next + j;
+    locs_out[2 * o] = 0; locs_out[2 * o + 1] = 0; parent_out[o] = 0; src_row[o] = -1; src_cell[o] = -1;
+  }
+}
+
+// One workgroup per output row: features from the next-level grid, LSTM state (h|c) from the kept parent.
+__global__ void __launch_bounds__(256)
+gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src_cell, int D,
+              const float* __restrict__ state_cur, int64_t n_cur, int64_t ld_state_cur, const int* __restrict__ src_row,
+              int Dp, const int64_t* __restrict__ num_out, int64_t n_next,
+              float* __restrict__ fts_out, float* __restrict__ state_out, int zero_pad) {
+  const int b = blockIdx.y;
+  const int64_t j = blockIdx.x;
+  const int64_t o = (int64_t)b * n_next + j;
+  const int tid = threadIdx.x;
+  f32x4* fo = reinterpret_cast<f32x4*>(fts_out + o * D);
+  f32x4* so = state_out ? reinterpret_cast<f32x4*>(state_out + o * Dp) : nullptr;
+  if (j < num_out[b]) {
+    const f32x4* fi = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(grid_ptrs[b]) + (int64_t)src_cell[o] * D);
+    for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
+    if (so) {
+      const f32x4* si = reinterpret_cast<const f32x4*>(state_cur + ((int64_t)b * n_cur + src_row[o]) * ld_state_cur);
+      for (int i = tid; i < Dp / 4; i += 256) so[i] = si[i];
+    }
+  } else if (zero_pad) {
+    const f32x4 z{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < D / 4; i += 256) fo[i] = z;
+    if (so) for (int i = tid; i < Dp / 4; i += 256) so[i] = z;
+  }
+}
+
+// Level 0: every grid cell, row-major, no background filter (slide.py:257-269).
+__global__ void __launch_bounds__(256)
+level0_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ gx, const int* __restrict__ gy, int D,
+              int patch_size, int64_t n0, float* __restrict__ fts, int64_t* __restrict__ locs,
+              int64_t* __restrict__ parent, int64_t* __restrict__ num_ims, int zero_pad) {
+  const int b = blockIdx.y;
+  const int64_t j = blockIdx.x;
+  const int X = gx[b], Y = gy[b];
+  const int64_t n = (int64_t)X * Y;
+  const int64_t o = (int64_t)b * n0 + j;
+  const int tid = threadIdx.x;
+  f32x4* fo = reinterpret_cast<f32x4*>(fts + o * D);
+  if (j == 0 && tid == 0) num_ims[b] = n;
+  if (j < n) {
+    const f32x4* fi = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(grid_ptrs[b]) + j * D);
+    for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
+    if (tid == 0) { locs[2 * o] = (j / Y) * patch_size; locs[2 * o + 1] = (j % Y) * patch_size; parent[o] = j; }
+  } else {
+    if (zero_pad) { const f32x4 z{0.f, 0.f, 0.f, 0.f}; for (int i = tid; i < D / 4; i += 256) fo[i] = z; }
+    if (tid == 0) { locs[2 * o] = 0; locs[2 * o + 1] = 0; parent[o] = 0; }
+  }
+}
+
+// tissue mask: 1 iff the row's fp32 sum != 0 (slide.py:324 `fts[...].sum(dim=1) != 0`); one wave per cell.
+__global__ void __launch_bounds__(256)
+tissue_mask_kernel(const float* __restrict__ grid, int64_t cells, int D, uint8_t* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= cells) return;
+  const f32x4* row = reinterpret_cast<const f32x4*>(grid + cell * D);
+  float s = 0.f;
+  for (int i = lane; i < D / 4; i += 64) { const f32x4 v = row[i]; s += (v[0] + v[1]) + (v[2] + v[3]); }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  if (lane == 0) mask[cell] = s != 0.f ? 1 : 0;
+}
+
+// Synthetic grid (paths_amd/synthetic.py): one thread per 4 channels.
+__global__ void __launch_bounds__(256)
+synth_grid_kernel(float* __restrict__ grid, int X, int Y, int D, uint32_t k2, int level, unsigned long long bg_thr) {
+  const int64_t cell = blockIdx.x;
+  const int x = (int)(cell / Y), y = (int)(cell % Y);
+  const uint32_t k3 = fmix32(k2 + (uint32_t)x * 0xC2B2AE3Du);
+  const uint32_t ck = fmix32(k3 + (uint32_t)y * 0x27D4EB2Fu);
+  const bool bg = level >= 1 && (unsigned long long)fmix32(ck ^ 0xB6B6B6B6u) < bg_thr;
+  for (int c4 = threadIdx.x; c4 < D / 4; c4 += 256) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t u = fmix32(ck + (uint32_t)(4 * c4 + e) * 0x165667B1u + 0x9E3779B9u);
+      const float f = ((float)(u >> 8) * 0x1p-23f - 1.0f) * 1.7320508075688772f;
+      v[e] = bg ? 0.f : f;
+    }
+    *reinterpret_cast<f32x4*>(grid + cell * D + 4 * c4) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, int n_max, int keep,
+               int* keep_idx, int64_t ldk, int* keep_count, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && n_max > 0 && n_max <= TOPK_MAX, "topk: n_max (%d) must be in [1, %d]", n_max, TOPK_MAX);
+  PATHS_REQUIRE(keep == -1 || keep > 0, "topk: keep must be -1 (all) or > 0");
+  PATHS_REQUIRE(ldk >= (keep < 0 ? n_max : (keep < n_max ? keep : n_max)), "topk: keep_idx row too short");
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, stream, scores, ld, num_ims, keep, keep_idx, ldk, keep_count);
+  PATHS_LAUNCH_CHECK("topk");
+  return PATHS_OK;
+}
+
+int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_count, const int64_t* locs, int64_t n_cur,
+                          int patch_size, const int* next_x, const int* next_y, const int64_t* mask_ptrs, int B,
+                          int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
+                          int* src_cell, int* status, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && n_cur > 0 && n_next > 0 && patch_size > 0, "expand_children: bad shape");
+  PATHS_REQUIRE(4 * ldk <= (int64_t)1 << 30, "expand_children: too many candidates");
+  hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(1024), 0, stream, keep_idx, ldk, keep_count, locs, n_cur, patch_size,
+                     next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status);
+  PATHS_LAUNCH_CHECK("expand_children");
+  return PATHS_OK;
+}
+
+int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,
+                      int64_t ld_state_cur, const int* src_row, int Dp, const int64_t* num_out, int B, int64_t n_next,
+                      float* fts_out, float* state_out, int zero_pad, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && n_next > 0 && D % 4 == 0 && Dp % 4 == 0 && ld_state_cur % 4 == 0, "gather_rows: bad shape");
+  PATHS_REQUIRE((state_cur == nullptr) == (state_out == nullptr), "gather_rows: state in/out must both be given or null");
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_next, B), dim3(256), 0, stream, grid_ptrs, src_cell, D, state_cur,
+                     n_cur, ld_state_cur, src_row, Dp, num_out, n_next, fts_out, state_out, zero_pad);
+  PATHS_LAUNCH_CHECK("gather_rows");
+  return PATHS_OK;
+}
+
+int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,
+                       float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && n0 > 0 && D % 4 == 0, "level0_batch: bad shape");
+  hipLaunchKernelGGL(level0_kernel, dim3((unsigned)n0, B), dim3(256), 0, stream, grid_ptrs, gx, gy, D, patch_size, n0,
+                     fts, locs, parent, num_ims, zero_pad);
+  PATHS_LAUNCH_CHECK("level0_batch");
+  return PATHS_OK;
+}
+
+int paths_tissue_mask(const float* grid, int64_t cells, int D, uint8_t* mask, hipStream_t stream) {
+  PATHS_REQUIRE(cells > 0 && D % 4 == 0, "tissue_mask: bad shape");
+  hipLaunchKernelGGL(tissue_mask_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, stream, grid, cells, D, mask);
+  PATHS_LAUNCH_CHECK("tissue_mask");
+  return PATHS_OK;
+}
+
+int paths_synth_grid(float* grid, int X, int Y, int D, uint32_t slide_level_key, int level, uint64_t bg_threshold, hipStream_t stream) {
+  PATHS_REQUIRE(X > 0 && Y > 0 && D % 4 == 0 && (int64_t)X * Y < ((int64_t)1 << 31), "synth_grid: bad shape");
+  hipLaunchKernelGGL(synth_grid_kernel, dim3((unsigned)((int64_t)X * Y)), dim3(256), 0, stream, grid, X, Y, D, slide_level_key, level, (unsigned long long)bg_threshold);
+  PATHS_LAUNCH_CHECK("synth_grid");
+  return PATHS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""HBM-resident preprocessed slides (the device-side analogue of reference
+data_utils/slide.py:PreprocessedSlide, :225-271).
+
+A slide is its per-level feature grids ``[X, Y, D]`` fp32 (reference grid format: an all-zero row is a
+background cell, preprocess/preprocess.py:89,172-175) kept RESIDENT in HBM, plus a one-byte-per-cell tissue
+mask computed once on upload (``sum(dim=1) != 0``, reference data_utils/slide.py:324).  The per-level host
+gather + H2D copy of the reference disappears: child rows are gathered on the device straight from these grids.
+At K=2048 one slide is 2.9 GB (level-4 grid alone 2.1 GB); 288 GB of HBM holds ~90 of them.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _lib, synthetic
+
+
+class DeviceSlide:
+    def __init__(self, grids: Sequence[torch.Tensor], patch_size: int = 256, slide_id: str = "", subtype=None):
+        assert len(grids) >= 1
+        self.patch_size = patch_size
+        self.slide_id = slide_id
+        self.subtype = subtype
+        self.grids: List[torch.Tensor] = []
+        self.masks: List[torch.Tensor] = []
+        for g in grids:
+            _lib.require_cuda(g)
+            assert g.dim() == 3 and g.dtype == torch.float32
+            g = g.contiguous()
+            X, Y, D = g.shape
+            m = torch.empty((X, Y), dtype=torch.uint8, device=g.device)
+            _lib.call("paths_tissue_mask", g.data_ptr(), X * Y, D, m.data_ptr(), _lib.stream())
+            self.grids.append(g)
+            self.masks.append(m)
+
+    @property
+    def num_levels(self) -> int:
+        return len(self.grids)
+
+    def shape(self, level: int) -> Tuple[int, int]:
+        return self.grids[level].shape[0], self.grids[level].shape[1]
+
+    @property
+    def dim(self) -> int:
+        return self.grids[0].shape[2]
+
+    @staticmethod
+    def from_host(grids: Sequence, device, **kw) -> "DeviceSlide":
+        """Upload host grids (numpy or CPU tensors, e.g. ``torch.load('<slide>_<power:.3f>.pt')``)."""
+        return DeviceSlide([torch.as_tensor(g, dtype=torch.float32).to(device) for g in grids], **kw)
+
+    @staticmethod
+    def synthetic(seed: int, slide: int, base_shape: Tuple[int, int], dim: int = 1024, num_levels: int = 5,
+                  p_bg: float = 0.1, device="cuda", patch_size: int = 256) -> "DeviceSlide":
+        """Generate the counter-based synthetic pyramid directly in HBM (paths_synth_grid)."""
+        grids = []
+        thr = synthetic.bg_threshold(p_bg)
+        for l in range(num_levels):
+            X, Y = base_shape[0] << l, base_shape[1] << l
+            g = torch.empty((X, Y, dim), dtype=torch.float32, device=device)
+            key = int(synthetic.slide_level_key(seed, slide, l))
+            _lib.call("paths_synth_grid", g.data_ptr(), X, Y, dim, key, l, thr, _lib.stream())
+            grids.append(g)
+        s = DeviceSlide(grids, patch_size=patch_size, slide_id=f"synthetic-{seed}-{slide}")
+        s.synthetic_spec = synthetic.SyntheticSlide(seed, slide, tuple(base_shape), dim, num_levels, p_bg)
+        return s

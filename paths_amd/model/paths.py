@@ -1,0 +1,75 @@
+"""``PATHSProcessor`` — one magnification level P_i (reference model/paths.py:12-151), MI355X-native.
+
+Same constructor / ``process(data, lstm=None)`` / ``ctx_dim()`` surface and state_dict keys as the reference;
+``process`` issues the HIP launch sequence of paths_amd/ops.py:level_forward and returns the reference's
+dict {"logits", "ctx_slide", "ctx_patch", "importance"} (model/paths.py:141-146).
+
+Round-1 limits (rejected loudly, never silently approximated): forward only (no autograd graph), lstm=True,
+trans_dim=128 / 4 heads / importance hidden 128, dropout inactive (eval or dropout=0).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+from torch import nn
+
+from .. import ops
+from .aggregator import TransformerAggregator
+from .interface import Processor
+
+
+class PATHSProcessor(nn.Module, Processor):
+    def __init__(self, config, train_config, depth: int):
+        super().__init__()
+        self.depth = depth
+        self.config = config
+        self.train_config = train_config
+        num_logits = train_config.nbins if train_config.task == "survival" else len(train_config.filter_to_subtypes)
+        self.dim = config.patch_embed_dim
+        self.slide_ctx_dim = config.trans_dim
+        cls_in = self.slide_ctx_dim * (depth + 1) if config.slide_ctx_mode == "concat" else self.slide_ctx_dim
+        self.classification_layer = nn.Linear(cls_in, num_logits)
+        self.importance_mlp = nn.Sequential(nn.Linear(self.dim, config.importance_mlp_hidden_dim), nn.ReLU(),
+                                            nn.Linear(config.importance_mlp_hidden_dim, 1))
+        if config.lstm:
+            self.hdim = config.hierarchical_ctx_mlp_hidden_dim
+        else:
+            self.hctx_mlp = nn.Sequential(nn.Linear(self.dim, config.hierarchical_ctx_mlp_hidden_dim), nn.ReLU(),
+                                          nn.Linear(config.hierarchical_ctx_mlp_hidden_dim, self.dim))
+        self.global_agg = TransformerAggregator(input_dim=self.dim, model_dim=config.trans_dim, output_dim=self.dim,
+                                                nhead=config.trans_heads, layers=config.trans_layers, dropout=config.dropout)
+
+    def process(self, data, lstm=None, skip_padding: bool = False) -> Dict[str, torch.Tensor]:
+        mc = self.config
+        ops.check_supported(mc)
+        assert lstm is not None, "lstm=True needs the shared LSTMCell (RecursiveModel passes it)"
+        if self.training and mc.dropout > 0:
+            raise NotImplementedError("paths_amd round 1: dropout (train mode) is not implemented on the HIP path")
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("paths_amd round 1 is forward-only: call under model.eval() / torch.no_grad(); "
+                                      "backward kernels are the next scope row (SURVEY.md §8a row T)")
+        fts = data.fts
+        if fts.dtype != torch.float32 or not fts.is_contiguous():
+            fts = fts.float().contiguous()
+        B, N, D = fts.shape
+        assert D == self.dim
+        state_prev = None
+        if self.depth > 0:
+            assert data.ctx_patch.dim() == 4 and data.ctx_patch.shape[-1] == self.dim + self.hdim
+            state_prev = data.ctx_patch[:, :, -1]                     # strided view, read in place by the kernel
+            if state_prev.stride(2) != 1 or state_prev.dtype != torch.float32 or state_prev.stride(1) % 4 or \
+                    state_prev.stride(0) != N * state_prev.stride(1) or state_prev.data_ptr() % 16:
+                state_prev = state_prev.float().contiguous()
+        ctx_prev = data.ctx_slide[:, -1] if (mc.slide_ctx_mode == "residual" and data.ctx_depth > 0) else None
+        if ctx_prev is not None and (ctx_prev.stride(1) != 1 or ctx_prev.dtype != torch.float32):
+            ctx_prev = ctx_prev.float().contiguous()
+        ctx_all = data.ctx_slide.float().contiguous() if mc.slide_ctx_mode == "concat" else None
+        with torch.no_grad():
+            return ops.level_forward(mc, ops.pack_lstm(lstm), ops.pack_level(self), fts, data.locs, data.num_ims,
+                                     state_prev, ctx_prev, ctx_all, skip_padding)
+
+    def ctx_dim(self) -> Tuple[int, int]:
+        if self.config.lstm:
+            return self.slide_ctx_dim, self.dim + self.hdim
+        return self.slide_ctx_dim, self.dim

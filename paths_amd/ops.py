@@ -1,0 +1,203 @@
+"""Host-side launch sequence of one magnification level on the HIP kernels (no math in Python).
+
+``level_forward`` is what both the drop-in ``PATHSProcessor.process`` (paths_amd/model/paths.py) and the
+device-resident recursion (paths_amd/utils.py) call.  It only allocates device buffers through PyTorch's
+caching allocator and issues C-ABI calls on the current stream; nothing synchronises.
+
+Per level (B slides, N padded rows, D features, T = N+1 tokens) the launch sequence is
+
+    paths_lstm_cell          3 launches   gates GEMM (c part, o part) + mem_to_out GEMM, fused epilogues
+    paths_importance_proj    1 launch     importance MLP + sigmoid + mask + proj_in + PE + special token
+    paths_token_layer_f32    1 launch     in_proj of layer 0
+    per layer l:  paths_attention_f32 + paths_token_layer_f32 (post-attention chain [+ in_proj of l+1])
+    paths_final_head         1 launch     decoder.norm(token 0) + slide ctx residual + classifier
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+LOG2E = 1.4426950408889634
+
+
+# ---------------------------------------------------------------------------------------------
+# weight packing (cached on the owning module, invalidated by parameter version counters)
+# ---------------------------------------------------------------------------------------------
+def _versions(params):
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+def pack_lstm(lstm) -> Dict[str, torch.Tensor]:
+    """Gate rows regrouped so that one 96-column wave tile holds forget|remember|map of 32 memory units."""
+    srcs = [lstm.forget_gate[0], lstm.remember_gate[0], lstm.remember_map[0], lstm.out_select_gate[0], lstm.mem_to_out[0]]
+    params = [t for m in srcs for t in (m.weight, m.bias)]
+    key = _versions(params)
+    cache = getattr(lstm, "_paths_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        f, r, m, o, mo = srcs
+        Hc = f.weight.shape[0]
+        assert Hc % 64 == 0, "hierarchical_ctx_mlp_hidden_dim must be a multiple of 64 for this build"
+        wc = torch.stack([f.weight.view(Hc // 32, 32, -1), r.weight.view(Hc // 32, 32, -1), m.weight.view(Hc // 32, 32, -1)], dim=1)
+        bc = torch.stack([f.bias.view(Hc // 32, 32), r.bias.view(Hc // 32, 32), m.bias.view(Hc // 32, 32)], dim=1)
+        packed = {
+            "w_gates": torch.cat([wc.reshape(3 * Hc, -1), o.weight], dim=0).float().contiguous(),
+            "b_gates": torch.cat([bc.reshape(3 * Hc), o.bias], dim=0).float().contiguous(),
+            "w_mem": mo.weight.detach().float().contiguous(),
+            "b_mem": mo.bias.detach().float().contiguous(),
+            "Hc": Hc,
+        }
+    lstm._paths_pack = (key, packed)
+    return packed
+
+
+def pack_level(proc) -> Dict[str, object]:
+    """Per-level tensors in the layout the kernels read.  Dead encoder / cross-attention matrices are
+    never touched (only ``multihead_attn.out_proj.bias`` is live)."""
+    agg = proc.global_agg
+    params = list(proc.importance_mlp.parameters()) + [agg.proj_in.weight, agg.proj_in.bias, agg.special_token]
+    params += list(agg.transformer.decoder.parameters()) + list(proc.classification_layer.parameters())
+    key = _versions(params)
+    cache = getattr(proc, "_paths_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        c = lambda t: t.detach().float().contiguous()
+        d = agg.dim
+        layers = []
+        for lyr in agg.transformer.decoder.layers:
+            layers.append({
+                "wqkv": c(lyr.self_attn.in_proj_weight), "bqkv": c(lyr.self_attn.in_proj_bias),
+                "wo": c(lyr.self_attn.out_proj.weight), "bo": c(lyr.self_attn.out_proj.bias),
+                "cab": c(lyr.multihead_attn.out_proj.bias),
+                "ln1g": c(lyr.norm1.weight), "ln1b": c(lyr.norm1.bias),
+                "ln2g": c(lyr.norm2.weight), "ln2b": c(lyr.norm2.bias),
+                "ln3g": c(lyr.norm3.weight), "ln3b": c(lyr.norm3.bias),
+                "w1": c(lyr.linear1.weight), "b1": c(lyr.linear1.bias),
+                "w2": c(lyr.linear2.weight), "b2": c(lyr.linear2.bias),
+                "eps": float(lyr.norm1.eps),
+            })
+        dev = agg.proj_in.weight.device
+        k = 10000.0
+        packed = {
+            "w_ip": torch.cat([proc.importance_mlp[0].weight, agg.proj_in.weight], dim=0).float().contiguous(),
+            "b1": c(proc.importance_mlp[0].bias), "w2": c(proc.importance_mlp[2].weight.view(-1)),
+            "b2": float(proc.importance_mlp[2].bias.item()),
+            "bp": c(agg.proj_in.bias), "special": c(agg.special_token),
+            # same expressions as reference utils.py:18 / :56, evaluated on the CPU like the CPU reference
+            "div_1d": torch.exp(torch.arange(0, d, 2) * (-math.log(k) / d)).float().to(dev),
+            "div_2d": torch.exp(torch.arange(0, d // 2, 2) * (-math.log(k) / d)).float().to(dev),
+            "layers": layers,
+            "lnfg": c(agg.transformer.decoder.norm.weight), "lnfb": c(agg.transformer.decoder.norm.bias),
+            "lnf_eps": float(agg.transformer.decoder.norm.eps),
+            "wcls": c(proc.classification_layer.weight), "bcls": c(proc.classification_layer.bias),
+        }
+    proc._paths_pack = (key, packed)
+    return packed
+
+
+def check_supported(mc, nhead_dim_ok: bool = True):
+    """Configurations this build runs on the HIP path; everything else is rejected loudly."""
+    if not mc.lstm:
+        raise NotImplementedError("paths_amd round 1: lstm=false (RNN hierarchical context) is not on the HIP path yet")
+    if mc.trans_dim != 128 or mc.trans_heads != 4 or mc.importance_mlp_hidden_dim != 128:
+        raise NotImplementedError("paths_amd round 1 kernels are specialised for trans_dim=128, trans_heads=4, "
+                                  f"importance_mlp_hidden_dim=128 (got {mc.trans_dim}, {mc.trans_heads}, {mc.importance_mlp_hidden_dim})")
+    if mc.patch_embed_dim % 128 or mc.hierarchical_ctx_mlp_hidden_dim % 64:
+        raise NotImplementedError("patch_embed_dim must be a multiple of 128 and hierarchical_ctx_mlp_hidden_dim of 64")
+    if mc.pos_encoding_mode not in ("1d", "2d"):
+        # the reference itself fails for any other value (size mismatch at the special-token concat)
+        raise RuntimeError(f"pos_encoding_mode '{mc.pos_encoding_mode}' skips proj_in in the reference and fails there too")
+    if mc.slide_ctx_mode not in ("residual", "concat", "none") or mc.importance_mode not in ("mul", "none"):
+        raise ValueError("unknown slide_ctx_mode / importance_mode")
+
+
+# ---------------------------------------------------------------------------------------------
+# one level
+# ---------------------------------------------------------------------------------------------
+def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor, num_ims: torch.Tensor,
+                  state_prev: Optional[torch.Tensor], ctx_prev: Optional[torch.Tensor], ctx_all: Optional[torch.Tensor],
+                  skip_padding: bool) -> Dict[str, torch.Tensor]:
+    """fts [B,N,D] fp32 contiguous; locs [B,N,2] int64; num_ims [B] int64;
+    state_prev: [B,N,>=D+Hc] view whose last dim holds (h|c) of the previous level (row stride arbitrary) or None;
+    ctx_prev [B,d] (residual source) or None; ctx_all [B,depth,d] contiguous (concat mode) or None."""
+    _lib.require_cuda(fts, locs, num_ims, state_prev, ctx_prev, ctx_all)
+    B, N, D = fts.shape
+    d, H, L = mc.trans_dim, mc.trans_heads, mc.trans_layers
+    Hc = lstm_pack["Hc"]
+    Dp = D + Hc
+    T = N + 1
+    M = B * N
+    dev = fts.device
+    st = _lib.stream()
+    p = _lib.ptr
+    f32 = dict(device=dev, dtype=torch.float32)
+    assert fts.is_contiguous() and fts.dtype == torch.float32
+    locs = locs.contiguous()
+    num_ims = num_ims.contiguous()
+    assert locs.dtype == torch.int64 and num_ims.dtype == torch.int64
+
+    state_out = torch.empty((B, N, Dp), **f32)
+    y = torch.empty((B, N, D), **f32)
+    ws_o = torch.empty((B, N, D), **f32)
+    nim = p(num_ims) if skip_padding else None
+    if state_prev is not None:
+        assert state_prev.shape[:2] == (B, N) and state_prev.shape[2] == Dp and state_prev.stride(2) == 1
+        assert state_prev.stride(0) == N * state_prev.stride(1), "state rows must be uniformly strided"
+        ld = state_prev.stride(1)
+        h0, c0 = state_prev.data_ptr(), state_prev.data_ptr() + 4 * D
+    else:
+        ld, h0, c0 = 0, None, None
+    _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
+              p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), M, D, Hc, nim, N, st)
+
+    importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
+    tokens = torch.empty((B, T, d), **f32)
+    pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+    _lib.call("paths_importance_proj", p(y), D, p(lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
+              p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs),
+              p(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, p(importance), p(tokens),
+              M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
+    del ws_o
+
+    hd = d // H
+    q = torch.empty((B, H, T, hd), **f32)
+    k = torch.empty((B, H, T, hd), **f32)
+    v = torch.empty((B, H, T, hd), **f32)
+    attn = torch.empty((B, T, d), **f32)
+    xa, xb = tokens, torch.empty((B, T, d), **f32)
+    qscale = LOG2E / math.sqrt(hd)
+    layers = lvl_pack["layers"]
+
+    def token_layer(x_in, x_out, post, nxt):
+        w = post or nxt
+        g = lambda dct, key: p(dct[key]) if dct is not None else None
+        _lib.call("paths_token_layer_f32", p(x_in), p(attn) if post else None, p(x_out) if post else None,
+                  g(post, "wo"), g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
+                  g(post, "w1"), g(post, "b1"), g(post, "w2"), g(post, "b2"), g(post, "ln3g"), g(post, "ln3b"),
+                  g(nxt, "wqkv"), g(nxt, "bqkv"), p(q), p(k), p(v), p(num_ims), B, T, d, H,
+                  1 if post else 0, 1 if nxt else 0, 1, qscale, w["eps"], st)
+
+    token_layer(xa, None, None, layers[0])
+    for l in range(L):
+        _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), p(num_ims), B, T, H, hd, st)
+        token_layer(xa, xb, layers[l], layers[l + 1] if l + 1 < L else None)
+        xa, xb = xb, xa
+
+    nlog = lvl_pack["wcls"].shape[0]
+    ctx_out = torch.empty((B, d), **f32)
+    logits = torch.empty((B, nlog), **f32)
+    res = ctx_prev if mc.slide_ctx_mode == "residual" else None
+    cat = ctx_all if mc.slide_ctx_mode == "concat" else None
+    depth = cat.shape[1] if cat is not None else 0
+    _lib.call("paths_final_head", p(xa), T * d, p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]),
+              p(res) if res is not None else None, res.stride(0) if res is not None else 0,
+              p(cat.contiguous()) if cat is not None and depth > 0 else None, depth,
+              p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1],
+              p(ctx_out), p(logits), B, d, lvl_pack["lnf_eps"], st)
+    return {"logits": logits, "ctx_slide": ctx_out, "ctx_patch": state_out, "importance": importance}

@@ -1,0 +1,135 @@
+"""Recursion driver (reference utils.py:228-305), device-resident.
+
+``inference_end2end`` keeps the reference's signature and return values but replaces its per-level host round
+trip (``importance.cpu()``, per-slide Python loop with ``torch.topk`` / child expansion / host gather /
+``collate_fn``; reference utils.py:248-260, data_utils/slide.py:277-360, data_utils/dataset.py:206-243) by three
+kernel launches per level (paths_topk, paths_expand_children, paths_gather_rows).  There is NO host
+synchronisation inside the level loop: padded length per level is the static capacity
+``4 * min(N_prev, keep)`` instead of the data-dependent per-batch max, padding is masked by ``num_ims``.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from .data_utils.slide import DeviceSlide
+
+
+def nll_loss(hazards, y, c, alpha=0.4, eps=1e-7):
+    """Discrete-time survival NLL (MCAT) — reference utils.py:283-305.  [B,4] tensors: host-side plumbing."""
+    B = hazards.shape[0]
+    surv = torch.cumprod(1 - hazards, dim=1)
+    surv_pad = torch.cat([torch.ones((B, 1), dtype=surv.dtype, device=surv.device), surv], dim=1)
+    r = torch.arange(B, device=hazards.device)
+    uncensored = -(1 - c) * (torch.log(surv_pad[r, y].clamp(min=eps)) + torch.log(hazards[r, y].clamp(min=eps)))
+    censored = -c * torch.log(surv_pad[r, y + 1].clamp(min=eps))
+    return ((1 - alpha) * (censored + uncensored) + alpha * uncensored).mean()
+
+
+class RecursionError_(RuntimeError):
+    pass
+
+
+def recurse(model, slides: Sequence[DeviceSlide], keep_patches: Sequence[int], num_levels: int,
+            trace: Optional[list] = None, check_status: bool = True) -> Dict[str, torch.Tensor]:
+    """Run all levels for a batch of HBM-resident slides.  Returns the last level's output dict (+ "status").
+
+    ``trace`` (a list) receives one dict per level with device tensors num_ims / locs / parent_inds / importance /
+    logits / ctx_slide / keep_idx / keep_count, for parity tests and heat-map export.
+    """
+    mc = model.procs[0].config
+    ops.check_supported(mc)
+    B = len(slides)
+    dev = slides[0].grids[0].device
+    D = slides[0].dim
+    Dp = D + mc.hierarchical_ctx_mlp_hidden_dim
+    st = _lib.stream()
+    p = _lib.ptr
+    i32 = dict(device=dev, dtype=torch.int32)
+    i64 = dict(device=dev, dtype=torch.int64)
+    f32 = dict(device=dev, dtype=torch.float32)
+
+    def per_level(fn, dtype):
+        return [torch.tensor([fn(s, l) for s in slides], device=dev, dtype=dtype) for l in range(num_levels)]
+
+    grid_ptrs = per_level(lambda s, l: s.grids[l].data_ptr(), torch.int64)
+    mask_ptrs = per_level(lambda s, l: s.masks[l].data_ptr(), torch.int64)
+    gx = per_level(lambda s, l: s.shape(l)[0], torch.int32)
+    gy = per_level(lambda s, l: s.shape(l)[1], torch.int32)
+    status = torch.zeros(1, **i32)
+
+    N = max(s.shape(0)[0] * s.shape(0)[1] for s in slides)
+    fts = torch.empty((B, N, D), **f32)
+    locs = torch.empty((B, N, 2), **i64)
+    parent = torch.empty((B, N), **i64)
+    num_ims = torch.empty((B,), **i64)
+    _lib.call("paths_level0_batch", p(grid_ptrs[0]), p(gx[0]), p(gy[0]), B, D, mc.patch_size, N,
+              p(fts), p(locs), p(parent), p(num_ims), 0, st)
+    state_prev, ctx_hist = None, []
+    out = None
+    lstm_pack = ops.pack_lstm(model.lstm)
+    for i in range(num_levels):
+        proc = model.procs[i]
+        ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
+        ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
+        out = ops.level_forward(mc, lstm_pack, ops.pack_level(proc), fts, locs, num_ims, state_prev, ctx_prev, ctx_all, True)
+        ctx_hist.append(out["ctx_slide"])
+        rec = None
+        if trace is not None:
+            rec = {"num_ims": num_ims, "locs": locs, "parent_inds": parent, "importance": out["importance"],
+                   "logits": out["logits"], "ctx_slide": out["ctx_slide"]}
+            trace.append(rec)
+        if i == num_levels - 1:
+            break
+        keep = int(keep_patches[i])
+        cap_keep = N if keep < 0 else min(N, keep)
+        keep_idx = torch.empty((B, cap_keep), **i32)
+        keep_count = torch.empty((B,), **i32)
+        _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
+        Nn = 4 * cap_keep
+        num_next = torch.empty((B,), **i64)
+        locs_next = torch.empty((B, Nn, 2), **i64)
+        parent_next = torch.empty((B, Nn), **i64)
+        src_row = torch.empty((B, Nn), **i32)
+        src_cell = torch.empty((B, Nn), **i32)
+        _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
+                  p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next), p(parent_next),
+                  p(src_row), p(src_cell), p(status), st)
+        fts_next = torch.empty((B, Nn, D), **f32)
+        state_next = torch.empty((B, Nn, Dp), **f32)
+        _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
+                  p(num_next), B, Nn, p(fts_next), p(state_next), 0, st)
+        if rec is not None:
+            rec["keep_idx"], rec["keep_count"] = keep_idx, keep_count
+        fts, locs, parent, num_ims, state_prev, N = fts_next, locs_next, parent_next, num_next, state_next, Nn
+    out = dict(out)
+    out["status"] = status
+    if check_status:
+        code = int(status.item())        # the only host sync, after the last level
+        if code & 1:
+            raise RecursionError_("a slide produced zero non-background children at some level; the reference's "
+                                  "'use every cell' fallback (data_utils/slide.py:336-352) is not on the device path")
+        if code & 2:
+            raise RecursionError_("child capacity exceeded (internal error)")
+    return out
+
+
+def inference_end2end(num_levels, keep_patches, model, base_power, batch, task: str):
+    """reference utils.py:228-279.  ``batch["slide"]`` is a list of :class:`DeviceSlide`; labels as in the reference
+    (``survival_bin`` / ``censored`` or ``subtype``).  Returns (hazards or logits, loss)."""
+    slides = batch["slide"]
+    dev = slides[0].grids[0].device
+    out = recurse(model, slides, keep_patches, num_levels)
+    logits = out["logits"]
+    if task == "survival":
+        labels = torch.as_tensor(batch["survival_bin"]).to(dev)
+        censors = torch.as_tensor(batch["censored"]).to(dev)
+        hazards = torch.sigmoid(logits)
+        return hazards, nll_loss(hazards, labels, censors)
+    elif task == "subtype_classification":
+        subtypes = torch.as_tensor(batch["subtype"]).to(dev)
+        return logits, F.cross_entropy(logits, subtypes)
+    raise ValueError(task)
