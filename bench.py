@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: slides/sec of the 5-level PATHS recursion at K=2048 patches/level x 1024-dim features
+(BASELINE.json metric), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (reference utils.py:228-279: 5 x [level forward, top-K, child expansion,
+gather]) over one batch of synthetic slides that are ALREADY RESIDENT in HBM.  Slides are independent, so ranks
+shard the batch with no data-path collective (weak scaling: --slides-per-gpu slides per rank); the only
+collectives are the barriers around the timed region and a MAX-reduce of the elapsed time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     dominant kernel (output-gate GEMM of the LSTM cell, fp32 matrix cores) timed live with events on the
+               launch stream inside the timed region; achieved = algorithmic FLOP / measured duration.
+  cpu_baseline the oracle (oracle/paths_oracle.py, plain torch CPU ops) timed on this box's host cores on a bounded
+               sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)" (measured 155)
+BASE_SHAPES = {2048: (32, 64), 1024: (32, 32), 256: (16, 16)}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cpu_share() -> int:
+    """Cores this process may really use: min(affinity, cgroup cpu quota, PATHS_CPU_THREADS or 16).  A GPU box shows
+    every core of the host (256) but gives one GPU job a 16-core share; oversubscribing makes torch CPU ops crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("PATHS_CPU_THREADS", "16"))))
+
+
+def build_model(K: int, dev):
+    from paths_amd import synthetic as syn
+    from paths_amd.config import Config
+    cfg = Config.load(os.path.join(ROOT, "tests", "golden", "sample"), test_mode=True)
+    cfg.model_config.dropout = 0.0
+    cfg.top_k_patches = [K // 4] * (cfg.num_levels - 1)
+    model = cfg.get_model()
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = syn.make_state_dict(0, shapes)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return cfg, model.to(dev).eval(), sd
+
+
+def cpu_baseline(cfg, sd, K: int, n_slides: int, reps: int):
+    """Oracle on the host cores: B = n_slides batch, full 5-level recursion, grids evaluated lazily and cached so
+    the timed repetitions do not pay for input generation (the GPU side has its inputs resident too)."""
+    from oracle import paths_oracle as orc
+    from paths_amd import synthetic as syn
+
+    class CachedGrids(orc.LazyGrids):
+        def __init__(self, slide):
+            super().__init__(slide)
+            self.cache = {}
+
+        def rows(self, level, x, y):
+            key = (level, x.numpy().tobytes(), y.numpy().tobytes())
+            if key not in self.cache:
+                self.cache[key] = super().rows(level, x, y)
+            return self.cache[key]
+
+    threads = host_cpu_share()
+    torch.set_num_threads(threads)
+    log(f"cpu_baseline: {threads} threads (os.cpu_count()={os.cpu_count()}), {n_slides} slides x {reps} reps")
+    ocfg = orc.OracleConfig(top_k_patches=list(cfg.top_k_patches))
+    params = {k: torch.from_numpy(v) for k, v in sd.items()}
+    grids = [CachedGrids(syn.SyntheticSlide(1234, 10_000 + i, BASE_SHAPES[K])) for i in range(n_slides)]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.inference_end2end(params, ocfg, grids)           # warm-up + fills the row cache
+        log(f"cpu_baseline: warm-up pass {time.perf_counter() - t0:.1f} s")
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            orc.inference_end2end(params, ocfg, grids)
+            times.append(time.perf_counter() - t0)
+            log(f"cpu_baseline: rep {times[-1]:.2f} s")
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n_slides / med, "unit": "slides/s", "cores": threads, "kind": "port",
+            "sample": f"{n_slides} slides x {reps} timed repetitions (median) of the same 5-level K={K} recursion, "
+                      f"fp32 torch CPU ops, {threads} threads, inputs cached"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slides-per-gpu", type=int, default=8)
+    ap.add_argument("--k", type=int, default=2048, choices=sorted(BASE_SHAPES))
+    ap.add_argument("--cpu-slides", type=int, default=2)
+    ap.add_argument("--cpu-reps", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from paths_amd import _lib, ops
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    _lib.load()
+    K, spg = args.k, args.slides_per_gpu
+    cfg, model, sd = build_model(K, dev)
+    slides = [DeviceSlide.synthetic(1234, rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)]
+    torch.cuda.synchronize()
+    log(f"model + {spg} slides resident ({torch.cuda.memory_allocated() / 2**30:.1f} GiB)")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(trace=None):
+        with torch.no_grad():
+            return putils.recurse(model, slides, cfg.top_k_patches, cfg.num_levels, trace=trace, check_status=False)
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    # ---- timed region; the dominant kernel is bracketed by events on the launch stream
+    events = []
+
+    def timer(name, launch, meta):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        events.append((name, e0, e1, meta))
+
+    ops.KERNEL_TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    status = int(out["status"].item())
+    assert status == 0, f"recursion status {status}"
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: algorithmic FLOP = 2 * valid_rows * K * N per launch
+    trace = []
+    step(trace)
+    torch.cuda.synchronize()
+    valid = [int(lv["num_ims"].sum().item()) for lv in trace]            # per level, this rank
+    flop = 0.0
+    ms = 0.0
+    for i, (name, e0, e1, meta) in enumerate(events):
+        lvl = i % cfg.num_levels
+        flop += 2.0 * valid[lvl] * meta["K"] * meta["Ncols"]
+        ms += e0.elapsed_time(e1)
+    n_launch = max(1, len(events))
+    achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_f32_kernel<2,2,2,2,EpiLstmO> (LSTM output-gate GEMM, v_mfma_f32_32x32x2_f32)",
+                "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": len(events),
+                "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
+
+    if rank == 0:
+        total_slides = spg * world * args.steps
+        line = {
+            "metric": "slides_per_sec_5level_K%d_D1024" % K, "value": round(total_slides / elapsed, 2), "unit": "slides/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"5-level PATHS recursion (forward, eval): K={K} patches/level (level-0 grid "
+                                   f"{BASE_SHAPES[K][0]}x{BASE_SHAPES[K][1]}, top_k {K // 4}, 10% background), D=1024 "
+                                   f"features, trans_dim 128 x 4 heads x 2 layers, LSTM ctx 256; {spg} HBM-resident slides per GPU",
+                       "slides_per_gpu": spg, "global_batch": spg * world, "levels": cfg.num_levels,
+                       "parallelism": f"slide-sharded x{world} (no data-path collective)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, K, args.cpu_slides, args.cpu_reps)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,11 +36,12 @@ int paths_abi_version(void);
  *   w_gates [3Hc+D, 2D] PACKED: rows [0,3Hc) in groups of 96 = forget|remember|map rows of one block of
  *   32 memory units, rows [3Hc, 3Hc+D) = out_select_gate; b_gates packed alike; w_mem [D,Hc], b_mem [D].
  *   state_out [M, D+Hc] <- (h1 | c1)  (= "ctx_patch"), y [M,D] <- x + h1, ws_o [M,D] scratch.
- *   num_ims != NULL: tiles that contain only padding rows (row index within slide >= num_ims[b]) are skipped. */
+ *   num_ims != NULL: tiles that contain only padding rows (row index within slide >= num_ims[b]) are skipped.
+ *   phases: bit0 memory-cell GEMM, bit1 output-gate GEMM, bit2 mem_to_out GEMM; pass 7 (all, in this order). */
 int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                     const float* w_gates, const float* b_gates, const float* w_mem, const float* b_mem,
                     float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o,
-                    int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, paths_stream_t stream);
+                    int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, paths_stream_t stream);
 
 /* importance MLP + sigmoid + padding mask, importance scaling, proj_in, positional encoding, special token
  * (reference model/paths.py:95-98,119-124; utils.py:16-23,47-67,106-115; model/aggregator.py:37-65).

@@ -20,7 +20,7 @@ _i64, _i32, _f32, _vp, _u32, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C
 # name -> argtypes (mirrors include/paths_hip.h; tests/test_abi.py checks both against the .so exports)
 SIGNATURES = {
     "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
-                        _i32, _i32, _i32, _vp, _i32, _vp],
+                        _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "paths_importance_proj": [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                               _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],

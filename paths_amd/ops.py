@@ -22,6 +22,7 @@ import torch
 from . import _lib
 
 LOG2E = 1.4426950408889634
+KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 
 
 # ---------------------------------------------------------------------------------------------
@@ -153,8 +154,16 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
         h0, c0 = state_prev.data_ptr(), state_prev.data_ptr() + 4 * D
     else:
         ld, h0, c0 = 0, None, None
-    _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
-              p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), M, D, Hc, nim, N, st)
+    def lstm(phases):
+        _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
+                  p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), M, D, Hc, nim, N, phases, st)
+
+    if KERNEL_TIMER is None:
+        lstm(7)
+    else:                       # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
+        lstm(1)
+        KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D})
+        lstm(4)
 
     importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
     tokens = torch.empty((B, T, d), **f32)
