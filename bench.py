@@ -118,18 +118,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from paths_amd import distributed as pdist
+    rank, world, local_rank = pdist.env_rank_world()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    pdist.init("nccl", dev)                      # RCCL; no-op for a single rank
 
     from paths_amd import _lib, ops
     from paths_amd import utils as putils
@@ -143,8 +138,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        pdist.barrier()
         torch.cuda.synchronize()
 
     def step(trace=None):
@@ -177,10 +171,7 @@ def main():
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     status = int(out["status"].item())
     assert status == 0, f"recursion status {status}"
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pdist.max_over_ranks(elapsed, dev)
 
     # ---- roofline of the dominant kernel: algorithmic FLOP = 2 * valid_rows * K * N per launch
     trace = []
@@ -218,7 +209,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, K, args.cpu_slides, args.cpu_reps)
         print(json.dumps(line), flush=True)
-    if dist is not None:
+    if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

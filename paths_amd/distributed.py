@@ -1,0 +1,63 @@
+"""Slide-sharded data parallelism: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI
+on ROCm; "gloo" for the CPU tests).
+
+The forward path shards naturally — a slide's recursion touches only its own rows (reference utils.py:252-258) —
+so there is NO data-path collective: ranks own disjoint slices of the slide batch, run the recursion
+independently, and only (a) barriers around a timed region, (b) a MAX-reduce of elapsed time and (c) an
+all-gather of the tiny per-slide outputs ([B, nbins] hazards) cross the fabric.  (The gradient all-reduce of
+the training step, SURVEY.md §8e, arrives with the backward kernels.)
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    rank, world, _ = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def shard_range(n_total: int, rank: int, world: int) -> range:
+    """Contiguous balanced slice of ``range(n_total)`` owned by ``rank`` (first ``n_total % world`` ranks get one more)."""
+    base, extra = divmod(n_total, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather per-slide rows (e.g. hazards [b_local, nbins]) into global slide order on every rank."""
+    if not dist.is_initialized():
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    cap = len(shard_range(n_total, 0, world))
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([bufs[r][: len(shard_range(n_total, r, world))] for r in range(world)], dim=0)

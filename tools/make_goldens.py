@@ -303,6 +303,16 @@ def nll_known(ref, name):
          {"kind": "nll"})
 
 
+def init_digest(ref, name, seed=0):
+    """Reference get_model() under a fixed seed: per-tensor (sum, abs-sum) in float64, for the init-order test."""
+    rcfg = ref[0]
+    c = rcfg.Config.load(os.path.join(REF, "models", "sample"), test_mode=True)
+    torch.manual_seed(seed)
+    sd = c.get_model().state_dict()
+    arrays = {k: np.asarray([float(v.double().sum()), float(v.double().abs().sum())]) for k, v in sd.items()}
+    save(name, arrays, {"kind": "init_digest", "seed": seed, "keys": list(sd.keys())})
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present: nothing to do")
@@ -313,6 +323,8 @@ def main():
     def want(n):
         return not only or n in only
 
+    if want("g0"):
+        init_digest(ref, "g0_init_digest")
     if want("g1"):
         single_level(ref, "g1_level0_b2_k256", 0, 2, 256, [256, 219], wseed=1, dseed=11)
     if want("g2"):
