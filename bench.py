@@ -128,11 +128,11 @@ def main():
 
     from paths_amd import _lib, ops
     from paths_amd import utils as putils
-    from paths_amd.data_utils.slide import DeviceSlide
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     _lib.load()
     K, spg = args.k, args.slides_per_gpu
     cfg, model, sd = build_model(K, dev)
-    slides = [DeviceSlide.synthetic(1234, rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)]
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)])
     torch.cuda.synchronize()
     log(f"model + {spg} slides resident ({torch.cuda.memory_allocated() / 2**30:.1f} GiB)")
 

@@ -59,19 +59,37 @@ int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b
 
 /* Masked multi-head self-attention, flash style (nn.MultiheadAttention inside nn.TransformerDecoderLayer as
  * called at reference model/aggregator.py:70-72, key mask utils.py:97-103).
- *   q,k,v [B,H,T,32] head-major, q pre-scaled by log2(e)/sqrt(32); o [B,T,H*32]; valid keys = num_ims[b]+1. */
+ *   q,k,v [B,H,T,32] head-major, q pre-scaled by log2(e)/sqrt(32); o [B,T,H*32]; valid keys = num_ims[b]+1.
+ *   max_queries > 0 restricts the computed query rows to [0, max_queries) (the last decoder layer is read at
+ *   token 0 only, reference model/aggregator.py:75); 0 = all T rows. */
 int paths_attention_f32(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims,
-                        int B, int T, int H, int head_dim, paths_stream_t stream);
+                        int B, int T, int H, int head_dim, int max_queries, paths_stream_t stream);
 
 /* Token-row chain of one post-LN decoder layer with empty memory + the next in_proj (same call site):
  *   do_post: x_out = norm3(x' + ffn(x')), x' = norm2(norm1(x_in + out_proj(attn)) + cross_attn_bias)
- *   do_qkv : q,k,v = in_proj(x)  (x = x_out if do_post else x_in) written head-major, q scaled by qscale. */
+ *   do_qkv : q,k,v = in_proj(x)  (x = x_out if do_post else x_in) written head-major, q scaled by qscale.
+ *   max_tokens > 0 restricts the processed token rows to [0, max_tokens) (last layer); 0 = all T rows. */
 int paths_token_layer_f32(const float* x_in, const float* attn, float* x_out,
                           const float* wo, const float* bo, const float* ln1g, const float* ln1b, const float* cab,
                           const float* ln2g, const float* ln2b, const float* w1, const float* b1, const float* w2,
                           const float* b2, const float* ln3g, const float* ln3b, const float* wqkv, const float* bqkv,
                           float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
-                          int do_post, int do_qkv, int skip_padding, float qscale, float eps, paths_stream_t stream);
+                          int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens,
+                          paths_stream_t stream);
+
+/* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
+ * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only
+ * out[:, 0] of the final layer is read: it needs K/V of every token (q,k,v as written by paths_token_layer_f32 for
+ * that layer) but queries / out_proj / norms / FFN of one row per slide.  x_in = the layer's input activations;
+ * ws_partials = scratch of B*H*16*36 floats (split-key attention partials). */
+int paths_token0_tail(const float* x_in, const float* q, const float* k, const float* v, const int64_t* num_ims,
+                      const float* wo, const float* bo, const float* ln1g, const float* ln1b, const float* cab,
+                      const float* ln2g, const float* ln2b, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,
+                      const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
+                      const float* wcls, const float* bcls, int num_logits, int cls_in,
+                      float* ctx_out, float* logits, float* ws_partials, int B, int T, int d, int H, float eps,
+                      float eps_final, paths_stream_t stream);
 
 /* decoder.norm on token 0, slide-context residual / concat, classifier
  * (reference model/aggregator.py:75, model/paths.py:130-139). */

@@ -82,38 +82,43 @@ attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const 
     if (kt + 1 < nkt) gload(kt + 1);
 
     // ---- S^T = K Q^T for 4 sub-tiles of 16 keys
-    f32x4 s[4];
+    f32x4 s[4], ka[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* kp = &sK[buf][(16 * t + ql) * LDKs + 4 * g4];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(kp + 16 * u);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[t] = mfma16(a[e], qreg[u][e], s[t]);
-      }
+      ka[t][0] = *reinterpret_cast<const f32x4*>(kp);
+      ka[t][1] = *reinterpret_cast<const f32x4*>(kp + 16);
     }
-    // ---- mask + online softmax (lane: one query; keys 16t + 4g + r)
-    const int kbase = kt * KT + 4 * g4;
+    // 4 independent accumulators interleaved: back-to-back MFMAs never wait on their own result
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[t] = mfma16(ka[t][u][e], qreg[u][e], s[t]);
+    // ---- mask (last tile only) + online softmax (lane: one query; keys 16t + 4g + r)
+    if (kt == nkt - 1) {
+      const int kbase = kt * KT + 4 * g4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kbase + 16 * t + r >= len) s[t][r] = -INFINITY;
+    }
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (kbase + 16 * t + r >= len) s[t][r] = -INFINITY;
-        mx = fmaxf(mx, s[t][r]);
-      }
+    for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);       // finite: key 0 (special token) is always valid
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // raw v_exp_f32: arguments are <= 0, no denormal fix-up needed
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[t][r] = exp2f(s[t][r] - m_new);
+        s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m_new);
         psum += s[t][r];
       }
     l_run = l_run * alpha + psum;
@@ -149,11 +154,14 @@ attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const 
 }  // namespace
 
 extern "C" int paths_attention_f32(const float* q, const float* k, const float* v, float* o,
-                                   const int64_t* num_ims, int B, int T, int H, int head_dim, hipStream_t stream) {
+                                   const int64_t* num_ims, int B, int T, int H, int head_dim, int max_queries,
+                                   hipStream_t stream) {
   PATHS_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
   PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && num_ims != nullptr, "attention: bad shape B=%d T=%d H=%d", B, T, H);
   PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "attention: buffers must be 16-byte aligned");
-  dim3 grid((T + 63) / 64, H, B);
+  // max_queries > 0: only queries [0, max_queries) are needed (last decoder layer: token 0 only, aggregator.py:75)
+  const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
+  dim3 grid((nq + 63) / 64, H, B);
   hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, stream, q, k, v, o, num_ims, T, H);
   PATHS_LAUNCH_CHECK("attention");
   return PATHS_OK;

@@ -29,6 +29,9 @@ int paths_set_error(int code, const char* fmt, ...);
 
 // ---- device math (accurate forms: the selection chain must stay within ~1e-7 of the fp32 CPU path)
 __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// branch-free tanh: 1 - 2/(1+e^{2x}); absolute error ~1e-7 (what the h = o*tanh(.) and c-update chains need),
+// saturates correctly at +-1 (e^{2x} -> inf / 0).  libm's tanhf branches per lane and serialises epilogues.
+__device__ __forceinline__ float tanh_acc(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }
 
 // ---- MFMA wrappers.  f32-input MFMA = exact k-ordered fp32 FMA chain (guide §3 "FP32-input MFMA").
 // 32x32x2: A lane l -> A[l&31][l>>5], B lane l -> B[l>>5][l&31]; C: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)

@@ -42,7 +42,22 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][(BM+BN)*LDK]
 
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (speed only, any placement is correct): workgroups are dealt round-robin over the 8 XCDs,
+  // so give XCD x (= linear id % 8) a contiguous run of the tile sequence; inside that run tiles advance
+  // column-block fastest within groups of GM row-blocks, so the ~64 workgroups resident on one XCD cover a
+  // GM x (N/BN) patch and re-use each A and W k-tile from that XCD's private L2.
+  const int nbx = gridDim.x, nby = gridDim.y, nblk = nbx * nby;
+  int lin = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = lin & 7, j = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any nblk
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * nbx;
+  const int grp = lin / per_group, in_grp = lin - grp * per_group;
+  const int rows_in_grp = min(GM, nby - grp * GM);
+  const int by = grp * GM + in_grp % rows_in_grp, bx = in_grp / rows_in_grp;
+  const int m0 = by * BM, n0 = bx * BN;
   if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M)) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,6 +138,11 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
 // Epilogues.  acc[i][j][r] is C[row0 + 32 i + c32_row(r, lane)][col0 + 32 j + (lane & 31)].
 // ------------------------------------------------------------------------------------------------
 
+// Epilogue structure (all of them): per 32x32 tile FIRST issue every load the tile needs (clamped row index: always
+// a legal address, no branch), THEN compute, THEN store under a row predicate.  Written naively (load -> math ->
+// store per element inside `if (row < M)`) hipcc emits one exec-masked branch + one s_waitcnt vmcnt(0) per element:
+// 64-128 dependent L2 round trips per thread, which made the K=256 GEMM spend 2/3 of its time in its epilogue.
+
 // c1 = c0 * sigmoid(f) + sigmoid(r) * tanh(m); packed columns per wave = [f(32) | r(32) | m(32)] of one j-block.
 struct EpiLstmC {
   const float* bias;     // packed like the weight rows
@@ -135,18 +155,23 @@ struct EpiLstmC {
     const int j = (col0 / 96) * 32 + jj;
     const float bf = bias[col0 + jj], br = bias[col0 + 32 + jj], bm = bias[col0 + 64 + jj];
 #pragma unroll
-    for (int i = 0; i < WTM; ++i)
+    for (int i = 0; i < WTM; ++i) {
+      float cp[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
+        cp[r] = c0 ? c0[(int64_t)rowc * ldc0 + j] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + 32 * i + c32_row(r, lane);
-        if (row < M) {
-          const float f = sigmoid_acc(acc[i][0][r] + bf);
-          const float rg = sigmoid_acc(acc[i][1][r] + br);
-          const float mp = tanhf(acc[i][2][r] + bm);
-          const float cprev = c0 ? c0[(int64_t)row * ldc0 + j] : 0.f;
-          c1[(int64_t)row * ldc1 + j] = cprev * f + rg * mp;
-        }
+        const float f = sigmoid_acc(acc[i][0][r] + bf);
+        const float rg = sigmoid_acc(acc[i][1][r] + br);
+        const float mp = tanh_acc(acc[i][2][r] + bm);
+        const float v = cp[r] * f + rg * mp;
+        if (row < M) c1[(int64_t)row * ldc1 + j] = v;
       }
+    }
   }
 };
 
@@ -165,7 +190,8 @@ struct EpiLstmO {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + 32 * i + c32_row(r, lane);
-          if (row < M) o[(int64_t)row * ldo + col] = sigmoid_acc(acc[i][j][r] + b);
+          const float v = sigmoid_acc(acc[i][j][r] + b);
+          if (row < M) o[(int64_t)row * ldo + col] = v;
         }
     }
   }
@@ -179,20 +205,28 @@ struct EpiLstmH {
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
-      const int col = col0 + 32 * j + (lane & 31);
-      if (col >= N) continue;
+      const int col = min(col0 + 32 * j + (lane & 31), N - 1);
+      const bool colok = col0 + 32 * j + (lane & 31) < N;
       const float b = bias[col];
 #pragma unroll
-      for (int i = 0; i < WTM; ++i)
+      for (int i = 0; i < WTM; ++i) {
+        float ov[16], xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
+          ov[r] = o[(int64_t)rowc * ldo + col];
+          xv[r] = x[(int64_t)rowc * ldx + col];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + 32 * i + c32_row(r, lane);
-          if (row < M) {
-            const float h = o[(int64_t)row * ldo + col] * tanhf(acc[i][j][r] + b);
+          const float h = ov[r] * tanh_acc(acc[i][j][r] + b);
+          if (row < M && colok) {
             h1[(int64_t)row * ldh + col] = h;
-            y[(int64_t)row * ldy + col] = x[(int64_t)row * ldx + col] + h;
+            y[(int64_t)row * ldy + col] = xv[r] + h;
           }
         }
+      }
     }
   }
 };
@@ -271,6 +305,20 @@ struct EpiImpProj {
     }
     __syncthreads();
     if (wn == 1) {
+      int64_t lx[16], ly[16];               // all position loads first (see the epilogue note above)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowc = min(row0 + c32_row(r, lane), M - 1);
+        lx[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc] : 0;
+        ly[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc + 1] : 0;
+      }
+      float bpv[4], dtv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 32 * j + (lane & 31);
+        bpv[j] = bp[c];
+        dtv[j] = pe_mode == 2 ? div_term[(c & (d / 2 - 1)) >> 1] : div_term[c >> 1];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lrow = c32_row(r, lane);
@@ -280,8 +328,8 @@ struct EpiImpProj {
         const float a = imp_mul ? alpha_s[wm * 32 + lrow] : 1.f;
         float px = 0.f, py = 0.f;
         if (pe_mode == 2) {
-          px = (float)(locs[2 * (int64_t)row] / patch_size);
-          py = (float)(locs[2 * (int64_t)row + 1] / patch_size);
+          px = (float)(lx[r] / patch_size);
+          py = (float)(ly[r] / patch_size);
         } else {
           px = (float)idx;
         }
@@ -289,16 +337,10 @@ struct EpiImpProj {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int c = 32 * j + (lane & 31);
-          float pe;
-          if (pe_mode == 2) {
-            const float pos = (c < d / 2) ? px : py;
-            const float ang = pos * div_term[(c & (d / 2 - 1)) >> 1];
-            pe = (c & 1) ? cosf(ang) : sinf(ang);
-          } else {
-            const float ang = px * div_term[c >> 1];
-            pe = (c & 1) ? cosf(ang) : sinf(ang);
-          }
-          trow[c] = a * acc[0][j][r] + bp[c] + pe;
+          const float pos = (pe_mode == 2 && c >= d / 2) ? py : px;
+          const float ang = pos * dtv[j];
+          const float pe = (c & 1) ? cosf(ang) : sinf(ang);
+          trow[c] = a * acc[0][j][r] + bpv[j] + pe;
           if (idx == 0) tokens[(int64_t)b * (rows_per_slide + 1) * d + c] = special[c];
         }
       }

@@ -77,7 +77,9 @@ __device__ __forceinline__ void mm_chunk(const float* sW, int ldw, f32x4 (&acc)[
 
 __global__ void __launch_bounds__(256, 2)
 tlayer_f32_kernel(TLayerParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][CHUNK_FLOATS]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][CHUNK_FLOATS] + in-loop biases [512 + 384]
+  float* s_b1 = smem + 2 * CHUNK_FLOATS;
+  float* s_bqkv = s_b1 + DFF;
   const int b = blockIdx.y, t0 = blockIdx.x * 64;
   if (p.skip_padding && t0 >= (int)p.num_ims[b] + 1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
@@ -109,6 +111,14 @@ tlayer_f32_kernel(TLayerParams p) {
       for (int i = 0; i < 8; ++i) { const int idx = tid + i * 256; *reinterpret_cast<f32x4*>(dst + (idx >> 5) * LDA_ + 4 * (idx & 31)) = rs[i]; }
     }
   };
+  // In-loop biases live in LDS: an LDS read is counted by lgkmcnt, so consuming it never forces the vmcnt wait that
+  // would drain the weight-chunk prefetch (vector-memory loads retire in order; hipcc sinks small global loads next
+  // to their use, i.e. behind the prefetch).
+  act_t x;      // activations first (oldest loads), then biases, then the first weight chunk
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = *reinterpret_cast<const f32x4*>(p.x_in + rowoff + 16 * t + 4 * g4);
+  if (p.do_post) for (int i = threadIdx.x; i < DFF; i += 256) s_b1[i] = p.b1[i];
+  if (p.do_qkv) for (int i = threadIdx.x; i < 3 * DM; i += 256) s_bqkv[i] = p.bqkv[i];
   int buf = 0, c = c_first;
   stage_load(c);
   stage_store(c, 0);
@@ -116,10 +126,6 @@ tlayer_f32_kernel(TLayerParams p) {
   // begin(): start fetching the chunk after the current one; end(): publish it and flip buffers
   auto begin = [&]() { if (c + 1 < c_last) stage_load(c + 1); };
   auto end = [&]() { if (c + 1 < c_last) stage_store(c + 1, buf ^ 1); __syncthreads(); buf ^= 1; ++c; };
-
-  act_t x;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) x[t] = *reinterpret_cast<const f32x4*>(p.x_in + rowoff + 16 * t + 4 * g4);
 
   if (p.do_post) {
     // ---- out_proj(attn) + residual -> norm1 -> + cross-attn bias -> norm2
@@ -152,17 +158,17 @@ tlayer_f32_kernel(TLayerParams p) {
     for (int t = 0; t < 8; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int hc = 0; hc < 8; ++hc) {
-      f32x4 hid[4];
+      f32x4 hid[4], b1v[4];
       begin();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b1v[i] = *reinterpret_cast<const f32x4*>(s_b1 + 64 * hc + 16 * i + 4 * g4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) hid[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       mm_chunk<4, 8>(smem + buf * CHUNK_FLOATS, LDA_, hid, x, ql, g4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.b1 + 64 * hc + 16 * i + 4 * g4);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hid[i][r] = fmaxf(hid[i][r] + b1[r], 0.f);
-      }
+        for (int r = 0; r < 4; ++r) hid[i][r] = fmaxf(hid[i][r] + b1v[i][r], 0.f);
       end();
       begin();
       mm_chunk<8, 4>(smem + buf * CHUNK_FLOATS, LDB_, y, hid, ql, g4);
@@ -184,7 +190,10 @@ tlayer_f32_kernel(TLayerParams p) {
     // ---- in_proj: 6 chunks of 64 output rows: q(0,1) k(2,3) v(4,5); head = feature >> 5
 #pragma unroll 1
     for (int qc = 0; qc < 6; ++qc) {
+      f32x4 bb[4];
       begin();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bb[i] = *reinterpret_cast<const f32x4*>(s_bqkv + 128 * (qc >> 1) + 64 * (qc & 1) + 16 * i + 4 * g4);
       f32x4 acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -195,9 +204,8 @@ tlayer_f32_kernel(TLayerParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int f = 64 * (qc & 1) + 16 * i + 4 * g4;          // feature within q / k / v
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bqkv + 128 * (qc >> 1) + f);
           const int head = f >> 5, dd = f & 31;
-          *reinterpret_cast<f32x4*>(dst + (((int64_t)b * p.H + head) * p.T + tok) * 32 + dd) = (acc[i] + bb) * sc;
+          *reinterpret_cast<f32x4*>(dst + (((int64_t)b * p.H + head) * p.T + tok) * 32 + dd) = (acc[i] + bb[i]) * sc;
         }
       }
       end();
@@ -247,6 +255,197 @@ final_head_kernel(const float* __restrict__ x, int64_t slide_stride, const float
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Last decoder layer, token 0 only (the aggregator reads out[:, 0], reference model/aggregator.py:75): that
+// layer needs K/V of every token but the query / out_proj / LayerNorms / FFN of ONE row per slide.  One
+// workgroup per slide: wave h = attention head h (lane-strided keys, per-lane online softmax, wave merge), then
+// the row chain as wave-cooperative GEMVs (weights read straight from L2, 512 B coalesced rows), decoder.norm,
+// slide-context residual / concat and the classifier (reference model/paths.py:130-139).
+// ------------------------------------------------------------------------------------------------
+constexpr int T0_SPLITS = 16;     // key partitions per (slide, head) in the single-query attention
+constexpr int T0_PSTRIDE = 36;    // floats per partial: m, l, o[32], pad
+
+struct Token0Params {
+  const float* x_in; const float* partials; const int64_t* num_ims;
+  const float *wo, *bo, *ln1g, *ln1b, *cab, *ln2g, *ln2b, *w1, *b1, *w2, *b2, *ln3g, *ln3b, *lnfg, *lnfb;
+  const float* ctx_prev; int64_t ctx_stride; const float* ctx_all; int ctx_depth;
+  const float *wcls, *bcls; int num_logits, cls_in;
+  float *ctx_out, *logits; int T, H; float eps, eps_f;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// y[f] = dot(W[f][0:K], xin[0:K]) for f in [f0, f0+nf), nf a multiple of R: R rows in flight per wave so the
+// row loads and the cross-lane reductions of different rows overlap (this kernel is latency-, not bandwidth-bound)
+template <int K, int R>
+__device__ __forceinline__ void wave_gemv(const float* __restrict__ W, int ldw, const float* xin, float* yout, int f0, int nf, int lane) {
+  constexpr int PER = K / 64;
+  float xv[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) xv[i] = xin[lane * PER + i];
+  for (int f = f0; f < f0 + nf; f += R) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float* w = W + (int64_t)(f + r) * ldw + lane * PER;
+      acc[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) acc[r] += w[i] * xv[i];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r] += __shfl_xor(acc[r], o);
+    if (lane == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) yout[f + r] = acc[r];
+    }
+  }
+}
+
+__device__ __forceinline__ void block_layernorm128(float* v, const float* g, const float* bta, float eps, int tid) {
+  // wave 0 normalises v[0:128] in place (2 values per lane)
+  if (tid < 64) {
+    const float a = v[tid], c = v[tid + 64];
+    const float mean = wave_sum(a + c) * (1.0f / DM);
+    const float da = a - mean, dc = c - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum(da * da + dc * dc) * (1.0f / DM) + eps);
+    v[tid] = da * rstd * g[tid] + bta[tid];
+    v[tid + 64] = dc * rstd * g[tid + 64] + bta[tid + 64];
+  }
+  __syncthreads();
+}
+
+// Single-query (token 0) attention partials: one wave per (key partition, head, slide); lane-strided keys, per-lane
+// online softmax, wave merge.  Writes (m, l, o[32]) per partition; token0_tail_kernel combines them.
+__global__ void __launch_bounds__(64)
+attn_token0_partial_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                           const int64_t* __restrict__ num_ims, float* __restrict__ partials, int T, int H) {
+  const int part = blockIdx.x, head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const int len = (int)num_ims[b] + 1;
+  const int chunk = ((len + T0_SPLITS - 1) / T0_SPLITS + 63) & ~63;
+  const int k0 = part * chunk, k1 = min(len, k0 + chunk);
+  const int64_t base = ((int64_t)b * H + head) * T * 32;
+  float qv[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(q + base + 4 * i);        // query row 0 (already scaled)
+    qv[4 * i] = t[0]; qv[4 * i + 1] = t[1]; qv[4 * i + 2] = t[2]; qv[4 * i + 3] = t[3];
+  }
+  float m = -INFINITY, l = 0.f, o[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) o[i] = 0.f;
+#pragma unroll 2
+  for (int key = k0 + lane; key < k1; key += 64) {
+    const float* kp = k + base + (int64_t)key * 32;
+    const float* vp = v + base + (int64_t)key * 32;
+    f32x4 kk[8], vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { kk[i] = *reinterpret_cast<const f32x4*>(kp + 4 * i); vv[i] = *reinterpret_cast<const f32x4*>(vp + 4 * i); }
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      sc += kk[i][0] * qv[4 * i] + kk[i][1] * qv[4 * i + 1] + kk[i][2] * qv[4 * i + 2] + kk[i][3] * qv[4 * i + 3];
+    const float mn = fmaxf(m, sc);
+    const float al = exp2f(m - mn), pr = exp2f(sc - mn);
+    l = l * al + pr;
+    m = mn;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o[4 * i] = o[4 * i] * al + pr * vv[i][0];
+      o[4 * i + 1] = o[4 * i + 1] * al + pr * vv[i][1];
+      o[4 * i + 2] = o[4 * i + 2] * al + pr * vv[i][2];
+      o[4 * i + 3] = o[4 * i + 3] * al + pr * vv[i][3];
+    }
+  }
+  float mg = m;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) mg = fmaxf(mg, __shfl_xor(mg, off));
+  const float scale = (m == -INFINITY) ? 0.f : exp2f(m - mg);          // lanes without keys contribute nothing
+  l *= scale;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) o[i] *= scale;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    l += __shfl_xor(l, off);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] += __shfl_xor(o[i], off);
+  }
+  float* dst = partials + (((int64_t)b * H + head) * T0_SPLITS + part) * T0_PSTRIDE;
+  if (lane == 0) { dst[0] = mg; dst[1] = l; }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) if (lane == 0) dst[2 + i] = o[i];
+}
+
+constexpr int T0_WAVES = 16;
+
+__global__ void __launch_bounds__(64 * T0_WAVES)
+token0_tail_kernel(Token0Params p) {
+  __shared__ float s_x[DM], s_a[DM], s_y[DM], s_h[DFF];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < DM) {                                  // merge the key partitions of head tid>>5 (flash-decoding style)
+    const int head = tid >> 5, i = tid & 31;
+    const float* sp = p.partials + ((int64_t)b * p.H + head) * T0_SPLITS * T0_PSTRIDE;
+    float M = -INFINITY;
+#pragma unroll
+    for (int pt = 0; pt < T0_SPLITS; ++pt) M = fmaxf(M, sp[pt * T0_PSTRIDE]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int pt = 0; pt < T0_SPLITS; ++pt) {
+      const float mp = sp[pt * T0_PSTRIDE];
+      const float w = (mp == -INFINITY) ? 0.f : exp2f(mp - M);
+      num += sp[pt * T0_PSTRIDE + 2 + i] * w; den += sp[pt * T0_PSTRIDE + 1] * w;
+    }
+    s_a[tid] = num / den;
+    s_x[tid] = p.x_in[(int64_t)b * p.T * DM + tid];
+  }
+  __syncthreads();
+  // ---- x = norm1(x + out_proj(a)) ; x = norm2(x + cab)
+  wave_gemv<DM, 8>(p.wo, DM, s_a, s_y, wave * 8, 8, lane);
+  __syncthreads();
+  if (tid < DM) s_x[tid] = s_x[tid] + (s_y[tid] + p.bo[tid]);
+  __syncthreads();
+  block_layernorm128(s_x, p.ln1g, p.ln1b, p.eps, tid);
+  if (tid < DM) s_x[tid] += p.cab[tid];
+  __syncthreads();
+  block_layernorm128(s_x, p.ln2g, p.ln2b, p.eps, tid);
+  // ---- x = norm3(x + linear2(relu(linear1(x))))
+  wave_gemv<DM, 16>(p.w1, DM, s_x, s_h, wave * 32, 32, lane);
+  __syncthreads();
+  if (tid < DFF) s_h[tid] = fmaxf(s_h[tid] + p.b1[tid], 0.f);
+  __syncthreads();
+  wave_gemv<DFF, 4>(p.w2, DFF, s_h, s_y, wave * 8, 8, lane);
+  __syncthreads();
+  if (tid < DM) s_x[tid] = s_x[tid] + (s_y[tid] + p.b2[tid]);
+  __syncthreads();
+  block_layernorm128(s_x, p.ln3g, p.ln3b, p.eps, tid);
+  // ---- decoder.norm, slide-context residual, classifier
+  block_layernorm128(s_x, p.lnfg, p.lnfb, p.eps_f, tid);
+  if (tid < DM) {
+    float f = s_x[tid];
+    if (p.ctx_prev) f += p.ctx_prev[(int64_t)b * p.ctx_stride + tid];
+    s_x[tid] = f;
+    p.ctx_out[(int64_t)b * DM + tid] = f;
+  }
+  __syncthreads();
+  for (int j = wave; j < p.num_logits; j += T0_WAVES) {
+    const float* w = p.wcls + (int64_t)j * p.cls_in;
+    float acc = 0.f;
+    if (p.ctx_all) {
+      for (int i = lane; i < p.ctx_depth * DM; i += 64) acc += w[i] * p.ctx_all[(int64_t)b * p.ctx_depth * DM + i];
+      w += p.ctx_depth * DM;
+    }
+    acc += w[lane] * s_x[lane] + w[lane + 64] * s_x[lane + 64];
+    acc = wave_sum(acc);
+    if (lane == 0) p.logits[(int64_t)b * p.num_logits + j] = acc + p.bcls[j];
+  }
+}
+
 // ---- stand-alone LayerNorm over rows of width 128 (one wave per row; wavefront reduction).
 __global__ void __launch_bounds__(256)
 layernorm128_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ bta,
@@ -278,21 +477,50 @@ int paths_token_layer_f32(const float* x_in, const float* attn, float* x_out,
                           const float* ln2g, const float* ln2b, const float* w1, const float* b1, const float* w2,
                           const float* b2, const float* ln3g, const float* ln3b, const float* wqkv, const float* bqkv,
                           float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
-                          int do_post, int do_qkv, int skip_padding, float qscale, float eps, hipStream_t stream) {
+                          int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens,
+                          hipStream_t stream) {
   PATHS_REQUIRE(d == DM && H == 4, "token_layer: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer: nothing to do");
   PATHS_REQUIRE(!skip_padding || num_ims, "token_layer: skip_padding needs num_ims");
   PATHS_REQUIRE(x_in && (!do_post || (attn && x_out && wo && w1 && w2)) && (!do_qkv || (wqkv && q && k && v)), "token_layer: null operand");
   TLayerParams p{x_in, attn, x_out, wo, bo, ln1g, ln1b, cab, ln2g, ln2b, w1, b1, w2, b2, ln3g, ln3b, wqkv, bqkv,
                  q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps};
-  constexpr size_t lds = 2ull * CHUNK_FLOATS * sizeof(float);
+  constexpr size_t lds_min = (2ull * CHUNK_FLOATS + DFF + 3 * DM) * sizeof(float);      // 77,312 B: two workgroups per CU
+  constexpr size_t lds_solo = 84 * 1024;                                                 // > 80 KiB: one workgroup per CU
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solo);
     attr_set = true;
   }
-  hipLaunchKernelGGL(tlayer_f32_kernel, dim3((T + 63) / 64, B), dim3(256), lds, stream, p);
+  // max_tokens > 0: only token rows [0, max_tokens) are needed (last layer: only token 0 is read downstream)
+  const int nt = max_tokens > 0 && max_tokens < T ? max_tokens : T;
+  const int nblk = ((nt + 63) / 64) * B;
+  // Placement (speed only): with about one workgroup per CU in the grid, two co-resident workgroups would share a CU's
+  // matrix pipes while other CUs idle and the kernel lasts as long as the doubled-up CUs (measured 0.51 waves/SIMD
+  // average).  Asking for > half the LDS makes the dispatcher spread workgroups one per CU.
+  const size_t lds = nblk <= 2 * 256 ? lds_solo : lds_min;
+  hipLaunchKernelGGL(tlayer_f32_kernel, dim3((nt + 63) / 64, B), dim3(256), lds, stream, p);
   PATHS_LAUNCH_CHECK("token_layer");
+  return PATHS_OK;
+}
+
+int paths_token0_tail(const float* x_in, const float* q, const float* k, const float* v, const int64_t* num_ims,
+                      const float* wo, const float* bo, const float* ln1g, const float* ln1b, const float* cab,
+                      const float* ln2g, const float* ln2b, const float* w1, const float* b1, const float* w2,
+                      const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,
+                      const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
+                      const float* wcls, const float* bcls, int num_logits, int cls_in,
+                      float* ctx_out, float* logits, float* ws_partials /*[B*H*16*36]*/, int B, int T, int d, int H,
+                      float eps, float eps_final, hipStream_t stream) {
+  PATHS_REQUIRE(d == DM && H == 4, "token0_tail: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
+  PATHS_REQUIRE(B > 0 && T > 0 && num_ims && x_in && q && k && v && wo && w1 && w2 && wcls && ctx_out && logits && ws_partials, "token0_tail: null operand");
+  PATHS_REQUIRE(num_logits > 0 && cls_in == (ctx_all ? (ctx_depth + 1) * DM : DM), "token0_tail: bad classifier shape");
+  hipLaunchKernelGGL(attn_token0_partial_kernel, dim3(T0_SPLITS, H, B), dim3(64), 0, stream, q, k, v, num_ims, ws_partials, T, H);
+  PATHS_LAUNCH_CHECK("token0_tail(attention partials)");
+  Token0Params p{x_in, ws_partials, num_ims, wo, bo, ln1g, ln1b, cab, ln2g, ln2b, w1, b1, w2, b2, ln3g, ln3b, lnfg, lnfb,
+                 ctx_prev, ctx_stride, ctx_all, ctx_depth, wcls, bcls, num_logits, cls_in, ctx_out, logits, T, H, eps, eps_final};
+  hipLaunchKernelGGL(token0_tail_kernel, dim3(B), dim3(64 * T0_WAVES), 0, stream, p);
+  PATHS_LAUNCH_CHECK("token0_tail");
   return PATHS_OK;
 }
 

@@ -66,3 +66,32 @@ class DeviceSlide:
         s = DeviceSlide(grids, patch_size=patch_size, slide_id=f"synthetic-{seed}-{slide}")
         s.synthetic_spec = synthetic.SyntheticSlide(seed, slide, tuple(base_shape), dim, num_levels, p_bg)
         return s
+
+
+class DeviceSlideBatch:
+    """Per-batch device tables (grid / mask base pointers and grid dims per level) built ONCE.
+
+    ``torch.tensor(list, device=...)`` is a blocking host->device copy that also waits for everything queued on
+    the stream; building these tables inside every recursion call cost ~1.5 ms of idle GPU per step.
+    """
+
+    def __init__(self, slides):
+        assert len(slides) > 0
+        self.slides = list(slides)
+        dev = self.slides[0].grids[0].device
+        L = min(s.num_levels for s in self.slides)
+        self.device, self.num_levels = dev, L
+        self.dim = self.slides[0].dim
+        assert all(s.dim == self.dim for s in self.slides)
+
+        def table(fn, dtype):
+            return [torch.tensor([fn(s, l) for s in self.slides], device=dev, dtype=dtype) for l in range(L)]
+
+        self.grid_ptrs = table(lambda s, l: s.grids[l].data_ptr(), torch.int64)
+        self.mask_ptrs = table(lambda s, l: s.masks[l].data_ptr(), torch.int64)
+        self.gx = table(lambda s, l: s.shape(l)[0], torch.int32)
+        self.gy = table(lambda s, l: s.shape(l)[1], torch.int32)
+        self.n0 = max(s.shape(0)[0] * s.shape(0)[1] for s in self.slides)
+
+    def __len__(self):
+        return len(self.slides)

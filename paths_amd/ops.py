@@ -9,8 +9,8 @@ Per level (B slides, N padded rows, D features, T = N+1 tokens) the launch seque
     paths_lstm_cell          3 launches   gates GEMM (c part, o part) + mem_to_out GEMM, fused epilogues
     paths_importance_proj    1 launch     importance MLP + sigmoid + mask + proj_in + PE + special token
     paths_token_layer_f32    1 launch     in_proj of layer 0
-    per layer l:  paths_attention_f32 + paths_token_layer_f32 (post-attention chain [+ in_proj of l+1])
-    paths_final_head         1 launch     decoder.norm(token 0) + slide ctx residual + classifier
+    per layer l < L-1:  paths_attention_f32 + paths_token_layer_f32 (post-attention chain + in_proj of l+1)
+    paths_token0_tail        1 launch     last layer at token 0 only + decoder.norm + slide ctx residual + classifier
 """
 from __future__ import annotations
 
@@ -183,30 +183,35 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     qscale = LOG2E / math.sqrt(hd)
     layers = lvl_pack["layers"]
 
-    def token_layer(x_in, x_out, post, nxt):
+    def token_layer(x_in, x_out, post, nxt, max_tokens=0):
         w = post or nxt
         g = lambda dct, key: p(dct[key]) if dct is not None else None
         _lib.call("paths_token_layer_f32", p(x_in), p(attn) if post else None, p(x_out) if post else None,
                   g(post, "wo"), g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
                   g(post, "w1"), g(post, "b1"), g(post, "w2"), g(post, "b2"), g(post, "ln3g"), g(post, "ln3b"),
                   g(nxt, "wqkv"), g(nxt, "bqkv"), p(q), p(k), p(v), p(num_ims), B, T, d, H,
-                  1 if post else 0, 1 if nxt else 0, 1, qscale, w["eps"], st)
-
-    token_layer(xa, None, None, layers[0])
-    for l in range(L):
-        _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), p(num_ims), B, T, H, hd, st)
-        token_layer(xa, xb, layers[l], layers[l + 1] if l + 1 < L else None)
-        xa, xb = xb, xa
+                  1 if post else 0, 1 if nxt else 0, 1, qscale, w["eps"], max_tokens, st)
 
     nlog = lvl_pack["wcls"].shape[0]
     ctx_out = torch.empty((B, d), **f32)
     logits = torch.empty((B, nlog), **f32)
     res = ctx_prev if mc.slide_ctx_mode == "residual" else None
-    cat = ctx_all if mc.slide_ctx_mode == "concat" else None
+    cat = ctx_all.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_all is not None and ctx_all.shape[1] > 0) else None
     depth = cat.shape[1] if cat is not None else 0
-    _lib.call("paths_final_head", p(xa), T * d, p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]),
-              p(res) if res is not None else None, res.stride(0) if res is not None else 0,
-              p(cat.contiguous()) if cat is not None and depth > 0 else None, depth,
-              p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1],
-              p(ctx_out), p(logits), B, d, lvl_pack["lnf_eps"], st)
+
+    token_layer(xa, None, None, layers[0])
+    for l in range(L - 1):
+        _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), p(num_ims), B, T, H, hd, 0, st)
+        token_layer(xa, xb, layers[l], layers[l + 1])
+        xa, xb = xb, xa
+    # Last layer: only token 0 of its output is read (aggregator.py:75) -> one fused launch per level computes the
+    # single-query attention, the row chain, decoder.norm, the slide-context residual and the classifier.
+    w = layers[L - 1]
+    ws_part = torch.empty((B * H * 16 * 36,), **f32)
+    _lib.call("paths_token0_tail", p(xa), p(q), p(k), p(v), p(num_ims), p(w["wo"]), p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
+              p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["w1"]), p(w["b1"]), p(w["w2"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]),
+              p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
+              res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
+              p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
+              p(ws_part), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
     return {"logits": logits, "ctx_slide": ctx_out, "ctx_patch": state_out, "importance": importance}

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, ops
-from .data_utils.slide import DeviceSlide
+from .data_utils.slide import DeviceSlide, DeviceSlideBatch
 
 
 def nll_loss(hazards, y, c, alpha=0.4, eps=1e-7):
@@ -33,18 +33,21 @@ class RecursionError_(RuntimeError):
     pass
 
 
-def recurse(model, slides: Sequence[DeviceSlide], keep_patches: Sequence[int], num_levels: int,
+def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
             trace: Optional[list] = None, check_status: bool = True) -> Dict[str, torch.Tensor]:
-    """Run all levels for a batch of HBM-resident slides.  Returns the last level's output dict (+ "status").
+    """Run all levels for a batch of HBM-resident slides (a list of DeviceSlide, or a DeviceSlideBatch built once
+    and re-used across calls).  Returns the last level's output dict (+ "status").
 
     ``trace`` (a list) receives one dict per level with device tensors num_ims / locs / parent_inds / importance /
     logits / ctx_slide / keep_idx / keep_count, for parity tests and heat-map export.
     """
     mc = model.procs[0].config
     ops.check_supported(mc)
-    B = len(slides)
-    dev = slides[0].grids[0].device
-    D = slides[0].dim
+    batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
+    assert batch.num_levels >= num_levels
+    B = len(batch)
+    dev = batch.device
+    D = batch.dim
     Dp = D + mc.hierarchical_ctx_mlp_hidden_dim
     st = _lib.stream()
     p = _lib.ptr
@@ -52,16 +55,10 @@ def recurse(model, slides: Sequence[DeviceSlide], keep_patches: Sequence[int], n
     i64 = dict(device=dev, dtype=torch.int64)
     f32 = dict(device=dev, dtype=torch.float32)
 
-    def per_level(fn, dtype):
-        return [torch.tensor([fn(s, l) for s in slides], device=dev, dtype=dtype) for l in range(num_levels)]
-
-    grid_ptrs = per_level(lambda s, l: s.grids[l].data_ptr(), torch.int64)
-    mask_ptrs = per_level(lambda s, l: s.masks[l].data_ptr(), torch.int64)
-    gx = per_level(lambda s, l: s.shape(l)[0], torch.int32)
-    gy = per_level(lambda s, l: s.shape(l)[1], torch.int32)
+    grid_ptrs, mask_ptrs, gx, gy = batch.grid_ptrs, batch.mask_ptrs, batch.gx, batch.gy
     status = torch.zeros(1, **i32)
 
-    N = max(s.shape(0)[0] * s.shape(0)[1] for s in slides)
+    N = batch.n0
     fts = torch.empty((B, N, D), **f32)
     locs = torch.empty((B, N, 2), **i64)
     parent = torch.empty((B, N), **i64)
@@ -121,7 +118,7 @@ def inference_end2end(num_levels, keep_patches, model, base_power, batch, task: 
     """reference utils.py:228-279.  ``batch["slide"]`` is a list of :class:`DeviceSlide`; labels as in the reference
     (``survival_bin`` / ``censored`` or ``subtype``).  Returns (hazards or logits, loss)."""
     slides = batch["slide"]
-    dev = slides[0].grids[0].device
+    dev = slides.device if isinstance(slides, DeviceSlideBatch) else slides[0].grids[0].device
     out = recurse(model, slides, keep_patches, num_levels)
     logits = out["logits"]
     if task == "survival":
