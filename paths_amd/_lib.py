@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpaths_hip.so")
+LIB_PATH = os.environ.get("PATHS_HIP_LIB") or os.path.join(_HERE, "libpaths_hip.so")
 
 _i64, _i32, _f32, _vp, _u32, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint64
 

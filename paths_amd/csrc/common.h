@@ -43,6 +43,13 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 16-byte load through an explicit GLOBAL address-space pointer.  A pointer obtained by selecting between two kernel
+// arguments is "generic" to hipcc, which then emits flat_load (counted by BOTH vmcnt and lgkmcnt -> forces full drains).
+__device__ __forceinline__ f32x4 ldg_f32x4(const float* p) {
+  typedef const f32x4 __attribute__((address_space(1))) * gptr;
+  return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ int c32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // Is [m0, m0+rows) entirely padding?  Rows are laid out [slide][rows_per_slide]; slide b has

@@ -69,30 +69,27 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
   for (int p = 0; p < PA; ++p) {
     int row = min(m0 + r0 + p * RPP, g.M - 1);
     a0p[p] = g.A0 + (int64_t)row * g.lda0 + 4 * c4;
-    a1p[p] = g.A1 ? g.A1 + (int64_t)row * g.lda1 + 4 * c4 : nullptr;
+    a1p[p] = g.A1 ? g.A1 + (int64_t)row * g.lda1 + 4 * c4 : a0p[p];   // never dereferenced when K1 == 0; keeps the select in the global address space
   }
 #pragma unroll
   for (int p = 0; p < PB; ++p) bp[p] = g.Bt + (int64_t)(n0 + r0 + p * RPP) * g.ldb + 4 * c4;
 
   f32x4 ra[PA], rb[PB];
-  auto gload = [&](int kt) {
+  // One staged row-chunk at a time, addressed by a compile-time index (everything below is fully unrolled).
+  // Panel select is pointer arithmetic, not a branch: the k-tile body must stay ONE basic block.
+  auto gload_one = [&](int idx, int kt) {
     const int k = kt * BK;
-    if (k < g.K0) {
-#pragma unroll
-      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a0p[p] + k);
+    if (idx < PA) {
+      const bool first = k < g.K0;
+      ra[idx] = ldg_f32x4((first ? a0p[idx] : a1p[idx]) + (first ? k : k - g.K0));
     } else {
-#pragma unroll
-      for (int p = 0; p < PA; ++p) ra[p] = *reinterpret_cast<const f32x4*>(a1p[p] + (k - g.K0));
+      rb[idx - PA] = ldg_f32x4(bp[idx - PA] + k);
     }
-#pragma unroll
-    for (int p = 0; p < PB; ++p) rb[p] = *reinterpret_cast<const f32x4*>(bp[p] + k);
   };
-  auto swrite = [&](int buf) {
+  auto swrite_one = [&](int idx, int buf) {
     float* s = smem + buf * (BM + BN) * LDK;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(s + (r0 + p * RPP) * LDK + 4 * c4) = ra[p];
-#pragma unroll
-    for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(s + (BM + r0 + p * RPP) * LDK + 4 * c4) = rb[p];
+    if (idx < PA) *reinterpret_cast<f32x4*>(s + (r0 + idx * RPP) * LDK + 4 * c4) = ra[idx];
+    else *reinterpret_cast<f32x4*>(s + (BM + r0 + (idx - PA) * RPP) * LDK + 4 * c4) = rb[idx - PA];
   };
 
   f32x16 acc[WTM][WTN];
@@ -105,32 +102,67 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
 
   const int nk = (g.K0 + g.K1) / BK;
   const int fragoff = (lane & 31) * LDK + 4 * (lane >> 5);
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);
-    const float* sA = smem + buf * (BM + BN) * LDK + (wm * WTM * 32) * LDK + fragoff;
-    const float* sB = smem + buf * (BM + BN) * LDK + (BM + wn * WTN * 32) * LDK + fragoff;
+  const float* sAbase = smem + (wm * WTM * 32) * LDK + fragoff;
+  const float* sBbase = smem + (BM + wn * WTN * 32) * LDK + fragoff;
+  constexpr int NF = WTM + WTN;           // fragments (16-byte LDS reads) per k-group
+  constexpr int NG = PA + PB;             // staged chunks per thread per k-tile
+  static_assert(NG <= 12, "staging schedule assumes <= 12 chunks per thread");
+  f32x4 fa[2][WTM], fb[2][WTN];
+  auto read_frag = [&](int buf, int q, int slot, int f) {
+    if (f < WTM) fa[slot][f] = *reinterpret_cast<const f32x4*>(sAbase + buf * (BM + BN) * LDK + 8 * q + f * 32 * LDK);
+    else fb[slot][f - WTM] = *reinterpret_cast<const f32x4*>(sBbase + buf * (BM + BN) * LDK + 8 * q + (f - WTM) * 32 * LDK);
+  };
+  auto mfma_step = [&](int slot, int e) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 a[WTM], b[WTN];
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDK + 8 * q);
+      for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(fa[slot][i][e], fb[slot][j][e], acc[i][j]);
+  };
+  // A wave issues IN ORDER and an fp32 MFMA holds the matrix pipe for 64 cycles, so everything that is not an MFMA
+  // must sit between MFMAs, not in a cluster at the tile boundary (hipcc's default placement left ~2,100 non-MFMA
+  // cycles per 4,096-cycle k-tile).  A k-tile is 16 pinned groups; group gq = (k-group q = gq/4, step e = gq%4):
+  //     WTM*WTN MFMAs | fragment reads of k-group q+1 | ONE global load of tile kt+1 (early groups) or ONE LDS
+  //     write of it (late groups, >= 6 groups = 1,500+ cycles after its load)
+  // Group 15 is rotated past the barrier so that its MFMAs cover the first fragment reads of the next tile.
+  auto group = [&](int gq, int buf, int kt, bool stage) {
+    const int q = gq >> 2, e = gq & 3, slot = q & 1;
+    mfma_step(slot, e);
+    if (q < 3) {
 #pragma unroll
-      for (int j = 0; j < WTN; ++j) b[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LDK + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-          for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+      for (int f = e; f < NF; f += 4) read_frag(buf, q + 1, slot ^ 1, f);
     }
-    if (kt + 1 < nk) swrite(buf ^ 1);
+    if (stage) {
+      if (gq < NG) gload_one(gq, kt + 1);
+      if (gq >= 16 - NG) swrite_one(gq - (16 - NG), buf ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#pragma unroll
+  for (int idx = 0; idx < NG; ++idx) gload_one(idx, 0);
+#pragma unroll
+  for (int idx = 0; idx < NG; ++idx) swrite_one(idx, 0);
+  __syncthreads();
+#pragma unroll
+  for (int f = 0; f < NF; ++f) read_frag(0, 0, 0, f);
+  int buf = 0;
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int gq = 0; gq < 15; ++gq) group(gq, buf, kt, true);
+    // group 15 = last MFMA step of this tile; its LDS write goes BEFORE the barrier, its MFMAs after it
+    swrite_one(NG - 1, buf ^ 1);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     buf ^= 1;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) read_frag(buf, 0, 0, f);
+    mfma_step(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int gq = 0; gq < 16; ++gq) group(gq, buf, 0, false);
+  __syncthreads();     // epilogues may reuse LDS
   epi.template run<WTM, WTN, WGM, WGN>(acc, m0 + wm * WTM * 32, n0 + wn * WTN * 32, lane, wm, wn, g.M, smem);
 }
 
