@@ -186,8 +186,14 @@ def main():
         ms += e0.elapsed_time(e1)
     n_launch = max(1, len(events))
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    traffic = None            # HBM-side bytes per launch from the committed PMC passes (separate --pmc runs, profiles/)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["kernels"]["EpiLstmO"]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "kernel": "gemm_f32_kernel<2,2,2,2,EpiLstmO> (LSTM output-gate GEMM, v_mfma_f32_32x32x2_f32)",
                 "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": len(events),
                 "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
