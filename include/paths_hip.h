@@ -125,6 +125,11 @@ int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, cons
 int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,
                        float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, paths_stream_t stream);
 
+/* z = alpha * x (+ h on valid rows): importance scaling and the non-LSTM hierarchical-context add
+ * (reference model/paths.py:96-109). */
+int paths_scale_add_rows(const float* x, const float* alpha, const float* h, const int64_t* num_ims, int rows_per_slide,
+                         int D, int64_t M, int use_alpha, float* z, paths_stream_t stream);
+
 /* Tissue mask of a preprocessed grid [cells, D]: 1 iff fp32 row sum != 0 (reference slide.py:324). */
 int paths_tissue_mask(const float* grid, int64_t cells, int D, uint8_t* mask, paths_stream_t stream);
 

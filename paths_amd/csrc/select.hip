@@ -196,6 +196,28 @@ tissue_mask_kernel(const float* __restrict__ grid, int64_t cells, int D, uint8_t
   if (lane == 0) mask[cell] = s != 0.f ? 1 : 0;
 }
 
+
+// Z[row] = alpha[row] * X[row] (+ H[row] on valid rows): the non-LSTM hierarchical-context update
+// (reference model/paths.py:96-109: Z = Y * alpha; Z += apply_to_non_padded(hctx_mlp, prev Z)).
+__global__ void __launch_bounds__(256)
+scale_add_rows_kernel(const float* __restrict__ x, const float* __restrict__ alpha, const float* __restrict__ h,
+                      const int64_t* __restrict__ num_ims, int rows_per_slide, int D, int64_t M, int use_alpha,
+                      float* __restrict__ z) {
+  const int64_t row = blockIdx.x;
+  if (row >= M) return;
+  const int b = (int)(row / rows_per_slide), idx = (int)(row % rows_per_slide);
+  const bool valid = idx < (int)num_ims[b];
+  const float a = use_alpha ? alpha[row] : 1.0f;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+  const f32x4* hr = h ? reinterpret_cast<const f32x4*>(h + row * D) : nullptr;
+  f32x4* zr = reinterpret_cast<f32x4*>(z + row * D);
+  for (int i = threadIdx.x; i < D / 4; i += 256) {
+    f32x4 v = xr[i] * a;
+    if (hr && valid) v += hr[i];
+    zr[i] = v;
+  }
+}
+
 // Synthetic grid (paths_amd/synthetic.py): one thread per 4 channels.
 __global__ void __launch_bounds__(256)
 synth_grid_kernel(float* __restrict__ grid, int X, int Y, int D, uint32_t k2, int level, unsigned long long bg_thr) {
@@ -259,6 +281,14 @@ int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, i
   hipLaunchKernelGGL(level0_kernel, dim3((unsigned)n0, B), dim3(256), 0, stream, grid_ptrs, gx, gy, D, patch_size, n0,
                      fts, locs, parent, num_ims, zero_pad);
   PATHS_LAUNCH_CHECK("level0_batch");
+  return PATHS_OK;
+}
+
+int paths_scale_add_rows(const float* x, const float* alpha, const float* h, const int64_t* num_ims, int rows_per_slide,
+                         int D, int64_t M, int use_alpha, float* z, hipStream_t stream) {
+  PATHS_REQUIRE(M > 0 && D % 4 == 0 && rows_per_slide > 0 && num_ims && x && z && (alpha || !use_alpha), "scale_add_rows: bad arguments");
+  hipLaunchKernelGGL(scale_add_rows_kernel, dim3((unsigned)M), dim3(256), 0, stream, x, alpha, h, num_ims, rows_per_slide, D, M, use_alpha, z);
+  PATHS_LAUNCH_CHECK("scale_add_rows");
   return PATHS_OK;
 }
 

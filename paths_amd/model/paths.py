@@ -4,7 +4,7 @@ Same constructor / ``process(data, lstm=None)`` / ``ctx_dim()`` surface and stat
 ``process`` issues the HIP launch sequence of paths_amd/ops.py:level_forward and returns the reference's
 dict {"logits", "ctx_slide", "ctx_patch", "importance"} (model/paths.py:141-146).
 
-Round-1 limits (rejected loudly, never silently approximated): forward only (no autograd graph), lstm=True,
+Round-1 limits (rejected loudly, never silently approximated): forward only (no autograd graph),
 trans_dim=128 / 4 heads / importance hidden 128, dropout inactive (eval or dropout=0).
 """
 from __future__ import annotations
@@ -43,7 +43,7 @@ class PATHSProcessor(nn.Module, Processor):
     def process(self, data, lstm=None, skip_padding: bool = False) -> Dict[str, torch.Tensor]:
         mc = self.config
         ops.check_supported(mc)
-        assert lstm is not None, "lstm=True needs the shared LSTMCell (RecursiveModel passes it)"
+        assert lstm is not None or not mc.lstm, "lstm=True needs the shared LSTMCell (RecursiveModel passes it)"
         if self.training and mc.dropout > 0:
             raise NotImplementedError("paths_amd round 1: dropout (train mode) is not implemented on the HIP path")
         if torch.is_grad_enabled() and self.training:
@@ -56,7 +56,7 @@ class PATHSProcessor(nn.Module, Processor):
         assert D == self.dim
         state_prev = None
         if self.depth > 0:
-            assert data.ctx_patch.dim() == 4 and data.ctx_patch.shape[-1] == self.dim + self.hdim
+            assert data.ctx_patch.dim() == 4 and data.ctx_patch.shape[-1] == self.ctx_dim()[1]
             state_prev = data.ctx_patch[:, :, -1]                     # strided view, read in place by the kernel
             if state_prev.stride(2) != 1 or state_prev.dtype != torch.float32 or state_prev.stride(1) % 4 or \
                     state_prev.stride(0) != N * state_prev.stride(1) or state_prev.data_ptr() % 16:
@@ -66,7 +66,7 @@ class PATHSProcessor(nn.Module, Processor):
             ctx_prev = ctx_prev.float().contiguous()
         ctx_all = data.ctx_slide.float().contiguous() if mc.slide_ctx_mode == "concat" else None
         with torch.no_grad():
-            return ops.level_forward(mc, ops.pack_lstm(lstm), ops.pack_level(self), fts, data.locs, data.num_ims,
+            return ops.level_forward(mc, ops.pack_lstm(lstm) if mc.lstm else None, ops.pack_level(self), fts, data.locs, data.num_ims,
                                      state_prev, ctx_prev, ctx_all, skip_padding)
 
     def ctx_dim(self) -> Tuple[int, int]:

@@ -63,6 +63,8 @@ def pack_level(proc) -> Dict[str, object]:
     agg = proc.global_agg
     params = list(proc.importance_mlp.parameters()) + [agg.proj_in.weight, agg.proj_in.bias, agg.special_token]
     params += list(agg.transformer.decoder.parameters()) + list(proc.classification_layer.parameters())
+    if hasattr(proc, "hctx_mlp"):
+        params += list(proc.hctx_mlp.parameters())
     key = _versions(params)
     cache = getattr(proc, "_paths_pack", None)
     if cache is not None and cache[0] == key:
@@ -98,14 +100,15 @@ def pack_level(proc) -> Dict[str, object]:
             "lnf_eps": float(agg.transformer.decoder.norm.eps),
             "wcls": c(proc.classification_layer.weight), "bcls": c(proc.classification_layer.bias),
         }
+        if hasattr(proc, "hctx_mlp"):      # lstm=false: RNN hierarchical context (reference model/paths.py:49-54)
+            packed.update({"wh1": c(proc.hctx_mlp[0].weight), "bh1": c(proc.hctx_mlp[0].bias),
+                           "wh2": c(proc.hctx_mlp[2].weight), "bh2": c(proc.hctx_mlp[2].bias)})
     proc._paths_pack = (key, packed)
     return packed
 
 
 def check_supported(mc, nhead_dim_ok: bool = True):
     """Configurations this build runs on the HIP path; everything else is rejected loudly."""
-    if not mc.lstm:
-        raise NotImplementedError("paths_amd round 1: lstm=false (RNN hierarchical context) is not on the HIP path yet")
     if mc.trans_dim != 128 or mc.trans_heads != 4 or mc.importance_mlp_hidden_dim != 128:
         raise NotImplementedError("paths_amd round 1 kernels are specialised for trans_dim=128, trans_heads=4, "
                                   f"importance_mlp_hidden_dim=128 (got {mc.trans_dim}, {mc.trans_heads}, {mc.importance_mlp_hidden_dim})")
@@ -130,8 +133,6 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     _lib.require_cuda(fts, locs, num_ims, state_prev, ctx_prev, ctx_all)
     B, N, D = fts.shape
     d, H, L = mc.trans_dim, mc.trans_heads, mc.trans_layers
-    Hc = lstm_pack["Hc"]
-    Dp = D + Hc
     T = N + 1
     M = B * N
     dev = fts.device
@@ -142,37 +143,62 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     locs = locs.contiguous()
     num_ims = num_ims.contiguous()
     assert locs.dtype == torch.int64 and num_ims.dtype == torch.int64
-
-    state_out = torch.empty((B, N, Dp), **f32)
-    y = torch.empty((B, N, D), **f32)
-    ws_o = torch.empty((B, N, D), **f32)
     nim = p(num_ims) if skip_padding else None
-    if state_prev is not None:
-        assert state_prev.shape[:2] == (B, N) and state_prev.shape[2] == Dp and state_prev.stride(2) == 1
-        assert state_prev.stride(0) == N * state_prev.stride(1), "state rows must be uniformly strided"
-        ld = state_prev.stride(1)
-        h0, c0 = state_prev.data_ptr(), state_prev.data_ptr() + 4 * D
-    else:
-        ld, h0, c0 = 0, None, None
-    def lstm(phases):
-        _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
-                  p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), M, D, Hc, nim, N, phases, st)
+    pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+    tokens = torch.empty((B, T, d), **f32)
 
-    if KERNEL_TIMER is None:
-        lstm(7)
-    else:                       # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
-        lstm(1)
-        KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D})
-        lstm(4)
+    def importance_proj(src, imp_mul, imp_out):
+        _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
+                  p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs),
+                  p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens),
+                  M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
 
     importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
-    tokens = torch.empty((B, T, d), **f32)
-    pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
-    _lib.call("paths_importance_proj", p(y), D, p(lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
-              p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs),
-              p(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, p(importance), p(tokens),
-              M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
-    del ws_o
+    if mc.lstm:
+        Hc = lstm_pack["Hc"]
+        Dp = D + Hc
+        state_out = torch.empty((B, N, Dp), **f32)
+        y = torch.empty((B, N, D), **f32)
+        ws_o = torch.empty((B, N, D), **f32)
+        if state_prev is not None:
+            assert state_prev.shape[:2] == (B, N) and state_prev.shape[2] == Dp and state_prev.stride(2) == 1
+            assert state_prev.stride(0) == N * state_prev.stride(1), "state rows must be uniformly strided"
+            ld = state_prev.stride(1)
+            h0, c0 = state_prev.data_ptr(), state_prev.data_ptr() + 4 * D
+        else:
+            ld, h0, c0 = 0, None, None
+
+        def lstm(phases):
+            _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
+                      p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), M, D, Hc, nim, N, phases, st)
+
+        if KERNEL_TIMER is None:
+            lstm(7)
+        else:                   # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
+            lstm(1)
+            KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D})
+            lstm(4)
+        importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance)
+        del ws_o
+    else:
+        # lstm=false (reference model/paths.py:95-109): alpha from X; Z = alpha*X (+ hctx_mlp(previous Z) on valid rows);
+        # patch ctx = Z; tokens = proj_in(Z) + PE.  Re-uses the GEMM kernels; not a tuned path.
+        importance_proj(fts, 0, importance)                      # pass 1: importance only (tokens overwritten below)
+        hctx = None
+        if state_prev is not None and mc.hierarchical_ctx:
+            assert state_prev.shape == (B, N, D) and state_prev.stride(2) == 1 and state_prev.stride(0) == N * state_prev.stride(1)
+            Hh = lvl_pack["wh1"].shape[0]
+            assert Hh % 128 == 0, "hierarchical_ctx_mlp_hidden_dim must be a multiple of 128 for lstm=false"
+            hid = torch.empty((B, N, Hh), **f32)
+            hctx = torch.empty((B, N, D), **f32)
+            _lib.call("paths_linear_f32", p(state_prev), state_prev.stride(1), p(lvl_pack["wh1"]), p(lvl_pack["bh1"]), p(hid), Hh,
+                      M, Hh, Hh, D, 1, st)
+            _lib.call("paths_linear_f32", p(hid), Hh, p(lvl_pack["wh2"]), p(lvl_pack["bh2"]), p(hctx), D, M, D, D, Hh, 0, st)
+        state_out = torch.empty((B, N, D), **f32)
+        _lib.call("paths_scale_add_rows", p(fts), p(importance), p(hctx) if hctx is not None else None, p(num_ims), N, D, M,
+                  1 if mc.importance_mode == "mul" else 0, p(state_out), st)
+        scratch_imp = torch.empty((B, N), **f32)
+        importance_proj(state_out, 0, scratch_imp)               # pass 2: tokens = proj_in(Z) + PE
 
     hd = d // H
     q = torch.empty((B, H, T, hd), **f32)

@@ -48,7 +48,7 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     B = len(batch)
     dev = batch.device
     D = batch.dim
-    Dp = D + mc.hierarchical_ctx_mlp_hidden_dim
+    Dp = model.procs[0].ctx_dim()[1]
     st = _lib.stream()
     p = _lib.ptr
     i32 = dict(device=dev, dtype=torch.int32)
@@ -67,7 +67,7 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
               p(fts), p(locs), p(parent), p(num_ims), 0, st)
     state_prev, ctx_hist = None, []
     out = None
-    lstm_pack = ops.pack_lstm(model.lstm)
+    lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
     for i in range(num_levels):
         proc = model.procs[i]
         ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None

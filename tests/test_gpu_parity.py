@@ -73,7 +73,7 @@ def test_single_level_vs_reference_golden(dev, name):
         assert (out["importance"][b, n:] == 0).all()
 
 
-@pytest.mark.parametrize("tag", ["pe1d", "concat", "impnone", "subtype"])
+@pytest.mark.parametrize("tag", ["pe1d", "nolstm", "concat", "impnone", "subtype"])
 def test_single_level_variants(dev, tag):
     g, info, out = run_single(dev, f"g5_{tag}_level1")
     np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
@@ -82,14 +82,17 @@ def test_single_level_variants(dev, tag):
     np.testing.assert_allclose(out["ctx_patch"].numpy(), g["ctx_patch"], atol=STATE_TOL, rtol=0)
 
 
-def test_unsupported_variant_rejected(dev):
+def test_unsupported_config_rejected(dev):
+    """Configurations outside this build's kernel specialisation fail loudly (never approximated)."""
     from paths_amd.data_utils.patch_batch import PatchBatch
-    g, info = load_golden("g5_nolstm_level1")
-    cfg, model, _ = build_model(dev, info["wseed"], info["cfg_over"])
-    inp = H.single_level_inputs(info, H.oracle_config(info["cfg_over"]))
+    g, info = load_golden("g1_level0_b2_k256")
+    cfg, model, _ = build_model(dev, info["wseed"], None)
+    model.procs[0].config.trans_heads = 8          # same tensors, unsupported head count
+    inp = H.single_level_inputs(info, H.oracle_config())
     pb = PatchBatch(**{k: torch.from_numpy(v).to(dev) for k, v in inp.items()})
     with pytest.raises(NotImplementedError):
-        model(1, pb)
+        model(0, pb)
+    model.procs[0].config.trans_heads = 4
 
 
 @pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])
@@ -171,6 +174,24 @@ def test_recursion_vs_oracle_random_seeds(dev):
     cfg, model, params = build_model(dev, 77, None, top_k_patches=[24] * 4)
     ocfg = H.oracle_config(top_k_patches=[24] * 4)
     slides = [DeviceSlide.synthetic(99, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    for l in range(5):
+        np.testing.assert_array_equal(trace[l]["num_ims"].cpu().numpy(), otrace[l]["num_ims"].numpy())
+    np.testing.assert_allclose(torch.sigmoid(out["logits"]).cpu().numpy(), hz.numpy(), atol=LOGIT_TOL, rtol=0)
+
+
+def test_recursion_nolstm_variant_vs_oracle(dev):
+    """lstm=false (RNN hierarchical context, reference model/paths.py:101-109) through the fused recursion."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    over = {"model_config": {"lstm": False}}
+    cfg, model, params = build_model(dev, 5, over, top_k_patches=[12] * 4)
+    ocfg = H.oracle_config(over, top_k_patches=[12] * 4)
+    slides = [DeviceSlide.synthetic(41, sid, (7, 6), p_bg=0.1, device=dev) for sid in range(2)]
     trace, otrace = [], []
     with torch.no_grad():
         out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
