@@ -115,6 +115,13 @@ int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_coun
                           int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
                           int* src_cell, int* status, paths_stream_t stream);
 
+/* Rare fallback of reference data_utils/slide.py:336-352 for slides with num_out[b] == 0 after paths_expand_children:
+ * continue with every tissue cell of the next grid (every cell if it has no tissue), zero patch context (src_row = -1),
+ * parent_inds = cell index.  Other slides are untouched.  status bit1 set if n_next is too small. */
+int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t* mask_ptrs, int patch_size, int B,
+                             int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
+                             int* src_cell, int* status, paths_stream_t stream);
+
 /* Gather child features from the next-level grids and parent LSTM state (reference slide.py:318,327-331;
  * zero padding of data_utils/dataset.py:216-227 when zero_pad != 0). */
 int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,

@@ -133,6 +133,56 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
   }
 }
 
+
+// Rare fallback (reference data_utils/slide.py:336-352): a slide whose kept patches have NO tissue children
+// continues with every tissue cell of the next grid (or every cell if the grid has no tissue at all), zero patch
+// context, parent_inds = cell index.  Only slides with num_out[b] == 0 are touched.
+__global__ void __launch_bounds__(1024)
+fallback_all_cells_kernel(const int* __restrict__ next_x, const int* __restrict__ next_y, const int64_t* __restrict__ mask_ptrs,
+                          int patch_size, int64_t n_next, int64_t* __restrict__ num_out, int64_t* __restrict__ locs_out,
+                          int64_t* __restrict__ parent_out, int* __restrict__ src_row, int* __restrict__ src_cell,
+                          int* __restrict__ status) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (num_out[b] != 0) return;
+  const int X = next_x[b], Y = next_y[b];
+  const int total = X * Y;
+  const uint8_t* mask = reinterpret_cast<const uint8_t*>(mask_ptrs[b]);
+  const int per = (total + 1023) / 1024;
+  const int c0 = min(tid * per, total), c1 = min(c0 + per, total);
+  int mine = 0;
+  for (int c = c0; c < c1; ++c) mine += mask[c] != 0;
+  part[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int tissue = part[1023];
+  const bool all = tissue == 0;                       // "hope that there will be tissue later" (slide.py:344-347)
+  const int n_out = all ? total : tissue;
+  int pos = all ? c0 : part[tid] - mine;
+  __syncthreads();
+  if (tid == 0) {
+    num_out[b] = n_out;
+    if (n_out > n_next) atomicOr(status, 2);
+  }
+  if (n_out > n_next) return;
+  for (int c = c0; c < c1; ++c) {
+    if (all || mask[c]) {
+      const int64_t o = (int64_t)b * n_next + pos;
+      locs_out[2 * o] = (int64_t)(c / Y) * patch_size;
+      locs_out[2 * o + 1] = (int64_t)(c % Y) * patch_size;
+      parent_out[o] = c;
+      src_row[o] = -1;
+      src_cell[o] = c;
+      ++pos;
+    }
+  }
+}
+
 // One workgroup per output row: features from the next-level grid, LSTM state (h|c) from the kept parent.
 __global__ void __launch_bounds__(256)
 gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src_cell, int D,
@@ -149,8 +199,14 @@ gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src
     const f32x4* fi = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(grid_ptrs[b]) + (int64_t)src_cell[o] * D);
     for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
     if (so) {
-      const f32x4* si = reinterpret_cast<const f32x4*>(state_cur + ((int64_t)b * n_cur + src_row[o]) * ld_state_cur);
-      for (int i = tid; i < Dp / 4; i += 256) so[i] = si[i];
+      const int sr = src_row[o];
+      if (sr >= 0) {
+        const f32x4* si = reinterpret_cast<const f32x4*>(state_cur + ((int64_t)b * n_cur + sr) * ld_state_cur);
+        for (int i = tid; i < Dp / 4; i += 256) so[i] = si[i];
+      } else {                                   // fallback rows (slide.py:338): fresh zero context
+        const f32x4 z{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < Dp / 4; i += 256) so[i] = z;
+      }
     }
   } else if (zero_pad) {
     const f32x4 z{0.f, 0.f, 0.f, 0.f};
@@ -261,6 +317,16 @@ int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_coun
   hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(1024), 0, stream, keep_idx, ldk, keep_count, locs, n_cur, patch_size,
                      next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status);
   PATHS_LAUNCH_CHECK("expand_children");
+  return PATHS_OK;
+}
+
+int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t* mask_ptrs, int patch_size, int B,
+                             int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
+                             int* src_cell, int* status, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && n_next > 0 && patch_size > 0, "fallback_all_cells: bad shape");
+  hipLaunchKernelGGL(fallback_all_cells_kernel, dim3(B), dim3(1024), 0, stream, next_x, next_y, mask_ptrs, patch_size, n_next,
+                     num_out, locs_out, parent_out, src_row, src_cell, status);
+  PATHS_LAUNCH_CHECK("fallback_all_cells");
   return PATHS_OK;
 }
 

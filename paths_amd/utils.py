@@ -35,6 +35,25 @@ class RecursionError_(RuntimeError):
 
 def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
             trace: Optional[list] = None, check_status: bool = True) -> Dict[str, torch.Tensor]:
+    """Optimistic sync-free pass; if some slide produced zero children (status bit 0, checked once at the end) the
+    batch is re-run level by level with the reference's rare fallback (data_utils/slide.py:336-352) handled on the
+    device.  See :func:`_recurse` for the arguments."""
+    out = _recurse(model, slides, keep_patches, num_levels, trace, careful=False)
+    if not check_status:
+        return out
+    code = int(out["status"].item())            # the only host sync of the fast path, after the last level
+    if code & 1:
+        if trace is not None:
+            trace.clear()
+        out = _recurse(model, slides, keep_patches, num_levels, trace, careful=True)
+        code = int(out["status"].item()) & ~1
+    if code & 2:
+        raise RecursionError_("child capacity exceeded (internal error)")
+    return out
+
+
+def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
+             trace: Optional[list] = None, careful: bool = False) -> Dict[str, torch.Tensor]:
     """Run all levels for a batch of HBM-resident slides (a list of DeviceSlide, or a DeviceSlideBatch built once
     and re-used across calls).  Returns the last level's output dict (+ "status").
 
@@ -87,14 +106,28 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
         keep_count = torch.empty((B,), **i32)
         _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
         Nn = 4 * cap_keep
-        num_next = torch.empty((B,), **i64)
-        locs_next = torch.empty((B, Nn, 2), **i64)
-        parent_next = torch.empty((B, Nn), **i64)
-        src_row = torch.empty((B, Nn), **i32)
-        src_cell = torch.empty((B, Nn), **i32)
-        _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
-                  p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next), p(parent_next),
-                  p(src_row), p(src_cell), p(status), st)
+        def expand(cap):
+            bufs = (torch.empty((B,), **i64), torch.empty((B, cap, 2), **i64), torch.empty((B, cap), **i64),
+                    torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
+            _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
+                      p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, cap, p(bufs[0]), p(bufs[1]), p(bufs[2]),
+                      p(bufs[3]), p(bufs[4]), p(status), st)
+            return bufs
+
+        num_next, locs_next, parent_next, src_row, src_cell = expand(Nn)
+        if careful:
+            empty = (num_next == 0).cpu()                      # per-level sync: slow path only
+            if bool(empty.any()):
+                need = Nn
+                for b in torch.nonzero(empty).flatten().tolist():
+                    tissue = int(batch.slides[b].masks[i + 1].sum().item())
+                    X, Y = batch.slides[b].shape(i + 1)
+                    need = max(need, tissue if tissue > 0 else X * Y)
+                if need > Nn:
+                    Nn = need
+                    num_next, locs_next, parent_next, src_row, src_cell = expand(Nn)
+                _lib.call("paths_fallback_all_cells", p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), mc.patch_size, B, Nn,
+                          p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status), st)
         fts_next = torch.empty((B, Nn, D), **f32)
         state_next = torch.empty((B, Nn, Dp), **f32)
         _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
@@ -104,13 +137,6 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
         fts, locs, parent, num_ims, state_prev, N = fts_next, locs_next, parent_next, num_next, state_next, Nn
     out = dict(out)
     out["status"] = status
-    if check_status:
-        code = int(status.item())        # the only host sync, after the last level
-        if code & 1:
-            raise RecursionError_("a slide produced zero non-background children at some level; the reference's "
-                                  "'use every cell' fallback (data_utils/slide.py:336-352) is not on the device path")
-        if code & 2:
-            raise RecursionError_("child capacity exceeded (internal error)")
     return out
 
 

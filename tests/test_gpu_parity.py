@@ -183,6 +183,29 @@ def test_recursion_vs_oracle_random_seeds(dev):
     np.testing.assert_allclose(torch.sigmoid(out["logits"]).cpu().numpy(), hz.numpy(), atol=LOGIT_TOL, rtol=0)
 
 
+def test_zero_children_fallback_vs_oracle(dev):
+    """Slides whose kept patches have no tissue children take the reference's rare fallback (slide.py:336-352):
+    the optimistic pass flags it, the careful pass handles it on the device; results equal the oracle's."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    cfg, model, params = build_model(dev, 9, None, top_k_patches=[2] * 4)
+    ocfg = H.oracle_config(top_k_patches=[2] * 4)
+    slides = [DeviceSlide.synthetic(57, sid, (4, 4), p_bg=0.93, device=dev) for sid in range(4)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        fast = putils._recurse(model, slides, cfg.top_k_patches, 5, None, careful=False)
+        assert int(fast["status"].item()) & 1, "test slides should trigger the fallback (pick another seed otherwise)"
+        out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    for l in range(5):
+        np.testing.assert_array_equal(trace[l]["num_ims"].cpu().numpy(), otrace[l]["num_ims"].numpy())
+        for j in range(4):
+            n = int(otrace[l]["num_ims"][j])
+            assert {tuple(r) for r in trace[l]["locs"][j, :n].cpu().numpy()} == {tuple(r) for r in otrace[l]["locs"][j, :n].numpy()}
+    np.testing.assert_allclose(torch.sigmoid(out["logits"]).cpu().numpy(), hz.numpy(), atol=LOGIT_TOL, rtol=0)
+
+
 def test_recursion_nolstm_variant_vs_oracle(dev):
     """lstm=false (RNN hierarchical context, reference model/paths.py:101-109) through the fused recursion."""
     from oracle import paths_oracle as orc
