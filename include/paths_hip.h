@@ -37,10 +37,12 @@ int paths_abi_version(void);
  *   32 memory units, rows [3Hc, 3Hc+D) = out_select_gate; b_gates packed alike; w_mem [D,Hc], b_mem [D].
  *   state_out [M, D+Hc] <- (h1 | c1)  (= "ctx_patch"), y [M,D] <- x + h1, ws_o [M,D] scratch.
  *   num_ims != NULL: tiles that contain only padding rows (row index within slide >= num_ims[b]) are skipped.
- *   phases: bit0 memory-cell GEMM, bit1 output-gate GEMM, bit2 mem_to_out GEMM; pass 7 (all, in this order). */
+ *   phases: bit0 memory-cell GEMM, bit1 output-gate GEMM, bit2 mem_to_out GEMM; pass 7 (all, in this order).
+ *   save_frm [M,3Hc] / save_tc [M,D] (both optional): gate activations f|r|m (packed order) and tanh(Wc c1 + bc),
+ *   kept for the backward pass; ws_o then holds the output gate o. */
 int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                     const float* w_gates, const float* b_gates, const float* w_mem, const float* b_mem,
-                    float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o,
+                    float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
                     int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, paths_stream_t stream);
 
 /* importance MLP + sigmoid + padding mask, importance scaling, proj_in, positional encoding, special token
@@ -50,8 +52,41 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
 int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const float* b1, const float* w2, float b2,
                           const float* bp, const float* special, const float* div_term, const int64_t* locs,
                           const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
-                          float* importance, float* tokens, int M, int D, int Hi, int d, int skip_padding,
-                          paths_stream_t stream);
+                          float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
+                          int skip_padding, paths_stream_t stream);
+
+/* ---- backward-pass building blocks (reference: autograd of train.py:65 loss.backward()) --------------------------
+ * paths_gemm_nt_f32: out (+)= maskop(act(a W^T + b)) + residual; with W = a transposed weight copy this is dX = dY W.
+ * paths_gemm_tn_f32: out[N1,N2] (+)= a[M,N1]^T [b0|b1][M,N2]  (weight gradients; split-M slabs summed in a fixed order).
+ * paths_colsum_f32 : out[N] (+)= sum over rows (bias gradients).  paths_transpose_f32: out = in^T. */
+int paths_gemm_nt_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* b, float* out, int64_t ldo,
+                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
+                      int64_t ldm, int accumulate, paths_stream_t stream);
+int64_t paths_gemm_tn_workspace(int N1, int N2, int splits);
+int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
+                      float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
+                      paths_stream_t stream);
+int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int splits, int accumulate, float* workspace,
+                     paths_stream_t stream);
+int paths_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, paths_stream_t stream);
+
+/* LSTMCell backward, element-wise parts (reference model/interface.py:52-56 differentiated):
+ *   a: dpre_o = dh1 tc o(1-o) -> dG[:, 3Hc:], dpre_h = dh1 o (1-tc^2);  b: packed df|dr|dm -> dG[:, :3Hc], dc0 = dc1 f. */
+int paths_lstm_bwd_a(const float* dh1, int64_t ldd, const float* dh1b, int64_t lddb, const float* o, const float* tc,
+                     const int64_t* num_ims, int rows_per_slide, int64_t M, int D, float* dpre_o, int64_t ldo,
+                     float* dpre_h, paths_stream_t stream);
+int paths_lstm_bwd_b(const float* dc1_h, const float* dc1_ext, int64_t lde, const float* frm, const float* c0, int64_t ldc0,
+                     const int64_t* num_ims, int rows_per_slide, int64_t M, int Hc, float* dg, int64_t ldg, float* dc0,
+                     int64_t lddc0, paths_stream_t stream);
+/* importance MLP / scaling backward per patch row (reference model/paths.py:95-98 differentiated). */
+int paths_importance_bwd(const float* dtok, const float* pproj, const float* hid, const float* alpha, const float* w2,
+                         const int64_t* num_ims, int rows_per_slide, int64_t M, int imp_mul, float* du, float* da, float* dah,
+                         paths_stream_t stream);
+/* LayerNorm (width 128) forward with saved xhat / rstd, and backward (dx, dy*xhat for the gamma gradient). */
+int paths_layernorm_fwd_stats(const float* x, const float* add, const float* gamma, const float* beta, float* y, float* xhat,
+                              float* rstd, int64_t rows, int d, float eps, paths_stream_t stream);
+int paths_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* dyxhat,
+                        int64_t rows, int d, paths_stream_t stream);
 
 /* Generic out = act(a W^T + b) on the fp32 matrix cores (W rows zero-padded to Npad, a multiple of 128). */
 int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b, float* out, int64_t ldo,
@@ -62,7 +97,7 @@ int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b
  *   q,k,v [B,H,T,32] head-major, q pre-scaled by log2(e)/sqrt(32); o [B,T,H*32]; valid keys = num_ims[b]+1.
  *   max_queries > 0 restricts the computed query rows to [0, max_queries) (the last decoder layer is read at
  *   token 0 only, reference model/aggregator.py:75); 0 = all T rows. */
-int paths_attention_f32(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims,
+int paths_attention_f32(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims,
                         int B, int T, int H, int head_dim, int max_queries, paths_stream_t stream);
 
 /* Token-row chain of one post-LN decoder layer with empty memory + the next in_proj (same call site):

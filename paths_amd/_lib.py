@@ -19,12 +19,21 @@ _i64, _i32, _f32, _vp, _u32, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C
 
 # name -> argtypes (mirrors include/paths_hip.h; tests/test_abi.py checks both against the .so exports)
 SIGNATURES = {
-    "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+    "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                         _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "paths_importance_proj": [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
-                              _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+                              _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "paths_gemm_nt_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp],
+    "paths_gemm_tn_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "paths_colsum_f32": [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
+    "paths_transpose_f32": [_vp, _i64, _i32, _i32, _vp, _i64, _vp],
+    "paths_lstm_bwd_a": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp],
+    "paths_lstm_bwd_b": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp],
+    "paths_importance_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
+    "paths_layernorm_fwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "paths_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "paths_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
-    "paths_attention_f32": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "paths_attention_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_token_layer_f32": [_vp] * 21 + [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "paths_token0_tail": [_vp] * 20 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "paths_final_head": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
@@ -38,7 +47,7 @@ SIGNATURES = {
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],
 }
-_PLAIN = {"paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, [])}
+_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, [])}
 
 _lib: Optional[C.CDLL] = None
 

@@ -26,7 +26,7 @@ constexpr int LDVs = 36;     // V tile row stride: conflict-free b32 reads
 
 __global__ void __launch_bounds__(256)
 attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                float* __restrict__ o, const int64_t* __restrict__ num_ims, int T, int H) {
+                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int H) {
   __shared__ __attribute__((aligned(16))) float sK[2][KT * LDKs];
   __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVs];
 
@@ -148,21 +148,23 @@ attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const 
     float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * g4;
     *reinterpret_cast<f32x4*>(op) = oacc[0] * inv;
     *reinterpret_cast<f32x4*>(op + 16) = oacc[1] * inv;
+    // training: log2-domain log-sum-exp of the (pre-scaled) scores, P = exp2(s - lse) in the backward kernels
+    if (lse && g4 == 0) lse[((int64_t)b * H + head) * T + qi] = m_run + log2f(l_run);
   }
 }
 
 }  // namespace
 
 extern "C" int paths_attention_f32(const float* q, const float* k, const float* v, float* o,
-                                   const int64_t* num_ims, int B, int T, int H, int head_dim, int max_queries,
-                                   hipStream_t stream) {
+                                   float* lse /*[B,H,T] or null*/, const int64_t* num_ims, int B, int T, int H, int head_dim,
+                                   int max_queries, hipStream_t stream) {
   PATHS_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
   PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && num_ims != nullptr, "attention: bad shape B=%d T=%d H=%d", B, T, H);
   PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "attention: buffers must be 16-byte aligned");
   // max_queries > 0: only queries [0, max_queries) are needed (last decoder layer: token 0 only, aggregator.py:75)
   const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
   dim3 grid((nq + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, stream, q, k, v, o, num_ims, T, H);
+  hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, stream, q, k, v, o, lse, num_ims, T, H);
   PATHS_LAUNCH_CHECK("attention");
   return PATHS_OK;
 }

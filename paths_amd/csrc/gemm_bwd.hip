@@ -1,0 +1,208 @@
+// Backward-pass GEMM building blocks (fp32-exact MFMA, gfx950).
+//
+//   paths_gemm_tn_f32   C[N1,N2] (+)= A[M,N1]^T * [B0 | B1][M,N2]      weight gradients dW = dY^T X (reduction over rows)
+//   paths_colsum_f32    out[N]   (+)= sum_m A[m,N]                     bias gradients
+//   paths_transpose_f32 out[C,R]   = in[R,C]^T                        W^T copies so that dX = dY W runs on the NT kernel
+//
+// These replace what autograd does for nn.Linear inside the reference's train step (train.py:65 loss.backward()):
+// aten::mm(dY^T, X), aten::sum(dY, 0), aten::mm(dY, W).
+//
+// TN mapping: both operands are row-major with the REDUCTION index (row m) as the slow dimension, so a k-tile is 32
+// consecutive rows staged as-is ([m][n] in LDS, 16-byte coalesced loads along n); the MFMA A/B fragments
+// (A[i=n1][k=m], B[k=m][j=n2]) are then 4-byte LDS reads with lanes running along n: conflict-free, four times the
+// read instructions of the NT kernel, still far from the LDS limit for 64-cycle fp32 MFMAs.  The reduction over M is
+// split across gridDim.z; every split writes its own fp32 slab and a second kernel adds the slabs in a fixed order
+// (deterministic: needed for N-rank == 1-rank gradient parity, no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TK = 32;                 // rows of the reduction dimension per k-tile
+constexpr int TLD = 128;               // LDS row stride (floats) of a [TK][128] tile
+
+struct TnOperands {
+  const float* A; int64_t lda;         // [M, N1]
+  const float* B0; int64_t ldb0; int NB0;   // [M, NB0]  columns [0, NB0) of the logical B
+  const float* B1; int64_t ldb1;       // [M, N2-NB0] columns [NB0, N2)  (may be null)
+  int M, N1, N2;
+  float* slabs;                        // [splits][N1][N2]
+  int rows_per_split;                  // multiple of TK
+};
+
+__global__ void __launch_bounds__(256)
+gemm_tn_kernel(TnOperands g) {
+  __shared__ __attribute__((aligned(16))) float sA[2][TK * TLD];
+  __shared__ __attribute__((aligned(16))) float sB[2][TK * TLD];
+  const int n1_0 = blockIdx.y * 128, n2_0 = blockIdx.x * 128;
+  const int m_begin = blockIdx.z * g.rows_per_split;
+  const int m_end = min(g.M, m_begin + g.rows_per_split);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // B column block comes from one panel (NB0 is a multiple of 128)
+  const bool second = g.B1 != nullptr && n2_0 >= g.NB0;
+  const float* Bp = second ? g.B1 + (n2_0 - g.NB0) : g.B0 + n2_0;
+  const int64_t ldb = second ? g.ldb1 : g.ldb0;
+  const float* Ap = g.A + n1_0;
+
+  // staging: 32 rows x 32 float4 per operand -> 4 float4 per thread per operand
+  const int c4 = tid & 31, r0 = tid >> 5;          // r0 in [0,8): rows r0 + 8p
+  f32x4 ra[4], rb[4];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = m0 + r0 + 8 * p;
+      if (m < m_end) {
+        ra[p] = ldg_f32x4(Ap + (int64_t)m * g.lda + 4 * c4);
+        rb[p] = ldg_f32x4(Bp + (int64_t)m * ldb + 4 * c4);
+      } else {
+        ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<f32x4*>(&sA[buf][(r0 + 8 * p) * TLD + 4 * c4]) = ra[p];
+      *reinterpret_cast<f32x4*>(&sB[buf][(r0 + 8 * p) * TLD + 4 * c4]) = rb[p];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (m_end - m_begin + TK - 1) / TK;
+  if (nk > 0) {
+    gload(m_begin);
+    swrite(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  const int h = lane >> 5, li = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(m_begin + (kt + 1) * TK);
+    const float* a = &sA[buf][h * TLD + wm * 64 + li];
+    const float* b = &sB[buf][h * TLD + wn * 64 + li];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float a0 = a[2 * s * TLD], a1 = a[2 * s * TLD + 32];
+      const float b0 = b[2 * s * TLD], b1 = b[2 * s * TLD + 32];
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+    if (kt + 1 < nk) swrite(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* out = g.slabs + (int64_t)blockIdx.z * g.N1 * g.N2;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n2_0 + wn * 64 + 32 * j + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n1_0 + wm * 64 + 32 * i + c32_row(r, lane);
+        if (row < g.N1 && col < g.N2) out[(int64_t)row * g.N2 + col] = acc[i][j][r];
+      }
+    }
+}
+
+// out[i] (+)= sum_s slabs[s][i]   (fixed order: deterministic)
+__global__ void __launch_bounds__(256)
+reduce_slabs_kernel(const float* __restrict__ slabs, int splits, int64_t n, float* __restrict__ out, int64_t ldo, int ncols,
+                    int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * n + i];
+  const int64_t r = i / ncols, c = i % ncols;
+  float* o = out + r * ldo + c;
+  *o = accumulate ? *o + s : s;
+}
+
+// partial column sums: block (x = column chunk of 256, y = row split)
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float* __restrict__ a, int64_t lda, int M, int N, int rows_per_split, float* __restrict__ slabs) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+  if (col >= N) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int m = m0;
+  for (; m + 3 < m1; m += 4) {
+    s0 += a[(int64_t)m * lda + col]; s1 += a[(int64_t)(m + 1) * lda + col];
+    s2 += a[(int64_t)(m + 2) * lda + col]; s3 += a[(int64_t)(m + 3) * lda + col];
+  }
+  for (; m < m1; ++m) s0 += a[(int64_t)m * lda + col];
+  slabs[(int64_t)blockIdx.y * N + col] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float* __restrict__ in, int64_t ldi, int R, int C, float* __restrict__ out, int64_t ldo) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? in[(int64_t)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (c < C && r < R) out[(int64_t)c * ldo + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// workspace floats needed by paths_gemm_tn_f32 for a given shape / split count
+int64_t paths_gemm_tn_workspace(int N1, int N2, int splits) { return (int64_t)splits * N1 * N2; }
+
+int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
+                      float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
+                      hipStream_t stream) {
+  PATHS_REQUIRE(M > 0 && N1 > 0 && N2 > 0 && splits > 0 && a && b0 && out && workspace, "gemm_tn: bad arguments");
+  PATHS_REQUIRE(N1 % 4 == 0 && N2 % 4 == 0 && lda % 4 == 0 && ldb0 % 4 == 0 && (b1 == nullptr || ldb1 % 4 == 0), "gemm_tn: dims must be multiples of 4");
+  PATHS_REQUIRE(N1 % 128 == 0 && N2 % 128 == 0, "gemm_tn: N1 (%d) and N2 (%d) must be multiples of 128", N1, N2);
+  PATHS_REQUIRE(b1 == nullptr || (nb0 % 128 == 0 && nb0 < N2), "gemm_tn: panel split must be a multiple of 128");
+  PATHS_REQUIRE(((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
+  int rps = (M + splits - 1) / splits;
+  rps = (rps + TK - 1) / TK * TK;
+  TnOperands g{a, lda, b0, ldb0, b1 ? nb0 : N2, b1, ldb1, M, N1, N2, workspace, rps};
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N2 / 128, N1 / 128, splits), dim3(256), 0, stream, g);
+  PATHS_LAUNCH_CHECK("gemm_tn");
+  const int64_t n = (int64_t)N1 * N2;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, splits, n, out, ldo, N2, accumulate);
+  PATHS_LAUNCH_CHECK("gemm_tn(reduce)");
+  return PATHS_OK;
+}
+
+int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int splits, int accumulate, float* workspace,
+                     hipStream_t stream) {
+  PATHS_REQUIRE(M > 0 && N > 0 && splits > 0 && a && out && workspace, "colsum: bad arguments");
+  const int rps = (M + splits - 1) / splits;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, stream, a, lda, M, N, rps, workspace);
+  PATHS_LAUNCH_CHECK("colsum");
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, workspace, splits, (int64_t)N, out, (int64_t)N, N, accumulate);
+  PATHS_LAUNCH_CHECK("colsum(reduce)");
+  return PATHS_OK;
+}
+
+int paths_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, hipStream_t stream) {
+  PATHS_REQUIRE(R > 0 && C > 0 && in && out && ldi >= C && ldo >= R, "transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, in, ldi, R, C, out, ldo);
+  PATHS_LAUNCH_CHECK("transpose");
+  return PATHS_OK;
+}
+
+}  // extern "C"

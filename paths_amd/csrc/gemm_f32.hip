@@ -180,6 +180,7 @@ struct EpiLstmC {
   const float* bias;     // packed like the weight rows
   const float* c0; int64_t ldc0;   // nullptr at depth 0 (c0 = 0)
   float* c1; int64_t ldc1;         // state_out + D
+  float* frm; int64_t ldfrm;       // optional (training): post-activation f|r|m in the packed column order
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
     static_assert(WTN == 3, "LSTM c epilogue wants f|r|m tiles");
@@ -201,7 +202,13 @@ struct EpiLstmC {
         const float rg = sigmoid_acc(acc[i][1][r] + br);
         const float mp = tanh_acc(acc[i][2][r] + bm);
         const float v = cp[r] * f + rg * mp;
-        if (row < M) c1[(int64_t)row * ldc1 + j] = v;
+        if (row < M) {
+          c1[(int64_t)row * ldc1 + j] = v;
+          if (frm) {
+            float* fr = frm + (int64_t)row * ldfrm + col0 + jj;
+            fr[0] = f; fr[32] = rg; fr[64] = mp;
+          }
+        }
       }
     }
   }
@@ -233,6 +240,7 @@ struct EpiLstmO {
 struct EpiLstmH {
   const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
   float* h1; int64_t ldh; float* y; int64_t ldy; int N;
+  float* tc_out;                   // optional (training): tanh(Wc c1 + bc), [M, N]
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
 #pragma unroll
@@ -252,8 +260,10 @@ struct EpiLstmH {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + 32 * i + c32_row(r, lane);
-          const float h = ov[r] * tanh_acc(acc[i][j][r] + b);
+          const float tcv = tanh_acc(acc[i][j][r] + b);
+          const float h = ov[r] * tcv;
           if (row < M && colok) {
+            if (tc_out) tc_out[(int64_t)row * N + col] = tcv;
             h1[(int64_t)row * ldh + col] = h;
             y[(int64_t)row * ldy + col] = xv[r] + h;
           }
@@ -263,27 +273,38 @@ struct EpiLstmH {
   }
 };
 
-// Plain bias epilogue (generic linear; used by the non-LSTM hctx MLP and tests).  act: 0 none, 1 relu.
+// Generic linear epilogue (forward of the non-LSTM variant, every dX = dY W of the backward pass):
+//   v = acc + bias ; act 1: relu ; mask: v = mask > 0 ? v : 0 (relu backward) ; v += residual ; accumulate: v += out
 struct EpiBias {
   const float* bias; float* out; int64_t ldo; int N; int act;
+  const float* residual; int64_t ldr; const float* mask; int64_t ldm; int accumulate;
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
-      const int col = col0 + 32 * j + (lane & 31);
-      if (col >= N) continue;
+      const int colr = col0 + 32 * j + (lane & 31);
+      const int col = min(colr, N - 1);
       const float b = bias ? bias[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < WTM; ++i)
+      for (int i = 0; i < WTM; ++i) {
+        float rv[16], mv[16], ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
+          rv[r] = residual ? residual[(int64_t)rowc * ldr + col] : 0.f;
+          mv[r] = mask ? mask[(int64_t)rowc * ldm + col] : 1.f;
+          ov[r] = accumulate ? out[(int64_t)rowc * ldo + col] : 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + 32 * i + c32_row(r, lane);
-          if (row < M) {
-            float v = acc[i][j][r] + b;
-            if (act == 1) v = fmaxf(v, 0.f);
-            out[(int64_t)row * ldo + col] = v;
-          }
+          float v = acc[i][j][r] + b;
+          if (act == 1) v = fmaxf(v, 0.f);
+          if (!(mv[r] > 0.f)) v = 0.f;
+          v += rv[r] + ov[r];
+          if (row < M && colr < N) out[(int64_t)row * ldo + col] = v;
         }
+      }
     }
   }
 };
@@ -304,6 +325,8 @@ struct EpiImpProj {
   int imp_mul;                     // importance_mode == "mul"
   float* importance;               // [M]
   float* tokens;                   // [B, N+1, d]
+  float* hid_out;                  // optional (training): relu(Y W1^T + b1) [M,128]
+  float* pproj_out;                // optional (training): Y Wp^T (before alpha / bias / PE) [M,128]
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int wm, int wn, int M, float* smem) const {
     static_assert(WTM == 1 && WTN == 4 && WGN == 2, "imp/proj epilogue layout");
@@ -318,7 +341,11 @@ struct EpiImpProj {
         const int col = 32 * j + (lane & 31);
         const float b = b1[col], w = w2[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] += fmaxf(acc[0][j][r] + b, 0.f) * w;
+        for (int r = 0; r < 16; ++r) {
+          const float hv = fmaxf(acc[0][j][r] + b, 0.f);
+          part[r] += hv * w;
+          if (hid_out && row0 + c32_row(r, lane) < M) hid_out[(int64_t)(row0 + c32_row(r, lane)) * 128 + col] = hv;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -373,6 +400,7 @@ struct EpiImpProj {
           const float ang = pos * dtv[j];
           const float pe = (c & 1) ? cosf(ang) : sinf(ang);
           trow[c] = a * acc[0][j][r] + bpv[j] + pe;
+          if (pproj_out) pproj_out[(int64_t)row * 128 + c] = acc[0][j][r];
           if (idx == 0) tokens[(int64_t)b * (rows_per_slide + 1) * d + c] = special[c];
         }
       }
@@ -414,7 +442,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
                     const float* w_gates /*[3Hc+D, 2D] packed*/, const float* b_gates /*[3Hc+D] packed*/,
                     const float* w_mem /*[D, Hc]*/, const float* b_mem /*[D]*/,
                     float* state_out /*[M, D+Hc]: h1 | c1*/, int64_t ldso, float* y /*[M,D]*/, int64_t ldy,
-                    float* ws_o /*[M,D] workspace*/,
+                    float* ws_o /*[M,D] workspace*/, float* save_frm /*[M,3Hc] or null*/, float* save_tc /*[M,D] or null*/,
                     int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, hipStream_t stream) {
   PATHS_REQUIRE(D % 128 == 0 && Hc % 64 == 0, "lstm_cell: D (%d) must be a multiple of 128 and Hc (%d) of 64", D, Hc);
   PATHS_REQUIRE((h0 == nullptr) == (c0 == nullptr), "lstm_cell: h0 and c0 must both be given or both be null");
@@ -424,7 +452,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
   // Callers normally pass 7; the bench brackets single phases with events.
   // (1) c-part: N = 3Hc, wave tile 64x96, block 128x192
   if (phases & 1) {
-    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso};
+    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc};
     int rc = launch_gemm<2, 3, 2, 2>(g, 3 * Hc, e, stream, "lstm_cell(c)");
     if (rc) return rc;
   }
@@ -439,7 +467,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
   // (3) h1 = o * tanh(Wc c1 + bc), Y = X + h1
   if (phases & 4) {
     GemmOperands gh{state_out + D, ldso, Hc, nullptr, 0, 0, w_mem, Hc, M, num_ims, rows_per_slide};
-    EpiLstmH e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D};
+    EpiLstmH e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
     int rc = launch_gemm<2, 2, 2, 2>(gh, D, e, stream, "lstm_cell(h)");
     if (rc) return rc;
   }
@@ -450,14 +478,15 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256,
                           const float* b1, const float* w2, float b2, const float* bp, const float* special,
                           const float* div_term, const int64_t* locs, const int64_t* num_ims,
                           int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
-                          float* importance, float* tokens, int M, int D, int Hi, int d, int skip_padding,
-                          hipStream_t stream) {
+                          float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
+                          int skip_padding, hipStream_t stream) {
   PATHS_REQUIRE(Hi == 128 && d == 128, "importance_proj: this build supports importance_mlp_hidden_dim=128, trans_dim=128 (got %d, %d)", Hi, d);
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj: 2d positional encoding needs locs");
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj: bad slide layout");
   GemmOperands g{y, ldy, D, nullptr, 0, 0, w_ip, D, M, skip_padding ? num_ims : nullptr, rows_per_slide};
-  EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens};
+  EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
+               save_hid, save_pproj};
   return launch_gemm<1, 4, 2, 2>(g, 256, e, stream, "importance_proj");
 }
 
@@ -465,8 +494,19 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256,
 int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, hipStream_t stream) {
   GemmOperands g{a, lda, K, nullptr, 0, 0, w, K, M, nullptr, 0};
-  EpiBias e{b, out, ldo, N, act};
+  EpiBias e{b, out, ldo, N, act, nullptr, 0, nullptr, 0, 0};
   return launch_gemm<2, 2, 2, 2>(g, Npad, e, stream, "linear_f32");
+}
+
+// out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual      (W rows zero-padded to Npad, a multiple of 128)
+// The backward pass calls it with W = a transposed weight copy: dX = dY * W  ==  dY * (W^T)^T.
+int paths_gemm_nt_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* b, float* out, int64_t ldo,
+                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
+                      int64_t ldm, int accumulate, hipStream_t stream) {
+  PATHS_REQUIRE(ldw >= K, "gemm_nt: ldw < K");
+  GemmOperands g{a, lda, K, nullptr, 0, 0, w, ldw, M, nullptr, 0};
+  EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate};
+  return launch_gemm<2, 2, 2, 2>(g, Npad, e, stream, "gemm_nt_f32");
 }
 
 }  // extern "C"

@@ -150,7 +150,7 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     def importance_proj(src, imp_mul, imp_out):
         _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
                   p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs),
-                  p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens),
+                  p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), None, None,
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
 
     importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
@@ -170,7 +170,8 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
         def lstm(phases):
             _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
-                      p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), M, D, Hc, nim, N, phases, st)
+                      p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), None, None,
+                      M, D, Hc, nim, N, phases, st)
 
         if KERNEL_TIMER is None:
             lstm(7)
@@ -227,7 +228,7 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
     token_layer(xa, None, None, layers[0])
     for l in range(L - 1):
-        _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), p(num_ims), B, T, H, hd, 0, st)
+        _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st)
         token_layer(xa, xb, layers[l], layers[l + 1])
         xa, xb = xb, xa
     # Last layer: only token 0 of its output is read (aggregator.py:75) -> one fused launch per level computes the

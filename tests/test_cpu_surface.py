@@ -45,7 +45,7 @@ def test_invalid_arguments_are_reported_not_launched():
     """Host-side validation happens before any launch, so this is safe without a GPU."""
     from paths_amd import _lib
     lib = _lib.load()
-    rc = lib.paths_attention_f32(None, None, None, None, None, 1, 16, 4, 64, 0, None)     # head_dim 64 unsupported
+    rc = lib.paths_attention_f32(None, None, None, None, None, None, 1, 16, 4, 64, 0, None)     # head_dim 64 unsupported
     assert rc == -1 and b"head_dim" in lib.paths_last_error()
     rc = lib.paths_topk(None, 0, None, 1, 100000, 5, None, 5, None, None)              # n_max too large
     assert rc == -1 and b"n_max" in lib.paths_last_error()

@@ -1,0 +1,115 @@
+"""GPU tests of the hand-written backward kernels against torch autograd (float64) over the oracle's formulas."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import helpers as H
+from tests.test_gpu_parity import build_model, dev  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.double().cpu().reshape(-1), b.double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_level_inputs(B, N, num_ims, depth, D=1024, Dp=1280, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    valid = torch.arange(N)[None, :] < torch.tensor(num_ims)[:, None]
+    fts = (torch.rand(B, N, D, generator=g) * 2 - 1) * math.sqrt(3) * valid[..., None]
+    locs = torch.stack((torch.randint(0, 40, (B, N), generator=g), torch.randint(0, 40, (B, N), generator=g)), -1) * 256
+    state = (torch.rand(B, N, Dp, generator=g) - 0.5) * valid[..., None] if depth > 0 else None
+    return fts, locs, torch.tensor(num_ims), state, valid
+
+
+def test_gemm_tn_colsum_transpose(dev):
+    from paths_amd import backward as bw
+    torch.manual_seed(0)
+    M, N1, N2 = 1000, 256, 384
+    a, b0, b1 = torch.randn(M, N1), torch.randn(M, 256), torch.randn(M, 128)
+    ad, b0d, b1d = a.to(dev), b0.to(dev), b1.to(dev)
+    out = torch.full((N1, N2), 7.0, device=dev)
+    bw.gemm_tn(ad, N1, b0d, 256, out, M, N1, N2, b1=b1d, ldb1=128, nb0=256)
+    ref = a.double().t() @ torch.cat((b0, b1), 1).double()
+    assert rel_err(out, ref) < 2e-6
+    bw.gemm_tn(ad, N1, b0d, 256, out, M, N1, N2, b1=b1d, ldb1=128, nb0=256, accumulate=True)
+    assert rel_err(out, 2 * ref) < 2e-6
+    cs = bw.colsum(ad, N1, M, N1)
+    assert rel_err(cs, a.double().sum(0)) < 2e-6
+    wt = bw.transpose(b0d, M, 256)
+    assert torch.equal(wt.cpu(), b0.t())
+    # NT with residual / mask / accumulate
+    w = torch.randn(128, N1)
+    res, mask = torch.randn(M, 128), (torch.randn(M, 128) > 0).float()
+    o = torch.ones(M, 128, device=dev)
+    wd, resd, maskd = w.to(dev), res.to(dev), mask.to(dev)
+    bw.gemm_nt(ad, N1, wd, o, 128, M, 128, N1, residual=resd, ldr=128, mask=maskd, ldm=128, accumulate=True)
+    ref = (a.double() @ w.double().t()) * mask.double() + res.double() + 1.0
+    assert rel_err(o, ref) < 2e-6
+
+
+@pytest.mark.parametrize("depth", [0, 2])
+def test_selection_chain_backward(dev, depth):
+    """LSTM cell + importance MLP + proj_in: gradients of all parameters and of the previous (h|c) state."""
+    from oracle import paths_oracle as orc
+    from paths_amd import backward as bw, ops
+    cfg, model, params = build_model(dev, 21)
+    mc = cfg.model_config
+    B, N = 2, 160
+    fts, locs, num_ims, state, valid = make_level_inputs(B, N, [160, 117], depth, seed=3 + depth)
+    lp, vp = ops.pack_lstm(model.lstm), ops.pack_level(model.procs[depth])
+    sv = bw.selection_forward_train(mc, lp, vp, fts.to(dev), locs.to(dev), num_ims.to(dev),
+                                    state.to(dev) if state is not None else None)
+    g = torch.Generator().manual_seed(99)
+    tokvalid = torch.cat((torch.ones(B, 1, dtype=torch.bool), valid), 1)
+    G_tok = torch.randn(B, N + 1, 128, generator=g) * tokvalid[..., None]
+    G_state = torch.randn(B, N, 1280, generator=g) * valid[..., None]
+    grads, dprev = bw.selection_backward(mc, lp, vp, sv, G_tok.to(dev), G_state.to(dev))
+    lg = bw.unpack_lstm_grads(model.lstm, grads)
+
+    # ---- float64 autograd reference over the oracle's formulas
+    p = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    X = fts.double()
+    pre = f"procs.{depth}."
+    if depth == 0:
+        h0, c0 = torch.zeros(B, N, 1024, dtype=torch.float64), torch.zeros(B, N, 256, dtype=torch.float64)
+        sp = None
+    else:
+        sp = state.double().requires_grad_(True)
+        h0, c0 = sp[..., :1024], sp[..., 1024:]
+    hs, cs = orc.lstm_cell(p, X, h0, c0)
+    Y = X + hs
+    state_out = torch.cat((hs, cs), -1)
+    hid = torch.relu(F.linear(Y, p[pre + "importance_mlp.0.weight"], p[pre + "importance_mlp.0.bias"]))
+    alpha = torch.sigmoid(F.linear(hid, p[pre + "importance_mlp.2.weight"], p[pre + "importance_mlp.2.bias"]))[..., 0] * valid
+    gk = pre + "global_agg."
+    pl = torch.div(locs, 256, rounding_mode="floor")
+    pe = orc.positional_encoding_2d_from_pos(pl[..., 0].reshape(-1), pl[..., 1].reshape(-1), 128).view(B, N, 128).double()
+    tok = F.linear(Y * alpha[..., None], p[gk + "proj_in.weight"], p[gk + "proj_in.bias"]) + pe
+    tok = torch.cat((p[gk + "special_token"].view(1, 1, -1).repeat(B, 1, 1), tok), 1)
+    # forward parity of the saved tensors
+    assert rel_err(sv["tokens"][tokvalid], tok.detach()[tokvalid]) < 1e-5
+    assert rel_err(sv["state_out"][valid], state_out.detach()[valid]) < 1e-5
+    L = (tok * G_tok.double()).sum() + (state_out * G_state.double()).sum()
+    L.backward()
+    tol = 2e-4
+    for name in ("forget_gate", "remember_gate", "remember_map", "out_select_gate", "mem_to_out"):
+        for leaf in ("weight", "bias"):
+            ref = p[f"lstm.{name}.0.{leaf}"].grad
+            assert rel_err(lg[f"{name}.0.{leaf}"], ref) < tol, (name, leaf)
+    w_ip_ref = torch.cat((p[pre + "importance_mlp.0.weight"].grad, p[gk + "proj_in.weight"].grad), 0)
+    assert rel_err(grads["w_ip"], w_ip_ref) < tol
+    assert rel_err(grads["b1"], p[pre + "importance_mlp.0.bias"].grad) < tol
+    assert rel_err(grads["w2"], p[pre + "importance_mlp.2.weight"].grad) < tol
+    assert rel_err(grads["b2"], p[pre + "importance_mlp.2.bias"].grad) < tol
+    assert rel_err(grads["bp"], p[gk + "proj_in.bias"].grad) < tol
+    assert rel_err(grads["special"], p[gk + "special_token"].grad) < tol
+    if depth > 0:
+        assert rel_err(dprev, sp.grad) < tol
+        assert float(dprev[~valid.to(dev)].abs().max()) == 0.0
+    else:
+        assert dprev is None

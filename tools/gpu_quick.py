@@ -56,7 +56,7 @@ q = torch.randn(B, H, T, 32); k = torch.randn(B, H, T, 32); v = torch.randn(B, H
 o = torch.zeros(B, T, 128, device=dev)
 qs = q * (1.4426950408889634 / math.sqrt(32))
 q_d, k_d, v_d, nim_d = qs.to(dev), k.to(dev), v.to(dev), nim.to(dev)
-_lib.call("paths_attention_f32", p(q_d), p(k_d), p(v_d), p(o), p(nim_d), B, T, H, 32, 0, st())
+_lib.call("paths_attention_f32", p(q_d), p(k_d), p(v_d), p(o), None, p(nim_d), B, T, H, 32, 0, st())
 torch.cuda.synchronize()
 sc = (q @ k.transpose(-1, -2)) / math.sqrt(32)
 mask = torch.arange(T)[None, :] >= (nim + 1)[:, None]
