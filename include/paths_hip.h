@@ -88,6 +88,16 @@ int paths_layernorm_fwd_stats(const float* x, const float* add, const float* gam
 int paths_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* dyxhat,
                         int64_t rows, int d, paths_stream_t stream);
 
+/* Self-attention backward, flash style (recompute from q, k, lse; reference: autograd through the attention of
+ * model/aggregator.py:70-72).  q is the stored pre-scaled query; gradients land token-major in dqkv [B,T,384] =
+ * [dq_scaled | dk | dv] (zero-initialised by the caller); ws_dsum: B*H*T floats. */
+int paths_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                            const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim,
+                            paths_stream_t stream);
+/* Same for the last decoder layer, where only token 0 is a query: a0 / da0 [B,128]. */
+int paths_attention_token0_bwd(const float* q, const float* k, const float* v, const float* a0, const float* da0,
+                               const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, paths_stream_t stream);
+
 /* Generic out = act(a W^T + b) on the fp32 matrix cores (W rows zero-padded to Npad, a multiple of 128). */
 int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, paths_stream_t stream);

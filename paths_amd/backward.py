@@ -189,3 +189,212 @@ def unpack_lstm_grads(lstm, g: Dict[str, torch.Tensor]) -> Dict[str, torch.Tenso
         "out_select_gate.0.weight": g["w_gates"][3 * Hc:], "out_select_gate.0.bias": g["b_gates"][3 * Hc:],
         "mem_to_out.0.weight": g["w_mem"], "mem_to_out.0.bias": g["b_mem"],
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# transformer aggregator (post-LN decoder stack over an empty memory; last layer evaluated at token 0 only)
+# ---------------------------------------------------------------------------------------------------------------
+LOG2E = 1.4426950408889634
+
+
+def _ln_fwd(x, add, g, b, rows, eps, want_y=True):
+    f32 = _f32(x.device)
+    y = torch.empty((rows, 128), **f32) if want_y else None
+    xh = torch.empty((rows, 128), **f32)
+    rs = torch.empty((rows,), **f32)
+    _lib.call("paths_layernorm_fwd_stats", P(x), P(add), P(g), P(b), P(y), P(xh), P(rs), rows, 128, eps, _lib.stream())
+    return y, xh, rs
+
+
+def _ln_bwd(dy, xh, rs, g, rows):
+    f32 = _f32(dy.device)
+    dx = torch.empty((rows, 128), **f32)
+    dyx = torch.empty((rows, 128), **f32)
+    _lib.call("paths_layernorm_bwd", P(dy), P(xh), P(rs), P(g), P(dx), P(dyx), rows, 128, _lib.stream())
+    return dx, dyx
+
+
+def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dx_out: torch.Tensor, dev):
+    """Row chain of one decoder layer (out_proj .. norm3): recompute its intermediates with the generic kernels,
+    then differentiate.  x_in / attn are raw pointers with row strides (token-0 rows of the last layer are strided).
+    Returns (grads, dx_in [M,128], dattn [M,128])."""
+    f32 = _f32(dev)
+    eps = w["eps"]
+    g: Dict[str, torch.Tensor] = {}
+    # ---- recompute
+    u1 = torch.empty((M, 128), **f32)
+    gemm_nt(attn_ptr, lda, w["wo"], u1, 128, M, 128, 128, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
+    n1, xh1, rs1 = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps)
+    n2, xh2, rs2 = _ln_fwd(n1, w["cab"], w["ln2g"], w["ln2b"], M, eps)
+    hid = torch.empty((M, 512), **f32)
+    gemm_nt(n2, 128, w["w1"], hid, 512, M, 512, 128, bias=w["b1"], act=1)
+    u3 = torch.empty((M, 128), **f32)
+    gemm_nt(hid, 512, w["w2"], u3, 128, M, 128, 512, bias=w["b2"], residual=n2, ldr=128)
+    _, xh3, rs3 = _ln_fwd(u3, None, w["ln3g"], w["ln3b"], M, eps, want_y=False)
+    # ---- backward
+    du3, dyx3 = _ln_bwd(dx_out, xh3, rs3, w["ln3g"], M)
+    g["ln3g"], g["ln3b"] = colsum(dyx3, 128, M, 128), colsum(dx_out, 128, M, 128)
+    g["b2"] = colsum(du3, 128, M, 128)
+    dhid = torch.empty((M, 512), **f32)
+    gemm_nt(du3, 128, transpose(w["w2"], 128, 512), dhid, 512, M, 512, 128, mask=hid, ldm=512)
+    g["w2"] = torch.empty((128, 512), **f32)
+    gemm_tn(du3, 128, hid, 512, g["w2"], M, 128, 512)
+    dn2 = torch.empty((M, 128), **f32)
+    gemm_nt(dhid, 512, transpose(w["w1"], 512, 128), dn2, 128, M, 128, 512, residual=du3, ldr=128)
+    g["w1"] = torch.empty((512, 128), **f32)
+    gemm_tn(dhid, 512, n2, 128, g["w1"], M, 512, 128)
+    g["b1"] = colsum(dhid, 512, M, 512)
+    du2, dyx2 = _ln_bwd(dn2, xh2, rs2, w["ln2g"], M)
+    g["ln2g"], g["ln2b"] = colsum(dyx2, 128, M, 128), colsum(dn2, 128, M, 128)
+    g["cab"] = colsum(du2, 128, M, 128)
+    du1, dyx1 = _ln_bwd(du2, xh1, rs1, w["ln1g"], M)
+    g["ln1g"], g["ln1b"] = colsum(dyx1, 128, M, 128), colsum(du2, 128, M, 128)
+    g["bo"] = colsum(du1, 128, M, 128)
+    dattn = torch.empty((M, 128), **f32)
+    gemm_nt(du1, 128, transpose(w["wo"], 128, 128), dattn, 128, M, 128, 128)
+    g["wo"] = torch.empty((128, 128), **f32)
+    gemm_tn(du1, 128, attn_ptr, lda, g["wo"], M, 128, 128)
+    return g, du1, dattn
+
+
+def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: float, dx_accum: torch.Tensor):
+    """in_proj backward.  dqkv [M,384] = [dq_scaled | dk | dv]; dx_accum [M,128] += dqkv_pre W_in."""
+    f32 = _f32(x_in.device)
+    g: Dict[str, torch.Tensor] = {}
+    wt = transpose(w["wqkv"], 384, 128)                       # [128, 384]
+    wt[:, :128] *= qscale                                     # fold d(q_scaled)/d(q) into the weight copy
+    gemm_nt(dqkv, 384, wt, dx_accum, 128, M, 128, 384, accumulate=True)
+    g["wqkv"] = torch.empty((384, 128), **f32)
+    gemm_tn(dqkv, 384, x_in, 128, g["wqkv"], M, 384, 128)
+    g["bqkv"] = colsum(dqkv, 384, M, 384)
+    g["wqkv"][:128] *= qscale
+    g["bqkv"][:128] *= qscale
+    return g
+
+
+def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev):
+    """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output)."""
+    B, T, d = tokens.shape
+    H, L = mc.trans_heads, mc.trans_layers
+    hd = d // H
+    f32 = _f32(tokens.device)
+    st = _lib.stream()
+    qscale = LOG2E / math.sqrt(hd)
+    layers = lvl_pack["layers"]
+    sv = {"layers": [], "num_ims": num_ims, "tokens": tokens, "ctx_prev": ctx_prev}
+
+    def token_layer(x_in, x_out, post, nxt, attn, q, k, v):
+        w = post or nxt
+        gg = lambda dct, key: P(dct[key]) if dct is not None else None
+        _lib.call("paths_token_layer_f32", P(x_in), P(attn) if post else None, P(x_out) if post else None,
+                  gg(post, "wo"), gg(post, "bo"), gg(post, "ln1g"), gg(post, "ln1b"), gg(post, "cab"), gg(post, "ln2g"), gg(post, "ln2b"),
+                  gg(post, "w1"), gg(post, "b1"), gg(post, "w2"), gg(post, "b2"), gg(post, "ln3g"), gg(post, "ln3b"),
+                  gg(nxt, "wqkv"), gg(nxt, "bqkv"), P(q), P(k), P(v), P(num_ims), B, T, d, H,
+                  1 if post else 0, 1 if nxt else 0, 0, qscale, w["eps"], 0, st)
+
+    x = tokens
+    q, k, v = (torch.empty((B, H, T, hd), **f32) for _ in range(3))
+    token_layer(x, None, None, layers[0], None, q, k, v)
+    for l in range(L - 1):
+        attn = torch.zeros((B, T, d), **f32)
+        lse = torch.zeros((B, H, T), **f32)
+        _lib.call("paths_attention_f32", P(q), P(k), P(v), P(attn), P(lse), P(num_ims), B, T, H, hd, 0, st)
+        x_out = torch.empty((B, T, d), **f32)
+        q2, k2, v2 = (torch.empty((B, H, T, hd), **f32) for _ in range(3))
+        token_layer(x, x_out, layers[l], layers[l + 1], attn, q2, k2, v2)
+        sv["layers"].append({"x_in": x, "q": q, "k": k, "v": v, "attn": attn, "lse": lse})
+        x, q, k, v = x_out, q2, k2, v2
+    # last layer at token 0 (+ decoder.norm, residual, classifier): one fused launch
+    w = layers[L - 1]
+    nlog = lvl_pack["wcls"].shape[0]
+    ctx_out = torch.empty((B, d), **f32)
+    logits = torch.empty((B, nlog), **f32)
+    ws = torch.empty((B * H * 16 * 36,), **f32)
+    _lib.call("paths_token0_tail", P(x), P(q), P(k), P(v), P(num_ims), P(w["wo"]), P(w["bo"]), P(w["ln1g"]), P(w["ln1b"]),
+              P(w["cab"]), P(w["ln2g"]), P(w["ln2b"]), P(w["w1"]), P(w["b1"]), P(w["w2"]), P(w["b2"]), P(w["ln3g"]), P(w["ln3b"]),
+              P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev), ctx_prev.stride(0) if ctx_prev is not None else 0, None, 0,
+              P(lvl_pack["wcls"]), P(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), P(ws),
+              B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
+    sv["last"] = {"x_in": x, "q": q, "k": k, "v": v}
+    sv["ctx_out"], sv["logits"] = ctx_out, logits
+    return sv
+
+
+def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_ctx_out: Optional[torch.Tensor]):
+    """Returns (grads, d_tokens [B,T,128], d_ctx_prev [B,128] or None).  grads: {"layers": [per-layer dict], "lnfg", "lnfb",
+    "wcls", "bcls"}.  d_logits / d_ctx_out may be None (zero)."""
+    tokens, num_ims, ctx_prev = sv["tokens"], sv["num_ims"], sv["ctx_prev"]
+    B, T, d = tokens.shape
+    H, L = mc.trans_heads, mc.trans_layers
+    hd = d // H
+    dev = tokens.device
+    f32 = _f32(dev)
+    st = _lib.stream()
+    qscale = LOG2E / math.sqrt(hd)
+    layers = lvl_pack["layers"]
+    grads = {"layers": [None] * L}
+    nlog = lvl_pack["wcls"].shape[0]
+
+    # ---- head: logits = F Wcls^T + bcls, F = decoder.norm(x3) (+ ctx_prev);  only residual / none modes in training
+    wl = layers[L - 1]
+    last = sv["last"]
+    x_last = last["x_in"]
+    # recompute token 0 of the last layer up to x3 (its attention output first)
+    attn0 = torch.zeros((B, T, d), **f32)
+    _lib.call("paths_attention_f32", P(last["q"]), P(last["k"]), P(last["v"]), P(attn0), None, P(num_ims), B, T, H, hd, 1, st)
+    u1 = torch.empty((B, 128), **f32)
+    gemm_nt(attn0.data_ptr(), T * d, wl["wo"], u1, 128, B, 128, 128, bias=wl["bo"], residual=x_last.data_ptr(), ldr=T * d)
+    n1, _, _ = _ln_fwd(u1, None, wl["ln1g"], wl["ln1b"], B, wl["eps"])
+    n2, _, _ = _ln_fwd(n1, wl["cab"], wl["ln2g"], wl["ln2b"], B, wl["eps"])
+    hid = torch.empty((B, 512), **f32)
+    gemm_nt(n2, 128, wl["w1"], hid, 512, B, 512, 128, bias=wl["b1"], act=1)
+    u3 = torch.empty((B, 128), **f32)
+    gemm_nt(hid, 512, wl["w2"], u3, 128, B, 128, 512, bias=wl["b2"], residual=n2, ldr=128)
+    x3, _, _ = _ln_fwd(u3, None, wl["ln3g"], wl["ln3b"], B, wl["eps"])
+    xf, xhf, rsf = _ln_fwd(x3, None, lvl_pack["lnfg"], lvl_pack["lnfb"], B, lvl_pack["lnf_eps"])
+    feat = xf + ctx_prev if ctx_prev is not None else xf                     # [B,128] (8 rows: bookkeeping)
+    dF = torch.zeros((B, 128), **f32)
+    if d_ctx_out is not None:
+        dF += d_ctx_out
+    if d_logits is not None:
+        dl = torch.zeros((B, 128), **f32)
+        dl[:, :nlog] = d_logits
+        wc = torch.zeros((128, 128), **f32)
+        wc[:, :nlog] = lvl_pack["wcls"].t()                                  # [in=128, out padded]
+        gemm_nt(dl, 128, wc, dF, 128, B, 128, 128, accumulate=True)          # dF += dlogits Wcls
+        gw = torch.empty((128, 128), **f32)
+        gemm_tn(dl, 128, feat, 128, gw, B, 128, 128)                         # (dlogits^T F), rows >= nlog are zero
+        grads["wcls"] = gw[:nlog].contiguous()
+        grads["bcls"] = colsum(dl, 128, B, 128)[:nlog].contiguous()
+    else:
+        grads["wcls"] = torch.zeros_like(lvl_pack["wcls"])
+        grads["bcls"] = torch.zeros_like(lvl_pack["bcls"])
+    d_ctx_prev = dF.clone() if ctx_prev is not None else None
+    dx3, dyxf = _ln_bwd(dF, xhf, rsf, lvl_pack["lnfg"], B)
+    grads["lnfg"], grads["lnfb"] = colsum(dyxf, 128, B, 128), colsum(dF, 128, B, 128)
+
+    # ---- last layer, token 0 only
+    g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dx3, dev)
+    dqkv = torch.zeros((B, T, 3 * d), **f32)
+    a0 = attn0[:, 0, :].contiguous()
+    _lib.call("paths_attention_token0_bwd", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(num_ims), P(dqkv),
+              B, T, H, hd, st)
+    dx = torch.zeros((B, T, d), **f32)                                       # gradient of the last layer's input
+    dx[:, 0, :] = dx0
+    g.update(qkv_backward(wl, x_last, dqkv, B * T, qscale, dx))
+    grads["layers"][L - 1] = g
+
+    # ---- full layers
+    for l in range(L - 2, -1, -1):
+        lv = sv["layers"][l]
+        w = layers[l]
+        M = B * T
+        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev)
+        dqkv = torch.zeros((B, T, 3 * d), **f32)
+        ws = torch.empty((B * H * T,), **f32)
+        _lib.call("paths_attention_bwd_f32", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
+                  P(num_ims), P(dqkv), P(ws), B, T, H, hd, st)
+        g.update(qkv_backward(w, lv["x_in"], dqkv, M, qscale, dx_in))
+        grads["layers"][l] = g
+        dx = dx_in.view(B, T, d)
+    return grads, dx, d_ctx_prev

@@ -113,3 +113,53 @@ def test_selection_chain_backward(dev, depth):
         assert float(dprev[~valid.to(dev)].abs().max()) == 0.0
     else:
         assert dprev is None
+
+
+def test_transformer_backward(dev):
+    """Aggregator (2 post-LN decoder layers over an empty memory, last layer at token 0, decoder.norm, residual,
+    classifier): gradients of every live parameter, of the token sequence and of the previous slide context."""
+    from oracle import paths_oracle as orc
+    from paths_amd import backward as bw, ops
+    cfg, model, params = build_model(dev, 33)
+    mc = cfg.model_config
+    depth, B, N = 1, 3, 150
+    num_ims = torch.tensor([150, 97, 31])
+    T = N + 1
+    g = torch.Generator().manual_seed(5)
+    tokvalid = torch.arange(T)[None, :] < (num_ims + 1)[:, None]
+    tokens = torch.randn(B, T, 128, generator=g) * tokvalid[..., None]
+    ctx_prev = torch.randn(B, 128, generator=g)
+    vp = ops.pack_level(model.procs[depth])
+    sv = bw.transformer_forward_train(mc, vp, tokens.to(dev), num_ims.to(dev), ctx_prev.to(dev))
+    G_log = torch.randn(B, 4, generator=g)
+    G_ctx = torch.randn(B, 128, generator=g)
+    grads, d_tok, d_ctx = bw.transformer_backward(mc, vp, sv, G_log.to(dev), G_ctx.to(dev))
+
+    p = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    tk = tokens.double().requires_grad_(True)
+    cp = ctx_prev.double().requires_grad_(True)
+    pre = f"procs.{depth}."
+    key_pad = ~tokvalid
+    S = orc.decoder_stack(p, pre + "global_agg.transformer", tk, key_pad, 4, 2)
+    F_ = S[:, 0] + cp
+    logits = F.linear(F_, p[pre + "classification_layer.weight"], p[pre + "classification_layer.bias"])
+    assert rel_err(sv["logits"], logits.detach()) < 1e-5 and rel_err(sv["ctx_out"], F_.detach()) < 1e-5
+    ((logits * G_log.double()).sum() + (F_ * G_ctx.double()).sum()).backward()
+    tol = 3e-4
+    assert rel_err(d_tok[tokvalid.to(dev)], tk.grad[tokvalid]) < tol
+    assert float(d_tok[~tokvalid.to(dev)].abs().max()) == 0.0
+    assert rel_err(d_ctx, cp.grad) < tol
+    assert rel_err(grads["wcls"], p[pre + "classification_layer.weight"].grad) < tol
+    assert rel_err(grads["bcls"], p[pre + "classification_layer.bias"].grad) < tol
+    t = pre + "global_agg.transformer.decoder."
+    assert rel_err(grads["lnfg"], p[t + "norm.weight"].grad) < tol and rel_err(grads["lnfb"], p[t + "norm.bias"].grad) < tol
+    names = {"wqkv": "self_attn.in_proj_weight", "bqkv": "self_attn.in_proj_bias", "wo": "self_attn.out_proj.weight",
+             "bo": "self_attn.out_proj.bias", "cab": "multihead_attn.out_proj.bias", "ln1g": "norm1.weight", "ln1b": "norm1.bias",
+             "ln2g": "norm2.weight", "ln2b": "norm2.bias", "ln3g": "norm3.weight", "ln3b": "norm3.bias",
+             "w1": "linear1.weight", "b1": "linear1.bias", "w2": "linear2.weight", "b2": "linear2.bias"}
+    for l in range(2):
+        for k, name in names.items():
+            ref = p[t + f"layers.{l}.{name}"].grad
+            if l == 1 and k in ("wqkv", "bqkv"):
+                pass            # last layer: q gradient exists for token 0 only; k,v for all tokens — same tensors, same check
+            assert rel_err(grads["layers"][l][k], ref) < tol, (l, k, rel_err(grads["layers"][l][k], ref))
