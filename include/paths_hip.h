@@ -154,11 +154,12 @@ int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, i
 
 /* 4-child expansion, bounds + background filter, stable compaction (reference data_utils/slide.py:303-331).
  *   mask_ptrs[b] -> uint8 [X*Y] tissue mask of the NEXT level (1 = row sum != 0).  status bit0: a slide
- *   produced zero children (reference fallback slide.py:336-352 needed), bit1: capacity n_next exceeded. */
+ *   produced zero children (reference fallback slide.py:336-352 needed), bit1: capacity n_next exceeded.
+ *   child_pos (optional, [B, 4*ldk]): output row of every candidate child (-1 if dropped), for paths_gather_rows_bwd. */
 int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_count, const int64_t* locs, int64_t n_cur,
                           int patch_size, const int* next_x, const int* next_y, const int64_t* mask_ptrs, int B,
                           int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
-                          int* src_cell, int* status, paths_stream_t stream);
+                          int* src_cell, int* status, int* child_pos, paths_stream_t stream);
 
 /* Rare fallback of reference data_utils/slide.py:336-352 for slides with num_out[b] == 0 after paths_expand_children:
  * continue with every tissue cell of the next grid (every cell if it has no tissue), zero patch context (src_row = -1),
@@ -172,6 +173,11 @@ int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t
 int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,
                       int64_t ld_state_cur, const int* src_row, int Dp, const int64_t* num_out, int B, int64_t n_next,
                       float* fts_out, float* state_out, int zero_pad, paths_stream_t stream);
+
+/* Backward of the parent-state gather: d_cur[b, keep_idx[i]] = sum over the surviving children of parent i of d_next
+ * (d_cur zero-initialised by the caller). */
+int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_count, const int* child_pos, const float* d_next,
+                          int64_t n_next, int Dp, float* d_cur, int64_t n_cur, int B, paths_stream_t stream);
 
 /* Level-0 batch: every grid cell in row-major order (reference data_utils/slide.py:257-269,362-381). */
 int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,

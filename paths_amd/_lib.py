@@ -41,7 +41,8 @@ SIGNATURES = {
     "paths_final_head": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
     "paths_layernorm_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "paths_topk": [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
-    "paths_expand_children": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "paths_expand_children": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "paths_gather_rows_bwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp],
     "paths_fallback_all_cells": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp],
     "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp],

@@ -1,0 +1,130 @@
+"""torch.autograd glue for training (reference train.py:59-68: ``loss.backward(); opt.step()``).
+
+torch's autograd ENGINE only orders the calls and accumulates ``.grad``; every derivative is computed by the HIP
+launch sequences of paths_amd/backward.py:
+
+  * :class:`LevelFn`  — one magnification level (``PATHSProcessor.process``): forward = the training forward that keeps
+    the tensors the backward needs, backward = transformer_backward + selection_backward;
+  * :class:`GatherFn` — the child gather between levels (``PreprocessedSlide.iter``): backward = paths_gather_rows_bwd.
+
+Round-1 training limits (raised, never approximated): lstm=True, slide_ctx_mode in {residual, none}, dropout inactive.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import _lib, backward as bw, ops
+
+LSTM_ORDER = ["forget_gate.0.weight", "forget_gate.0.bias", "remember_gate.0.weight", "remember_gate.0.bias",
+              "remember_map.0.weight", "remember_map.0.bias", "out_select_gate.0.weight", "out_select_gate.0.bias",
+              "mem_to_out.0.weight", "mem_to_out.0.bias"]
+LAYER_ORDER = [("self_attn.in_proj_weight", "wqkv"), ("self_attn.in_proj_bias", "bqkv"), ("self_attn.out_proj.weight", "wo"),
+               ("self_attn.out_proj.bias", "bo"), ("multihead_attn.out_proj.bias", "cab"), ("norm1.weight", "ln1g"),
+               ("norm1.bias", "ln1b"), ("norm2.weight", "ln2g"), ("norm2.bias", "ln2b"), ("norm3.weight", "ln3g"),
+               ("norm3.bias", "ln3b"), ("linear1.weight", "w1"), ("linear1.bias", "b1"), ("linear2.weight", "w2"),
+               ("linear2.bias", "b2")]
+
+
+def lstm_params(lstm) -> List[torch.nn.Parameter]:
+    sd = dict(lstm.named_parameters())
+    return [sd[k] for k in LSTM_ORDER]
+
+
+def level_params(proc) -> List[torch.nn.Parameter]:
+    """Live parameters of one level in the order LevelFn returns their gradients."""
+    out = [proc.importance_mlp[0].weight, proc.importance_mlp[0].bias, proc.importance_mlp[2].weight, proc.importance_mlp[2].bias,
+           proc.global_agg.proj_in.weight, proc.global_agg.proj_in.bias, proc.global_agg.special_token]
+    dec = proc.global_agg.transformer.decoder
+    for lyr in dec.layers:
+        sd = dict(lyr.named_parameters())
+        out += [sd[name] for name, _ in LAYER_ORDER]
+    out += [dec.norm.weight, dec.norm.bias, proc.classification_layer.weight, proc.classification_layer.bias]
+    return out
+
+
+def dead_params(model) -> List[torch.nn.Parameter]:
+    """Parameters that exist for checkpoint compatibility but never influence an output: the whole nn.Transformer
+    encoder and the cross-attention matrices.  The reference gives them ZERO gradients (so AdamW still
+    applies weight decay to them); :func:`fill_dead_grads` reproduces that."""
+    out = []
+    for proc in model.procs:
+        tr = proc.global_agg.transformer
+        out += list(tr.encoder.parameters())
+        for lyr in tr.decoder.layers:
+            out += [lyr.multihead_attn.in_proj_weight, lyr.multihead_attn.in_proj_bias, lyr.multihead_attn.out_proj.weight]
+    return out
+
+
+def fill_dead_grads(model):
+    for p in dead_params(model):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+
+
+class LevelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proc, lstm, fts, locs, num_ims, state_prev, ctx_prev, *params):
+        mc = proc.config
+        if mc.slide_ctx_mode == "concat":
+            raise NotImplementedError("training with slide_ctx_mode='concat' is not implemented on the HIP path")
+        lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
+        sel = bw.selection_forward_train(mc, lp, vp, fts, locs.contiguous(), num_ims.contiguous(), state_prev)
+        res = ctx_prev if mc.slide_ctx_mode == "residual" else None
+        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res)
+        ctx.proc, ctx.lstm, ctx.sel, ctx.tr = proc, lstm, sel, tr
+        ctx.has_state, ctx.has_ctx = state_prev is not None, res is not None
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(sel["importance"])
+        return tr["logits"], tr["ctx_out"], sel["state_out"], sel["importance"]
+
+    @staticmethod
+    def backward(ctx, d_logits, d_ctx_out, d_state_out, _d_imp):
+        proc, lstm, sel, tr = ctx.proc, ctx.lstm, ctx.sel, ctx.tr
+        mc = proc.config
+        lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
+        cont = lambda t: t.contiguous() if t is not None else None
+        tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+        sg, d_state_prev = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
+        lg = bw.unpack_lstm_grads(lstm, sg)
+        grads = [lg[k] for k in LSTM_ORDER]
+        Hi = mc.importance_mlp_hidden_dim
+        grads += [sg["w_ip"][:Hi], sg["b1"], sg["w2"].view(1, -1), sg["b2"], sg["w_ip"][Hi:], sg["bp"], sg["special"]]
+        for l, g in enumerate(tg["layers"]):
+            grads += [g[key] for _, key in LAYER_ORDER]
+        grads += [tg["lnfg"], tg["lnfb"]]
+        grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]     # unused logits: grad stays None
+        return (None, None, None, None, None, d_state_prev if ctx.has_state else None,
+                d_ctx_prev if ctx.has_ctx else None, *grads)
+
+
+def level_apply(proc, lstm, fts, locs, num_ims, state_prev, ctx_prev):
+    """Differentiable ``process``: returns (logits, ctx_slide, ctx_patch, importance)."""
+    return LevelFn.apply(proc, lstm, fts, locs, num_ims, state_prev, ctx_prev, *lstm_params(lstm), *level_params(proc))
+
+
+class GatherFn(torch.autograd.Function):
+    """fts_next, state_next = gather(next-level grid rows, parent state rows)  (paths_gather_rows, zero padded)."""
+
+    @staticmethod
+    def forward(ctx, state_cur, grid_ptrs, src_cell, src_row, num_next, keep_idx, keep_count, child_pos, D, n_next):
+        B, n_cur, Dp = state_cur.shape
+        f32 = dict(device=state_cur.device, dtype=torch.float32)
+        fts_next = torch.empty((B, n_next, D), **f32)
+        state_next = torch.empty((B, n_next, Dp), **f32)
+        p = _lib.ptr
+        _lib.call("paths_gather_rows", p(grid_ptrs), p(src_cell), D, p(state_cur), n_cur, Dp, p(src_row), Dp, p(num_next), B,
+                  n_next, p(fts_next), p(state_next), 1, _lib.stream())
+        ctx.meta = (keep_idx, keep_count, child_pos, n_cur, n_next, Dp, B)
+        ctx.mark_non_differentiable(fts_next)
+        return fts_next, state_next
+
+    @staticmethod
+    def backward(ctx, _d_fts, d_state_next):
+        keep_idx, keep_count, child_pos, n_cur, n_next, Dp, B = ctx.meta
+        d_cur = torch.zeros((B, n_cur, Dp), device=d_state_next.device, dtype=torch.float32)
+        p = _lib.ptr
+        _lib.call("paths_gather_rows_bwd", p(keep_idx), keep_idx.shape[1], p(keep_count), p(child_pos),
+                  p(d_state_next.contiguous()), n_next, Dp, p(d_cur), n_cur, B, _lib.stream())
+        return (d_cur,) + (None,) * 9

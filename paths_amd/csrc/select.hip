@@ -73,7 +73,8 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
               const int64_t* __restrict__ mask_ptrs,                                     // [B] -> uint8 [X*Y], 1 = tissue
               int64_t n_next,
               int64_t* __restrict__ num_out, int64_t* __restrict__ locs_out, int64_t* __restrict__ parent_out,
-              int* __restrict__ src_row, int* __restrict__ src_cell, int* __restrict__ status) {
+              int* __restrict__ src_row, int* __restrict__ src_cell, int* __restrict__ status,
+              int* __restrict__ child_pos /*[B, 4*ldk] or null: output row of every candidate child, -1 if dropped*/) {
   __shared__ int part[1024];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int count = keep_count[b];
@@ -116,7 +117,9 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
   if (n_out > n_next) return;
   for (int c = c0; c < c1; ++c) {
     int cx, cy, i;
-    if (child(c, cx, cy, i)) {
+    const bool keepc = child(c, cx, cy, i);
+    if (child_pos) child_pos[(int64_t)b * 4 * ldk + c] = keepc ? pos : -1;
+    if (keepc) {
       const int64_t o = (int64_t)b * n_next + pos;
       locs_out[2 * o] = (int64_t)cx * patch_size;
       locs_out[2 * o + 1] = (int64_t)cy * patch_size;
@@ -212,6 +215,30 @@ gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src
     const f32x4 z{0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < D / 4; i += 256) fo[i] = z;
     if (so) for (int i = tid; i < Dp / 4; i += 256) so[i] = z;
+  }
+}
+
+
+// Backward of the parent-state gather (reference data_utils/slide.py:318 `ctx_patch = cat((ctx_patch,)*4)` + filter):
+// a kept parent receives the sum of the gradients of its (up to 4) surviving children, in block order (deterministic).
+__global__ void __launch_bounds__(256)
+gather_bwd_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restrict__ keep_count,
+                  const int* __restrict__ child_pos, const float* __restrict__ d_next, int64_t n_next, int Dp,
+                  float* __restrict__ d_cur, int64_t n_cur) {
+  const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const int count = keep_count[b];
+  if (i >= count) return;
+  const int row = keep_idx[(int64_t)b * ldk + i];
+  int pos[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) pos[blk] = child_pos[(int64_t)b * 4 * ldk + blk * count + i];
+  f32x4* out = reinterpret_cast<f32x4*>(d_cur + ((int64_t)b * n_cur + row) * Dp);
+  for (int c = tid; c < Dp / 4; c += 256) {
+    f32x4 s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      if (pos[blk] >= 0) s += reinterpret_cast<const f32x4*>(d_next + ((int64_t)b * n_next + pos[blk]) * Dp)[c];
+    out[c] = s;
   }
 }
 
@@ -311,11 +338,11 @@ int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, i
 int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_count, const int64_t* locs, int64_t n_cur,
                           int patch_size, const int* next_x, const int* next_y, const int64_t* mask_ptrs, int B,
                           int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
-                          int* src_cell, int* status, hipStream_t stream) {
+                          int* src_cell, int* status, int* child_pos, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && n_cur > 0 && n_next > 0 && patch_size > 0, "expand_children: bad shape");
   PATHS_REQUIRE(4 * ldk <= (int64_t)1 << 30, "expand_children: too many candidates");
   hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(1024), 0, stream, keep_idx, ldk, keep_count, locs, n_cur, patch_size,
-                     next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status);
+                     next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status, child_pos);
   PATHS_LAUNCH_CHECK("expand_children");
   return PATHS_OK;
 }
@@ -338,6 +365,15 @@ int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, cons
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_next, B), dim3(256), 0, stream, grid_ptrs, src_cell, D, state_cur,
                      n_cur, ld_state_cur, src_row, Dp, num_out, n_next, fts_out, state_out, zero_pad);
   PATHS_LAUNCH_CHECK("gather_rows");
+  return PATHS_OK;
+}
+
+// d_cur [B, n_cur, Dp] must be zero-initialised (rows that were not kept receive no gradient).
+int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_count, const int* child_pos, const float* d_next,
+                          int64_t n_next, int Dp, float* d_cur, int64_t n_cur, int B, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && ldk > 0 && Dp % 4 == 0 && keep_idx && keep_count && child_pos && d_next && d_cur, "gather_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)ldk, B), dim3(256), 0, stream, keep_idx, ldk, keep_count, child_pos, d_next, n_next, Dp, d_cur, n_cur);
+  PATHS_LAUNCH_CHECK("gather_rows_bwd");
   return PATHS_OK;
 }
 

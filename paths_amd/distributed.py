@@ -61,3 +61,22 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([bufs[r][: len(shard_range(n_total, r, world))] for r in range(world)], dim=0)
+
+
+def allreduce_gradients(model, average: bool = False):
+    """ONE flat-bucket all-reduce(sum) of every existing gradient (RCCL over xGMI with backend "nccl").
+    The loss of each rank is already scaled by local_batch / global_batch (paths_amd.utils.loss_from_logits), so the sum
+    of the shards' gradients IS the gradient of the global-batch mean loss; parameters whose grad is None (the unused
+    classifiers of the non-final levels) are None on every rank and are skipped consistently."""
+    if not dist.is_initialized():
+        return
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])          # 9.9 M fp32 = 39.5 MB: one message per step
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

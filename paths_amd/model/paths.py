@@ -4,8 +4,7 @@ Same constructor / ``process(data, lstm=None)`` / ``ctx_dim()`` surface and stat
 ``process`` issues the HIP launch sequence of paths_amd/ops.py:level_forward and returns the reference's
 dict {"logits", "ctx_slide", "ctx_patch", "importance"} (model/paths.py:141-146).
 
-Round-1 limits (rejected loudly, never silently approximated): forward only (no autograd graph),
-trans_dim=128 / 4 heads / importance hidden 128, dropout inactive (eval or dropout=0).
+Round-1 limits (rejected loudly, never silently approximated): trans_dim=128 / 4 heads / importance hidden 128, dropout inactive (eval or dropout=0).
 """
 from __future__ import annotations
 
@@ -46,9 +45,21 @@ class PATHSProcessor(nn.Module, Processor):
         assert lstm is not None or not mc.lstm, "lstm=True needs the shared LSTMCell (RecursiveModel passes it)"
         if self.training and mc.dropout > 0:
             raise NotImplementedError("paths_amd round 1: dropout (train mode) is not implemented on the HIP path")
-        if torch.is_grad_enabled() and self.training:
-            raise NotImplementedError("paths_amd round 1 is forward-only: call under model.eval() / torch.no_grad(); "
-                                      "backward kernels are the next scope row (SURVEY.md §8a row T)")
+        if torch.is_grad_enabled():
+            # differentiable path (training): same kernels + saved activations, backward in HIP (paths_amd/autograd.py)
+            if not mc.lstm:
+                raise NotImplementedError("training with lstm=false is not implemented on the HIP path")
+            from .. import autograd as pag
+            fts = data.fts.float().contiguous()
+            state_prev = data.ctx_patch[:, :, -1] if self.depth > 0 else None
+            if state_prev is not None and (state_prev.stride(2) != 1 or state_prev.stride(1) % 4 or
+                                           state_prev.stride(0) != fts.shape[1] * state_prev.stride(1) or state_prev.data_ptr() % 16):
+                state_prev = state_prev.contiguous()
+            ctx_prev = data.ctx_slide[:, -1] if (mc.slide_ctx_mode == "residual" and data.ctx_depth > 0) else None
+            if ctx_prev is not None and ctx_prev.stride(1) != 1:
+                ctx_prev = ctx_prev.contiguous()
+            logits, ctx_slide, ctx_patch, importance = pag.level_apply(self, lstm, fts, data.locs, data.num_ims, state_prev, ctx_prev)
+            return {"logits": logits, "ctx_slide": ctx_slide, "ctx_patch": ctx_patch, "importance": importance}
         fts = data.fts
         if fts.dtype != torch.float32 or not fts.is_contiguous():
             fts = fts.float().contiguous()

@@ -111,7 +111,7 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
                     torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
             _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
                       p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, cap, p(bufs[0]), p(bufs[1]), p(bufs[2]),
-                      p(bufs[3]), p(bufs[4]), p(status), st)
+                      p(bufs[3]), p(bufs[4]), p(status), None, st)
             return bufs
 
         num_next, locs_next, parent_next, src_row, src_cell = expand(Nn)
@@ -138,6 +138,89 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     out = dict(out)
     out["status"] = status
     return out
+
+
+def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int) -> Dict[str, torch.Tensor]:
+    """Differentiable recursion for training: same kernels as :func:`recurse`, but every level goes through
+    paths_amd.autograd.LevelFn / GatherFn so that ``loss.backward()`` runs the hand-written backward kernels.
+    Padded rows are zero-filled and computed (no tile skipping) so that every saved activation is finite."""
+    from . import autograd as pag
+    mc = model.procs[0].config
+    ops.check_supported(mc)
+    assert model.use_lstm, "training on the HIP path needs lstm=true"
+    batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
+    B, dev, D = len(batch), batch.device, batch.dim
+    st = _lib.stream()
+    p = _lib.ptr
+    i32 = dict(device=dev, dtype=torch.int32)
+    i64 = dict(device=dev, dtype=torch.int64)
+    f32 = dict(device=dev, dtype=torch.float32)
+    status = torch.zeros(1, **i32)
+    N = batch.n0
+    fts = torch.empty((B, N, D), **f32)
+    locs = torch.empty((B, N, 2), **i64)
+    parent = torch.empty((B, N), **i64)
+    num_ims = torch.empty((B,), **i64)
+    _lib.call("paths_level0_batch", p(batch.grid_ptrs[0]), p(batch.gx[0]), p(batch.gy[0]), B, D, mc.patch_size, N,
+              p(fts), p(locs), p(parent), p(num_ims), 1, st)
+    state_prev, ctx_prev = None, None
+    logits = None
+    for i in range(num_levels):
+        logits, ctx_slide, state_out, importance = pag.level_apply(model.procs[i], model.lstm, fts, locs, num_ims, state_prev, ctx_prev)
+        ctx_prev = ctx_slide
+        if i == num_levels - 1:
+            break
+        keep = int(keep_patches[i])
+        cap_keep = N if keep < 0 else min(N, keep)
+        keep_idx = torch.empty((B, cap_keep), **i32)
+        keep_count = torch.empty((B,), **i32)
+        _lib.call("paths_topk", p(importance), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
+        Nn = 4 * cap_keep
+        num_next = torch.empty((B,), **i64)
+        locs_next = torch.empty((B, Nn, 2), **i64)
+        parent_next = torch.empty((B, Nn), **i64)
+        src_row = torch.empty((B, Nn), **i32)
+        src_cell = torch.empty((B, Nn), **i32)
+        child_pos = torch.empty((B, 4 * cap_keep), **i32)
+        _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
+                  p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next),
+                  p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), st)
+        fts, state_prev = pag.GatherFn.apply(state_out, batch.grid_ptrs[i + 1], src_cell, src_row, num_next, keep_idx,
+                                             keep_count, child_pos, D, Nn)
+        locs, parent, num_ims, N = locs_next, parent_next, num_next, Nn
+    return {"logits": logits, "status": status}
+
+
+def loss_from_logits(logits, batch, task: str, global_batch: Optional[int] = None):
+    """Loss of reference utils.py:263-279 on the last level's logits.  With ``global_batch`` the mean is taken over the
+    GLOBAL batch (sum of local terms / global_batch) so that data-parallel shards add up exactly."""
+    dev = logits.device
+    n = logits.shape[0]
+    scale = 1.0 if global_batch is None else n / float(global_batch)
+    if task == "survival":
+        hazards = torch.sigmoid(logits)
+        loss = nll_loss(hazards, torch.as_tensor(batch["survival_bin"]).to(dev), torch.as_tensor(batch["censored"]).to(dev))
+        return hazards, loss * scale
+    elif task == "subtype_classification":
+        return logits, F.cross_entropy(logits, torch.as_tensor(batch["subtype"]).to(dev)) * scale
+    raise ValueError(task)
+
+
+def train_step(model, optimizer, batch, num_levels, keep_patches, task: str = "survival", global_batch: Optional[int] = None,
+               allreduce=None):
+    """One optimisation step with the reference's semantics (train.py:59-68): forward recursion, mean loss,
+    backward, [gradient all-reduce], optimizer step.  Dead parameters get the reference's zero gradients.
+    Returns the (local share of the) loss as a tensor."""
+    from . import autograd as pag
+    optimizer.zero_grad(set_to_none=True)
+    out = recurse_train(model, batch["slide"], keep_patches, num_levels)
+    _, loss = loss_from_logits(out["logits"], batch, task, global_batch)
+    loss.backward()
+    pag.fill_dead_grads(model)
+    if allreduce is not None:
+        allreduce(model)
+    optimizer.step()
+    return loss.detach()
 
 
 def inference_end2end(num_levels, keep_patches, model, base_power, batch, task: str):

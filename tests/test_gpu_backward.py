@@ -163,3 +163,87 @@ def test_transformer_backward(dev):
             if l == 1 and k in ("wqkv", "bqkv"):
                 pass            # last layer: q gradient exists for token 0 only; k,v for all tokens — same tensors, same check
             assert rel_err(grads["layers"][l][k], ref) < tol, (l, k, rel_err(grads["layers"][l][k], ref))
+
+
+def _train_setup(dev, wseed=3, dseed=14, top_k=64, base=(16, 16), n_slides=4):
+    from paths_amd import synthetic as syn
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, params = build_model(dev, wseed, None, top_k_patches=[top_k] * 4)
+    slides = [DeviceSlide.synthetic(dseed, sid, base, p_bg=0.1, device=dev) for sid in range(n_slides)]
+    labels = np.asarray([s.synthetic_spec.label(4) for s in slides], np.int64)
+    batch = {"slide": DeviceSlideBatch(slides), "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
+    return cfg, model, params, slides, batch
+
+
+def test_recursion_gradients_vs_oracle_autograd(dev):
+    """Full 5-level training forward/backward on the device vs torch autograd through the oracle (fp32 CPU)."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils, autograd as pag
+    cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3)
+    model.train()
+    out = putils.recurse_train(model, batch["slide"], cfg.top_k_patches, 5)
+    hazards, loss = putils.loss_from_logits(out["logits"], batch, "survival")
+    loss.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(top_k_patches=[16] * 4)
+    labels = {"survival_bin": batch["survival_bin"], "censored": batch["censored"]}
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], labels)
+    oloss.backward()
+    assert abs(float(loss) - float(oloss)) < 2e-5
+    sd = dict(model.named_parameters())
+    live = 0
+    for k, ref in p.items():
+        g = sd[k].grad
+        if ref.grad is None:
+            assert g is None, k
+            continue
+        if float(ref.grad.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, k       # dead parameters
+            continue
+        assert g is not None, k
+        assert rel_err(g, ref.grad) < 2e-3, (k, rel_err(g, ref.grad))
+        live += 1
+    assert live > 100
+
+
+def test_three_adamw_steps_match_reference_g6(dev):
+    """Reference train-step semantics (train.py:49-50,59-68): losses of 3 AdamW steps vs the fixture captured from the
+    reference (G6), dead parameters included in weight decay, unused classifiers left with grad None."""
+    from paths_amd import utils as putils
+    from tests.conftest import load_golden
+    g, info = load_golden("g6_train_16x16_top64")
+    cfg, model, params, slides, batch = _train_setup(dev, info["wseed"], info["dseed"], info["top_k"], tuple(info["base_shape"]), info["B"])
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=info["lr"], weight_decay=info["weight_decay"])
+    losses = []
+    for _ in range(len(g["losses"])):
+        losses.append(float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)))
+    np.testing.assert_allclose(losses, g["losses"], atol=2e-5, rtol=0)
+    none = sorted(n for n, p_ in model.named_parameters() if p_.grad is None)
+    assert none == sorted(info["grad_none"])
+
+
+def test_data_parallel_shards_sum_to_global_batch(dev):
+    """Two simulated ranks on one GPU (RCCL refuses two ranks of one communicator on the same device): the sum of the
+    shards' gradients (each loss scaled by local/global batch) equals the single-rank global-batch gradient."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlideBatch
+    from paths_amd.distributed import shard_range
+    cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(8, 8), n_slides=4)
+    model.train()
+
+    def grads_for(idx, global_batch):
+        model.zero_grad(set_to_none=True)
+        sub = {"slide": DeviceSlideBatch([slides[i] for i in idx]), "survival_bin": batch["survival_bin"][idx],
+               "censored": batch["censored"][idx]}
+        out = putils.recurse_train(model, sub["slide"], cfg.top_k_patches, 5)
+        _, loss = putils.loss_from_logits(out["logits"], sub, "survival", global_batch)
+        loss.backward()
+        return {n: p_.grad.clone() for n, p_ in model.named_parameters() if p_.grad is not None}, float(loss)
+
+    full, lf = grads_for(list(range(4)), 4)
+    parts = [grads_for(list(shard_range(4, r, 2)), 4) for r in range(2)]
+    assert abs(lf - (parts[0][1] + parts[1][1])) < 1e-6
+    for n, gfull in full.items():
+        s = parts[0][0][n] + parts[1][0][n]
+        assert rel_err(s, gfull) < 2e-5, n
