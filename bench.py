@@ -106,6 +106,47 @@ def cpu_baseline(cfg, sd, K: int, n_slides: int, reps: int):
                       f"fp32 torch CPU ops, {threads} threads, inputs cached"}
 
 
+def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unused):
+    """Secondary metric (BASELINE.json configs[3]): training slides/s = recursion forward + hand-written HIP backward +
+    AdamW, one flat 39.5 MB gradient all-reduce per step over RCCL when world > 1."""
+    import numpy as np
+    model.train()
+    labels = np.asarray([s.synthetic_spec.label(4) for s in slides.slides], np.int64)
+    batch = {"slide": slides, "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    gb = len(slides) * world
+    ar = pdist.allreduce_gradients if world > 1 else None
+
+    def sync():
+        torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss = putils.train_step(model, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
+        torch.cuda.synchronize()
+        log(f"train warm-up step {i}: local loss share {float(loss):.4f}")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = putils.train_step(model, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
+    sync()
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        K = args.k
+        print(json.dumps({
+            "metric": "train_slides_per_sec_5level_K%d_D1024" % K, "value": round(gb * args.steps / elapsed, 2), "unit": "slides/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train step (reference train.py:59-68 semantics): 5-level recursion K={K}, forward + HIP backward + "
+                                   f"AdamW, {len(slides)} slides per GPU, dropout 0", "global_batch": gb,
+                       "parallelism": f"dp{world}: one flat fp32 gradient all-reduce per step" if world > 1 else "single GPU"},
+            "final_loss_share": float(loss), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +157,8 @@ def main():
     ap.add_argument("--cpu-slides", type=int, default=2)
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, the BASELINE metric) or train: forward + HIP backward + AdamW + gradient all-reduce")
     args = ap.parse_args()
 
     from paths_amd import distributed as pdist
@@ -140,6 +183,10 @@ def main():
         torch.cuda.synchronize()
         pdist.barrier()
         torch.cuda.synchronize()
+
+    if args.mode == "train":
+        train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, barrier if False else None)
+        return
 
     def step(trace=None):
         with torch.no_grad():

@@ -160,6 +160,13 @@ allrows = pd.gather_rows(local, n_total)
 assert allrows.shape == (n_total, 2) and torch.equal(allrows[:, 0], torch.arange(n_total, dtype=torch.float32)), allrows
 t = pd.max_over_ranks(1.0 + rank, torch.device("cpu"))
 assert t == float(world), t
+# flat-bucket gradient all-reduce: params with grad None are skipped consistently, the others are summed
+lin = torch.nn.Linear(3, 2); unused = torch.nn.Linear(2, 2)
+model = torch.nn.ModuleList([lin, unused])
+lin.weight.grad = torch.full((2, 3), float(rank + 1)); lin.bias.grad = torch.tensor([1.0 * rank, 2.0])
+pd.allreduce_gradients(model)
+assert torch.equal(lin.weight.grad, torch.full((2, 3), 3.0)) and torch.equal(lin.bias.grad, torch.tensor([1.0, 4.0]))
+assert unused.weight.grad is None
 pd.barrier()
 print("rank", rank, "ok", list(mine))
 '''

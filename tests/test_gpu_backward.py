@@ -247,3 +247,32 @@ def test_data_parallel_shards_sum_to_global_batch(dev):
     for n, gfull in full.items():
         s = parts[0][0][n] + parts[1][0][n]
         assert rel_err(s, gfull) < 2e-5, n
+
+
+def test_dropin_process_is_differentiable(dev):
+    """``model(depth, PatchBatch)`` under grad mode (the reference's host loop + loss.backward(), train.py:62-65)."""
+    from oracle import paths_oracle as orc
+    from paths_amd.data_utils.patch_batch import PatchBatch
+    cfg, model, params = build_model(dev, 12)
+    model.train()
+    depth, B, N = 2, 2, 64
+    fts, locs, num_ims, state, valid = make_level_inputs(B, N, [64, 40], depth, seed=8)
+    ctx_patch = torch.zeros(B, N, depth, 1280); ctx_patch[:, :, -1] = state
+    ctx_slide = torch.randn(B, depth, 128, generator=torch.Generator().manual_seed(2))
+    cp_d = ctx_patch.to(dev).requires_grad_(True)
+    cs_d = ctx_slide.to(dev).requires_grad_(True)
+    pb = PatchBatch(locs=locs.to(dev), num_ims=num_ims.to(dev), parent_inds=torch.zeros(B, N, dtype=torch.int64, device=dev),
+                    ctx_slide=cs_d, ctx_patch=cp_d, fts=fts.to(dev))
+    out = model(depth, pb)
+    G1 = torch.randn(B, 4, generator=torch.Generator().manual_seed(3))
+    G2 = torch.randn(B, N, 1280, generator=torch.Generator().manual_seed(4)) * valid[..., None]
+    ((out["logits"] * G1.to(dev)).sum() + (out["ctx_patch"] * G2.to(dev)).sum()).backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    cp, cs = ctx_patch.clone().requires_grad_(True), ctx_slide.clone().requires_grad_(True)
+    ref = orc.process_level(p, H.oracle_config(), depth, fts, locs, num_ims, cs, cp)
+    ((ref["logits"] * G1).sum() + (ref["ctx_patch"] * G2).sum()).backward()
+    assert rel_err(cs_d.grad, cs.grad) < 1e-3 and rel_err(cp_d.grad[:, :, -1][valid], cp.grad[:, :, -1][valid]) < 1e-3
+    sd = dict(model.named_parameters())
+    for k in ("lstm.forget_gate.0.weight", "procs.2.importance_mlp.0.weight", "procs.2.global_agg.proj_in.weight",
+              "procs.2.global_agg.transformer.decoder.layers.0.linear1.weight", "procs.2.classification_layer.weight"):
+        assert rel_err(sd[k].grad, p[k].grad) < 2e-3, k
