@@ -165,9 +165,16 @@ def main():
     rank, world, local_rank = pdist.env_rank_world()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    pdist.init("nccl", dev)                      # RCCL; no-op for a single rank
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(1, ndev)        # (rehearsals on a 1-GPU box put every rank on device 0)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    backend = os.environ.get("PATHS_DIST_BACKEND", "nccl")     # "nccl" = RCCL; "gloo" only for 1-GPU rehearsals
+    pdist.init(backend, dev)                     # no-op for a single rank
+    if backend != "nccl":
+        dev_reduce = torch.device("cpu")
+    else:
+        dev_reduce = dev
 
     from paths_amd import _lib, ops
     from paths_amd import utils as putils
@@ -185,7 +192,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.mode == "train":
-        train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, barrier if False else None)
+        train_bench(args, cfg, model, slides, rank, world, dev_reduce, pdist, putils, None)
         return
 
     def step(trace=None):
@@ -218,7 +225,7 @@ def main():
     log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     status = int(out["status"].item())
     assert status == 0, f"recursion status {status}"
-    elapsed = pdist.max_over_ranks(elapsed, dev)
+    elapsed = pdist.max_over_ranks(elapsed, dev_reduce)
 
     # ---- roofline of the dominant kernel: algorithmic FLOP = 2 * valid_rows * K * N per launch
     trace = []

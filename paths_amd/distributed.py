@@ -72,7 +72,12 @@ def allreduce_gradients(model, average: bool = False):
         return
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     flat = torch.cat([g.reshape(-1) for g in grads])          # 9.9 M fp32 = 39.5 MB: one message per step
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if dist.get_backend() == "gloo" and flat.is_cuda:         # CPU-collective rehearsal path (tests / 1-GPU boxes)
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= dist.get_world_size()
     off = 0
