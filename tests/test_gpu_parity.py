@@ -316,3 +316,37 @@ def test_full_size_properties(dev):
                 par = nxt["parent_inds"][j, :n2].cpu().numpy()
                 assert np.array_equal(pl, locs[j][ki[par]])
     assert torch.isfinite(out_pair["logits"]).all()
+
+
+def test_graft_entry_smoke(dev):
+    """The driver's smoke() entry point (one small recursion on cuda:0 checked against the oracle)."""
+    import __graft_entry__
+    __graft_entry__.smoke()
+
+
+def test_stress_single_level_k8192_d1536(dev):
+    """BASELINE configs[4] shape on the fp32 path: one level, 8192 patches (full quadratic attention over 8193 tokens),
+    1536-dim features; vs the oracle on the same seeded inputs (no fixture: the oracle itself is pinned by G1-G9)."""
+    import math
+    from oracle import paths_oracle as orc
+    from paths_amd.data_utils.patch_batch import PatchBatch
+    over = {"model_config": {"patch_embed_dim": 1536}}
+    cfg, model, params = build_model(dev, 44, over)
+    ocfg = H.oracle_config(over)
+    N = 8192
+    g = torch.Generator().manual_seed(6)
+    fts = (torch.rand(1, N, 1536, generator=g) * 2 - 1) * math.sqrt(3)
+    locs = torch.stack((torch.arange(N) // 128, torch.arange(N) % 128), -1)[None] * 256
+    num_ims = torch.tensor([N])
+    pb = PatchBatch(locs=locs.to(dev), num_ims=num_ims.to(dev), parent_inds=torch.zeros(1, N, dtype=torch.int64, device=dev),
+                    ctx_slide=torch.zeros(1, 0, 128, device=dev), ctx_patch=torch.zeros(1, N, 0, 1792, device=dev), fts=fts.to(dev))
+    with torch.no_grad():
+        out = model(0, pb)
+        ref = orc.process_level(params, ocfg, 0, fts, locs, num_ims, torch.zeros(1, 0, 128), torch.zeros(1, N, 0, 1792))
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].numpy(), atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["importance"].cpu().numpy(), ref["importance"].numpy(), atol=STATE_TOL, rtol=0)
+    a = torch.topk(out["importance"][0].cpu(), 2048).indices.numpy()
+    r = torch.topk(ref["importance"][0], 2048).indices.numpy()
+    srt = np.sort(ref["importance"][0].numpy())[::-1]
+    if srt[2047] - srt[2048] >= 2e-6:
+        assert H.set_agreement(a, r)
