@@ -52,6 +52,22 @@ class DeviceSlide:
         return DeviceSlide([torch.as_tensor(g, dtype=torch.float32).to(device) for g in grids], **kw)
 
     @staticmethod
+    def from_preprocessed(root: str, slide_id: str, powers: Sequence[float], device="cuda", patch_size: int = 256,
+                          subtype=None) -> "DeviceSlide":
+        """Load the reference's preprocessed-grid files ``<root>/<slide_id>_<power:.3f>.pt`` (one ``[X, Y, D]`` float
+        tensor per magnification, all-zero row = background; written by reference preprocess/preprocess.py:89,134 and
+        read by preprocess/loader.py:14-18 / data_utils/slide.py:247-253) and make them resident in HBM."""
+        import os
+        grids = []
+        for power in powers:
+            path = os.path.join(root, slide_id + f"_{power:.3f}.pt")
+            assert os.path.isfile(path), f"Pre-process load: path '{path}' not found!"
+            g = torch.load(path, map_location="cpu")
+            assert g.dim() == 3, f"{path}: expected a [X, Y, D] grid, got {tuple(g.shape)}"
+            grids.append(g.float())
+        return DeviceSlide.from_host(grids, device, patch_size=patch_size, slide_id=slide_id, subtype=subtype)
+
+    @staticmethod
     def synthetic(seed: int, slide: int, base_shape: Tuple[int, int], dim: int = 1024, num_levels: int = 5,
                   p_bg: float = 0.1, device="cuda", patch_size: int = 256) -> "DeviceSlide":
         """Generate the counter-based synthetic pyramid directly in HBM (paths_synth_grid)."""

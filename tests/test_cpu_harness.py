@@ -1,0 +1,92 @@
+"""CPU tests of the train/eval harness pieces that need no GPU: metrics, checkpoint format, shuffle semantics."""
+import itertools
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+
+def brute_cindex(event, time, risk):
+    num = conc = 0.0
+    n = len(time)
+    for i, j in itertools.permutations(range(n), 2):
+        if not event[i]:
+            continue
+        if time[i] < time[j] or (time[i] == time[j] and not event[j]):
+            num += 1
+            if abs(risk[i] - risk[j]) <= 1e-8:
+                conc += 0.5
+            elif risk[i] > risk[j]:
+                conc += 1
+    return conc / num
+
+
+def test_concordance_index_matches_definition():
+    from paths_amd.eval import concordance_index_censored
+    rng = np.random.RandomState(0)
+    for n in (5, 17, 60):
+        event = rng.rand(n) < 0.6
+        event[0] = True
+        time = rng.randint(0, 8, n).astype(float)          # many tied times
+        risk = np.round(rng.randn(n), 1)                   # some tied risks
+        assert abs(concordance_index_censored(event, time, risk) - brute_cindex(event, time, risk)) < 1e-12
+    # known answers: perfectly ordered / reversed
+    e, t = np.ones(4, bool), np.array([1.0, 2, 3, 4])
+    assert concordance_index_censored(e, t, np.array([4.0, 3, 2, 1])) == 1.0
+    assert concordance_index_censored(e, t, np.array([1.0, 2, 3, 4])) == 0.0
+    assert concordance_index_censored(e, t, np.zeros(4)) == 0.5
+
+
+def test_binary_auroc_matches_pair_counting():
+    from paths_amd.eval import binary_auroc
+    rng = np.random.RandomState(1)
+    for n in (6, 40):
+        s = np.round(rng.rand(n), 1)
+        y = rng.rand(n) < 0.4
+        y[0], y[1] = True, False
+        pos, neg = s[y], s[~y]
+        ref = ((pos[:, None] > neg[None, :]).sum() + 0.5 * (pos[:, None] == neg[None, :]).sum()) / (len(pos) * len(neg))
+        assert abs(binary_auroc(s, y) - ref) < 1e-12
+    assert binary_auroc(np.array([0.1, 0.2]), np.array([1, 1])) == 0.5
+
+
+def test_survival_evaluator_and_train_stats():
+    from paths_amd.eval import SurvivalEvaluator
+    ev = SurvivalEvaluator("val")
+    hz = torch.tensor([[0.9, 0.5, 0.5, 0.5], [0.1, 0.1, 0.1, 0.1], [0.5, 0.5, 0.5, 0.5]])
+    batch = {"censored": torch.tensor([0, 0, 1]), "survival": torch.tensor([1.0, 9.0, 5.0])}
+    ev.register(batch, hz, torch.tensor(0.7))
+    stats = {"val_loss": {}, "val_c-index": {}}
+    out = ev.calculate(stats, 3)
+    assert out["val_c-index"] == 1.0 and abs(out["val_loss"] - 0.7) < 1e-6      # high hazard <-> short survival
+    assert stats["val_c-index"][3] == 1.0
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    """model.pt = state_dict, train_stats.pkl = pickled dict with 'epoch' (reference utils.py:169-198)."""
+    from paths_amd.config import Config
+    from paths_amd.train import load_state, save_state
+    cfg = Config.load(os.path.join(os.path.dirname(__file__), "golden", "sample"), test_mode=True)
+    torch.manual_seed(1)
+    m1 = cfg.get_model()
+    save_state(str(tmp_path), m1, {"epoch": 7, "train_loss": {1: 0.5}})
+    assert sorted(os.listdir(tmp_path)) == ["model.pt", "train_stats.pkl"]
+    assert pickle.load(open(tmp_path / "train_stats.pkl", "rb"))["epoch"] == 7
+    torch.manual_seed(2)
+    m2 = cfg.get_model()
+    stats = load_state(str(tmp_path), m2, map_location="cpu")
+    assert stats["epoch"] == 7 and all(torch.equal(a, b) for a, b in zip(m1.state_dict().values(), m2.state_dict().values()))
+    assert load_state(str(tmp_path / "nope"), m2) == {"epoch": 1}
+
+
+def test_epoch_permutation_equals_dataloader_shuffle():
+    from paths_amd.train import epoch_permutation
+    data = list(range(23))
+    torch.manual_seed(123)
+    ref = [int(x) for x in torch.utils.data.DataLoader(data, batch_size=1, shuffle=True)]
+    ref2 = [int(x) for x in torch.utils.data.DataLoader(data, batch_size=1, shuffle=True)]
+    torch.manual_seed(123)
+    assert epoch_permutation(23, True) == ref and epoch_permutation(23, True) == ref2
+    assert epoch_permutation(5, False) == [0, 1, 2, 3, 4]

@@ -350,3 +350,19 @@ def test_stress_single_level_k8192_d1536(dev):
     srt = np.sort(ref["importance"][0].numpy())[::-1]
     if srt[2047] - srt[2048] >= 2e-6:
         assert H.set_agreement(a, r)
+
+
+def test_preprocessed_grid_files_roundtrip(dev, tmp_path):
+    """The reference's on-disk format (<slide_id>_<power:.3f>.pt, [X,Y,D], zero row = background) -> DeviceSlide."""
+    from paths_amd import synthetic as syn
+    from paths_amd.config import Config
+    from paths_amd.data_utils.slide import DeviceSlide
+    import os
+    cfg = Config.load(os.path.join(os.path.dirname(__file__), "golden", "sample"), test_mode=True)
+    spec = syn.SyntheticSlide(3, 0, (3, 4), 1024, 5, 0.2)
+    for l, power in enumerate(cfg.power_levels()):
+        torch.save(torch.from_numpy(spec.grid(l)), tmp_path / f"slideA_{power:.3f}.pt")
+    s = DeviceSlide.from_preprocessed(str(tmp_path), "slideA", cfg.power_levels(), device=dev)
+    ref = DeviceSlide.synthetic(3, 0, (3, 4), p_bg=0.2, device=dev)
+    for l in range(5):
+        assert torch.equal(s.grids[l], ref.grids[l]) and torch.equal(s.masks[l], ref.masks[l])
