@@ -27,6 +27,8 @@ def _f32(dev):
 
 def _splits(M: int, n_tiles: int) -> int:
     """Split the row reduction so that about 2 x 256 workgroups are in flight, each with >= 256 rows."""
+    if n_tiles >= 192:
+        return 1                      # already about one workgroup per CU: no split, result written in place
     return max(1, min(64, (512 + n_tiles - 1) // n_tiles, M // 256 if M >= 256 else 1))
 
 
@@ -167,7 +169,9 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     _lib.call("paths_lstm_bwd_b", P(dc1_h), ext_c, Dp, P(sv["frm"]), c0_ptr, state_prev.stride(1) if state_prev is not None else 0,
               P(num_ims), N, M, Hc, P(dG), G, d_state_prev.data_ptr() + 4 * D if d_state_prev is not None else None, Dp, st)
     grads["b_gates"] = colsum(dG, G, M, G)
-    grads["w_gates"] = torch.zeros((G, 2 * D), **f32)
+    grads["w_gates"] = torch.empty((G, 2 * D), **f32)
+    if state_prev is None:
+        grads["w_gates"][:, D:].zero_()                                      # the h panel is dead at depth 0
     if state_prev is not None:
         gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, 2 * D, b1=state_prev.data_ptr(), ldb1=state_prev.stride(1), nb0=D)
         wh_t = transpose(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)   # [D, G] = (W_gates[:, D:2D])^T

@@ -25,7 +25,8 @@ struct TnOperands {
   const float* B0; int64_t ldb0; int NB0;   // [M, NB0]  columns [0, NB0) of the logical B
   const float* B1; int64_t ldb1;       // [M, N2-NB0] columns [NB0, N2)  (may be null)
   int M, N1, N2;
-  float* slabs;                        // [splits][N1][N2]
+  float* slabs;                        // [splits][N1][N2]  (or the output itself when there is one split)
+  int64_t ld_out;                      // row stride of a slab / of the output
   int rows_per_split;                  // multiple of TK
 };
 
@@ -100,7 +101,7 @@ gemm_tn_kernel(TnOperands g) {
     __syncthreads();
     buf ^= 1;
   }
-  float* out = g.slabs + (int64_t)blockIdx.z * g.N1 * g.N2;
+  float* out = g.slabs + (int64_t)blockIdx.z * g.N1 * g.ld_out;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -109,7 +110,7 @@ gemm_tn_kernel(TnOperands g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = n1_0 + wm * 64 + 32 * i + c32_row(r, lane);
-        if (row < g.N1 && col < g.N2) out[(int64_t)row * g.N2 + col] = acc[i][j][r];
+        if (row < g.N1 && col < g.N2) out[(int64_t)row * g.ld_out + col] = acc[i][j][r];
       }
     }
 }
@@ -178,7 +179,13 @@ int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0
   PATHS_REQUIRE(((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
   int rps = (M + splits - 1) / splits;
   rps = (rps + TK - 1) / TK * TK;
-  TnOperands g{a, lda, b0, ldb0, b1 ? nb0 : N2, b1, ldb1, M, N1, N2, workspace, rps};
+  if (splits == 1 && !accumulate) {      // enough tiles to fill the chip: write the result in place, no slab pass
+    TnOperands g1{a, lda, b0, ldb0, b1 ? nb0 : N2, b1, ldb1, M, N1, N2, out, ldo, rps};
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(N2 / 128, N1 / 128, 1), dim3(256), 0, stream, g1);
+    PATHS_LAUNCH_CHECK("gemm_tn");
+    return PATHS_OK;
+  }
+  TnOperands g{a, lda, b0, ldb0, b1 ? nb0 : N2, b1, ldb1, M, N1, N2, workspace, (int64_t)N2, rps};
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(N2 / 128, N1 / 128, splits), dim3(256), 0, stream, g);
   PATHS_LAUNCH_CHECK("gemm_tn");
   const int64_t n = (int64_t)N1 * N2;

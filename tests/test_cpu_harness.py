@@ -90,3 +90,16 @@ def test_epoch_permutation_equals_dataloader_shuffle():
     torch.manual_seed(123)
     assert epoch_permutation(23, True) == ref and epoch_permutation(23, True) == ref2
     assert epoch_permutation(5, False) == [0, 1, 2, 3, 4]
+
+
+def test_importance_map_weighting():
+    """Two levels: a 2x1 level-0 grid, the second patch expanded into two children."""
+    from paths_amd.heatmap import importance_map
+    levels = [{"locs": np.array([[0, 0], [256, 0]]), "importance": np.array([0.2, 0.8])},
+              {"locs": np.array([[512, 0], [768, 256]]), "importance": np.array([0.5, 0.1])}]
+    m = importance_map(levels, (2, 1))
+    assert m.shape == (4, 2)
+    np.testing.assert_allclose(m[0:2], 0.2 + 1e-4)                                   # never expanded
+    np.testing.assert_allclose(m[2, 0], 0.8 + 1e-4 + 0.5 * (0.5 + 1e-4))
+    np.testing.assert_allclose(m[3, 1], 0.8 + 1e-4 + 0.5 * (0.1 + 1e-4))
+    np.testing.assert_allclose(m[2, 1], 0.8 + 1e-4)                                  # child filtered out (background)

@@ -366,3 +366,22 @@ def test_preprocessed_grid_files_roundtrip(dev, tmp_path):
     ref = DeviceSlide.synthetic(3, 0, (3, 4), p_bg=0.2, device=dev)
     for l in range(5):
         assert torch.equal(s.grids[l], ref.grids[l]) and torch.equal(s.masks[l], ref.masks[l])
+
+
+def test_heatmap_export_from_trace(dev):
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    from paths_amd.heatmap import hierarchy_from_trace, importance_map
+    cfg, model, _ = build_model(dev, 2, None, top_k_patches=[6] * 4)
+    slides = [DeviceSlide.synthetic(13, sid, (6, 7), p_bg=0.2, device=dev) for sid in range(2)]
+    trace = []
+    with torch.no_grad():
+        putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
+    lv = hierarchy_from_trace(trace, 1)
+    assert len(lv) == 5 and lv[0]["locs"].shape == (42, 2) and len(lv[0]["keep_inds"]) == 6
+    m = importance_map(lv, (6, 7))
+    assert m.shape == (96, 112) and (m > 0).all()            # level 0 covers the whole slide
+    kept = lv[0]["locs"][lv[0]["keep_inds"]] // 256
+    others = np.ones((6, 7), bool); others[kept[:, 0], kept[:, 1]] = False
+    coarse = m.reshape(6, 16, 7, 16)
+    assert all(len(np.unique(coarse[x, :, y, :])) == 1 for x, y in zip(*np.nonzero(others)))   # unexpanded patches are flat
