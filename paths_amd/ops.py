@@ -130,7 +130,15 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     """fts [B,N,D] fp32 contiguous; locs [B,N,2] int64; num_ims [B] int64;
     state_prev: [B,N,>=D+Hc] view whose last dim holds (h|c) of the previous level (row stride arbitrary) or None;
     ctx_prev [B,d] (residual source) or None; ctx_all [B,depth,d] contiguous (concat mode) or None."""
-    _lib.require_cuda(fts, locs, num_ims, state_prev, ctx_prev, ctx_all)
+    sel = selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding)
+    agg = aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
+    return {"logits": agg["logits"], "ctx_slide": agg["ctx_slide"], "ctx_patch": sel["ctx_patch"], "importance": sel["importance"]}
+
+
+def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool) -> Dict[str, torch.Tensor]:
+    """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
+    (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims."""
+    _lib.require_cuda(fts, locs, num_ims, state_prev)
     B, N, D = fts.shape
     d, H, L = mc.trans_dim, mc.trans_heads, mc.trans_layers
     T = N + 1
@@ -201,6 +209,18 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
         scratch_imp = torch.empty((B, N), **f32)
         importance_proj(state_out, 0, scratch_imp)               # pass 2: tokens = proj_in(Z) + PE
 
+    return {"ctx_patch": state_out, "importance": importance, "tokens": tokens, "num_ims": num_ims}
+
+
+def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
+    """The transformer aggregator + classifier of a level (reference model/aggregator.py:58-76, model/paths.py:126-139).
+    Nothing here feeds the next level's patch selection, so the device recursion runs it on a second HIP stream."""
+    _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
+    B, T, d = tokens.shape
+    H, L = mc.trans_heads, mc.trans_layers
+    st = _lib.stream()
+    p = _lib.ptr
+    f32 = dict(device=tokens.device, dtype=torch.float32)
     hd = d // H
     q = torch.empty((B, H, T, hd), **f32)
     k = torch.empty((B, H, T, hd), **f32)
@@ -241,4 +261,4 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
               res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
               p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
               p(ws_part), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
-    return {"logits": logits, "ctx_slide": ctx_out, "ctx_patch": state_out, "importance": importance}
+    return {"logits": logits, "ctx_slide": ctx_out}

@@ -87,11 +87,16 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     state_prev, ctx_hist = None, []
     out = None
     lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
+    # (Tried and dropped: running the aggregator of level i on a second HIP stream beside the selection chain of level i+1.
+    #  Both are MFMA-bound, co-running kernels just share the matrix pipes: +0.5 % end to end, measured.)
     for i in range(num_levels):
         proc = model.procs[i]
+        lvl_pack = ops.pack_level(proc)
+        sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True)
         ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
         ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
-        out = ops.level_forward(mc, lstm_pack, ops.pack_level(proc), fts, locs, num_ims, state_prev, ctx_prev, ctx_all, True)
+        agg = ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
+        out = {"logits": agg["logits"], "ctx_slide": agg["ctx_slide"], "ctx_patch": sel["ctx_patch"], "importance": sel["importance"]}
         ctx_hist.append(out["ctx_slide"])
         rec = None
         if trace is not None:
