@@ -68,7 +68,7 @@ def colsum(a, lda, M, N, out=None, accumulate=False):
     dev = a.device if not isinstance(a, int) else out.device
     if out is None:
         out = torch.empty((N,), **_f32(dev))
-    splits = max(1, min(256, M // 64))
+    splits = max(1, min(64, M // 128))
     ws = torch.empty((splits * N,), **_f32(dev))
     ap = a if isinstance(a, int) else a.data_ptr()
     _lib.call("paths_colsum_f32", ap, lda, M, N, P(out), splits, 1 if accumulate else 0, P(ws), _lib.stream())

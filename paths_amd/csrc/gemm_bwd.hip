@@ -45,28 +45,26 @@ gemm_tn_kernel(TnOperands g) {
   const int64_t ldb = second ? g.ldb1 : g.ldb0;
   const float* Ap = g.A + n1_0;
 
-  // staging: 32 rows x 32 float4 per operand -> 4 float4 per thread per operand
+  // staging: 32 rows x 32 float4 per operand -> 4 float4 per thread per operand (8 chunks per k-tile)
   const int c4 = tid & 31, r0 = tid >> 5;          // r0 in [0,8): rows r0 + 8p
   f32x4 ra[4], rb[4];
-  auto gload = [&](int m0) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int m = m0 + r0 + 8 * p;
-      if (m < m_end) {
-        ra[p] = ldg_f32x4(Ap + (int64_t)m * g.lda + 4 * c4);
-        rb[p] = ldg_f32x4(Bp + (int64_t)m * ldb + 4 * c4);
-      } else {
-        ra[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
+  // one chunk (compile-time index after unrolling); rows past the end are read clamped and zeroed by a select, not a
+  // branch: the k-tile body must stay one basic block so its instruction order can be pinned (see gemm_f32.hip)
+  auto gload_one = [&](int idx, int m0) {
+    const int p = idx & 3;
+    const int m = m0 + r0 + 8 * p;
+    const int mc = min(m, m_end - 1);
+    if (idx < 4) ra[p] = ldg_f32x4(Ap + (int64_t)mc * g.lda + 4 * c4);
+    else rb[p] = ldg_f32x4(Bp + (int64_t)mc * ldb + 4 * c4);
   };
-  auto swrite = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      *reinterpret_cast<f32x4*>(&sA[buf][(r0 + 8 * p) * TLD + 4 * c4]) = ra[p];
-      *reinterpret_cast<f32x4*>(&sB[buf][(r0 + 8 * p) * TLD + 4 * c4]) = rb[p];
-    }
+  // the zeroing of rows past the end happens HERE (8 groups after the load was issued): touching the loaded value
+  // earlier would put an s_waitcnt vmcnt(0) right behind every load
+  auto swrite_one = [&](int idx, int buf, int m0) {
+    const int p = idx & 3;
+    const bool ok = m0 + r0 + 8 * p < m_end;
+    const f32x4 z{0.f, 0.f, 0.f, 0.f};
+    if (idx < 4) *reinterpret_cast<f32x4*>(&sA[buf][(r0 + 8 * p) * TLD + 4 * c4]) = ok ? ra[p] : z;
+    else *reinterpret_cast<f32x4*>(&sB[buf][(r0 + 8 * p) * TLD + 4 * c4]) = ok ? rb[p] : z;
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -77,29 +75,55 @@ gemm_tn_kernel(TnOperands g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (m_end - m_begin + TK - 1) / TK;
+  const int h = lane >> 5, li = lane & 31;
   if (nk > 0) {
-    gload(m_begin);
-    swrite(0);
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) gload_one(idx, m_begin);
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) swrite_one(idx, 0, m_begin);
   }
   __syncthreads();
   int buf = 0;
-  const int h = lane >> 5, li = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(m_begin + (kt + 1) * TK);
-    const float* a = &sA[buf][h * TLD + wm * 64 + li];
-    const float* b = &sB[buf][h * TLD + wn * 64 + li];
+  float fa[2][2], fb[2][2];          // fragments of MFMA step s: [slot][tile]
+  auto read_step = [&](int bufi, int s_, int slot) {
+    const float* a = &sA[bufi][(2 * s_ + h) * TLD + wm * 64 + li];
+    const float* b = &sB[bufi][(2 * s_ + h) * TLD + wn * 64 + li];
+    fa[slot][0] = a[0]; fa[slot][1] = a[32]; fb[slot][0] = b[0]; fb[slot][1] = b[32];
+  };
+  auto mfma_step = [&](int slot) {
+    acc[0][0] = mfma32(fa[slot][0], fb[slot][0], acc[0][0]);
+    acc[0][1] = mfma32(fa[slot][0], fb[slot][1], acc[0][1]);
+    acc[1][0] = mfma32(fa[slot][1], fb[slot][0], acc[1][0]);
+    acc[1][1] = mfma32(fa[slot][1], fb[slot][1], acc[1][1]);
+  };
+  if (nk > 0) read_step(0, 0, 0);
+  // 16 pinned groups per k-tile: 4 MFMAs | fragment reads of the next step | one global load (groups 0-7) or one LDS
+  // write (groups 8-15) of the next tile; the last group's MFMAs sit behind the barrier and cover the next tile's first reads
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float a0 = a[2 * s * TLD], a1 = a[2 * s * TLD + 32];
-      const float b0 = b[2 * s * TLD], b1 = b[2 * s * TLD + 32];
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    for (int s_ = 0; s_ < 15; ++s_) {
+      mfma_step(s_ & 1);
+      read_step(buf, s_ + 1, (s_ + 1) & 1);
+      if (s_ < 8) gload_one(s_, m_begin + (kt + 1) * TK);
+      else swrite_one(s_ - 8, buf ^ 1, m_begin + (kt + 1) * TK);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nk) swrite(buf ^ 1);
+    swrite_one(7, buf ^ 1, m_begin + (kt + 1) * TK);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     buf ^= 1;
+    read_step(buf, 0, 0);
+    mfma_step(1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nk > 0) {
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) {
+      mfma_step(s_ & 1);
+      if (s_ < 15) read_step(buf, s_ + 1, (s_ + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   float* out = g.slabs + (int64_t)blockIdx.z * g.N1 * g.ld_out;
 #pragma unroll
@@ -121,8 +145,16 @@ reduce_slabs_kernel(const float* __restrict__ slabs, int splits, int64_t n, floa
                     int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * n + i];
+  // fixed summation order (deterministic) with 8 independent partial sums so that 8 loads are in flight per thread:
+  // a one-workgroup launch of this kernel with 256 splits was a chain of 256 dependent L2 round trips (23 us)
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] += slabs[(int64_t)(k + u) * n + i];
+  }
+  for (; k < splits; ++k) p[k & 7] += slabs[(int64_t)k * n + i];
+  const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   const int64_t r = i / ncols, c = i % ncols;
   float* o = out + r * ldo + c;
   *o = accumulate ? *o + s : s;
