@@ -71,28 +71,42 @@ attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
   f32x4 dk[2], dv[2];
   dk[0] = dk[1] = dv[0] = dv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int q0 = 0; q0 < len; q0 += 16) {
-    __syncthreads();
-    if (tid < 128) {                                 // 16 rows x 8 float4 of Q_s ; second half: dO (head slice)
-      const int r = tid >> 3, c4 = tid & 7;
-      const int qi = min(q0 + r, T - 1);
-      const f32x4 t = *reinterpret_cast<const f32x4*>(q + base + (int64_t)qi * HD + 4 * c4);
-      *reinterpret_cast<f32x4*>(&sQ40[r * LD40 + 4 * c4]) = t;
-      *reinterpret_cast<f32x4*>(&sQ36[r * LD36 + 4 * c4]) = t;
+  // staging registers: threads 0-127 carry Q_s (16 rows x 8 float4), 128-255 carry dO; threads 0-15 also lse / D.
+  // The NEXT query tile is fetched into registers while the current one is being consumed from LDS (the loop was a
+  // global round trip per 16 queries before).
+  const int sr = (tid & 127) >> 3, sc4 = tid & 7;
+  f32x4 stage;
+  float st_lse = 0.f, st_d = 0.f;
+  auto fetch = [&](int q0) {
+    const int qi = min(q0 + sr, T - 1);
+    if (tid < 128) {
+      stage = *reinterpret_cast<const f32x4*>(q + base + (int64_t)qi * HD + 4 * sc4);
     } else {
-      const int r = (tid - 128) >> 3, c4 = tid & 7;
-      const int qi = min(q0 + r, T - 1);
-      f32x4 t = *reinterpret_cast<const f32x4*>(d_o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * c4);
-      if (q0 + r >= len) t = f32x4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(&sG40[r * LD40 + 4 * c4]) = t;
-      *reinterpret_cast<f32x4*>(&sG36[r * LD36 + 4 * c4]) = t;
+      stage = *reinterpret_cast<const f32x4*>(d_o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * sc4);
+      if (q0 + sr >= len) stage = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (tid < 16) {
-      const int qi = min(q0 + tid, T - 1);
-      sLse[tid] = lse[((int64_t)b * H + head) * T + qi];
-      sD[tid] = dsum[((int64_t)b * H + head) * T + qi];
+      const int qj = min(q0 + tid, T - 1);
+      st_lse = lse[((int64_t)b * H + head) * T + qj];
+      st_d = dsum[((int64_t)b * H + head) * T + qj];
     }
+  };
+  auto publish = [&]() {
+    if (tid < 128) {
+      *reinterpret_cast<f32x4*>(&sQ40[sr * LD40 + 4 * sc4]) = stage;
+      *reinterpret_cast<f32x4*>(&sQ36[sr * LD36 + 4 * sc4]) = stage;
+    } else {
+      *reinterpret_cast<f32x4*>(&sG40[sr * LD40 + 4 * sc4]) = stage;
+      *reinterpret_cast<f32x4*>(&sG36[sr * LD36 + 4 * sc4]) = stage;
+    }
+    if (tid < 16) { sLse[tid] = st_lse; sD[tid] = st_d; }
+  };
+  fetch(0);
+  for (int q0 = 0; q0 < len; q0 += 16) {
+    __syncthreads();                  // everyone is done reading the previous tile
+    publish();
     __syncthreads();
+    if (q0 + 16 < len) fetch(q0 + 16);
     // S[q][key] and dP[q][key]: A = Q_s / dO rows (16-byte reads), B = K^T / V^T registers
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
