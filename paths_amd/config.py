@@ -9,61 +9,44 @@ from __future__ import annotations
 
 import json
 import os
-from dataclasses import dataclass, field, fields
+from dataclasses import field, make_dataclass
 from typing import List, Optional
 
 
-@dataclass
 class ModelConfig:
-    pass
+    """Base class of per-model configuration blocks (reference config.py:13-15)."""
 
 
-@dataclass
-class PATHSProcessorConfig(ModelConfig):          # reference config.py:19-37
-    hierarchical_ctx: bool = True
-    slide_ctx_mode: str = "residual"              # residual / concat / none
-    patch_embed_dim: int = 1024
-    dropout: float = 0.0
-    patch_size: int = 256
-    importance_mode: str = "mul"                  # mul / none
-    trans_dim: int = 192
-    trans_heads: int = 4
-    trans_layers: int = 2
-    pos_encoding_mode: str = "1d"                 # 1d / 2d
-    importance_mlp_hidden_dim: int = 128
-    hierarchical_ctx_mlp_hidden_dim: int = 256
-    lstm: bool = True
+def _spec(rows):
+    return [(name, typ, field(default=default)) if default is not ... else (name, typ) for name, typ, default in rows]
 
 
-@dataclass
-class Config:                                     # reference config.py:41-79
-    model_config: ModelConfig
-    base_power: float
-    magnification_factor: int
-    num_levels: int
-    num_epochs: int
-    top_k_patches: List[int]
-    model_type: str
-    wsi_dir: str
-    csv_path: str
-    nbins: int = 4
-    loss: str = "nll"
-    task: str = "survival"
-    filter_to_subtypes: Optional[List[str]] = None
-    preprocess_dir: Optional[str] = None
-    batch_size: int = 32
-    save_epochs: int = 10
-    eval_epochs: int = 1
-    lr: float = 2e-5
-    lr_decay_per_epoch: float = 0.99
-    seed: int = 0
-    early_stopping: bool = False
-    weight_decay: float = 1e-2
-    min_epochs: int = 0
-    root_name: str = ""
-    hipt_splits: bool = False
-    hipt_val_proportion: float = 0
+# The field surface of config.json.  (name, type, default) — names and defaults are the reference's (config.py:19-37 and
+# :41-79); `...` marks a required key.
+_MODEL_FIELDS = [
+    ("hierarchical_ctx", bool, True), ("slide_ctx_mode", str, "residual"),          # residual / concat / none
+    ("patch_embed_dim", int, 1024), ("dropout", float, 0.0), ("patch_size", int, 256),
+    ("importance_mode", str, "mul"),                                                # mul / none
+    ("trans_dim", int, 192), ("trans_heads", int, 4), ("trans_layers", int, 2),
+    ("pos_encoding_mode", str, "1d"),                                               # 1d / 2d
+    ("importance_mlp_hidden_dim", int, 128), ("hierarchical_ctx_mlp_hidden_dim", int, 256), ("lstm", bool, True),
+]
+_TRAIN_FIELDS = [
+    ("model_config", ModelConfig, ...),
+    ("base_power", float, ...), ("magnification_factor", int, ...), ("num_levels", int, ...), ("num_epochs", int, ...),
+    ("top_k_patches", List[int], ...), ("model_type", str, ...), ("wsi_dir", str, ...), ("csv_path", str, ...),
+    ("nbins", int, 4), ("loss", str, "nll"), ("task", str, "survival"), ("filter_to_subtypes", Optional[List[str]], None),
+    ("preprocess_dir", Optional[str], None), ("batch_size", int, 32), ("save_epochs", int, 10), ("eval_epochs", int, 1),
+    ("lr", float, 2e-5), ("lr_decay_per_epoch", float, 0.99), ("seed", int, 0), ("early_stopping", bool, False),
+    ("weight_decay", float, 1e-2), ("min_epochs", int, 0), ("root_name", str, ""), ("hipt_splits", bool, False),
+    ("hipt_val_proportion", float, 0),
+]
 
+PATHSProcessorConfig = make_dataclass("PATHSProcessorConfig", _spec(_MODEL_FIELDS), bases=(ModelConfig,))
+PATHSProcessorConfig.__module__ = __name__
+
+
+class _ConfigMethods:
     @staticmethod
     def from_dict(data: dict) -> "Config":
         data = dict(data)
@@ -112,3 +95,7 @@ class Config:                                     # reference config.py:41-79
 
     def get_dataset(self, *a, **k):
         raise NotImplementedError("dataset / split loading is outside the hot-path scope (SURVEY.md §2 row 12)")
+
+
+Config = make_dataclass("Config", _spec(_TRAIN_FIELDS), bases=(_ConfigMethods,))
+Config.__module__ = __name__
