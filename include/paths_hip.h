@@ -39,10 +39,14 @@ int paths_abi_version(void);
  *   num_ims != NULL: tiles that contain only padding rows (row index within slide >= num_ims[b]) are skipped.
  *   phases: bit0 memory-cell GEMM, bit1 output-gate GEMM, bit2 mem_to_out GEMM; pass 7 (all, in this order).
  *   save_frm [M,3Hc] / save_tc [M,D] (both optional): gate activations f|r|m (packed order) and tanh(Wc c1 + bc),
- *   kept for the backward pass; ws_o then holds the output gate o. */
+ *   kept for the backward pass; ws_o then holds the output gate o.
+ *   hp [rows, 3Hc+D] + hp_row [M] (optional, instead of h0): siblings share their parent's h, so h_parent Wh^T is computed
+ *   ONCE per kept parent (paths_gather_kept_rows + paths_gemm_nt_f32 on w_gates[:, D:2D]) and added in the epilogue
+ *   through hp_row (-1 = no parent: zero state); the gate GEMM then only runs over the x panel (K = D). */
 int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                     const float* w_gates, const float* b_gates, const float* w_mem, const float* b_mem,
                     float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
+                    const float* hp, const int* hp_row,
                     int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, paths_stream_t stream);
 
 /* importance MLP + sigmoid + padding mask, importance scaling, proj_in, positional encoding, special token
@@ -155,24 +159,30 @@ int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, i
 /* 4-child expansion, bounds + background filter, stable compaction (reference data_utils/slide.py:303-331).
  *   mask_ptrs[b] -> uint8 [X*Y] tissue mask of the NEXT level (1 = row sum != 0).  status bit0: a slide
  *   produced zero children (reference fallback slide.py:336-352 needed), bit1: capacity n_next exceeded.
- *   child_pos (optional, [B, 4*ldk]): output row of every candidate child (-1 if dropped), for paths_gather_rows_bwd. */
+ *   child_pos (optional, [B, 4*ldk]): output row of every candidate child (-1 if dropped), for paths_gather_rows_bwd.
+ *   hp_row (optional, [B, n_next]): row b*ldk + i of the kept-parent table for every child (-1 on padding), see paths_lstm_cell. */
 int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_count, const int64_t* locs, int64_t n_cur,
                           int patch_size, const int* next_x, const int* next_y, const int64_t* mask_ptrs, int B,
                           int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
-                          int* src_cell, int* status, int* child_pos, paths_stream_t stream);
+                          int* src_cell, int* status, int* child_pos, int* hp_row, paths_stream_t stream);
 
 /* Rare fallback of reference data_utils/slide.py:336-352 for slides with num_out[b] == 0 after paths_expand_children:
  * continue with every tissue cell of the next grid (every cell if it has no tissue), zero patch context (src_row = -1),
  * parent_inds = cell index.  Other slides are untouched.  status bit1 set if n_next is too small. */
 int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t* mask_ptrs, int patch_size, int B,
                              int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
-                             int* src_cell, int* status, paths_stream_t stream);
+                             int* src_cell, int* status, int* hp_row, paths_stream_t stream);
 
 /* Gather child features from the next-level grids and parent LSTM state (reference slide.py:318,327-331;
- * zero padding of data_utils/dataset.py:216-227 when zero_pad != 0). */
+ * zero padding of data_utils/dataset.py:216-227 when zero_pad != 0).  state_cur points at the first state column to copy
+ * (row stride ld_state_cur), Dp = number of columns copied into state_out [B, n_next, Dp]. */
 int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,
                       int64_t ld_state_cur, const int* src_row, int Dp, const int64_t* num_out, int B, int64_t n_next,
                       float* fts_out, float* state_out, int zero_pad, paths_stream_t stream);
+
+/* Compact table of the kept parents' rows: out[b*ldk + i] = src[b, keep_idx[b,i], 0:D] (zeros beyond keep_count). */
+int paths_gather_kept_rows(const float* src, int64_t n_cur, int64_t ld_src, const int* keep_idx, int64_t ldk, const int* keep_count,
+                           int D, int B, float* out, paths_stream_t stream);
 
 /* Backward of the parent-state gather: d_cur[b, keep_idx[i]] = sum over the surviving children of parent i of d_next
  * (d_cur zero-initialised by the caller). */

@@ -19,7 +19,7 @@ _i64, _i32, _f32, _vp, _u32, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C
 
 # name -> argtypes (mirrors include/paths_hip.h; tests/test_abi.py checks both against the .so exports)
 SIGNATURES = {
-    "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+    "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                         _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "paths_importance_proj": [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32,
                               _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -41,9 +41,10 @@ SIGNATURES = {
     "paths_final_head": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
     "paths_layernorm_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "paths_topk": [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
-    "paths_expand_children": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "paths_expand_children": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "paths_gather_kept_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp],
     "paths_gather_rows_bwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp],
-    "paths_fallback_all_cells": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "paths_fallback_all_cells": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp],
     "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp],
     "paths_scale_add_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],

@@ -101,7 +101,7 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
         ld, h0, c0 = 0, None, None
     _lib.call("paths_lstm_cell", P(fts), D, h0, ld, c0, ld, P(lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
               P(lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]),
-              P(sv["tc"]), M, D, Hc, None, N, 7, st)
+              P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
     sv["importance"] = torch.empty((B, N), **f32)
     sv["tokens"] = torch.empty((B, T, d), **f32)
     sv["hid"] = torch.empty((B, N, 128), **f32)

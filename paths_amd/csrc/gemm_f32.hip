@@ -92,13 +92,10 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
     else *reinterpret_cast<f32x4*>(s + (BM + r0 + (idx - PA) * RPP) * LDK + 4 * c4) = rb[idx - PA];
   };
 
+  // accumulators start from the epilogue's initial value (zero, or the once-per-parent partial pre-activation): issued
+  // here, the loads overlap the first tile's staging instead of sitting in the epilogue
   f32x16 acc[WTM][WTN];
-#pragma unroll
-  for (int i = 0; i < WTM; ++i)
-#pragma unroll
-    for (int j = 0; j < WTN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  epi.template init<WTM, WTN>(acc, m0 + wm * WTM * 32, n0 + wn * WTN * 32, lane, g.M);
 
   const int nk = (g.K0 + g.K1) / BK;
   const int fragoff = (lane & 31) * LDK + 4 * (lane >> 5);
@@ -181,6 +178,25 @@ struct EpiLstmC {
   const float* c0; int64_t ldc0;   // nullptr at depth 0 (c0 = 0)
   float* c1; int64_t ldc1;         // state_out + D
   float* frm; int64_t ldfrm;       // optional (training): post-activation f|r|m in the packed column order
+  const float* hp; int64_t ldhp; const int* hp_row;   // optional: once-per-parent partial pre-activations h_parent Wh^T
+  template <int WTM, int WTN>
+  __device__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    const int jj = lane & 31;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float hf = 0.f, hr = 0.f, hm = 0.f;
+        if (hp) {                      // siblings share the parent's h: its half of the gate GEMM was done once per parent
+          const int pr = hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)];
+          if (pr >= 0) {
+            const float* ph = hp + (int64_t)pr * ldhp + col0 + jj;
+            hf = ph[0]; hr = ph[32]; hm = ph[64];
+          }
+        }
+        acc[i][0][r] = hf; acc[i][1][r] = hr; acc[i][2][r] = hm;
+      }
+  }
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
     static_assert(WTN == 3, "LSTM c epilogue wants f|r|m tiles");
@@ -217,6 +233,21 @@ struct EpiLstmC {
 // o = sigmoid(acc + b)
 struct EpiLstmO {
   const float* bias; float* o; int64_t ldo; int N;
+  const float* hp; int64_t ldhp; const int* hp_row; int hp_col0;   // optional parent partials (columns hp_col0 + col)
+  template <int WTM, int WTN>
+  __device__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pr = hp ? hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)] : -1;
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+          const int col = min(col0 + 32 * j + (lane & 31), N - 1);
+          acc[i][j][r] = pr >= 0 ? hp[(int64_t)pr * ldhp + hp_col0 + col] : 0.f;
+        }
+      }
+  }
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
 #pragma unroll
@@ -238,6 +269,16 @@ struct EpiLstmO {
 
 // h1 = o * tanh(acc + bc) ; Y = X + h1
 struct EpiLstmH {
+  template <int WTM, int WTN>
+  __device__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
   const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
   float* h1; int64_t ldh; float* y; int64_t ldy; int N;
   float* tc_out;                   // optional (training): tanh(Wc c1 + bc), [M, N]
@@ -276,6 +317,16 @@ struct EpiLstmH {
 // Generic linear epilogue (forward of the non-LSTM variant, every dX = dY W of the backward pass):
 //   v = acc + bias ; act 1: relu ; mask: v = mask > 0 ? v : 0 (relu backward) ; v += residual ; accumulate: v += out
 struct EpiBias {
+  template <int WTM, int WTN>
+  __device__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
   const float* bias; float* out; int64_t ldo; int N; int act;
   const float* residual; int64_t ldr; const float* mask; int64_t ldm; int accumulate;
   template <int WTM, int WTN, int WGM, int WGN>
@@ -313,6 +364,16 @@ struct EpiBias {
 // Waves with wn == 0 own the importance hidden units, wn == 1 the projected token channels.
 //   alpha = valid ? sigmoid(w2 . relu(acc + b1) + b2) : 0            (importance_mode "mul": token = alpha*acc + bp + PE)
 struct EpiImpProj {
+  template <int WTM, int WTN>
+  __device__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
   const float* b1; const float* w2; float b2;
   const float* bp;                 // proj_in bias [d]
   const float* special;            // special token [d]
@@ -443,16 +504,19 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
                     const float* w_mem /*[D, Hc]*/, const float* b_mem /*[D]*/,
                     float* state_out /*[M, D+Hc]: h1 | c1*/, int64_t ldso, float* y /*[M,D]*/, int64_t ldy,
                     float* ws_o /*[M,D] workspace*/, float* save_frm /*[M,3Hc] or null*/, float* save_tc /*[M,D] or null*/,
+                    const float* hp /*[*, 3Hc+D] or null*/, const int* hp_row /*[M] or null*/,
                     int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, hipStream_t stream) {
   PATHS_REQUIRE(D % 128 == 0 && Hc % 64 == 0, "lstm_cell: D (%d) must be a multiple of 128 and Hc (%d) of 64", D, Hc);
-  PATHS_REQUIRE((h0 == nullptr) == (c0 == nullptr), "lstm_cell: h0 and c0 must both be given or both be null");
+  PATHS_REQUIRE(hp != nullptr || (h0 == nullptr) == (c0 == nullptr), "lstm_cell: h0 and c0 must both be given or both be null");
+  PATHS_REQUIRE((hp == nullptr) == (hp_row == nullptr) && (hp == nullptr || h0 == nullptr),
+                "lstm_cell: hp/hp_row come together and replace h0 (the h half of the gate GEMM was done per parent)");
   const int Ktot = 2 * D;
   GemmOperands g{x, ldx, D, h0, ldh0, h0 ? D : 0, w_gates, Ktot, M, num_ims, rows_per_slide};
   // phases: bit0 = memory-cell GEMM (f,r,m -> c1), bit1 = output-gate GEMM, bit2 = mem_to_out GEMM (+ residual).
   // Callers normally pass 7; the bench brackets single phases with events.
   // (1) c-part: N = 3Hc, wave tile 64x96, block 128x192
   if (phases & 1) {
-    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc};
+    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row};
     int rc = launch_gemm<2, 3, 2, 2>(g, 3 * Hc, e, stream, "lstm_cell(c)");
     if (rc) return rc;
   }
@@ -460,7 +524,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
   if (phases & 2) {
     GemmOperands go = g;
     go.Bt = w_gates + (int64_t)3 * Hc * Ktot;
-    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D};
+    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc};
     int rc = launch_gemm<2, 2, 2, 2>(go, D, e, stream, "lstm_cell(o)");
     if (rc) return rc;
   }

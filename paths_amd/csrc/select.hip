@@ -74,7 +74,8 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
               int64_t n_next,
               int64_t* __restrict__ num_out, int64_t* __restrict__ locs_out, int64_t* __restrict__ parent_out,
               int* __restrict__ src_row, int* __restrict__ src_cell, int* __restrict__ status,
-              int* __restrict__ child_pos /*[B, 4*ldk] or null: output row of every candidate child, -1 if dropped*/) {
+              int* __restrict__ child_pos /*[B, 4*ldk] or null: output row of every candidate child, -1 if dropped*/,
+              int* __restrict__ hp_row /*[B, n_next] or null: row of the kept-parent table (b*ldk + i) of every child*/) {
   __shared__ int part[1024];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int count = keep_count[b];
@@ -126,6 +127,7 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
       parent_out[o] = i;
       src_row[o] = keep_idx[(int64_t)b * ldk + i];
       src_cell[o] = cx * Y + cy;
+      if (hp_row) hp_row[o] = (int)((int64_t)b * ldk + i);
       ++pos;
     }
   }
@@ -133,6 +135,7 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
   for (int j = n_out + tid; j < n_next; j += 1024) {
     const int64_t o = (int64_t)b * n_next + j;
     locs_out[2 * o] = 0; locs_out[2 * o + 1] = 0; parent_out[o] = 0; src_row[o] = -1; src_cell[o] = -1;
+    if (hp_row) hp_row[o] = -1;
   }
 }
 
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(1024)
 fallback_all_cells_kernel(const int* __restrict__ next_x, const int* __restrict__ next_y, const int64_t* __restrict__ mask_ptrs,
                           int patch_size, int64_t n_next, int64_t* __restrict__ num_out, int64_t* __restrict__ locs_out,
                           int64_t* __restrict__ parent_out, int* __restrict__ src_row, int* __restrict__ src_cell,
-                          int* __restrict__ status) {
+                          int* __restrict__ status, int* __restrict__ hp_row) {
   __shared__ int part[1024];
   const int b = blockIdx.x, tid = threadIdx.x;
   if (num_out[b] != 0) return;
@@ -181,6 +184,7 @@ fallback_all_cells_kernel(const int* __restrict__ next_x, const int* __restrict_
       parent_out[o] = c;
       src_row[o] = -1;
       src_cell[o] = c;
+      if (hp_row) hp_row[o] = -1;
       ++pos;
     }
   }
@@ -189,8 +193,8 @@ fallback_all_cells_kernel(const int* __restrict__ next_x, const int* __restrict_
 // One workgroup per output row: features from the next-level grid, LSTM state (h|c) from the kept parent.
 __global__ void __launch_bounds__(256)
 gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src_cell, int D,
-              const float* __restrict__ state_cur, int64_t n_cur, int64_t ld_state_cur, const int* __restrict__ src_row,
-              int Dp, const int64_t* __restrict__ num_out, int64_t n_next,
+              const float* __restrict__ state_cur /*already offset to the first copied column*/, int64_t n_cur, int64_t ld_state_cur,
+              const int* __restrict__ src_row, int Dp /*columns copied*/, const int64_t* __restrict__ num_out, int64_t n_next,
               float* __restrict__ fts_out, float* __restrict__ state_out, int zero_pad) {
   const int b = blockIdx.y;
   const int64_t j = blockIdx.x;
@@ -218,6 +222,23 @@ gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src
   }
 }
 
+
+
+// Kept parents' h rows -> compact table [B*ldk, D] (rows beyond keep_count are zero): the A operand of the
+// once-per-parent half of the next level's LSTM gate GEMM.
+__global__ void __launch_bounds__(256)
+gather_kept_rows_kernel(const float* __restrict__ src, int64_t n_cur, int64_t ld_src, const int* __restrict__ keep_idx, int64_t ldk,
+                        const int* __restrict__ keep_count, int D, float* __restrict__ out) {
+  const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  f32x4* o = reinterpret_cast<f32x4*>(out + ((int64_t)b * ldk + i) * D);
+  if (i < keep_count[b]) {
+    const f32x4* r = reinterpret_cast<const f32x4*>(src + ((int64_t)b * n_cur + keep_idx[(int64_t)b * ldk + i]) * ld_src);
+    for (int c = tid; c < D / 4; c += 256) o[c] = r[c];
+  } else {
+    const f32x4 z{0.f, 0.f, 0.f, 0.f};
+    for (int c = tid; c < D / 4; c += 256) o[c] = z;
+  }
+}
 
 // Backward of the parent-state gather (reference data_utils/slide.py:318 `ctx_patch = cat((ctx_patch,)*4)` + filter):
 // a kept parent receives the sum of the gradients of its (up to 4) surviving children, in block order (deterministic).
@@ -338,21 +359,21 @@ int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, i
 int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_count, const int64_t* locs, int64_t n_cur,
                           int patch_size, const int* next_x, const int* next_y, const int64_t* mask_ptrs, int B,
                           int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
-                          int* src_cell, int* status, int* child_pos, hipStream_t stream) {
+                          int* src_cell, int* status, int* child_pos, int* hp_row, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && n_cur > 0 && n_next > 0 && patch_size > 0, "expand_children: bad shape");
   PATHS_REQUIRE(4 * ldk <= (int64_t)1 << 30, "expand_children: too many candidates");
   hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(1024), 0, stream, keep_idx, ldk, keep_count, locs, n_cur, patch_size,
-                     next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status, child_pos);
+                     next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status, child_pos, hp_row);
   PATHS_LAUNCH_CHECK("expand_children");
   return PATHS_OK;
 }
 
 int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t* mask_ptrs, int patch_size, int B,
                              int64_t n_next, int64_t* num_out, int64_t* locs_out, int64_t* parent_out, int* src_row,
-                             int* src_cell, int* status, hipStream_t stream) {
+                             int* src_cell, int* status, int* hp_row, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && n_next > 0 && patch_size > 0, "fallback_all_cells: bad shape");
   hipLaunchKernelGGL(fallback_all_cells_kernel, dim3(B), dim3(1024), 0, stream, next_x, next_y, mask_ptrs, patch_size, n_next,
-                     num_out, locs_out, parent_out, src_row, src_cell, status);
+                     num_out, locs_out, parent_out, src_row, src_cell, status, hp_row);
   PATHS_LAUNCH_CHECK("fallback_all_cells");
   return PATHS_OK;
 }
@@ -369,6 +390,14 @@ int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, cons
 }
 
 // d_cur [B, n_cur, Dp] must be zero-initialised (rows that were not kept receive no gradient).
+int paths_gather_kept_rows(const float* src, int64_t n_cur, int64_t ld_src, const int* keep_idx, int64_t ldk, const int* keep_count,
+                           int D, int B, float* out, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && ldk > 0 && D % 4 == 0 && ld_src % 4 == 0 && src && keep_idx && keep_count && out, "gather_kept_rows: bad arguments");
+  hipLaunchKernelGGL(gather_kept_rows_kernel, dim3((unsigned)ldk, B), dim3(256), 0, stream, src, n_cur, ld_src, keep_idx, ldk, keep_count, D, out);
+  PATHS_LAUNCH_CHECK("gather_kept_rows");
+  return PATHS_OK;
+}
+
 int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_count, const int* child_pos, const float* d_next,
                           int64_t n_next, int Dp, float* d_cur, int64_t n_cur, int B, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && ldk > 0 && Dp % 4 == 0 && keep_idx && keep_count && child_pos && d_next && d_cur, "gather_rows_bwd: bad arguments");

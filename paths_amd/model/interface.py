@@ -48,7 +48,7 @@ class LSTMCell(nn.Module):
         Dp = self.hdim + self.cdim
         _lib.call("paths_lstm_cell", p(x), self.xdim, state.data_ptr(), Dp, state.data_ptr() + 4 * self.hdim, Dp,
                   p(pk["w_gates"]), p(pk["b_gates"]), p(pk["w_mem"]), p(pk["b_mem"]), p(out), Dp, p(y), self.xdim,
-                  p(ws), None, None, M, self.xdim, self.cdim, None, 1, 7, _lib.stream())
+                  p(ws), None, None, None, None, M, self.xdim, self.cdim, None, 1, 7, _lib.stream())
         return out[:, : self.hdim].reshape(*lead, self.hdim), out[:, self.hdim:].reshape(*lead, self.cdim)
 
 

@@ -135,9 +135,14 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     return {"logits": agg["logits"], "ctx_slide": agg["ctx_slide"], "ctx_patch": sel["ctx_patch"], "importance": sel["importance"]}
 
 
-def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool) -> Dict[str, torch.Tensor]:
+def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool,
+                      parent=None) -> Dict[str, torch.Tensor]:
     """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
-    (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims."""
+    (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims.
+
+    ``parent`` (device recursion only) = {"hp": [rows, 3Hc+D], "hp_row": [B,N] int32, "c0": [B,N,Hc]}: the up-to-4 children
+    of a kept patch share the parent's h, so the h half of the gate GEMM is computed once per kept PARENT
+    (:func:`parent_partials`) and added in the children's epilogue; ``state_prev`` is then None."""
     _lib.require_cuda(fts, locs, num_ims, state_prev)
     B, N, D = fts.shape
     d, H, L = mc.trans_dim, mc.trans_heads, mc.trans_layers
@@ -168,7 +173,14 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         state_out = torch.empty((B, N, Dp), **f32)
         y = torch.empty((B, N, D), **f32)
         ws_o = torch.empty((B, N, D), **f32)
-        if state_prev is not None:
+        hp, hp_row = None, None
+        if parent is not None:
+            assert state_prev is None
+            c0t = parent["c0"]
+            assert c0t.shape == (B, N, Hc) and c0t.is_contiguous()
+            ld, h0, c0 = Hc, None, c0t.data_ptr()
+            hp, hp_row = p(parent["hp"]), p(parent["hp_row"])
+        elif state_prev is not None:
             assert state_prev.shape[:2] == (B, N) and state_prev.shape[2] == Dp and state_prev.stride(2) == 1
             assert state_prev.stride(0) == N * state_prev.stride(1), "state rows must be uniformly strided"
             ld = state_prev.stride(1)
@@ -178,14 +190,15 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
 
         def lstm(phases):
             _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
-                      p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), None, None,
+                      p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), None, None, hp, hp_row,
                       M, D, Hc, nim, N, phases, st)
 
         if KERNEL_TIMER is None:
             lstm(7)
         else:                   # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
             lstm(1)
-            KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D})
+            KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D,
+                                                          "parent_partials": parent is not None})
             lstm(4)
         importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance)
         del ws_o
@@ -210,6 +223,25 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         importance_proj(state_out, 0, scratch_imp)               # pass 2: tokens = proj_in(Z) + PE
 
     return {"ctx_patch": state_out, "importance": importance, "tokens": tokens, "num_ims": num_ims}
+
+
+def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, keep_count: torch.Tensor) -> torch.Tensor:
+    """HP[b*cap + i] = h1[b, keep_idx[b,i]] @ W_gates[:, D:2D]^T  (no bias) for the kept parents of every slide:
+    [B*cap, 3Hc+D] in the packed gate-column order.  ~4x fewer rows than the children that will consume it."""
+    B, N, Dp = state_out.shape
+    Hc = lstm_pack["Hc"]
+    D = Dp - Hc
+    G = 3 * Hc + D
+    cap = keep_idx.shape[1]
+    f32 = dict(device=state_out.device, dtype=torch.float32)
+    st = _lib.stream()
+    p = _lib.ptr
+    hk = torch.empty((B * cap, D), **f32)
+    _lib.call("paths_gather_kept_rows", p(state_out), N, Dp, p(keep_idx), cap, p(keep_count), D, B, p(hk), st)
+    hp = torch.empty((B * cap, G), **f32)
+    _lib.call("paths_gemm_nt_f32", p(hk), D, lstm_pack["w_gates"].data_ptr() + 4 * D, 2 * D, None, p(hp), G, B * cap, G, G, D, 0,
+              None, 0, None, 0, 0, st)
+    return hp
 
 
 def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:

@@ -80,19 +80,20 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     N = batch.n0
     fts = torch.empty((B, N, D), **f32)
     locs = torch.empty((B, N, 2), **i64)
-    parent = torch.empty((B, N), **i64)
+    parent_inds = torch.empty((B, N), **i64)
     num_ims = torch.empty((B,), **i64)
     _lib.call("paths_level0_batch", p(grid_ptrs[0]), p(gx[0]), p(gy[0]), B, D, mc.patch_size, N,
-              p(fts), p(locs), p(parent), p(num_ims), 0, st)
-    state_prev, ctx_hist = None, []
+              p(fts), p(locs), p(parent_inds), p(num_ims), 0, st)
+    state_prev, ctx_hist, parent = None, [], None
     out = None
     lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
+    share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
     # (Tried and dropped: running the aggregator of level i on a second HIP stream beside the selection chain of level i+1.
     #  Both are MFMA-bound, co-running kernels just share the matrix pipes: +0.5 % end to end, measured.)
     for i in range(num_levels):
         proc = model.procs[i]
         lvl_pack = ops.pack_level(proc)
-        sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True)
+        sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent)
         ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
         ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
         agg = ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
@@ -100,7 +101,7 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
         ctx_hist.append(out["ctx_slide"])
         rec = None
         if trace is not None:
-            rec = {"num_ims": num_ims, "locs": locs, "parent_inds": parent, "importance": out["importance"],
+            rec = {"num_ims": num_ims, "locs": locs, "parent_inds": parent_inds, "importance": out["importance"],
                    "logits": out["logits"], "ctx_slide": out["ctx_slide"]}
             trace.append(rec)
         if i == num_levels - 1:
@@ -113,13 +114,13 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
         Nn = 4 * cap_keep
         def expand(cap):
             bufs = (torch.empty((B,), **i64), torch.empty((B, cap, 2), **i64), torch.empty((B, cap), **i64),
-                    torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
+                    torch.empty((B, cap), **i32), torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
             _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
                       p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, cap, p(bufs[0]), p(bufs[1]), p(bufs[2]),
-                      p(bufs[3]), p(bufs[4]), p(status), None, st)
+                      p(bufs[3]), p(bufs[4]), p(status), None, p(bufs[5]) if share_parent else None, st)
             return bufs
 
-        num_next, locs_next, parent_next, src_row, src_cell = expand(Nn)
+        num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
         if careful:
             empty = (num_next == 0).cpu()                      # per-level sync: slow path only
             if bool(empty.any()):
@@ -130,16 +131,26 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
                     need = max(need, tissue if tissue > 0 else X * Y)
                 if need > Nn:
                     Nn = need
-                    num_next, locs_next, parent_next, src_row, src_cell = expand(Nn)
+                    num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
                 _lib.call("paths_fallback_all_cells", p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), mc.patch_size, B, Nn,
-                          p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status), st)
+                          p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status),
+                          p(hp_row) if share_parent else None, st)
         fts_next = torch.empty((B, Nn, D), **f32)
-        state_next = torch.empty((B, Nn, Dp), **f32)
-        _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
-                  p(num_next), B, Nn, p(fts_next), p(state_next), 0, st)
+        if share_parent:
+            # children only need their parent's c row (h enters through the per-parent partials below)
+            Hc = Dp - D
+            state_next = torch.empty((B, Nn, Hc), **f32)
+            _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
+                      p(src_row), Hc, p(num_next), B, Nn, p(fts_next), p(state_next), 0, st)
+            parent = {"hp": ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count), "hp_row": hp_row, "c0": state_next}
+            state_next = None
+        else:
+            state_next = torch.empty((B, Nn, Dp), **f32)
+            _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
+                      p(num_next), B, Nn, p(fts_next), p(state_next), 0, st)
         if rec is not None:
             rec["keep_idx"], rec["keep_count"] = keep_idx, keep_count
-        fts, locs, parent, num_ims, state_prev, N = fts_next, locs_next, parent_next, num_next, state_next, Nn
+        fts, locs, parent_inds, num_ims, state_prev, N = fts_next, locs_next, parent_next, num_next, state_next, Nn
     out = dict(out)
     out["status"] = status
     return out
@@ -189,7 +200,7 @@ def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int) -
         child_pos = torch.empty((B, 4 * cap_keep), **i32)
         _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
                   p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next),
-                  p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), st)
+                  p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), None, st)
         fts, state_prev = pag.GatherFn.apply(state_out, batch.grid_ptrs[i + 1], src_cell, src_row, num_next, keep_idx,
                                              keep_count, child_pos, D, Nn)
         locs, parent, num_ims, N = locs_next, parent_next, num_next, Nn

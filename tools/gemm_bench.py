@@ -21,7 +21,7 @@ so = torch.empty(M, D + Hc, device=dev); y = torch.empty(M, D, device=dev); ws =
 p = _lib.ptr
 def run(ph):
     _lib.call("paths_lstm_cell", p(x), D, st0.data_ptr(), D + Hc, st0.data_ptr() + 4 * D, D + Hc, p(wg), p(bg), p(wm), p(bm),
-              p(so), D + Hc, p(y), D, p(ws), None, None, M, D, Hc, None, 1, ph, _lib.stream())
+              p(so), D + Hc, p(y), D, p(ws), None, None, None, None, M, D, Hc, None, 1, ph, _lib.stream())
 for ph, name, flop in ((1, "c-part", 2.0 * M * 2 * D * 3 * Hc), (2, "o-gate", 2.0 * M * 2 * D * D), (4, "h-part", 2.0 * M * Hc * D)):
     for _ in range(3): run(ph)
     torch.cuda.synchronize()
