@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -27,11 +28,27 @@ int paths_set_error(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - indices stay constants without relying on the unroller
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // ---- device math (accurate forms: the selection chain must stay within ~1e-7 of the fp32 CPU path)
-__device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1/d for d in [1, 1e30]: hardware reciprocal (1 ulp) + one Newton step = correctly rounded in all but a few cases; 3
+// instructions against the ~12 of an IEEE division (these run 256 times per lane in a 256x256 GEMM epilogue)
+__device__ __forceinline__ float rcp_nr(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+// the clamp keeps d finite (exp overflow would turn the Newton step into inf*0); sigmoid(-69) = 1e-30 either way
+__device__ __forceinline__ float sigmoid_acc(float x) { return rcp_nr(1.0f + fminf(expf(-x), 1e30f)); }
 // branch-free tanh: 1 - 2/(1+e^{2x}); absolute error ~1e-7 (what the h = o*tanh(.) and c-update chains need),
 // saturates correctly at +-1 (e^{2x} -> inf / 0).  libm's tanhf branches per lane and serialises epilogues.
-__device__ __forceinline__ float tanh_acc(float x) { return 1.0f - 2.0f / (1.0f + expf(2.0f * x)); }
+__device__ __forceinline__ float tanh_acc(float x) { return 1.0f - 2.0f * rcp_nr(1.0f + fminf(expf(2.0f * x), 1e30f)); }
 
 // ---- MFMA wrappers.  f32-input MFMA = exact k-ordered fp32 FMA chain (guide §3 "FP32-input MFMA").
 // 32x32x2: A lane l -> A[l&31][l>>5], B lane l -> B[l>>5][l&31]; C: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)

@@ -1,0 +1,454 @@
+// Fused epilogues of the PATHS selection chain, shared by the f32-MFMA GEMM (gemm_f32.hip) and the split-bf16 GEMM
+// (gemm_x6.hip).  Both kernels hand an epilogue the same thing: per wave WTM x WTN accumulator tiles of 32x32 fp32 in the
+// v_mfma 32x32 C layout.
+#pragma once
+#include "common.h"
+
+namespace paths_epi {
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  acc[i][j][r] is C[row0 + 32 i + c32_row(r, lane)][col0 + 32 j + (lane & 31)].
+// ------------------------------------------------------------------------------------------------
+
+// Epilogue structure (all of them): per 32x32 tile FIRST issue every load the tile needs (clamped row index: always
+// a legal address, no branch), THEN compute, THEN store under a row predicate.  Written naively (load -> math ->
+// store per element inside `if (row < M)`) hipcc emits one exec-masked branch + one s_waitcnt vmcnt(0) per element:
+// 64-128 dependent L2 round trips per thread, which made the K=256 GEMM spend 2/3 of its time in its epilogue.
+
+// Addressing.  An epilogue touches each of its arrays once per accumulator element; done naively that is a 64-bit
+// multiply-add, a bounds compare and an exec-masked branch PER ELEMENT (45 instructions per sigmoid output, measured), and
+// with one wave per SIMD (gemm_x6) nothing hides it.  So: (1) the row-bounds test is made once per workgroup
+// (FULL = the whole BM-row block is inside M: every block but the last), (2) element addresses are a wave-uniform 64-bit
+// base (tile origin + the element's row offset, scalar arithmetic) plus ONE per-lane 32-bit offset computed once.
+struct TileView {
+  char* base; int64_t ldb; uint32_t lane_off;
+  __device__ TileView(const float* p, int64_t ld, int lane)
+      : base(reinterpret_cast<char*>(const_cast<float*>(p))), ldb(ld * 4), lane_off((uint32_t)((4 * (lane >> 5)) * ld + (lane & 31)) * 4u) {}
+  // element r of the 32x32 tile whose top-left corner is (trow, tcol); trow / tcol wave-uniform
+  __device__ float* at(int trow, int tcol, int r) const {
+    char* tile = base + (int64_t)trow * ldb + (int64_t)tcol * 4;                              // uniform: one per (array, tile)
+    const uint32_t off = lane_off + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)ldb;        // per lane, 32-bit
+    return reinterpret_cast<float*>(tile + off);
+  }
+  // the same element with the row clamped to M-1 (partial blocks: always a legal address)
+  __device__ float* at_clamped(int trow, int tcol, int r, int lane, int M) const {
+    const int row = min(trow + c32_row(r, lane), M - 1);
+    return reinterpret_cast<float*>(base + (int64_t)row * ldb + (int64_t)(tcol + (lane & 31)) * 4);
+  }
+};
+template <bool FULL>
+__device__ __forceinline__ float* tile_elem(const TileView& v, int trow, int tcol, int r, int lane, int M) {
+  if constexpr (FULL) return v.at(trow, tcol, r);
+  else return v.at_clamped(trow, tcol, r, lane, M);
+}
+template <bool FULL>
+__device__ __forceinline__ bool tile_row_ok(int trow, int r, int lane, int M) {
+  if constexpr (FULL) return true;
+  else return trow + c32_row(r, lane) < M;
+}
+
+// c1 = c0 * sigmoid(f) + sigmoid(r) * tanh(m); packed columns per wave = [f(32) | r(32) | m(32)] of one j-block.
+struct EpiLstmC {
+  const float* bias;     // packed like the weight rows
+  const float* c0; int64_t ldc0;   // nullptr at depth 0 (c0 = 0)
+  float* c1; int64_t ldc1;         // state_out + D
+  float* frm; int64_t ldfrm;       // optional (training): post-activation f|r|m in the packed column order
+  const float* hp; int64_t ldhp; const int* hp_row;   // optional: once-per-parent partial pre-activations h_parent Wh^T
+  template <int WTM, int WTN>
+  __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    const int jj = lane & 31;
+    if (hp == nullptr) {
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; acc[i][2][r] = 0.f; }
+      return;
+    }
+    // siblings share the parent's h: its half of the gate GEMM was done once per parent.  All parent indices first (one
+    // round trip for the lot), then the gathers; rows without a parent (hp_row < 0) read row 0 and select zero.
+    int pr[WTM][16];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[i][r] = hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {     // batched like EpiLstmO::init
+      float t[3][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* ph = hp + (int64_t)max(pr[i][r], 0) * ldhp + col0 + jj;
+        t[0][r] = ph[0]; t[1][r] = ph[32]; t[2][r] = ph[64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool has = pr[i][r] >= 0;
+        acc[i][0][r] = has ? t[0][r] : 0.f; acc[i][1][r] = has ? t[1][r] : 0.f; acc[i][2][r] = has ? t[2][r] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  template <bool FULL, int WTM, int WTN>
+  __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    const int jj = lane & 31;
+    const int tcol = (col0 / 96) * 32;             // memory-unit block of this wave's f|r|m triple
+    const float bf = bias[col0 + jj], br = bias[col0 + 32 + jj], bm = bias[col0 + 64 + jj];
+    const TileView c0v(c0, ldc0, lane), c1v(c1, ldc1, lane), fv(frm, ldfrm, lane);
+    static_for<0, WTM>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int trow = row0 + 32 * i;
+      float cp[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cp[r] = c0 ? *tile_elem<FULL>(c0v, trow, tcol, r, lane, M) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float f = sigmoid_acc(acc[i][0][r] + bf);
+        const float rg = sigmoid_acc(acc[i][1][r] + br);
+        const float mp = tanh_acc(acc[i][2][r] + bm);
+        const float v = cp[r] * f + rg * mp;
+        if (tile_row_ok<FULL>(trow, r, lane, M)) {
+          *tile_elem<FULL>(c1v, trow, tcol, r, lane, M) = v;
+          if (frm) {
+            float* fr = tile_elem<FULL>(fv, trow, col0, r, lane, M);
+            fr[0] = f; fr[32] = rg; fr[64] = mp;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep one row-tile's loads in flight at a time (register pressure at WTM = 4)
+    });
+  }
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+    static_assert(WTN == 3, "LSTM c epilogue wants f|r|m tiles");
+    if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
+    else run_impl<false>(acc, row0, col0, lane, M);
+  }
+};
+
+// o = sigmoid(acc + b)
+struct EpiLstmO {
+  const float* bias; float* o; int64_t ldo; int N;   // N % 32 == 0
+  const float* hp; int64_t ldhp; const int* hp_row; int hp_col0;   // optional parent partials (columns hp_col0 + col)
+  template <int WTM, int WTN>
+  __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    if (hp == nullptr) {
+#pragma unroll
+      for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      return;
+    }
+    int pr[WTM][16];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[i][r] = hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)];
+    // one row-tile (16 x WTN gathers per lane) per batch: all of a batch's loads are issued before the first is consumed
+    // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> v_accvgpr_write per element: 256 serial L2 round trips)
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      float t[WTN][16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* ph = hp + (int64_t)max(pr[i][r], 0) * ldhp + hp_col0 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) t[j][r] = ph[min(col0 + 32 * j, N - 32)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) acc[i][j][r] = pr[i][r] >= 0 ? t[j][r] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  template <bool FULL, int WTM, int WTN>
+  __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    const TileView ov(o, ldo, lane);
+    static_for<0, WTM * WTN>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM;
+      const int trow = row0 + 32 * i, tcol = col0 + 32 * j;
+      if (tcol < N) {                              // wave-uniform (zero-padded weight rows beyond N)
+        const float b = bias[tcol + (lane & 31)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = sigmoid_acc(acc[i][j][r] + b);
+          if (tile_row_ok<FULL>(trow, r, lane, M)) *tile_elem<FULL>(ov, trow, tcol, r, lane, M) = v;
+        }
+      }
+    });
+  }
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+    if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
+    else run_impl<false>(acc, row0, col0, lane, M);
+  }
+};
+
+// h1 = o * tanh(acc + bc) ; Y = X + h1
+struct EpiLstmH {
+  template <int WTM, int WTN>
+  __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
+  const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
+  float* h1; int64_t ldh; float* y; int64_t ldy; int N;      // N % 32 == 0
+  float* tc_out;                   // optional (training): tanh(Wc c1 + bc), [M, N]
+  template <bool FULL, int WTM, int WTN>
+  __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    // tile-pipelined: the loads of tile t+1 are in flight while tile t is computed and stored (two register buffers)
+    constexpr int NT = WTM * WTN;
+    const TileView ovw(o, ldo, lane), xvw(x, ldx, lane), hv(h1, ldh, lane), yv(y, ldy, lane), tv(tc_out, N, lane);
+    float ov[2][16], xv[2][16];
+    auto load = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t & 1;
+      const int trow = row0 + 32 * i, tcol = min(col0 + 32 * j, N - 32);
+      static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        ov[s][r] = *tile_elem<FULL>(ovw, trow, tcol, r, lane, M);
+        xv[s][r] = *tile_elem<FULL>(xvw, trow, tcol, r, lane, M);
+      });
+    };
+    load(std::integral_constant<int, 0>{});
+    static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t & 1;
+      if constexpr (t + 1 < NT) load(std::integral_constant<int, t + 1>{});
+      const int trow = row0 + 32 * i, tcol = col0 + 32 * j;
+      if (tcol < N) {
+        const float b = bias[tcol + (lane & 31)];
+        static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+          constexpr int r = decltype(rc)::value;
+          const float tcv = tanh_acc(acc[i][j][r] + b);
+          const float h = ov[s][r] * tcv;
+          if (tile_row_ok<FULL>(trow, r, lane, M)) {
+            if (tc_out) *tile_elem<FULL>(tv, trow, tcol, r, lane, M) = tcv;
+            *tile_elem<FULL>(hv, trow, tcol, r, lane, M) = h;
+            *tile_elem<FULL>(yv, trow, tcol, r, lane, M) = xv[s][r] + h;
+          }
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+    if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
+    else run_impl<false>(acc, row0, col0, lane, M);
+  }
+};
+
+// Generic linear epilogue (forward of the non-LSTM variant, every dX = dY W of the backward pass):
+//   v = acc + bias ; act 1: relu ; mask: v = mask > 0 ? v : 0 (relu backward) ; v += residual ; accumulate: v += out
+struct EpiBias {
+  template <int WTM, int WTN>
+  __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
+  const float* bias; float* out; int64_t ldo; int N; int act;
+  const float* residual; int64_t ldr; const float* mask; int64_t ldm; int accumulate;
+  template <bool FULL, int WTM, int WTN>
+  __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    constexpr int NT = WTM * WTN;
+    const TileView outv(out, ldo, lane), resv(residual, ldr, lane), maskv(mask, ldm, lane);
+    float rv[2][16], mv[2][16], ov[2][16];
+    const bool any_load = residual != nullptr || mask != nullptr || accumulate != 0;
+    auto load = [&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t & 1;
+      const int trow = row0 + 32 * i, tcol = col0 + 32 * j;
+      const int lcol = min(tcol + (lane & 31), N - 1) - (lane & 31);     // keeps partial last column tiles in bounds
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        rv[s][r] = residual ? *tile_elem<FULL>(resv, trow, lcol, r, lane, M) : 0.f;
+        mv[s][r] = mask ? *tile_elem<FULL>(maskv, trow, lcol, r, lane, M) : 1.f;
+        ov[s][r] = accumulate ? *tile_elem<FULL>(outv, trow, lcol, r, lane, M) : 0.f;
+      }
+    };
+    if (any_load) load(std::integral_constant<int, 0>{});
+    static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t & 1;
+      if constexpr (t + 1 < NT) {
+        if (any_load) load(std::integral_constant<int, t + 1>{});
+      }
+      const int trow = row0 + 32 * i, tcol = col0 + 32 * j;
+      const int colr = tcol + (lane & 31);
+      const float b = bias ? bias[min(colr, N - 1)] : 0.f;
+      if (tcol < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + b;
+          if (act == 1) v = fmaxf(v, 0.f);
+          if (any_load) {
+            if (!(mv[s][r] > 0.f)) v = 0.f;
+            v += rv[s][r] + ov[s][r];
+          }
+          if (tile_row_ok<FULL>(trow, r, lane, M) && (tcol + 32 <= N || colr < N)) *tile_elem<FULL>(outv, trow, tcol, r, lane, M) = v;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
+    if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
+    else run_impl<false>(acc, row0, col0, lane, M);
+  }
+};
+
+// Exact x / d for 0 <= x < 2^24, d > 0 (rd = 1.0f / d): a float estimate that is off by at most one, then one fix-up.
+// (A 64-bit integer division is ~150 instructions on this ISA and the token epilogue needed two per row.)
+__device__ __forceinline__ int div_u24(int x, int d, float rd) {
+  int q = (int)((float)x * rd);
+  const int r = x - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
+__device__ __forceinline__ int div_pos(int64_t x, int d, float rd) {      // pixel coordinate / patch_size
+  return (x >= 0 && x < (1 << 24)) ? div_u24((int)x, d, rd) : (int)(x / d);
+}
+
+// Packed weight rows = [W1 (Hi=128 rows) ; Wp (d=128 rows)], block covers all 256 columns.
+// Waves with wn == 0 own the importance hidden units, wn == 1 the projected token channels.
+//   alpha = valid ? sigmoid(w2 . relu(acc + b1) + b2) : 0            (importance_mode "mul": token = alpha*acc + bp + PE)
+struct EpiImpProj {
+  template <int WTM, int WTN>
+  __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
+  const float* b1; const float* w2; float b2;
+  const float* bp;                 // proj_in bias [d]
+  const float* special;            // special token [d]
+  const float* div_term;           // 2d: [d/4] ; 1d: [d/2]   (host: torch.exp(arange * -ln(1e4)/d), utils.py:18,56)
+  const int64_t* locs;             // [M,2] pixel coords (2d mode)
+  const int64_t* num_ims;          // [B]
+  int rows_per_slide;              // N
+  int patch_size;
+  int pe_mode;                     // 2 = "2d", 1 = "1d"
+  int imp_mul;                     // importance_mode == "mul"
+  float* importance;               // [M]
+  float* tokens;                   // [B, N+1, d]
+  float* hid_out;                  // optional (training): relu(Y W1^T + b1) [M,128]
+  float* pproj_out;                // optional (training): Y Wp^T (before alpha / bias / PE) [M,128]
+  const float* pe_table; int pe_rows;   // optional: paths_pe_table output (same sinf/cosf values, read instead of recomputed)
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int wm, int wn, int M, float* smem) const {
+    static_assert(WTN == 4 && WGN == 2, "imp/proj epilogue layout: one block spans the 128 hidden + 128 projected columns");
+    constexpr int d = 128;
+    const float rps_inv = 1.0f / (float)rows_per_slide, ps_inv = 1.0f / (float)patch_size;
+    const bool small_rows = M < (1 << 24);
+    float* alpha_s = smem;                       // [WGM*WTM*32] (main loop is done; LDS is free after its last barrier)
+    if (wn == 0) {
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        float part[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = 32 * j + (lane & 31);
+          const float b = b1[col], w = w2[col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float hv = fmaxf(acc[i][j][r] + b, 0.f);
+            part[r] += hv * w;
+            const int row = row0 + 32 * i + c32_row(r, lane);
+            if (hid_out && row < M) hid_out[(int64_t)row * 128 + col] = hv;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = part[r];
+          v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+          const int lrow = 32 * i + c32_row(r, lane);
+          const int row = row0 + lrow;
+          float a = 0.f;
+          if (row < M) {
+            const int b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide, idx = row - b * rows_per_slide;
+            if (idx < (int)num_ims[b]) a = sigmoid_acc(v + b2);
+            if ((lane & 31) == 0) importance[row] = a;
+          }
+          if ((lane & 31) == 0) alpha_s[wm * WTM * 32 + lrow] = a;
+        }
+      }
+    }
+    __syncthreads();
+    if (wn == 1) {
+      float bpv[4], dtv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = 32 * j + (lane & 31);
+        bpv[j] = bp[c];
+        dtv[j] = pe_mode == 2 ? div_term[(c & (d / 2 - 1)) >> 1] : div_term[c >> 1];
+      }
+#pragma unroll
+      for (int i = 0; i < WTM; ++i) {
+        int64_t lx[16], ly[16];               // all position loads first (see the epilogue note above)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
+          lx[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc] : 0;
+          ly[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc + 1] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lrow = 32 * i + c32_row(r, lane);
+          const int row = row0 + lrow;
+          if (row >= M) continue;
+          const int b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide, idx = row - b * rows_per_slide;
+          const float a = imp_mul ? alpha_s[wm * WTM * 32 + lrow] : 1.f;
+          const int ipx = pe_mode == 2 ? div_pos(lx[r], patch_size, ps_inv) : idx, ipy = pe_mode == 2 ? div_pos(ly[r], patch_size, ps_inv) : 0;
+          const float px = (float)ipx, py = (float)ipy;
+          float* trow = tokens + ((int64_t)b * (rows_per_slide + 1) + idx + 1) * d;
+          // positional encoding: from the precomputed table when this row's coordinates are inside it (positions are small
+          // integers, so the table holds exactly the values the expressions below produce), else evaluated here
+          const bool tab = pe_table != nullptr && (unsigned)ipx < (unsigned)pe_rows && (unsigned)ipy < (unsigned)pe_rows;
+          float pev[4];
+          if (tab) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = 32 * j + (lane & 31);
+              pev[j] = pe_mode == 2 ? pe_table[(int64_t)(c >= d / 2 ? ipy : ipx) * (d / 2) + (c & (d / 2 - 1))]
+                                    : pe_table[(int64_t)ipx * d + c];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int c = 32 * j + (lane & 31);
+              const float pos = (pe_mode == 2 && c >= d / 2) ? py : px;
+              const float ang = pos * dtv[j];
+              pev[j] = (c & 1) ? cosf(ang) : sinf(ang);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int c = 32 * j + (lane & 31);
+            trow[c] = a * acc[i][j][r] + bpv[j] + pev[j];
+            if (pproj_out) pproj_out[(int64_t)row * 128 + c] = acc[i][j][r];
+            if (idx == 0) tokens[(int64_t)b * (rows_per_slide + 1) * d + c] = special[c];
+          }
+        }
+      }
+    }
+  }
+};
+
+}  // namespace paths_epi

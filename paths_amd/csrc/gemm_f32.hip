@@ -18,8 +18,10 @@
 // A and B use the same permutation, the sum over k is unchanged.  The "concat(x, h)" of the reference is
 // never materialised: the k loop walks panel A0 (features) then A1 (previous h state, strided view).
 #include "common.h"
+#include "gemm_epi.h"
 
 namespace {
+using namespace paths_epi;
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // padded LDS row stride (floats)
@@ -60,7 +62,7 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
   const int m0 = by * BM, n0 = bx * BN;
   if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M)) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
   const int c4 = tid & 7, r0 = tid >> 3;
 
@@ -163,312 +165,6 @@ gemm_f32_kernel(GemmOperands g, Epi epi) {
   epi.template run<WTM, WTN, WGM, WGN>(acc, m0 + wm * WTM * 32, n0 + wn * WTN * 32, lane, wm, wn, g.M, smem);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Epilogues.  acc[i][j][r] is C[row0 + 32 i + c32_row(r, lane)][col0 + 32 j + (lane & 31)].
-// ------------------------------------------------------------------------------------------------
-
-// Epilogue structure (all of them): per 32x32 tile FIRST issue every load the tile needs (clamped row index: always
-// a legal address, no branch), THEN compute, THEN store under a row predicate.  Written naively (load -> math ->
-// store per element inside `if (row < M)`) hipcc emits one exec-masked branch + one s_waitcnt vmcnt(0) per element:
-// 64-128 dependent L2 round trips per thread, which made the K=256 GEMM spend 2/3 of its time in its epilogue.
-
-// c1 = c0 * sigmoid(f) + sigmoid(r) * tanh(m); packed columns per wave = [f(32) | r(32) | m(32)] of one j-block.
-struct EpiLstmC {
-  const float* bias;     // packed like the weight rows
-  const float* c0; int64_t ldc0;   // nullptr at depth 0 (c0 = 0)
-  float* c1; int64_t ldc1;         // state_out + D
-  float* frm; int64_t ldfrm;       // optional (training): post-activation f|r|m in the packed column order
-  const float* hp; int64_t ldhp; const int* hp_row;   // optional: once-per-parent partial pre-activations h_parent Wh^T
-  template <int WTM, int WTN>
-  __device__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
-    const int jj = lane & 31;
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float hf = 0.f, hr = 0.f, hm = 0.f;
-        if (hp) {                      // siblings share the parent's h: its half of the gate GEMM was done once per parent
-          const int pr = hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)];
-          if (pr >= 0) {
-            const float* ph = hp + (int64_t)pr * ldhp + col0 + jj;
-            hf = ph[0]; hr = ph[32]; hm = ph[64];
-          }
-        }
-        acc[i][0][r] = hf; acc[i][1][r] = hr; acc[i][2][r] = hm;
-      }
-  }
-  template <int WTM, int WTN, int WGM, int WGN>
-  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
-    static_assert(WTN == 3, "LSTM c epilogue wants f|r|m tiles");
-    const int jj = lane & 31;
-    const int j = (col0 / 96) * 32 + jj;
-    const float bf = bias[col0 + jj], br = bias[col0 + 32 + jj], bm = bias[col0 + 64 + jj];
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) {
-      float cp[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
-        cp[r] = c0 ? c0[(int64_t)rowc * ldc0 + j] : 0.f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + 32 * i + c32_row(r, lane);
-        const float f = sigmoid_acc(acc[i][0][r] + bf);
-        const float rg = sigmoid_acc(acc[i][1][r] + br);
-        const float mp = tanh_acc(acc[i][2][r] + bm);
-        const float v = cp[r] * f + rg * mp;
-        if (row < M) {
-          c1[(int64_t)row * ldc1 + j] = v;
-          if (frm) {
-            float* fr = frm + (int64_t)row * ldfrm + col0 + jj;
-            fr[0] = f; fr[32] = rg; fr[64] = mp;
-          }
-        }
-      }
-    }
-  }
-};
-
-// o = sigmoid(acc + b)
-struct EpiLstmO {
-  const float* bias; float* o; int64_t ldo; int N;
-  const float* hp; int64_t ldhp; const int* hp_row; int hp_col0;   // optional parent partials (columns hp_col0 + col)
-  template <int WTM, int WTN>
-  __device__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pr = hp ? hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)] : -1;
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) {
-          const int col = min(col0 + 32 * j + (lane & 31), N - 1);
-          acc[i][j][r] = pr >= 0 ? hp[(int64_t)pr * ldhp + hp_col0 + col] : 0.f;
-        }
-      }
-  }
-  template <int WTM, int WTN, int WGM, int WGN>
-  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-      const int col = col0 + 32 * j + (lane & 31);
-      if (col >= N) continue;
-      const float b = bias[col];
-#pragma unroll
-      for (int i = 0; i < WTM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + 32 * i + c32_row(r, lane);
-          const float v = sigmoid_acc(acc[i][j][r] + b);
-          if (row < M) o[(int64_t)row * ldo + col] = v;
-        }
-    }
-  }
-};
-
-// h1 = o * tanh(acc + bc) ; Y = X + h1
-struct EpiLstmH {
-  template <int WTM, int WTN>
-  __device__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int j = 0; j < WTN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
-
-  const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
-  float* h1; int64_t ldh; float* y; int64_t ldy; int N;
-  float* tc_out;                   // optional (training): tanh(Wc c1 + bc), [M, N]
-  template <int WTM, int WTN, int WGM, int WGN>
-  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-      const int col = min(col0 + 32 * j + (lane & 31), N - 1);
-      const bool colok = col0 + 32 * j + (lane & 31) < N;
-      const float b = bias[col];
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) {
-        float ov[16], xv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
-          ov[r] = o[(int64_t)rowc * ldo + col];
-          xv[r] = x[(int64_t)rowc * ldx + col];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + 32 * i + c32_row(r, lane);
-          const float tcv = tanh_acc(acc[i][j][r] + b);
-          const float h = ov[r] * tcv;
-          if (row < M && colok) {
-            if (tc_out) tc_out[(int64_t)row * N + col] = tcv;
-            h1[(int64_t)row * ldh + col] = h;
-            y[(int64_t)row * ldy + col] = xv[r] + h;
-          }
-        }
-      }
-    }
-  }
-};
-
-// Generic linear epilogue (forward of the non-LSTM variant, every dX = dY W of the backward pass):
-//   v = acc + bias ; act 1: relu ; mask: v = mask > 0 ? v : 0 (relu backward) ; v += residual ; accumulate: v += out
-struct EpiBias {
-  template <int WTM, int WTN>
-  __device__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int j = 0; j < WTN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
-
-  const float* bias; float* out; int64_t ldo; int N; int act;
-  const float* residual; int64_t ldr; const float* mask; int64_t ldm; int accumulate;
-  template <int WTM, int WTN, int WGM, int WGN>
-  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
-#pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-      const int colr = col0 + 32 * j + (lane & 31);
-      const int col = min(colr, N - 1);
-      const float b = bias ? bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < WTM; ++i) {
-        float rv[16], mv[16], ov[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
-          rv[r] = residual ? residual[(int64_t)rowc * ldr + col] : 0.f;
-          mv[r] = mask ? mask[(int64_t)rowc * ldm + col] : 1.f;
-          ov[r] = accumulate ? out[(int64_t)rowc * ldo + col] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + 32 * i + c32_row(r, lane);
-          float v = acc[i][j][r] + b;
-          if (act == 1) v = fmaxf(v, 0.f);
-          if (!(mv[r] > 0.f)) v = 0.f;
-          v += rv[r] + ov[r];
-          if (row < M && colr < N) out[(int64_t)row * ldo + col] = v;
-        }
-      }
-    }
-  }
-};
-
-// Packed weight rows = [W1 (Hi=128 rows) ; Wp (d=128 rows)], block covers all 256 columns.
-// Waves with wn == 0 own the importance hidden units, wn == 1 the projected token channels.
-//   alpha = valid ? sigmoid(w2 . relu(acc + b1) + b2) : 0            (importance_mode "mul": token = alpha*acc + bp + PE)
-struct EpiImpProj {
-  template <int WTM, int WTN>
-  __device__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
-#pragma unroll
-    for (int i = 0; i < WTM; ++i)
-#pragma unroll
-      for (int j = 0; j < WTN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
-
-  const float* b1; const float* w2; float b2;
-  const float* bp;                 // proj_in bias [d]
-  const float* special;            // special token [d]
-  const float* div_term;           // 2d: [d/4] ; 1d: [d/2]   (host: torch.exp(arange * -ln(1e4)/d), utils.py:18,56)
-  const int64_t* locs;             // [M,2] pixel coords (2d mode)
-  const int64_t* num_ims;          // [B]
-  int rows_per_slide;              // N
-  int patch_size;
-  int pe_mode;                     // 2 = "2d", 1 = "1d"
-  int imp_mul;                     // importance_mode == "mul"
-  float* importance;               // [M]
-  float* tokens;                   // [B, N+1, d]
-  float* hid_out;                  // optional (training): relu(Y W1^T + b1) [M,128]
-  float* pproj_out;                // optional (training): Y Wp^T (before alpha / bias / PE) [M,128]
-  template <int WTM, int WTN, int WGM, int WGN>
-  __device__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int wm, int wn, int M, float* smem) const {
-    static_assert(WTM == 1 && WTN == 4 && WGN == 2, "imp/proj epilogue layout");
-    constexpr int d = 128;
-    float* alpha_s = smem;                       // [WGM*32] (main loop is done; LDS is free after its last barrier)
-    if (wn == 0) {
-      float part[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[r] = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int col = 32 * j + (lane & 31);
-        const float b = b1[col], w = w2[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float hv = fmaxf(acc[0][j][r] + b, 0.f);
-          part[r] += hv * w;
-          if (hid_out && row0 + c32_row(r, lane) < M) hid_out[(int64_t)(row0 + c32_row(r, lane)) * 128 + col] = hv;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = part[r];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-        const int lrow = c32_row(r, lane);
-        const int row = row0 + lrow;
-        float a = 0.f;
-        if (row < M) {
-          const int b = row / rows_per_slide, idx = row % rows_per_slide;
-          if (idx < (int)num_ims[b]) a = sigmoid_acc(v + b2);
-          if ((lane & 31) == 0) importance[row] = a;
-        }
-        if ((lane & 31) == 0) alpha_s[wm * 32 + lrow] = a;
-      }
-    }
-    __syncthreads();
-    if (wn == 1) {
-      int64_t lx[16], ly[16];               // all position loads first (see the epilogue note above)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowc = min(row0 + c32_row(r, lane), M - 1);
-        lx[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc] : 0;
-        ly[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc + 1] : 0;
-      }
-      float bpv[4], dtv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 32 * j + (lane & 31);
-        bpv[j] = bp[c];
-        dtv[j] = pe_mode == 2 ? div_term[(c & (d / 2 - 1)) >> 1] : div_term[c >> 1];
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = c32_row(r, lane);
-        const int row = row0 + lrow;
-        if (row >= M) continue;
-        const int b = row / rows_per_slide, idx = row % rows_per_slide;
-        const float a = imp_mul ? alpha_s[wm * 32 + lrow] : 1.f;
-        float px = 0.f, py = 0.f;
-        if (pe_mode == 2) {
-          px = (float)(lx[r] / patch_size);
-          py = (float)(ly[r] / patch_size);
-        } else {
-          px = (float)idx;
-        }
-        float* trow = tokens + ((int64_t)b * (rows_per_slide + 1) + idx + 1) * d;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = 32 * j + (lane & 31);
-          const float pos = (pe_mode == 2 && c >= d / 2) ? py : px;
-          const float ang = pos * dtv[j];
-          const float pe = (c & 1) ? cosf(ang) : sinf(ang);
-          trow[c] = a * acc[0][j][r] + bpv[j] + pe;
-          if (pproj_out) pproj_out[(int64_t)row * 128 + c] = acc[0][j][r];
-          if (idx == 0) tokens[(int64_t)b * (rows_per_slide + 1) * d + c] = special[c];
-        }
-      }
-    }
-  }
-};
-
 template <int WTM, int WTN, int WGM, int WGN, class Epi>
 int launch_gemm(const GemmOperands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
   constexpr int BM = WTM * 32 * WGM, BN = WTN * 32 * WGN;
@@ -488,6 +184,16 @@ int launch_gemm(const GemmOperands& g, int Npad, const Epi& epi, hipStream_t str
   hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, stream, g, epi);
   PATHS_LAUNCH_CHECK(name);
   return PATHS_OK;
+}
+
+// PE table: out[pos][c] = c odd ? cosf(pos * div[c >> 1]) : sinf(pos * div[c >> 1]),  c < W (W = d/2 for "2d", d for "1d"):
+// exactly the expressions of EpiImpProj, evaluated once per (position, channel) instead of once per token element.
+__global__ void pe_table_kernel(const float* __restrict__ div_term, int W, int rows, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * W) return;
+  const int pos = i / W, c = i % W;
+  const float ang = (float)pos * div_term[c >> 1];
+  out[i] = (c & 1) ? cosf(ang) : sinf(ang);
 }
 
 }  // namespace
@@ -540,7 +246,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
 
 int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256, D]: W1 ; Wp*/,
                           const float* b1, const float* w2, float b2, const float* bp, const float* special,
-                          const float* div_term, const int64_t* locs, const int64_t* num_ims,
+                          const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims,
                           int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                           float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
                           int skip_padding, hipStream_t stream) {
@@ -550,8 +256,17 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256,
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj: bad slide layout");
   GemmOperands g{y, ldy, D, nullptr, 0, 0, w_ip, D, M, skip_padding ? num_ims : nullptr, rows_per_slide};
   EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-               save_hid, save_pproj};
+               save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0};
   return launch_gemm<1, 4, 2, 2>(g, 256, e, stream, "importance_proj");
+}
+
+// positional-encoding table for paths_importance_proj(_x6): out [rows, d/2] (pe_mode 2) or [rows, d] (pe_mode 1)
+int paths_pe_table(const float* div_term, int pe_mode, int d, int rows, float* out, hipStream_t stream) {
+  PATHS_REQUIRE((pe_mode == 1 || pe_mode == 2) && d > 0 && d % 4 == 0 && rows > 0, "pe_table: bad arguments");
+  const int W = pe_mode == 2 ? d / 2 : d;
+  hipLaunchKernelGGL(pe_table_kernel, dim3((rows * W + 255) / 256), dim3(256), 0, stream, div_term, W, rows, out);
+  PATHS_LAUNCH_CHECK("pe_table");
+  return PATHS_OK;
 }
 
 // out[M,N] = act(A[M,K] * W[N,K]^T + b).  W rows must be padded (zero rows) to a multiple of 128.

@@ -1,0 +1,402 @@
+// fp32-accurate GEMM on the CDNA4 bf16 matrix cores ("bf16x6"), with the fused epilogues of gemm_epi.h.
+//
+//   C[M, N] = [A0 | A1][M, K0+K1] * W[N, K0+K1]^T        same contract as gemm_f32.hip, same epilogues
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  Every fp32 value is the exact sum of three bf16
+// (8 significant bits each = the 24 of fp32): x = hi + mid + lo.  Then
+//     x*w = hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid) + [mid*lo + lo*mid + lo*lo <= 2^-25 |x w|]
+// and the six kept products are exact in the MFMA's fp32 accumulator: 6 v_mfma_f32_32x32x16_bf16 (32 cycles each) replace
+// 8 v_mfma_f32_32x32x2_f32 (64 cycles each) per 32x32x16 block = 2.67x the fp32-MFMA peak, with an error that is
+// measurably NOT larger than an fp32 FMA chain's (tools/x6_bench.hip: rms 2.8e-7 vs 3.4e-7 against fp64 at K = 1024;
+// tests/test_gpu_parity.py::test_x6_gemm_matches_fp64).  Products are accumulated smallest first.
+//
+// Data movement (what the microbenchmark showed matters on gfx950):
+//   * A stays fp32 in HBM (no extra pass, no extra bytes): each thread loads 4 consecutive k of one row, splits them in
+//     registers (v_cvt_pk_bf16_f32 + exact residuals, ~22 VALU ops riding in MFMA gaps) and writes the three planes to LDS.
+//   * W is split once at pack time (paths_x6_pack_weights) into the MFMA-native tiled image
+//         [n/32][k/16][plane 3][k-half 2][n%32][8 bf16]
+//     where one 32-row x 16-k x 1-plane fragment is 1 KiB and lane l owns bytes [16 l, 16 l + 16): every W load
+//     instruction is 1 KiB contiguous (8 full lines; the row-major split image cost 4x the TA line look-ups and capped
+//     the loop at 58 % MFMA busy), every LDS fragment read is lane-linear = conflict-free, no padding.
+//   * one workgroup = 4 waves (2 x 2), ONE wave per SIMD with the whole 512-register file (WTM x WTN accumulator tiles
+//     in AGPRs), BM x BN = 64 WTM x 64 WTN (256 x 256 for the gate GEMMs), k16 stages double-buffered in LDS, one
+//     barrier per stage, global loads issued a full stage (>= 3,000 cycles) before their LDS write.
+//   * every non-MFMA instruction is pinned into a gap between two MFMAs (sched_barrier after each), at most two LDS
+//     operations per gap; the last accumulator row of a stage runs after the barrier to cover the next stage's first
+//     fragment reads.
+// Measured (MI355X, M = 16384, N = K = 1024): 152 us = 226 TFLOP/s fp32-equivalent (1.36 PFLOP/s of bf16 MFMA issue,
+// 86 % MFMA-busy in the loop at the 1.7-1.9 GHz the chip holds under this load) vs 281 us on the f32 MFMA.
+#include "common.h"
+#include "gemm_epi.h"
+
+namespace {
+using namespace paths_epi;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: round to nearest even
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+constexpr int FRAG = 1024;         // bytes of one 32-row x 16-k fragment of one plane
+constexpr int SUBT = 3 * FRAG;     // one 32-row x 16-k sub-tile: hi | mid | lo
+
+struct X6Operands {
+  const float* A0; int64_t lda0; int K0;
+  const float* A1; int64_t lda1; int K1;
+  const char* Wt;                  // packed weights, already advanced to the first 32-row group and first k16 step used
+  int64_t w_group_stride;          // bytes between consecutive 32-row groups (= K_packed / 16 * SUBT)
+  int M;
+  const int64_t* num_ims;          // optional padding skip
+  int rows_per_slide;
+#ifdef PATHS_X6_DEBUG
+  uint64_t* dbg;                   // tools/x6_stages.py only: per-wave {init, loop, epilogue} shader-clock ticks, 100 MHz ticks, start/end 100 MHz stamps
+#endif
+};
+#ifdef PATHS_X6_DEBUG
+uint64_t* g_x6_dbg = nullptr;
+#endif
+
+// PF = how many stages ahead of its LDS write a stage is loaded into registers (1 or 2 register sets).  Stages of the
+// 128-row tiles are only ~1,500 cycles long, shorter than a loaded-L2 round trip, so those run two stages ahead.
+template <int WTM, int WTN, int PF, class Epi>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+gemm_x6_kernel(X6Operands g, Epi epi) {
+  constexpr int BM = WTM * 64, BN = WTN * 64;
+  constexpr int SA = 2 * WTM, SB = 2 * WTN;            // 32-row sub-tiles per block
+  constexpr int STAGE = (SA + SB) * SUBT;
+  constexpr int NA = BM / 64;                          // fp32 A chunks (4 floats) per thread per stage
+  constexpr int NPB = SB * 3, NB = (NPB + 3) / 4;      // 1-KiB W pieces per stage, per wave
+  static_assert(WTM % 2 == 0, "A fragment register slots alternate per accumulator row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware tile order (speed only): XCD x (= linear id % 8) owns a contiguous run of the tile sequence, column-block
+  // fastest within groups of GM row-blocks, so the workgroups of one XCD re-use A and W stages from its private L2.
+  const int nbx = gridDim.x, nby = gridDim.y, nblk = nbx * nby;
+  int lin = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = lin & 7, j = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective for any nblk
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * nbx;
+  const int grp = lin / per_group, in_grp = lin - grp * per_group;
+  const int rows_in_grp = min(GM, nby - grp * GM);
+  const int by = grp * GM + in_grp % rows_in_grp, bx = in_grp / rows_in_grp;
+  const int m0 = by * BM, n0 = bx * BN;
+  if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M)) return;
+#ifdef PATHS_X6_DEBUG
+  const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t dbg_t1 = 0, dbg_t2 = 0;
+#endif
+
+  // ---- staging addresses.  A: thread -> (row = 64 p + tid/4, floats 4 (tid%4) .. +3 of the stage); 32-bit byte offsets
+  // against a wave-uniform panel base.  W: wave -> 1-KiB pieces wave + 4 i of the stage's SB x 3 fragments.
+  const int arow = tid >> 2, ac = tid & 3;
+  uint32_t aoff0[NA], aoff1[NA]; int awr[NA];
+#pragma unroll
+  for (int p = 0; p < NA; ++p) {
+    const int row = p * 64 + arow;
+    const int64_t grow = min(m0 + row, g.M - 1);
+    aoff0[p] = (uint32_t)((grow * g.lda0 + 4 * ac) * 4);
+    aoff1[p] = (uint32_t)((grow * g.lda1 + 4 * ac) * 4);
+    awr[p] = (row >> 5) * SUBT + (ac >> 1) * 512 + (row & 31) * 16 + (ac & 1) * 8;
+  }
+  const int nk0 = g.K0 >> 4, nk = (g.K0 + g.K1) >> 4;
+  const char* bbase[NB]; int bwr[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int pc = wave + 4 * i;
+    if (pc >= NPB) pc -= 4;                            // re-stage this wave's previous piece (same bytes, same slot)
+    const int sub = pc / 3, pl = pc % 3;
+    bbase[i] = g.Wt + ((int64_t)(n0 >> 5) + sub) * g.w_group_stride + pl * FRAG;
+    bwr[i] = (SA + sub) * SUBT + pl * FRAG + lane * 16;
+  }
+  static_assert(PF == 1 || PF == 2, "one or two register sets");
+  f32x4 sa[PF][NA]; u32x4 sbr[PF][NB];
+  uint32_t hi[NA][2], mid[NA][2], lo[NA][2];
+  typedef const f32x4 __attribute__((address_space(1))) * gptr_f4;
+  typedef const u32x4 __attribute__((address_space(1))) * gptr_u4;
+  auto gload_a = [&](int set, int q, int kt) {
+    const bool first = kt < nk0;                       // wave-uniform panel select: scalar base + per-lane 32-bit offset
+    const char* base = reinterpret_cast<const char*>(first ? g.A0 : g.A1) + (int64_t)(first ? kt : kt - nk0) * 64;
+    sa[set][q] = *reinterpret_cast<gptr_f4>(reinterpret_cast<uintptr_t>(base + (first ? aoff0[q] : aoff1[q])));
+  };
+  auto gload_b = [&](int set, int q, int kt) {
+    sbr[set][q] = *reinterpret_cast<gptr_u4>(reinterpret_cast<uintptr_t>(bbase[q] + (int64_t)kt * SUBT + lane * 16));
+  };
+  // split of one staged A chunk in 7 small steps (each <= 4 VALU ops, so that they ride in MFMA gaps); every residual is exact
+  auto a_step = [&](int set, int q, int st, int buf) __attribute__((always_inline)) {
+    f32x4& v = sa[set][q];
+    if (st == 0) { hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]); }
+    if (st == 1) { v[0] -= bf_lo(hi[q][0]); v[1] -= bf_hi(hi[q][0]); }
+    if (st == 2) { v[2] -= bf_lo(hi[q][1]); v[3] -= bf_hi(hi[q][1]); }
+    if (st == 3) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
+    if (st == 4) { v[0] -= bf_lo(mid[q][0]); v[1] -= bf_hi(mid[q][0]); }
+    if (st == 5) { v[2] -= bf_lo(mid[q][1]); v[3] -= bf_hi(mid[q][1]); }
+    if (st == 6) {
+      lo[q][0] = pk_bf16(v[0], v[1]); lo[q][1] = pk_bf16(v[2], v[3]);
+      char* d = smem + buf * STAGE + awr[q];
+      *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
+      *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
+      *reinterpret_cast<u32x2*>(d + 2 * FRAG) = u32x2{lo[q][0], lo[q][1]};
+    }
+  };
+  auto swrite_b = [&](int set, int q, int buf) { *reinterpret_cast<u32x4*>(smem + buf * STAGE + bwr[q]) = sbr[set][q]; };
+
+  // accumulators start from the epilogue's initial value (zero, or the once-per-parent partial pre-activation)
+  f32x16 acc[WTM][WTN];
+  epi.template init<WTM, WTN>(acc, m0 + wm * WTM * 32, n0 + wn * WTN * 32, lane, g.M);
+
+  const char* sA = smem + (wm * WTM) * SUBT + lane * 16;
+  const char* sB = smem + (SA + wn * WTN) * SUBT + lane * 16;
+  bf16x8 fa[2][3], fb[2][WTN][3];
+  auto read_a = [&](int buf, int i, int slot, int p) { fa[slot][p] = *reinterpret_cast<const bf16x8*>(sA + buf * STAGE + i * SUBT + p * FRAG); };
+  auto read_b = [&](int buf, int j, int slot, int p) { fb[slot][j][p] = *reinterpret_cast<const bf16x8*>(sB + buf * STAGE + j * SUBT + p * FRAG); };
+  constexpr int RG = WTN * 6;                          // MFMA gaps per accumulator row
+  auto one_mfma = [&](int gq, int sb) __attribute__((always_inline)) {
+    const int i = gq / RG, j = (gq % RG) / 6, t = gq % 6, sl = i & 1;
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sl][PA_[t]], fb[sb][j][PB_[t]], acc[i][j], 0, 0, 0);
+  };
+  // Staging slots before the barrier: A chunk q owns slots 8q .. 8q+7 (7 split steps, then its reload for stage kt+2);
+  // W piece q owns slots 8 NA + 2q (LDS write) and + 2q + 1 (reload).  SPG slots share one MFMA gap.
+  constexpr int TS = 8 * NA + 2 * NB, AG = (WTM - 1) * RG, SPG = (TS + AG - 1) / AG;
+  static_assert(SPG <= 2, "staging does not fit before the barrier");
+  constexpr int AR0 = RG / 2;                          // gaps AR0 .. AR0+2 of row i: fragment reads of A row i+1
+  auto stage_body = [&](int kt, auto bufc, auto m1c, auto m2c) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value, sb = buf;
+    constexpr bool more1 = decltype(m1c)::value, more2 = decltype(m2c)::value;
+    constexpr int set = PF == 2 ? (buf ^ 1) : 0;       // register set holding stage kt+1 (reloaded with stage kt+1+PF)
+    static_for<0, AG>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int gq = decltype(gc)::value, i = gq / RG, gr = gq % RG;
+      one_mfma(gq, sb);
+      if constexpr (gr >= AR0 && gr < AR0 + 3) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
+      static_for<gq * SPG, gq * SPG + SPG>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s < 8 * NA) {
+          if constexpr (more1 && s % 8 < 7) a_step(set, s / 8, s % 8, buf ^ 1);
+          if constexpr (more2 && s % 8 == 7) gload_a(set, s / 8, kt + 1 + PF);
+        } else if constexpr (s < TS) {
+          constexpr int q = (s - 8 * NA) / 2;
+          if constexpr (more1 && (s - 8 * NA) % 2 == 0) swrite_b(set, q, buf ^ 1);
+          if constexpr (more2 && (s - 8 * NA) % 2 == 1) gload_b(set, q, kt + 1 + PF);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<AG, WTM * RG>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int gq = decltype(gc)::value, gr = gq % RG;
+      one_mfma(gq, sb);
+      if constexpr (more1) {
+        static_for<2 * gr, 2 * gr + 2>([&](auto fc) __attribute__((always_inline)) {
+          constexpr int f = decltype(fc)::value;
+          if constexpr (f < 3) read_a(buf ^ 1, 0, 0, f);
+          else if constexpr (f < 3 + 3 * WTN) read_b(buf ^ 1, (f - 3) / 3, sb ^ 1, (f - 3) % 3);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  constexpr std::integral_constant<int, 0> I0{};
+  constexpr std::integral_constant<int, 1> I1{};
+  constexpr std::true_type T{};
+  constexpr std::false_type F{};
+
+  // prologue: stage 0 -> LDS buffer 0, stages 1 .. PF -> register sets
+#pragma unroll
+  for (int q = 0; q < NA; ++q) gload_a(0, q, 0);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) gload_b(0, q, 0);
+#pragma unroll
+  for (int q = 0; q < NA; ++q)
+#pragma unroll
+    for (int st = 0; st < 7; ++st) a_step(0, q, st, 0);
+#pragma unroll
+  for (int q = 0; q < NB; ++q) swrite_b(0, q, 0);
+#pragma unroll
+  for (int sidx = 1; sidx <= PF; ++sidx) {
+#pragma unroll
+    for (int q = 0; q < NA; ++q) gload_a(PF == 2 ? (sidx & 1) : 0, q, sidx);
+#pragma unroll
+    for (int q = 0; q < NB; ++q) gload_b(PF == 2 ? (sidx & 1) : 0, q, sidx);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 3; ++p) read_a(0, 0, 0, p);
+#pragma unroll
+  for (int j = 0; j < WTN; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) read_b(0, j, 0, p);
+#ifdef PATHS_X6_DEBUG
+  dbg_t1 = __builtin_amdgcn_s_memtime();
+#endif
+  for (int kt = 0; kt < nk - 2 * PF; kt += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+    stage_body(kt, I0, T, T);
+    stage_body(kt + 1, I1, T, T);
+  }
+  if constexpr (PF == 2) {
+    stage_body(nk - 4, I0, T, T);
+    stage_body(nk - 3, I1, T, F);
+  }
+  stage_body(nk - 2, I0, T, F);
+  stage_body(nk - 1, I1, F, F);
+#ifdef PATHS_X6_DEBUG
+  dbg_t2 = __builtin_amdgcn_s_memtime();
+#endif
+  __syncthreads();     // epilogues may reuse LDS
+  epi.template run<WTM, WTN, 2, 2>(acc, m0 + wm * WTM * 32, n0 + wn * WTN * 32, lane, wm, wn, g.M, reinterpret_cast<float*>(smem));
+#ifdef PATHS_X6_DEBUG
+  if (g.dbg) {
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint64_t t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      uint64_t* d = g.dbg + 6 * ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
+      d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t2 - dbg_t1; d[2] = t3 - dbg_t2; d[3] = r3 - dbg_r0; d[4] = dbg_r0; d[5] = r3;
+    }
+  }
+#endif
+}
+
+// fp32 [N, K] (row stride ldw) -> split tiled image, rows >= N zero
+__global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, __bf16* __restrict__ out, int N, int Npad, int K) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Npad * K) return;
+  const int n = (int)(i / K), k = (int)(i % K);
+  const float v = n < N ? w[(int64_t)n * ldw + k] : 0.f;
+  const __bf16 h = (__bf16)v; const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
+  const __bf16 l = (__bf16)r2;
+  __bf16* o = out + ((int64_t)(n >> 5) * (K >> 4) + (k >> 4)) * (SUBT / 2) + ((k >> 3) & 1) * 256 + (n & 31) * 8 + (k & 7);
+  o[0] = h; o[FRAG / 2] = m; o[FRAG] = l;
+}
+
+template <int WTM, int WTN, int PF, class Epi>
+int launch_x6(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
+  constexpr int BM = WTM * 64, BN = WTN * 64;
+  constexpr size_t lds = 2ull * (2 * WTM + 2 * WTN) * SUBT;
+  const int K = g.K0 + g.K1;
+  PATHS_REQUIRE(g.M > 0, "%s: M must be > 0", name);
+  PATHS_REQUIRE(g.K0 > 0 && g.K0 % 16 == 0 && g.K1 % 16 == 0 && K % 32 == 0 && K >= 128, "%s: K panels (%d,%d): multiples of 16, total a multiple of 32, >= 128", name, g.K0, g.K1);
+  PATHS_REQUIRE(Npad % BN == 0, "%s: packed N (%d) must be a multiple of %d", name, Npad, BN);
+  PATHS_REQUIRE(g.lda0 % 4 == 0 && g.lda1 % 4 == 0, "%s: leading dims must be multiples of 4 floats", name);
+  PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Wt % 16 == 0), "%s: operands must be 16-byte aligned", name);
+  PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? g.lda0 : g.lda1) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
+  auto kern = gemm_x6_kernel<WTM, WTN, PF, Epi>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(Npad / BN, (g.M + BM - 1) / BM);
+#ifdef PATHS_X6_DEBUG
+  X6Operands gd = g; gd.dbg = g_x6_dbg;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, gd, epi);
+#else
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g, epi);
+#endif
+  PATHS_LAUNCH_CHECK(name);
+  return PATHS_OK;
+}
+
+inline int64_t group_stride(int Kpacked) { return (int64_t)(Kpacked / 16) * SUBT; }
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+#ifdef PATHS_X6_DEBUG
+// development hook (tools/x6_stages.py, debug build only): buffer of 6 uint64 per wave, or NULL
+void paths_x6_debug_buffer(uint64_t* p) { g_x6_dbg = p; }
+#endif
+
+// bytes of the packed image of an [Npad, K] weight
+int64_t paths_x6_packed_bytes(int Npad, int K) { return (int64_t)Npad * K * 6; }
+
+// w [N, K] fp32 (row stride ldw) -> out (paths_x6_packed_bytes(Npad, K) bytes); Npad % 32 == 0, K % 16 == 0
+int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, hipStream_t stream) {
+  PATHS_REQUIRE(N > 0 && Npad >= N && Npad % 32 == 0 && K % 16 == 0, "x6_pack_weights: bad shape N=%d Npad=%d K=%d", N, Npad, K);
+  PATHS_REQUIRE((uintptr_t)out % 16 == 0, "x6_pack_weights: out must be 16-byte aligned");
+  const int64_t n = (int64_t)Npad * K;
+  hipLaunchKernelGGL(x6_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, ldw, reinterpret_cast<__bf16*>(out), N, Npad, K);
+  PATHS_LAUNCH_CHECK("x6_pack_weights");
+  return PATHS_OK;
+}
+
+// paths_lstm_cell with the gate / mem_to_out weights given as x6-packed images:
+//   w_gates_x6 = pack([3Hc + D, 2D] packed gate rows, see paths_lstm_cell), w_mem_x6 = pack([D, Hc])
+int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
+                       const void* w_gates_x6, const float* b_gates, const void* w_mem_x6, const float* b_mem,
+                       float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
+                       const float* hp, const int* hp_row, int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide,
+                       int phases, hipStream_t stream) {
+  PATHS_REQUIRE(D % 256 == 0 && Hc % 64 == 0, "lstm_cell_x6: D (%d) must be a multiple of 256 and Hc (%d) of 64", D, Hc);
+  PATHS_REQUIRE(hp != nullptr || (h0 == nullptr) == (c0 == nullptr), "lstm_cell_x6: h0 and c0 must both be given or both be null");
+  PATHS_REQUIRE((hp == nullptr) == (hp_row == nullptr) && (hp == nullptr || h0 == nullptr),
+                "lstm_cell_x6: hp/hp_row come together and replace h0 (the h half of the gate GEMM was done per parent)");
+  const char* wg = reinterpret_cast<const char*>(w_gates_x6);
+  const int64_t gs = group_stride(2 * D);
+  X6Operands g{x, ldx, D, h0, h0 ? ldh0 : 0, h0 ? D : 0, wg, gs, M, num_ims, rows_per_slide};
+  if (phases & 1) {   // c-part: N = 3Hc, block 256 x 192
+    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row};
+    int rc = launch_x6<4, 3, 1>(g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
+    if (rc) return rc;
+  }
+  if (phases & 2) {   // o gate: N = D, block 256 x 256
+    X6Operands go = g;
+    go.Wt = wg + (int64_t)(3 * Hc / 32) * gs;
+    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc};
+    int rc = launch_x6<4, 4, 1>(go, D, e, stream, "lstm_cell_x6(o)");
+    if (rc) return rc;
+  }
+  if (phases & 4) {   // h1 = o * tanh(Wc c1 + bc), Y = X + h1
+    X6Operands gh{state_out + D, ldso, Hc, nullptr, 0, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(Hc), M, num_ims, rows_per_slide};
+    EpiLstmH e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
+    int rc = launch_x6<4, 4, 1>(gh, D, e, stream, "lstm_cell_x6(h)");
+    if (rc) return rc;
+  }
+  return PATHS_OK;
+}
+
+// paths_importance_proj with w_ip_x6 = pack([W1 ; Wp] = [256, D])
+int paths_importance_proj_x6(const float* y, int64_t ldy, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+                             const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs,
+                             const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
+                             float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
+                             int skip_padding, hipStream_t stream) {
+  PATHS_REQUIRE(Hi == 128 && d == 128, "importance_proj_x6: this build supports importance_mlp_hidden_dim=128, trans_dim=128 (got %d, %d)", Hi, d);
+  PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj_x6: pe_mode must be 1 (1d) or 2 (2d)");
+  PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj_x6: 2d positional encoding needs locs");
+  PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj_x6: bad slide layout");
+  X6Operands g{y, ldy, D, nullptr, 0, 0, reinterpret_cast<const char*>(w_ip_x6), group_stride(D), M, skip_padding ? num_ims : nullptr, rows_per_slide};
+  EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
+               save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0};
+  return launch_x6<2, 4, 2>(g, 256, e, stream, "importance_proj_x6");
+}
+
+// out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual with W given as the x6-packed image of an [Npad, Kpacked]
+// weight; k0 selects the column window [k0, k0 + K) of it (k0 % 16 == 0), Npad % 256 == 0.
+int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
+                     int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
+                     int64_t ldm, int accumulate, hipStream_t stream) {
+  PATHS_REQUIRE(k0 % 16 == 0 && k0 >= 0 && k0 + K <= Kpacked, "gemm_nt_x6: bad k window");
+  X6Operands g{a, lda, K, nullptr, 0, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * SUBT, group_stride(Kpacked), M, nullptr, 0};
+  EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate};
+  return launch_x6<2, 4, 2>(g, Npad, e, stream, "gemm_nt_x6");
+}
+
+}  // extern "C"

@@ -108,6 +108,7 @@ class DeviceSlideBatch:
         self.gx = table(lambda s, l: s.shape(l)[0], torch.int32)
         self.gy = table(lambda s, l: s.shape(l)[1], torch.int32)
         self.n0 = max(s.shape(0)[0] * s.shape(0)[1] for s in self.slides)
+        self.max_dim = [max(max(s.shape(l)) for s in self.slides) for l in range(L)]   # bound of locs // patch_size per level
 
     def __len__(self):
         return len(self.slides)

@@ -15,6 +15,7 @@ Per level (B slides, N padded rows, D features, T = N+1 tokens) the launch seque
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -23,6 +24,47 @@ from . import _lib
 
 LOG2E = 1.4426950408889634
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
+# Which matrix pipe the big GEMMs of the selection chain use (both are HIP kernels of libpaths_hip.so, both fp32-accurate):
+#   "x6"  : split-bf16 GEMM (csrc/gemm_x6.hip, 6 bf16 MFMAs per fp32 product block)  - default
+#   "f32" : f32-input MFMA GEMM (csrc/gemm_f32.hip)
+GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "x6")
+
+
+def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
+    """fp32 [N, K] device weight -> its split-bf16 tiled image (paths_x6_pack_weights), as a byte tensor."""
+    assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    n_pad = N if n_pad is None else n_pad
+    out = torch.empty((n_pad * K * 6,), device=w.device, dtype=torch.uint8)
+    _lib.call("paths_x6_pack_weights", _lib.ptr(w), w.stride(0), _lib.ptr(out), N, n_pad, K, _lib.stream())
+    return out
+
+
+def _x6_of(pack: Dict[str, object], key: str) -> torch.Tensor:
+    """Packed image of pack[key], built on first use and cached beside it (the pack dict is rebuilt when weights change)."""
+    k6 = key + "_x6"
+    if k6 not in pack:
+        pack[k6] = x6_pack(pack[key])
+    return pack[k6]
+
+
+def pe_table(lvl_pack: Dict[str, object], pe_mode: int, d: int, rows: int) -> torch.Tensor:
+    """[cap >= rows, d/2 or d] table of the positional-encoding sin/cos values (paths_pe_table), cached beside the weights."""
+    key = f"pe_table_{pe_mode}"
+    tab = lvl_pack.get(key)
+    if tab is None or tab.shape[0] < rows:
+        cap = 1 << max(6, (rows - 1).bit_length())
+        div = lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]
+        tab = torch.empty((cap, d // 2 if pe_mode == 2 else d), device=div.device, dtype=torch.float32)
+        _lib.call("paths_pe_table", _lib.ptr(div), pe_mode, d, cap, _lib.ptr(tab), _lib.stream())
+        lvl_pack[key] = tab
+    return tab
+
+
+def use_x6(D: int, Hc: int = 64) -> bool:
+    if GEMM_MODE not in ("x6", "f32"):
+        raise ValueError(f"PATHS_GEMM_MODE must be 'x6' or 'f32' (got {GEMM_MODE!r})")
+    return GEMM_MODE == "x6" and D % 256 == 0 and Hc % 64 == 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -136,9 +178,12 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
 
 def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool,
-                      parent=None) -> Dict[str, torch.Tensor]:
+                      parent=None, max_pos: int = 0) -> Dict[str, torch.Tensor]:
     """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
     (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims.
+
+    ``max_pos`` (optional): an upper bound (exclusive) of ``locs // patch_size`` known to the caller (the grid size of the level);
+    positional-encoding values are then read from a cached table instead of evaluated per token element.
 
     ``parent`` (device recursion only) = {"hp": [rows, 3Hc+D], "hp_row": [B,N] int32, "c0": [B,N,Hc]}: the up-to-4 children
     of a kept patch share the parent's h, so the h half of the gate GEMM is computed once per kept PARENT
@@ -160,9 +205,15 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
     tokens = torch.empty((B, T, d), **f32)
 
+    x6 = use_x6(D, lstm_pack["Hc"] if mc.lstm else 64)
+    pe_rows = N if pe_mode == 1 else int(max_pos)
+    pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
+
     def importance_proj(src, imp_mul, imp_out):
-        _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
-                  p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs),
+        _lib.call("paths_importance_proj_x6" if x6 else "paths_importance_proj", p(src), D,
+                  p(_x6_of(lvl_pack, "w_ip") if x6 else lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
+                  p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]),
+                  p(pe_tab), pe_tab.shape[0] if pe_tab is not None else 0, p(locs),
                   p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), None, None,
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
 
@@ -189,16 +240,17 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             ld, h0, c0 = 0, None, None
 
         def lstm(phases):
-            _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
-                      p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D, p(ws_o), None, None, hp, hp_row,
-                      M, D, Hc, nim, N, phases, st)
+            _lib.call("paths_lstm_cell_x6" if x6 else "paths_lstm_cell", p(fts), D, h0, ld, c0, ld,
+                      p(_x6_of(lstm_pack, "w_gates") if x6 else lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
+                      p(_x6_of(lstm_pack, "w_mem") if x6 else lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D,
+                      p(ws_o), None, None, hp, hp_row, M, D, Hc, nim, N, phases, st)
 
         if KERNEL_TIMER is None:
             lstm(7)
         else:                   # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
             lstm(1)
             KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D,
-                                                          "parent_partials": parent is not None})
+                                                          "parent_partials": parent is not None, "x6": x6})
             lstm(4)
         importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance)
         del ws_o
@@ -239,8 +291,12 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
     hk = torch.empty((B * cap, D), **f32)
     _lib.call("paths_gather_kept_rows", p(state_out), N, Dp, p(keep_idx), cap, p(keep_count), D, B, p(hk), st)
     hp = torch.empty((B * cap, G), **f32)
-    _lib.call("paths_gemm_nt_f32", p(hk), D, lstm_pack["w_gates"].data_ptr() + 4 * D, 2 * D, None, p(hp), G, B * cap, G, G, D, 0,
-              None, 0, None, 0, 0, st)
+    if use_x6(D, Hc) and G % 256 == 0:
+        _lib.call("paths_gemm_nt_x6", p(hk), D, p(_x6_of(lstm_pack, "w_gates")), 2 * D, D, None, p(hp), G, B * cap, G, G, D, 0,
+                  None, 0, None, 0, 0, st)
+    else:
+        _lib.call("paths_gemm_nt_f32", p(hk), D, lstm_pack["w_gates"].data_ptr() + 4 * D, 2 * D, None, p(hp), G, B * cap, G, G, D, 0,
+                  None, 0, None, 0, 0, st)
     return hp
 
 

@@ -93,7 +93,8 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     for i in range(num_levels):
         proc = model.procs[i]
         lvl_pack = ops.pack_level(proc)
-        sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent)
+        sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
+                                    max_pos=batch.max_dim[i])
         ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
         ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
         agg = ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)

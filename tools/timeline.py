@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise one recursion from a rocprofv3 kernel-trace CSV: per-kernel durations by call position + idle gaps."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv') + glob.glob(sys.argv[1] + '/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'level0_kernel' in r['Kernel_Name']]
