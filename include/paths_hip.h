@@ -77,8 +77,9 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh
                        float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
                        const float* hp, const int* hp_row,
                        int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, paths_stream_t stream);
-/* w_ip_x6 = pack of [256, D] */
-int paths_importance_proj_x6(const float* y, int64_t ldy, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+/* w_ip_x6 = pack of [256, D]; y_add (optional): GEMM input = y + y_add summed in fp32 while staging, so that the caller can
+ * pass (x, h1) and skip materialising Y = X + h1 (paths_lstm_cell_x6 accepts y = NULL for that) */
+int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows,
                              const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,

@@ -44,11 +44,22 @@ __device__ __forceinline__ float rcp_nr(float d) {
   const float r = __builtin_amdgcn_rcpf(d);
   return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
+// e^x, <= 1 ulp: exp2 of x*log2(e) with the product carried in two floats (hi + lo), the integer part applied by ldexp.
+// libm's expf is this plus range checks (2 compares + 2 selects per call) that the callers' clamps already make redundant:
+// v_exp_f32 / v_ldexp_f32 saturate to +inf and 0 by themselves.
+__device__ __forceinline__ float exp_acc(float x) {
+  const float l2e_hi = 1.44269502162933349609375f, l2e_lo = 1.925963033500011306e-8f;   // log2(e) = hi + lo
+  const float ph = x * l2e_hi;
+  const float pl = fmaf(x, l2e_lo, fmaf(x, l2e_hi, -ph));
+  const float e = rintf(ph);
+  const float r = __builtin_amdgcn_exp2f((ph - e) + pl);
+  return __builtin_amdgcn_ldexpf(r, (int)e);
+}
 // the clamp keeps d finite (exp overflow would turn the Newton step into inf*0); sigmoid(-69) = 1e-30 either way
-__device__ __forceinline__ float sigmoid_acc(float x) { return rcp_nr(1.0f + fminf(expf(-x), 1e30f)); }
+__device__ __forceinline__ float sigmoid_acc(float x) { return rcp_nr(1.0f + fminf(exp_acc(-x), 1e30f)); }
 // branch-free tanh: 1 - 2/(1+e^{2x}); absolute error ~1e-7 (what the h = o*tanh(.) and c-update chains need),
 // saturates correctly at +-1 (e^{2x} -> inf / 0).  libm's tanhf branches per lane and serialises epilogues.
-__device__ __forceinline__ float tanh_acc(float x) { return 1.0f - 2.0f * rcp_nr(1.0f + fminf(expf(2.0f * x), 1e30f)); }
+__device__ __forceinline__ float tanh_acc(float x) { return 1.0f - 2.0f * rcp_nr(1.0f + fminf(exp_acc(2.0f * x), 1e30f)); }
 
 // ---- MFMA wrappers.  f32-input MFMA = exact k-ordered fp32 FMA chain (guide §3 "FP32-input MFMA").
 // 32x32x2: A lane l -> A[l&31][l>>5], B lane l -> B[l>>5][l&31]; C: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)

@@ -30,6 +30,11 @@ struct TileView {
     const uint32_t off = lane_off + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)ldb;        // per lane, 32-bit
     return reinterpret_cast<float*>(tile + off);
   }
+  // the two halves of at(), for epilogues that hoist the tile origin out of their element loop themselves
+  __device__ char* tile(int trow, int tcol) const { return base + (int64_t)trow * ldb + (int64_t)tcol * 4; }
+  __device__ float* elem(char* tile_origin, int r) const {
+    return reinterpret_cast<float*>(tile_origin + (lane_off + (uint32_t)((r & 3) + 8 * (r >> 2)) * (uint32_t)ldb));
+  }
   // the same element with the row clamped to M-1 (partial blocks: always a legal address)
   __device__ float* at_clamped(int trow, int tcol, int r, int lane, int M) const {
     const int row = min(trow + c32_row(r, lane), M - 1);
@@ -39,6 +44,11 @@ struct TileView {
 template <bool FULL>
 __device__ __forceinline__ float* tile_elem(const TileView& v, int trow, int tcol, int r, int lane, int M) {
   if constexpr (FULL) return v.at(trow, tcol, r);
+  else return v.at_clamped(trow, tcol, r, lane, M);
+}
+template <bool FULL>
+__device__ __forceinline__ float* tile_elem_o(const TileView& v, char* origin, int trow, int tcol, int r, int lane, int M) {
+  if constexpr (FULL) return v.elem(origin, r);
   else return v.at_clamped(trow, tcol, r, lane, M);
 }
 template <bool FULL>
@@ -88,7 +98,7 @@ struct EpiLstmC {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  template <bool FULL, int WTM, int WTN>
+  template <bool FULL, bool WITH_FRM, int WTM, int WTN>
   __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
     const int jj = lane & 31;
     const int tcol = (col0 / 96) * 32;             // memory-unit block of this wave's f|r|m triple
@@ -97,9 +107,10 @@ struct EpiLstmC {
     static_for<0, WTM>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       const int trow = row0 + 32 * i;
+      char* o0 = c0v.tile(trow, tcol); char* o1 = c1v.tile(trow, tcol); char* of = fv.tile(trow, col0);
       float cp[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) cp[r] = c0 ? *tile_elem<FULL>(c0v, trow, tcol, r, lane, M) : 0.f;
+      for (int r = 0; r < 16; ++r) cp[r] = c0 ? *tile_elem_o<FULL>(c0v, o0, trow, tcol, r, lane, M) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float f = sigmoid_acc(acc[i][0][r] + bf);
@@ -107,9 +118,9 @@ struct EpiLstmC {
         const float mp = tanh_acc(acc[i][2][r] + bm);
         const float v = cp[r] * f + rg * mp;
         if (tile_row_ok<FULL>(trow, r, lane, M)) {
-          *tile_elem<FULL>(c1v, trow, tcol, r, lane, M) = v;
-          if (frm) {
-            float* fr = tile_elem<FULL>(fv, trow, col0, r, lane, M);
+          *tile_elem_o<FULL>(c1v, o1, trow, tcol, r, lane, M) = v;
+          if constexpr (WITH_FRM) {
+            float* fr = tile_elem_o<FULL>(fv, of, trow, col0, r, lane, M);
             fr[0] = f; fr[32] = rg; fr[64] = mp;
           }
         }
@@ -120,8 +131,14 @@ struct EpiLstmC {
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
     static_assert(WTN == 3, "LSTM c epilogue wants f|r|m tiles");
-    if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
-    else run_impl<false>(acc, row0, col0, lane, M);
+    const bool full = row0 + 32 * WTM <= M;
+    if (frm == nullptr) {
+      if (full) run_impl<true, false>(acc, row0, col0, lane, M);
+      else run_impl<false, false>(acc, row0, col0, lane, M);
+    } else {
+      if (full) run_impl<true, true>(acc, row0, col0, lane, M);
+      else run_impl<false, true>(acc, row0, col0, lane, M);
+    }
   }
 };
 
@@ -172,10 +189,11 @@ struct EpiLstmO {
       const int trow = row0 + 32 * i, tcol = col0 + 32 * j;
       if (tcol < N) {                              // wave-uniform (zero-padded weight rows beyond N)
         const float b = bias[tcol + (lane & 31)];
+        char* origin = ov.tile(trow, tcol);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float v = sigmoid_acc(acc[i][j][r] + b);
-          if (tile_row_ok<FULL>(trow, r, lane, M)) *tile_elem<FULL>(ov, trow, tcol, r, lane, M) = v;
+          if (tile_row_ok<FULL>(trow, r, lane, M)) *tile_elem_o<FULL>(ov, origin, trow, tcol, r, lane, M) = v;
         }
       }
     });
@@ -187,7 +205,8 @@ struct EpiLstmO {
   }
 };
 
-// h1 = o * tanh(acc + bc) ; Y = X + h1
+// h1 = o * tanh(acc + bc) ; Y = X + h1 (WITH_Y; otherwise Y is never materialised: see paths_importance_proj_x6's y_add)
+template <bool WITH_Y, bool WITH_TC = false>
 struct EpiLstmH {
   template <int WTM, int WTN>
   __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
@@ -200,38 +219,51 @@ struct EpiLstmH {
   }
 
   const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
-  float* h1; int64_t ldh; float* y; int64_t ldy; int N;      // N % 32 == 0
+  float* h1; int64_t ldh; float* y; int64_t ldy; int N;      // N % 32 == 0; y optional (Y = X + h1 not materialised)
   float* tc_out;                   // optional (training): tanh(Wc c1 + bc), [M, N]
   template <bool FULL, int WTM, int WTN>
   __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
-    // tile-pipelined: the loads of tile t+1 are in flight while tile t is computed and stored (two register buffers)
-    constexpr int NT = WTM * WTN;
+    // tile-pipelined: the loads of tiles t+1 .. t+PD are in flight while tile t is computed and stored (PD+1 register
+    // buffers).  With one wave per SIMD nothing else hides the ~2 us a load takes under load: at PD = 1 this epilogue
+    // moved 2.4 TB/s, i.e. it was bound by (bytes in flight) / latency, not by HBM.
+    constexpr int NT = WTM * WTN, PD = (NT >= 4 && !WITH_Y) ? 3 : 1, NB = PD + 1;
     const TileView ovw(o, ldo, lane), xvw(x, ldx, lane), hv(h1, ldh, lane), yv(y, ldy, lane), tv(tc_out, N, lane);
-    float ov[2][16], xv[2][16];
+    float ov[NB][16], xv[WITH_Y ? NB : 1][16];
     auto load = [&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t & 1;
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t % NB;
       const int trow = row0 + 32 * i, tcol = min(col0 + 32 * j, N - 32);
+      char* to = ovw.tile(trow, tcol); char* tx = xvw.tile(trow, tcol);
       static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        ov[s][r] = *tile_elem<FULL>(ovw, trow, tcol, r, lane, M);
-        xv[s][r] = *tile_elem<FULL>(xvw, trow, tcol, r, lane, M);
+        if constexpr (FULL) {
+          ov[s][r] = *ovw.elem(to, r);
+          if constexpr (WITH_Y) xv[s][r] = *xvw.elem(tx, r);
+        } else {
+          ov[s][r] = *ovw.at_clamped(trow, tcol, r, lane, M);
+          if constexpr (WITH_Y) xv[s][r] = *xvw.at_clamped(trow, tcol, r, lane, M);
+        }
       });
     };
-    load(std::integral_constant<int, 0>{});
+    static_for<0, (PD < NT ? PD : NT)>([&](auto tc) __attribute__((always_inline)) { load(tc); });
     static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t & 1;
-      if constexpr (t + 1 < NT) load(std::integral_constant<int, t + 1>{});
+      constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t % NB;
+      if constexpr (t + PD < NT) load(std::integral_constant<int, t + PD>{});
       const int trow = row0 + 32 * i, tcol = col0 + 32 * j;
       if (tcol < N) {
         const float b = bias[tcol + (lane & 31)];
+        char* th = hv.tile(trow, tcol); char* ty = yv.tile(trow, tcol); char* tt = tv.tile(trow, tcol);
         static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
           constexpr int r = decltype(rc)::value;
           const float tcv = tanh_acc(acc[i][j][r] + b);
           const float h = ov[s][r] * tcv;
-          if (tile_row_ok<FULL>(trow, r, lane, M)) {
-            if (tc_out) *tile_elem<FULL>(tv, trow, tcol, r, lane, M) = tcv;
-            *tile_elem<FULL>(hv, trow, tcol, r, lane, M) = h;
-            *tile_elem<FULL>(yv, trow, tcol, r, lane, M) = xv[s][r] + h;
+          if constexpr (FULL) {
+            if constexpr (WITH_TC) *tv.elem(tt, r) = tcv;
+            *hv.elem(th, r) = h;
+            if constexpr (WITH_Y) *yv.elem(ty, r) = xv[s][r] + h;
+          } else if (tile_row_ok<false>(trow, r, lane, M)) {
+            if constexpr (WITH_TC) *tv.at_clamped(trow, tcol, r, lane, M) = tcv;
+            *hv.at_clamped(trow, tcol, r, lane, M) = h;
+            if constexpr (WITH_Y) *yv.at_clamped(trow, tcol, r, lane, M) = xv[s][r] + h;
           }
         });
       }

@@ -237,8 +237,15 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
   // (3) h1 = o * tanh(Wc c1 + bc), Y = X + h1
   if (phases & 4) {
     GemmOperands gh{state_out + D, ldso, Hc, nullptr, 0, 0, w_mem, Hc, M, num_ims, rows_per_slide};
-    EpiLstmH e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
-    int rc = launch_gemm<2, 2, 2, 2>(gh, D, e, stream, "lstm_cell(h)");
+    PATHS_REQUIRE(y != nullptr, "lstm_cell: y is required (only paths_lstm_cell_x6 can skip it)");
+    int rc;
+    if (save_tc != nullptr) {
+      EpiLstmH<true, true> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
+      rc = launch_gemm<2, 2, 2, 2>(gh, D, e, stream, "lstm_cell(h, save)");
+    } else {
+      EpiLstmH<true, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, nullptr};
+      rc = launch_gemm<2, 2, 2, 2>(gh, D, e, stream, "lstm_cell(h)");
+    }
     if (rc) return rc;
   }
   return PATHS_OK;

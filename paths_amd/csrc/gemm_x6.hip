@@ -51,6 +51,7 @@ constexpr int SUBT = 3 * FRAG;     // one 32-row x 16-k sub-tile: hi | mid | lo
 struct X6Operands {
   const float* A0; int64_t lda0; int K0;
   const float* A1; int64_t lda1; int K1;
+  const float* Aadd; int64_t ldadd;   // ADD kernels only: panel 0 is A0 + Aadd, summed in fp32 on the way to the split
   const char* Wt;                  // packed weights, already advanced to the first 32-row group and first k16 step used
   int64_t w_group_stride;          // bytes between consecutive 32-row groups (= K_packed / 16 * SUBT)
   int M;
@@ -66,7 +67,7 @@ uint64_t* g_x6_dbg = nullptr;
 
 // PF = how many stages ahead of its LDS write a stage is loaded into registers (1 or 2 register sets).  Stages of the
 // 128-row tiles are only ~1,500 cycles long, shorter than a loaded-L2 round trip, so those run two stages ahead.
-template <int WTM, int WTN, int PF, class Epi>
+template <int WTM, int WTN, int PF, bool ADD, class Epi>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_x6_kernel(X6Operands g, Epi epi) {
   constexpr int BM = WTM * 64, BN = WTN * 64;
@@ -101,13 +102,14 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // ---- staging addresses.  A: thread -> (row = 64 p + tid/4, floats 4 (tid%4) .. +3 of the stage); 32-bit byte offsets
   // against a wave-uniform panel base.  W: wave -> 1-KiB pieces wave + 4 i of the stage's SB x 3 fragments.
   const int arow = tid >> 2, ac = tid & 3;
-  uint32_t aoff0[NA], aoff1[NA]; int awr[NA];
+  uint32_t aoff0[NA], aoff1[NA], aoffs[ADD ? NA : 1]; int awr[NA];
 #pragma unroll
   for (int p = 0; p < NA; ++p) {
     const int row = p * 64 + arow;
     const int64_t grow = min(m0 + row, g.M - 1);
     aoff0[p] = (uint32_t)((grow * g.lda0 + 4 * ac) * 4);
     aoff1[p] = (uint32_t)((grow * g.lda1 + 4 * ac) * 4);
+    if constexpr (ADD) aoffs[p] = (uint32_t)((grow * g.ldadd + 4 * ac) * 4);
     awr[p] = (row >> 5) * SUBT + (ac >> 1) * 512 + (row & 31) * 16 + (ac & 1) * 8;
   }
   const int nk0 = g.K0 >> 4, nk = (g.K0 + g.K1) >> 4;
@@ -121,7 +123,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     bwr[i] = (SA + sub) * SUBT + pl * FRAG + lane * 16;
   }
   static_assert(PF == 1 || PF == 2, "one or two register sets");
-  f32x4 sa[PF][NA]; u32x4 sbr[PF][NB];
+  f32x4 sa[PF][NA], sadd[ADD ? PF : 1][ADD ? NA : 1]; u32x4 sbr[PF][NB];
   uint32_t hi[NA][2], mid[NA][2], lo[NA][2];
   typedef const f32x4 __attribute__((address_space(1))) * gptr_f4;
   typedef const u32x4 __attribute__((address_space(1))) * gptr_u4;
@@ -129,6 +131,10 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     const bool first = kt < nk0;                       // wave-uniform panel select: scalar base + per-lane 32-bit offset
     const char* base = reinterpret_cast<const char*>(first ? g.A0 : g.A1) + (int64_t)(first ? kt : kt - nk0) * 64;
     sa[set][q] = *reinterpret_cast<gptr_f4>(reinterpret_cast<uintptr_t>(base + (first ? aoff0[q] : aoff1[q])));
+    if constexpr (ADD) {                               // (ADD kernels have a single panel)
+      const char* badd = reinterpret_cast<const char*>(g.Aadd) + (int64_t)kt * 64;
+      sadd[set][q] = *reinterpret_cast<gptr_f4>(reinterpret_cast<uintptr_t>(badd + aoffs[q]));
+    }
   };
   auto gload_b = [&](int set, int q, int kt) {
     sbr[set][q] = *reinterpret_cast<gptr_u4>(reinterpret_cast<uintptr_t>(bbase[q] + (int64_t)kt * SUBT + lane * 16));
@@ -136,7 +142,10 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // split of one staged A chunk in 7 small steps (each <= 4 VALU ops, so that they ride in MFMA gaps); every residual is exact
   auto a_step = [&](int set, int q, int st, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[set][q];
-    if (st == 0) { hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]); }
+    if (st == 0) {
+      if constexpr (ADD) v += sadd[set][q];            // the fp32 sum the reference materialises (Y = X + h1)
+      hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]);
+    }
     if (st == 1) { v[0] -= bf_lo(hi[q][0]); v[1] -= bf_hi(hi[q][0]); }
     if (st == 2) { v[2] -= bf_lo(hi[q][1]); v[3] -= bf_hi(hi[q][1]); }
     if (st == 3) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
@@ -282,7 +291,7 @@ __global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, __bf16*
   o[0] = h; o[FRAG / 2] = m; o[FRAG] = l;
 }
 
-template <int WTM, int WTN, int PF, class Epi>
+template <int WTM, int WTN, int PF, bool ADD, class Epi>
 int launch_x6(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
   constexpr int BM = WTM * 64, BN = WTN * 64;
   constexpr size_t lds = 2ull * (2 * WTM + 2 * WTN) * SUBT;
@@ -292,8 +301,8 @@ int launch_x6(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream,
   PATHS_REQUIRE(Npad % BN == 0, "%s: packed N (%d) must be a multiple of %d", name, Npad, BN);
   PATHS_REQUIRE(g.lda0 % 4 == 0 && g.lda1 % 4 == 0, "%s: leading dims must be multiples of 4 floats", name);
   PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Wt % 16 == 0), "%s: operands must be 16-byte aligned", name);
-  PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? g.lda0 : g.lda1) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
-  auto kern = gemm_x6_kernel<WTM, WTN, PF, Epi>;
+  PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? (g.lda0 > g.ldadd ? g.lda0 : g.ldadd) : (g.lda1 > g.ldadd ? g.lda1 : g.ldadd)) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
+  auto kern = gemm_x6_kernel<WTM, WTN, PF, ADD, Epi>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -350,30 +359,41 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh
                 "lstm_cell_x6: hp/hp_row come together and replace h0 (the h half of the gate GEMM was done per parent)");
   const char* wg = reinterpret_cast<const char*>(w_gates_x6);
   const int64_t gs = group_stride(2 * D);
-  X6Operands g{x, ldx, D, h0, h0 ? ldh0 : 0, h0 ? D : 0, wg, gs, M, num_ims, rows_per_slide};
+  X6Operands g{x, ldx, D, h0, h0 ? ldh0 : 0, h0 ? D : 0, nullptr, 0, wg, gs, M, num_ims, rows_per_slide};
   if (phases & 1) {   // c-part: N = 3Hc, block 256 x 192
     EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row};
-    int rc = launch_x6<4, 3, 1>(g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
+    int rc = launch_x6<4, 3, 1, false>(g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
     if (rc) return rc;
   }
   if (phases & 2) {   // o gate: N = D, block 256 x 256
     X6Operands go = g;
     go.Wt = wg + (int64_t)(3 * Hc / 32) * gs;
     EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc};
-    int rc = launch_x6<4, 4, 1>(go, D, e, stream, "lstm_cell_x6(o)");
+    int rc = launch_x6<4, 4, 1, false>(go, D, e, stream, "lstm_cell_x6(o)");
     if (rc) return rc;
   }
   if (phases & 4) {   // h1 = o * tanh(Wc c1 + bc), Y = X + h1
-    X6Operands gh{state_out + D, ldso, Hc, nullptr, 0, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(Hc), M, num_ims, rows_per_slide};
-    EpiLstmH e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
-    int rc = launch_x6<4, 4, 1>(gh, D, e, stream, "lstm_cell_x6(h)");
+    X6Operands gh{state_out + D, ldso, Hc, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(Hc), M, num_ims, rows_per_slide};
+    int rc;
+    PATHS_REQUIRE(save_tc == nullptr || y != nullptr, "lstm_cell_x6: save_tc (training) needs y");
+    if (save_tc != nullptr) {
+      EpiLstmH<true, true> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
+      rc = launch_x6<4, 4, 1, false>(gh, D, e, stream, "lstm_cell_x6(h, save)");
+    } else if (y != nullptr) {
+      EpiLstmH<true, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, nullptr};
+      rc = launch_x6<4, 4, 1, false>(gh, D, e, stream, "lstm_cell_x6(h)");
+    } else {
+      EpiLstmH<false, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, nullptr, 0, D, nullptr};
+      rc = launch_x6<4, 4, 1, false>(gh, D, e, stream, "lstm_cell_x6(h, no y)");
+    }
     if (rc) return rc;
   }
   return PATHS_OK;
 }
 
-// paths_importance_proj with w_ip_x6 = pack([W1 ; Wp] = [256, D])
-int paths_importance_proj_x6(const float* y, int64_t ldy, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+// paths_importance_proj with w_ip_x6 = pack([W1 ; Wp] = [256, D]).  y_add (optional): the GEMM input is y + y_add, summed in
+// fp32 while staging - the caller passes (x, h1) and never materialises Y = X + h1 (paths_lstm_cell_x6 with y = NULL)
+int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                              float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
@@ -382,10 +402,12 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const void* w_ip_x6, c
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj_x6: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj_x6: 2d positional encoding needs locs");
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj_x6: bad slide layout");
-  X6Operands g{y, ldy, D, nullptr, 0, 0, reinterpret_cast<const char*>(w_ip_x6), group_stride(D), M, skip_padding ? num_ims : nullptr, rows_per_slide};
+  PATHS_REQUIRE(y_add == nullptr || (ldya % 4 == 0 && (uintptr_t)y_add % 16 == 0), "importance_proj_x6: y_add must be 16-byte aligned with ldya %% 4 == 0");
+  X6Operands g{y, ldy, D, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(D), M, skip_padding ? num_ims : nullptr, rows_per_slide};
   EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
                save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0};
-  return launch_x6<2, 4, 2>(g, 256, e, stream, "importance_proj_x6");
+  if (y_add != nullptr) return launch_x6<2, 4, 2, true>(g, 256, e, stream, "importance_proj_x6(sum)");
+  return launch_x6<2, 4, 2, false>(g, 256, e, stream, "importance_proj_x6");
 }
 
 // out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual with W given as the x6-packed image of an [Npad, Kpacked]
@@ -394,9 +416,9 @@ int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                      int64_t ldm, int accumulate, hipStream_t stream) {
   PATHS_REQUIRE(k0 % 16 == 0 && k0 >= 0 && k0 + K <= Kpacked, "gemm_nt_x6: bad k window");
-  X6Operands g{a, lda, K, nullptr, 0, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * SUBT, group_stride(Kpacked), M, nullptr, 0};
+  X6Operands g{a, lda, K, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * SUBT, group_stride(Kpacked), M, nullptr, 0};
   EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate};
-  return launch_x6<2, 4, 2>(g, Npad, e, stream, "gemm_nt_x6");
+  return launch_x6<2, 4, 2, false>(g, Npad, e, stream, "gemm_nt_x6");
 }
 
 }  // extern "C"

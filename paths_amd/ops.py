@@ -209,20 +209,26 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     pe_rows = N if pe_mode == 1 else int(max_pos)
     pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
 
-    def importance_proj(src, imp_mul, imp_out):
-        _lib.call("paths_importance_proj_x6" if x6 else "paths_importance_proj", p(src), D,
-                  p(_x6_of(lvl_pack, "w_ip") if x6 else lvl_pack["w_ip"]), p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
+    def importance_proj(src, imp_mul, imp_out, add=None):
+        """tokens / importance from ``src`` (+ ``add``: x6 only, the GEMM input is src + add, row stride of add arbitrary)."""
+        common = (p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
                   p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]),
                   p(pe_tab), pe_tab.shape[0] if pe_tab is not None else 0, p(locs),
                   p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), None, None,
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
+        if x6:
+            _lib.call("paths_importance_proj_x6", p(src), D, p(add), add.stride(1) if add is not None else 0,
+                      p(_x6_of(lvl_pack, "w_ip")), *common)
+        else:
+            assert add is None
+            _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip"]), *common)
 
     importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
     if mc.lstm:
         Hc = lstm_pack["Hc"]
         Dp = D + Hc
         state_out = torch.empty((B, N, Dp), **f32)
-        y = torch.empty((B, N, D), **f32)
+        y = None if x6 else torch.empty((B, N, D), **f32)   # x6: Y = X + h1 is summed inside the importance/proj GEMM's staging
         ws_o = torch.empty((B, N, D), **f32)
         hp, hp_row = None, None
         if parent is not None:
@@ -252,7 +258,10 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D,
                                                           "parent_partials": parent is not None, "x6": x6})
             lstm(4)
-        importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance)
+        if x6:
+            importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out)
+        else:
+            importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance)
         del ws_o
     else:
         # lstm=false (reference model/paths.py:95-109): alpha from X; Z = alpha*X (+ hctx_mlp(previous Z) on valid rows);

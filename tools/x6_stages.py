@@ -47,15 +47,17 @@ lib = _lib.load()
 lib.paths_x6_debug_buffer.argtypes = [C.c_void_p]; lib.paths_x6_debug_buffer.restype = None
 
 def lstm(ph):
-    _lib.call("paths_lstm_cell_x6", p(x), D, None, 0, p(c0), Hc, p(wg6), p(bg), p(wm6), p(bm), p(so), D + Hc, p(y), D, p(ws), None, None,
+    _lib.call("paths_lstm_cell_x6", p(x), D, None, 0, p(c0), Hc, p(wg6), p(bg), p(wm6), p(bm), p(so), D + Hc, None, D, p(ws), None, None,
               p(hp), p(hp_row), M, D, Hc, None, 1, ph, st())
 def parent():
     _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg6), 2 * D, D, None, p(hp), G, MP, G, G, D, 0, None, 0, None, 0, 0, st())
 def impproj():
-    _lib.call("paths_importance_proj_x6", p(yi), D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
+    _lib.call("paths_importance_proj_x6", p(yi), D, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
               p(imp), p(tok), None, None, Mi, D, 128, 128, 1, st())
 
 USE_TAB = True
+USE_ADD = True
+yadd = rnd(Mi, D)
 CASES = [("parent partials  <2,4> K=1024", parent, (MP + 127) // 128 * 7, 64, 2 * 4 * 6 * 32, 2.0 * MP * G * D),
          ("gate c-part      <4,3> K=1024", lambda: lstm(1), (M + 255) // 256 * 4, 64, 4 * 3 * 6 * 32, 2.0 * M * 768 * D),
          ("gate o-part      <4,4> K=1024", lambda: lstm(2), (M + 255) // 256 * 4, 64, 4 * 4 * 6 * 32, 2.0 * M * D * D),
