@@ -51,10 +51,12 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
 
 /* importance MLP + sigmoid + padding mask, importance scaling, proj_in, positional encoding, special token
  * (reference model/paths.py:95-98,119-124; utils.py:16-23,47-67,106-115; model/aggregator.py:37-65).
- *   w_ip [256, D] = [importance_mlp.0.weight ; proj_in.weight]; tokens [B, N+1, d]: row 0 = special token.
+ *   w_ip [256, D] = importance_mlp.0.weight (W1) and proj_in.weight (Wp) interleaved in blocks of 64 rows:
+ *   [W1[0:64] ; Wp[0:64] ; W1[64:128] ; Wp[64:128]]; b1 / w2 / bp in their natural order; tokens [B, N+1, d]: row 0 = special token.
  *   pe_mode 2 = "2d" (div_term has d/4 entries, locs [M,2] int64 pixel coords), 1 = "1d" (d/2 entries).
- *   pe_table (optional) = paths_pe_table output with pe_rows rows: rows whose positions are < pe_rows read their sin/cos
- *   values from it (bit-identical to evaluating them), the others evaluate them. */
+ *   pe_table (optional) = paths_pe_table output with pe_rows rows: sin/cos values are then read from it (bit-identical to
+ *   evaluating them).  The caller guarantees 0 <= locs / patch_size < pe_rows (paths_amd passes the level's grid size);
+ *   positions are clamped into the table for memory safety only. */
 int paths_pe_table(const float* div_term, int pe_mode, int d, int rows, float* out, paths_stream_t stream);
 int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const float* b1, const float* w2, float b2,
                           const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows,

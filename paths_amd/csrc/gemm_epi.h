@@ -352,9 +352,11 @@ __device__ __forceinline__ int div_pos(int64_t x, int d, float rd) {      // pix
   return (x >= 0 && x < (1 << 24)) ? div_u24((int)x, d, rd) : (int)(x / d);
 }
 
-// Packed weight rows = [W1 (Hi=128 rows) ; Wp (d=128 rows)], block covers all 256 columns.
-// Waves with wn == 0 own the importance hidden units, wn == 1 the projected token channels.
+// Packed weight rows (ops.pack_level "w_ip_fwd") = [W1[0:64] ; Wp[0:64] ; W1[64:128] ; Wp[64:128]]: the block covers all 256
+// columns and BOTH column halves (wn = 0, 1) own 64 importance hidden units and 64 projected token channels, so the two
+// epilogue phases (importance logit, tokens) are shared by all waves instead of running one after the other on half of them.
 //   alpha = valid ? sigmoid(w2 . relu(acc + b1) + b2) : 0            (importance_mode "mul": token = alpha*acc + bp + PE)
+template <bool PE_TAB>
 struct EpiImpProj {
   template <int WTM, int WTN>
   __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
@@ -380,102 +382,99 @@ struct EpiImpProj {
   float* tokens;                   // [B, N+1, d]
   float* hid_out;                  // optional (training): relu(Y W1^T + b1) [M,128]
   float* pproj_out;                // optional (training): Y Wp^T (before alpha / bias / PE) [M,128]
-  const float* pe_table; int pe_rows;   // optional: paths_pe_table output (same sinf/cosf values, read instead of recomputed)
+  const float* pe_table; int pe_rows;   // PE_TAB: paths_pe_table output (same sinf/cosf values, read instead of recomputed)
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int wm, int wn, int M, float* smem) const {
     static_assert(WTN == 4 && WGN == 2, "imp/proj epilogue layout: one block spans the 128 hidden + 128 projected columns");
-    constexpr int d = 128;
+    constexpr int d = 128, RB = WGM * WTM * 32;    // rows per block
     const float rps_inv = 1.0f / (float)rows_per_slide, ps_inv = 1.0f / (float)patch_size;
     const bool small_rows = M < (1 << 24);
-    float* alpha_s = smem;                       // [WGM*WTM*32] (main loop is done; LDS is free after its last barrier)
-    if (wn == 0) {
+    const int u0 = 64 * wn;                        // this wave's hidden units u0 .. u0+63 (tiles 0,1) and channels u0 .. u0+63 (tiles 2,3)
+    float* alpha_p = smem;                         // [2][RB] partial w2 . relu(..) sums of the two column halves (LDS is free here)
+    // ---- phase A (all waves): partial importance logits over this wave's 64 hidden units
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) {
-        float part[16];
+    for (int i = 0; i < WTM; ++i) {
+      float part[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[r] = 0.f;
+      for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int col = 32 * j + (lane & 31);
-          const float b = b1[col], w = w2[col];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float hv = fmaxf(acc[i][j][r] + b, 0.f);
-            part[r] += hv * w;
-            const int row = row0 + 32 * i + c32_row(r, lane);
-            if (hid_out && row < M) hid_out[(int64_t)row * 128 + col] = hv;
-          }
-        }
+      for (int j = 0; j < 2; ++j) {
+        const int u = u0 + 32 * j + (lane & 31);
+        const float b = b1[u], w = w2[u];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = part[r];
-          v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-          const int lrow = 32 * i + c32_row(r, lane);
-          const int row = row0 + lrow;
-          float a = 0.f;
-          if (row < M) {
-            const int b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide, idx = row - b * rows_per_slide;
-            if (idx < (int)num_ims[b]) a = sigmoid_acc(v + b2);
-            if ((lane & 31) == 0) importance[row] = a;
-          }
-          if ((lane & 31) == 0) alpha_s[wm * WTM * 32 + lrow] = a;
+          const float hv = fmaxf(acc[i][j][r] + b, 0.f);
+          part[r] += hv * w;
+          const int row = row0 + 32 * i + c32_row(r, lane);
+          if (hid_out && row < M) hid_out[(int64_t)row * 128 + u] = hv;
         }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = part[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
+        if ((lane & 31) == 0) alpha_p[wn * RB + wm * WTM * 32 + 32 * i + c32_row(r, lane)] = v;
       }
     }
     __syncthreads();
-    if (wn == 1) {
-      float bpv[4], dtv[4];
+    // ---- phase B (all waves): alpha of every row (both column halves compute the same value), tokens of this wave's 64 channels
+    float bpv[2], dtv[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = 32 * j + (lane & 31);
-        bpv[j] = bp[c];
-        dtv[j] = pe_mode == 2 ? div_term[(c & (d / 2 - 1)) >> 1] : div_term[c >> 1];
+    for (int j = 0; j < 2; ++j) {
+      const int c = u0 + 32 * j + (lane & 31);
+      bpv[j] = bp[c];
+      dtv[j] = pe_mode == 2 ? div_term[(c & (d / 2 - 1)) >> 1] : div_term[c >> 1];
+    }
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) {
+      int64_t lp[16];                              // 2-D mode: this wave's coordinate (x for channels < d/2, y for the others)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
+        lp[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc + wn] : 0;
+      }
+      int tokrow[16]; float av[16]; bool first[16]; float pev[16][2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = wm * WTM * 32 + 32 * i + c32_row(r, lane);
+        const int rowr = row0 + 32 * i + c32_row(r, lane);
+        const int row = min(rowr, M - 1);
+        const int b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide, idx = row - b * rows_per_slide;
+        float a = 0.f;
+        if (idx < (int)num_ims[b]) a = sigmoid_acc((alpha_p[lrow] + alpha_p[RB + lrow]) + b2);
+        if (wn == 0 && (lane & 31) == 0 && rowr < M) importance[rowr] = a;
+        av[r] = imp_mul ? a : 1.f;
+        tokrow[r] = b * (rows_per_slide + 1) + idx + 1;                   // token row (row 0 of a slide = special token)
+        first[r] = idx == 0;                                              // this row also emits its slide's special token
+        const int ipos = pe_mode == 2 ? div_pos(lp[r], patch_size, ps_inv) : idx;
+        if constexpr (PE_TAB) {
+          // the caller guarantees positions < pe_rows (paths_amd passes the level's grid size); clamped for memory safety
+          const int tp = min(max(ipos, 0), pe_rows - 1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c = u0 + 32 * j + (lane & 31);
+            pev[r][j] = pe_mode == 2 ? pe_table[(int64_t)tp * (d / 2) + (c & (d / 2 - 1))] : pe_table[(int64_t)tp * d + c];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c = u0 + 32 * j + (lane & 31);
+            const float ang = (float)ipos * dtv[j];
+            pev[r][j] = (c & 1) ? cosf(ang) : sinf(ang);
+          }
+        }
       }
 #pragma unroll
-      for (int i = 0; i < WTM; ++i) {
-        int64_t lx[16], ly[16];               // all position loads first (see the epilogue note above)
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + c32_row(r, lane);
+        if (row < M) {
+          float* trow = tokens + (int64_t)tokrow[r] * d;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
-          lx[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc] : 0;
-          ly[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc + 1] : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lrow = 32 * i + c32_row(r, lane);
-          const int row = row0 + lrow;
-          if (row >= M) continue;
-          const int b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide, idx = row - b * rows_per_slide;
-          const float a = imp_mul ? alpha_s[wm * WTM * 32 + lrow] : 1.f;
-          const int ipx = pe_mode == 2 ? div_pos(lx[r], patch_size, ps_inv) : idx, ipy = pe_mode == 2 ? div_pos(ly[r], patch_size, ps_inv) : 0;
-          const float px = (float)ipx, py = (float)ipy;
-          float* trow = tokens + ((int64_t)b * (rows_per_slide + 1) + idx + 1) * d;
-          // positional encoding: from the precomputed table when this row's coordinates are inside it (positions are small
-          // integers, so the table holds exactly the values the expressions below produce), else evaluated here
-          const bool tab = pe_table != nullptr && (unsigned)ipx < (unsigned)pe_rows && (unsigned)ipy < (unsigned)pe_rows;
-          float pev[4];
-          if (tab) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int c = 32 * j + (lane & 31);
-              pev[j] = pe_mode == 2 ? pe_table[(int64_t)(c >= d / 2 ? ipy : ipx) * (d / 2) + (c & (d / 2 - 1))]
-                                    : pe_table[(int64_t)ipx * d + c];
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int c = 32 * j + (lane & 31);
-              const float pos = (pe_mode == 2 && c >= d / 2) ? py : px;
-              const float ang = pos * dtv[j];
-              pev[j] = (c & 1) ? cosf(ang) : sinf(ang);
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int c = 32 * j + (lane & 31);
-            trow[c] = a * acc[i][j][r] + bpv[j] + pev[j];
-            if (pproj_out) pproj_out[(int64_t)row * 128 + c] = acc[i][j][r];
-            if (idx == 0) tokens[(int64_t)b * (rows_per_slide + 1) * d + c] = special[c];
+          for (int j = 0; j < 2; ++j) {
+            const int c = u0 + 32 * j + (lane & 31);
+            trow[c] = av[r] * acc[i][2 + j][r] + bpv[j] + pev[r][j];
+            if (pproj_out) pproj_out[(int64_t)row * 128 + c] = acc[i][2 + j][r];
+            if (first[r]) trow[c - d] = special[c];
           }
         }
       }

@@ -404,8 +404,15 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, in
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj_x6: bad slide layout");
   PATHS_REQUIRE(y_add == nullptr || (ldya % 4 == 0 && (uintptr_t)y_add % 16 == 0), "importance_proj_x6: y_add must be 16-byte aligned with ldya %% 4 == 0");
   X6Operands g{y, ldy, D, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(D), M, skip_padding ? num_ims : nullptr, rows_per_slide};
-  EpiImpProj e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-               save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0};
+  if (pe_table != nullptr) {
+    PATHS_REQUIRE(pe_rows > 0, "importance_proj_x6: pe_rows must be > 0 with a pe_table");
+    EpiImpProj<true> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
+                       save_hid, save_pproj, pe_table, pe_rows};
+    if (y_add != nullptr) return launch_x6<2, 4, 2, true>(g, 256, e, stream, "importance_proj_x6(sum, table)");
+    return launch_x6<2, 4, 2, false>(g, 256, e, stream, "importance_proj_x6(table)");
+  }
+  EpiImpProj<false> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
+                      save_hid, save_pproj, nullptr, 0};
   if (y_add != nullptr) return launch_x6<2, 4, 2, true>(g, 256, e, stream, "importance_proj_x6(sum)");
   return launch_x6<2, 4, 2, false>(g, 256, e, stream, "importance_proj_x6");
 }

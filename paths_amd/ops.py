@@ -131,6 +131,10 @@ def pack_level(proc) -> Dict[str, object]:
         k = 10000.0
         packed = {
             "w_ip": torch.cat([proc.importance_mlp[0].weight, agg.proj_in.weight], dim=0).float().contiguous(),
+            # forward kernels: rows interleaved in blocks of 64 so that each column half of a workgroup owns 64 hidden units
+            # and 64 token channels (csrc/gemm_epi.h EpiImpProj)
+            "w_ip_fwd": torch.cat([proc.importance_mlp[0].weight[:64], agg.proj_in.weight[:64],
+                                   proc.importance_mlp[0].weight[64:], agg.proj_in.weight[64:]], dim=0).float().contiguous(),
             "b1": c(proc.importance_mlp[0].bias), "w2": c(proc.importance_mlp[2].weight.view(-1)),
             "b2": float(proc.importance_mlp[2].bias.item()),
             "bp": c(agg.proj_in.bias), "special": c(agg.special_token),
@@ -218,10 +222,10 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
         if x6:
             _lib.call("paths_importance_proj_x6", p(src), D, p(add), add.stride(1) if add is not None else 0,
-                      p(_x6_of(lvl_pack, "w_ip")), *common)
+                      p(_x6_of(lvl_pack, "w_ip_fwd")), *common)
         else:
             assert add is None
-            _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip"]), *common)
+            _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip_fwd"]), *common)
 
     importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
     if mc.lstm:
