@@ -348,8 +348,14 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     depth = cat.shape[1] if cat is not None else 0
 
     token_layer(xa, None, None, layers[0])
+    attn_ws = None
     for l in range(L - 1):
-        _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st)
+        if GEMM_MODE == "x6":
+            if attn_ws is None:
+                attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd)),), device=tokens.device, dtype=torch.uint8)
+            _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), st)
+        else:
+            _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st)
         token_layer(xa, xb, layers[l], layers[l + 1])
         xa, xb = xb, xa
     # Last layer: only token 0 of its output is read (aggregator.py:75) -> one fused launch per level computes the

@@ -454,3 +454,31 @@ def test_f32_gemm_mode_matches_default(dev, monkeypatch):
     np.testing.assert_allclose(out_f32["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out_f32["importance"].numpy(), out_x6["importance"].numpy(), atol=2e-6, rtol=0)
     np.testing.assert_allclose(out_f32["ctx_patch"].numpy(), out_x6["ctx_patch"].numpy(), atol=5e-6, rtol=0)
+
+
+@pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37]), (65, [64, 65])])
+def test_attention_x6_matches_fp64(dev, T, lens):
+    """Split-bf16 attention against an fp64 softmax(q k^T) v and against the f32-MFMA kernel."""
+    from paths_amd import _lib
+    B, H, hd = len(lens), 4, 32
+    g = torch.Generator(device=dev); g.manual_seed(T)
+    q = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1) * 1.5
+    k = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1) * 1.5
+    v = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1)
+    num_ims = torch.tensor([n - 1 for n in lens], device=dev, dtype=torch.int64)
+    p, st = _lib.ptr, _lib.stream()
+    ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8)
+    o6 = torch.full((B, T, H * hd), float("nan"), device=dev)
+    o32 = torch.full((B, T, H * hd), float("nan"), device=dev)
+    lse6 = torch.empty((B, H, T), device=dev)
+    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o6), p(lse6), p(num_ims), B, T, H, hd, 0, p(ws), st)
+    _lib.call("paths_attention_f32", p(q), p(k), p(v), p(o32), None, p(num_ims), B, T, H, hd, 0, st)
+    for b, n in enumerate(lens):
+        s = (q[b, :, :n].double() @ k[b, :, :n].double().transpose(1, 2)) * np.log(2.0)      # kernels use exp2 of pre-scaled q
+        ref = (torch.softmax(s, dim=-1) @ v[b, :, :n].double()).permute(1, 0, 2).reshape(n, H * hd)
+        e6 = (o6[b, :n].double() - ref).abs().max().item()
+        e32 = (o32[b, :n].double() - ref).abs().max().item()
+        assert e6 < 2e-6, (b, e6)
+        assert e6 < 3 * e32 + 3e-7, (b, e6, e32)
+        lse_ref = torch.logsumexp(s, dim=-1) / np.log(2.0)
+        assert (lse6[b, :, :n].double() - lse_ref).abs().max().item() < 1e-4
