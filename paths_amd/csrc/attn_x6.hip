@@ -117,7 +117,8 @@ __device__ __forceinline__ f32x4 mfma_x6(const bf16x8 (&a)[3], const bf16x8 (&b)
 __global__ void __launch_bounds__(256)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
-  __shared__ __attribute__((aligned(16))) char smem[2][STEP_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];          // 2 x STEP_BYTES (+ occupancy padding, see the launcher)
+  char (*smem)[STEP_BYTES] = reinterpret_cast<char (*)[STEP_BYTES]>(smem_raw);
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
   const int len = min((int)num_ims[b] + 1, T);          // valid keys = special token + patches
   if (q0 >= len) return;                                // every query of this block is padding
@@ -267,7 +268,18 @@ int paths_attention_x6(const float* q, const float* k, const float* v, float* o,
   const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
   hipLaunchKernelGGL(attn_x6_prep_kernel, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
   PATHS_LAUNCH_CHECK("attention_x6(prep)");
-  hipLaunchKernelGGL(attn_x6_kernel, dim3((nq + 127) / 128, H, B), dim3(256), 0, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H);
+  // Workgroups per CU: registers allow 2 (170 VGPRs; capping them at 168 for 3 cost more than it gave), LDS would allow 3.
+  // The dispatcher fills a CU to its limit before it moves on, so small grids ask for more LDS than needed to spread out:
+  // depth = ceil(grid / 256).
+  const int nblk = ((nq + 127) / 128) * H * B;
+  const int depth = nblk <= 256 ? 1 : nblk <= 512 ? 2 : 3;
+  const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * STEP_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_x6_kernel, dim3((nq + 127) / 128, H, B), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H);
   PATHS_LAUNCH_CHECK("attention_x6");
   return PATHS_OK;
 }

@@ -8,7 +8,7 @@ idx = [i for i, r in enumerate(rows) if 'level0_kernel' in r['Kernel_Name']]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -3
 seg = rows[idx[which]:idx[which + 1]]
 t0 = int(seg[0]['Start_Timestamp']); prev_end = t0; tot_gap = 0; busy = 0
-KEYS = ('EpiLstmO','EpiLstmC','EpiLstmH','EpiImpProj','attn_f32','tlayer','token0_tail','final_head','topk','expand','gather','level0','copyBuffer','Fill','Cat')
+KEYS = ('attn_x6_prep','attn_x6','EpiLstmO','EpiLstmC','EpiLstmH','EpiImpProj','attn_f32','tlayer','token0_tail','final_head','topk','expand','gather','level0','copyBuffer','Fill','Cat')
 agg = {}
 for r in seg:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
