@@ -9,6 +9,7 @@ synchronisation inside the level loop: padded length per level is the static cap
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -52,6 +53,17 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     return out
 
 
+OVERLAP_AGGREGATOR = os.environ.get("PATHS_OVERLAP_AGGREGATOR", "1") != "0"
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[idx]
+
+
 def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
              trace: Optional[list] = None, careful: bool = False) -> Dict[str, torch.Tensor]:
     """Run all levels for a batch of HBM-resident slides (a list of DeviceSlide, or a DeviceSlideBatch built once
@@ -88,16 +100,30 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     out = None
     lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
     share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
-    # (Tried and dropped: running the aggregator of level i on a second HIP stream beside the selection chain of level i+1.
-    #  Both are MFMA-bound, co-running kernels just share the matrix pipes: +0.5 % end to end, measured.)
+    # The aggregator of level i (attention, token chain, classifier) feeds nothing of level i+1 except the slide context, so
+    # it runs on a second HIP stream beside the selection chain of level i+1 (top-K, expansion, gathers, gate GEMMs).  Several
+    # of those kernels cannot fill 256 CUs alone (116-232 workgroups, one per CU); the other chain's waves take the idle CUs.
+    overlap = OVERLAP_AGGREGATOR and dev.type == "cuda"
+    main_stream = torch.cuda.current_stream(dev) if overlap else None
+    side_stream = _side_stream(dev) if overlap else None
+    keepalive = []                         # main-stream tensors read on the side stream: kept until the streams join
     for i in range(num_levels):
         proc = model.procs[i]
         lvl_pack = ops.pack_level(proc)
         sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
                                     max_pos=batch.max_dim[i])
-        ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
-        ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
-        agg = ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
+        def aggregate():
+            ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
+            ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
+            return ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
+
+        if overlap:
+            side_stream.wait_stream(main_stream)          # tokens / num_ims of this level are ready
+            keepalive.append((sel["tokens"], sel["num_ims"]))
+            with torch.cuda.stream(side_stream):
+                agg = aggregate()
+        else:
+            agg = aggregate()
         out = {"logits": agg["logits"], "ctx_slide": agg["ctx_slide"], "ctx_patch": sel["ctx_patch"], "importance": sel["importance"]}
         ctx_hist.append(out["ctx_slide"])
         rec = None
@@ -152,6 +178,9 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
         if rec is not None:
             rec["keep_idx"], rec["keep_count"] = keep_idx, keep_count
         fts, locs, parent_inds, num_ims, state_prev, N = fts_next, locs_next, parent_next, num_next, state_next, Nn
+    if overlap:
+        main_stream.wait_stream(side_stream)
+        keepalive.clear()
     out = dict(out)
     out["status"] = status
     return out
