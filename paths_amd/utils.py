@@ -54,18 +54,35 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
 
 
 OVERLAP_AGGREGATOR = os.environ.get("PATHS_OVERLAP_AGGREGATOR", "1") != "0"
-_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+_STREAMS: Dict[int, tuple] = {}
 
 
-def _side_stream(dev) -> "torch.cuda.Stream":
+def _streams(dev):
+    """(selection-chain stream, aggregator stream) of a device.  The selection chain is the critical path of the recursion,
+    so it gets the high-priority queue: its workgroups are dispatched first and the aggregator fills what is left."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _SIDE_STREAMS:
-        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    return _SIDE_STREAMS[idx]
+    if idx not in _STREAMS:
+        _STREAMS[idx] = (torch.cuda.Stream(device=idx, priority=-1), torch.cuda.Stream(device=idx, priority=0))
+    return _STREAMS[idx]
 
 
 def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
              trace: Optional[list] = None, careful: bool = False) -> Dict[str, torch.Tensor]:
+    batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
+    if not (OVERLAP_AGGREGATOR and batch.device.type == "cuda"):
+        return _recurse_body(model, batch, keep_patches, num_levels, trace, careful, None)
+    caller = torch.cuda.current_stream(batch.device)
+    sel_stream, agg_stream = _streams(batch.device)
+    sel_stream.wait_stream(caller)
+    agg_stream.wait_stream(caller)
+    with torch.cuda.stream(sel_stream):
+        out = _recurse_body(model, batch, keep_patches, num_levels, trace, careful, agg_stream)
+    caller.wait_stream(sel_stream)          # (the body has already joined agg_stream into sel_stream)
+    return out
+
+
+def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
+                  trace: Optional[list], careful: bool, agg_stream) -> Dict[str, torch.Tensor]:
     """Run all levels for a batch of HBM-resident slides (a list of DeviceSlide, or a DeviceSlideBatch built once
     and re-used across calls).  Returns the last level's output dict (+ "status").
 
@@ -103,9 +120,9 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     # The aggregator of level i (attention, token chain, classifier) feeds nothing of level i+1 except the slide context, so
     # it runs on a second HIP stream beside the selection chain of level i+1 (top-K, expansion, gathers, gate GEMMs).  Several
     # of those kernels cannot fill 256 CUs alone (116-232 workgroups, one per CU); the other chain's waves take the idle CUs.
-    overlap = OVERLAP_AGGREGATOR and dev.type == "cuda"
+    overlap = agg_stream is not None
     main_stream = torch.cuda.current_stream(dev) if overlap else None
-    side_stream = _side_stream(dev) if overlap else None
+    side_stream = agg_stream
     keepalive = []                         # main-stream tensors read on the side stream: kept until the streams join
     for i in range(num_levels):
         proc = model.procs[i]
