@@ -16,7 +16,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 P = _lib.ptr
 
@@ -48,7 +48,15 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
     op = out if isinstance(out, int) else out.data_ptr()
     rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
     mp = None if mask is None else (mask if isinstance(mask, int) else mask.data_ptr())
-    _lib.call("paths_gemm_nt_f32", ap, lda, P(wt), ldw if ldw is not None else K, P(bias), op, ldo, M, N, N, K, act, rp, ldr,
+    ldw = ldw if ldw is not None else K
+    if ops.GEMM_MODE == "x6" and N % 256 == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
+            and wt.shape[0] >= N and wt.stride(0) == ldw and wt.stride(1) == 1:
+        # split-bf16 GEMM: the (transposed) weight is re-imaged per call - 6 N K bytes, microseconds next to an M >= 1024 product
+        wx = ops.x6_pack(wt[:N, :K])
+        _lib.call("paths_gemm_nt_x6", ap, lda, P(wx), K, 0, P(bias), op, ldo, M, N, N, K, act, rp, ldr, mp, ldm,
+                  1 if accumulate else 0, _lib.stream())
+        return
+    _lib.call("paths_gemm_nt_f32", ap, lda, P(wt), ldw, P(bias), op, ldo, M, N, N, K, act, rp, ldr,
               mp, ldm, 1 if accumulate else 0, _lib.stream())
 
 
@@ -99,18 +107,24 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
         ld, h0, c0 = state_prev.stride(1), state_prev.data_ptr(), state_prev.data_ptr() + 4 * D
     else:
         ld, h0, c0 = 0, None, None
-    _lib.call("paths_lstm_cell", P(fts), D, h0, ld, c0, ld, P(lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
-              P(lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]),
-              P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
+    x6 = ops.use_x6(D, Hc)        # forward GEMMs on the split-bf16 path (weight images are re-packed when the optimizer steps)
+    _lib.call("paths_lstm_cell_x6" if x6 else "paths_lstm_cell", P(fts), D, h0, ld, c0, ld,
+              P(ops._x6_of(lstm_pack, "w_gates") if x6 else lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
+              P(ops._x6_of(lstm_pack, "w_mem") if x6 else lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp,
+              P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
     sv["importance"] = torch.empty((B, N), **f32)
     sv["tokens"] = torch.empty((B, T, d), **f32)
     sv["hid"] = torch.empty((B, N, 128), **f32)
     sv["pproj"] = torch.empty((B, N, 128), **f32)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
-    _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), P(lvl_pack["b1"]), P(lvl_pack["w2"]), lvl_pack["b2"],
-              P(lvl_pack["bp"]), P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), None, 0, P(locs),
-              P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
-              P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)
+    tail = (P(lvl_pack["b1"]), P(lvl_pack["w2"]), lvl_pack["b2"],
+            P(lvl_pack["bp"]), P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), None, 0, P(locs),
+            P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
+            P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)
+    if x6:
+        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, 0, P(ops._x6_of(lvl_pack, "w_ip_fwd")), *tail)
+    else:
+        _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), *tail)
     return sv
 
 
