@@ -96,7 +96,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M)) return;
 #ifdef PATHS_X6_DEBUG
   const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-  uint64_t dbg_t1 = 0, dbg_t2 = 0;
+  uint64_t dbg_t1 = 0, dbg_t2 = 0, dbg_s[4] = {0, 0, 0, 0};
 #endif
 
   // ---- staging addresses.  A: thread -> (row = 64 p + tid/4, floats 4 (tid%4) .. +3 of the stage); 32-bit byte offsets
@@ -125,34 +125,58 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   static_assert(PF == 1 || PF == 2, "one or two register sets");
   f32x4 sa[PF][NA], sadd[ADD ? PF : 1][ADD ? NA : 1]; u32x4 sbr[PF][NB];
   uint32_t hi[NA][2], mid[NA][2], lo[NA][2];
-  typedef const f32x4 __attribute__((address_space(1))) * gptr_f4;
-  typedef const u32x4 __attribute__((address_space(1))) * gptr_u4;
+  // Loads go through buffer descriptors: a wave-uniform base (SGPRs), a scalar byte offset (stage, panel, W piece) and ONE
+  // per-lane 32-bit offset computed once.  As 64-bit pointers hipcc strength-reduced each load's address into a VGPR pair it
+  // then bumped with 3-4 VALU instructions per load; packed into the MFMA gaps of the 128-row tiles that stretched the first
+  // gaps of every stage to ~60 cycles.
+  const auto rsA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, 0xFFFFFFFFu, 0x00020000);
+  const auto rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A1 ? g.A1 : g.A0), 0, 0xFFFFFFFFu, 0x00020000);
+  const auto rsAdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? g.Aadd : g.A0), 0, 0xFFFFFFFFu, 0x00020000);
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.Wt), 0, 0xFFFFFFFFu, 0x00020000);
+  const int lane16 = lane * 16;
+  int bsoff[NB];                                       // scalar byte offset of W piece i at stage 0
+#pragma unroll
+  for (int i = 0; i < NB; ++i) bsoff[i] = (int)(bbase[i] - g.Wt);
   auto gload_a = [&](int set, int q, int kt) {
-    const bool first = kt < nk0;                       // wave-uniform panel select: scalar base + per-lane 32-bit offset
-    const char* base = reinterpret_cast<const char*>(first ? g.A0 : g.A1) + (int64_t)(first ? kt : kt - nk0) * 64;
-    sa[set][q] = *reinterpret_cast<gptr_f4>(reinterpret_cast<uintptr_t>(base + (first ? aoff0[q] : aoff1[q])));
+    const bool first = kt < nk0;                       // wave-uniform panel select
+#ifdef PATHS_X6_EXP_HOTA
+    const int soff = 0;                                // experiment: every stage re-reads stage 0 of A (cache-hot): is the pre-barrier loss load latency?
+#else
+    const int soff = (first ? kt : kt - nk0) * 64;
+#endif
+    const u32x4 raw = first ? __builtin_amdgcn_raw_buffer_load_b128(rsA0, (int)aoff0[q], soff, 0)
+                            : __builtin_amdgcn_raw_buffer_load_b128(rsA1, (int)aoff1[q], soff, 0);
+    sa[set][q] = __builtin_bit_cast(f32x4, raw);
     if constexpr (ADD) {                               // (ADD kernels have a single panel)
-      const char* badd = reinterpret_cast<const char*>(g.Aadd) + (int64_t)kt * 64;
-      sadd[set][q] = *reinterpret_cast<gptr_f4>(reinterpret_cast<uintptr_t>(badd + aoffs[q]));
+      sadd[set][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, (int)aoffs[q], kt * 64, 0));
     }
   };
   auto gload_b = [&](int set, int q, int kt) {
-    sbr[set][q] = *reinterpret_cast<gptr_u4>(reinterpret_cast<uintptr_t>(bbase[q] + (int64_t)kt * SUBT + lane * 16));
+    sbr[set][q] = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane16, bsoff[q] + kt * SUBT, 0);
   };
-  // split of one staged A chunk in 7 small steps (each <= 4 VALU ops, so that they ride in MFMA gaps); every residual is exact
-  auto a_step = [&](int set, int q, int st, int buf) __attribute__((always_inline)) {
+  // Split of one staged A chunk in NS micro-steps of at most 2 VALU instructions (the last one: the three LDS writes).  A gap
+  // between two 32-cycle MFMAs hides about 24 cycles of other issue; the first version used 7 steps of 4 VALU + waits, every
+  // such gap overflowed by ~15 cycles and idle gaps cannot win that back: ~500 cycles per stage (tools/x6_stages.py).
+  constexpr int NS = ADD ? 13 : 12;
+  float tf[NA][2];
+  auto a_step = [&](int set, int q, int st0, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[set][q];
-    if (st == 0) {
-      if constexpr (ADD) v += sadd[set][q];            // the fp32 sum the reference materialises (Y = X + h1)
-      hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]);
+    const int st = ADD ? st0 - 1 : st0;
+    if constexpr (ADD) {
+      if (st0 == 0) v += sadd[set][q];                 // the fp32 sum the reference materialises (Y = X + h1)
     }
-    if (st == 1) { v[0] -= bf_lo(hi[q][0]); v[1] -= bf_hi(hi[q][0]); }
-    if (st == 2) { v[2] -= bf_lo(hi[q][1]); v[3] -= bf_hi(hi[q][1]); }
-    if (st == 3) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
-    if (st == 4) { v[0] -= bf_lo(mid[q][0]); v[1] -= bf_hi(mid[q][0]); }
-    if (st == 5) { v[2] -= bf_lo(mid[q][1]); v[3] -= bf_hi(mid[q][1]); }
-    if (st == 6) {
-      lo[q][0] = pk_bf16(v[0], v[1]); lo[q][1] = pk_bf16(v[2], v[3]);
+    if (st == 0) { hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]); }
+    if (st == 1) { tf[q][0] = bf_lo(hi[q][0]); tf[q][1] = bf_hi(hi[q][0]); }
+    if (st == 2) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
+    if (st == 3) { tf[q][0] = bf_lo(hi[q][1]); tf[q][1] = bf_hi(hi[q][1]); }
+    if (st == 4) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
+    if (st == 5) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
+    if (st == 6) { tf[q][0] = bf_lo(mid[q][0]); tf[q][1] = bf_hi(mid[q][0]); }
+    if (st == 7) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
+    if (st == 8) { tf[q][0] = bf_lo(mid[q][1]); tf[q][1] = bf_hi(mid[q][1]); }
+    if (st == 9) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
+    if (st == 10) { lo[q][0] = pk_bf16(v[0], v[1]); lo[q][1] = pk_bf16(v[2], v[3]); }
+    if (st == 11) {
       char* d = smem + buf * STAGE + awr[q];
       *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
       *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
@@ -176,33 +200,64 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sl][PA_[t]], fb[sb][j][PB_[t]], acc[i][j], 0, 0, 0);
   };
-  // Staging slots before the barrier: A chunk q owns slots 8q .. 8q+7 (7 split steps, then its reload for stage kt+2);
-  // W piece q owns slots 8 NA + 2q (LDS write) and + 2q + 1 (reload).  SPG slots share one MFMA gap.
-  constexpr int TS = 8 * NA + 2 * NB, AG = (WTM - 1) * RG, SPG = (TS + AG - 1) / AG;
-  static_assert(SPG <= 2, "staging does not fit before the barrier");
+  // Staging slots, one MFMA gap each.
+  //   PF == 1: A chunk q owns gaps NS q .. NS q + NS-1 (its micro-steps; its reload with stage kt+2 shares the last one, so
+  //            the load has a full stage), W piece q gap NS NA + q (LDS write + reload).
+  //   PF == 2 (128-row tiles: only one accumulator row precedes the barrier): two micro-steps per gap, then the W writes -
+  //            everything that must precede the barrier - then the NA + NB reloads, which need not.
+  constexpr int AG = (WTM - 1) * RG;
+  constexpr int GA2 = (NS * NA + 1) / 2;
+  constexpr int TS = PF == 1 ? NS * NA + NB : GA2 + NB + NA + NB;
+  static_assert((PF == 1 ? TS : GA2 + NB) <= AG && TS <= WTM * RG, "staging does not fit");
   constexpr int AR0 = RG / 2;                          // gaps AR0 .. AR0+2 of row i: fragment reads of A row i+1
+  auto staging_slot = [&](auto sc, int kt, auto bufc, auto m1c, auto m2c) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value, buf = decltype(bufc)::value;
+    constexpr bool more1 = decltype(m1c)::value, more2 = decltype(m2c)::value;
+    constexpr int set = PF == 2 ? (buf ^ 1) : 0;       // register set holding stage kt+1 (reloaded with stage kt+1+PF)
+    if constexpr (PF == 1) {
+      if constexpr (s < NS * NA) {
+        if constexpr (more1) a_step(set, s / NS, s % NS, buf ^ 1);
+        if constexpr (more2 && s % NS == NS - 1) gload_a(set, s / NS, kt + 1 + PF);
+      } else if constexpr (s < TS) {
+        if constexpr (more1) swrite_b(set, s - NS * NA, buf ^ 1);
+        if constexpr (more2) gload_b(set, s - NS * NA, kt + 1 + PF);
+      }
+    } else {
+      if constexpr (s < GA2) {
+        if constexpr (more1) {
+          a_step(set, (2 * s) / NS, (2 * s) % NS, buf ^ 1);
+          if constexpr (2 * s + 1 < NS * NA) a_step(set, (2 * s + 1) / NS, (2 * s + 1) % NS, buf ^ 1);
+        }
+      } else if constexpr (s < GA2 + NB) {
+        if constexpr (more1) swrite_b(set, s - GA2, buf ^ 1);
+      } else if constexpr (s < GA2 + NB + NA) {
+        if constexpr (more2) gload_a(set, s - GA2 - NB, kt + 1 + PF);
+      } else if constexpr (s < TS) {
+        if constexpr (more2) gload_b(set, s - GA2 - NB - NA, kt + 1 + PF);
+      }
+    }
+  };
   auto stage_body = [&](int kt, auto bufc, auto m1c, auto m2c) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value, sb = buf;
     constexpr bool more1 = decltype(m1c)::value, more2 = decltype(m2c)::value;
     constexpr int set = PF == 2 ? (buf ^ 1) : 0;       // register set holding stage kt+1 (reloaded with stage kt+1+PF)
+#ifdef PATHS_X6_DEBUG
+    if (kt == 10) dbg_s[0] = __builtin_amdgcn_s_memtime();
+#endif
     static_for<0, AG>([&](auto gc) __attribute__((always_inline)) {
       constexpr int gq = decltype(gc)::value, i = gq / RG, gr = gq % RG;
       one_mfma(gq, sb);
       if constexpr (gr >= AR0 && gr < AR0 + 3) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
-      static_for<gq * SPG, gq * SPG + SPG>([&](auto sc) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (s < 8 * NA) {
-          if constexpr (more1 && s % 8 < 7) a_step(set, s / 8, s % 8, buf ^ 1);
-          if constexpr (more2 && s % 8 == 7) gload_a(set, s / 8, kt + 1 + PF);
-        } else if constexpr (s < TS) {
-          constexpr int q = (s - 8 * NA) / 2;
-          if constexpr (more1 && (s - 8 * NA) % 2 == 0) swrite_b(set, q, buf ^ 1);
-          if constexpr (more2 && (s - 8 * NA) % 2 == 1) gload_b(set, q, kt + 1 + PF);
-        }
-      });
+      staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);
       __builtin_amdgcn_sched_barrier(0);
     });
+#ifdef PATHS_X6_DEBUG
+    if (kt == 10) dbg_s[1] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef PATHS_X6_DEBUG
+    if (kt == 10) dbg_s[2] = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_sched_barrier(0);
     static_for<AG, WTM * RG>([&](auto gc) __attribute__((always_inline)) {
       constexpr int gq = decltype(gc)::value, gr = gq % RG;
@@ -214,8 +269,12 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
           else if constexpr (f < 3 + 3 * WTN) read_b(buf ^ 1, (f - 3) / 3, sb ^ 1, (f - 3) % 3);
         });
       }
+      staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);   // (reload slots of the PF == 2 layout)
       __builtin_amdgcn_sched_barrier(0);
     });
+#ifdef PATHS_X6_DEBUG
+    if (kt == 10) dbg_s[3] = __builtin_amdgcn_s_memtime();
+#endif
   };
   constexpr std::integral_constant<int, 0> I0{};
   constexpr std::integral_constant<int, 1> I1{};
@@ -230,7 +289,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
 #pragma unroll
   for (int q = 0; q < NA; ++q)
 #pragma unroll
-    for (int st = 0; st < 7; ++st) a_step(0, q, st, 0);
+    for (int st = 0; st < NS; ++st) a_step(0, q, st, 0);
 #pragma unroll
   for (int q = 0; q < NB; ++q) swrite_b(0, q, 0);
 #pragma unroll
@@ -271,8 +330,9 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     __builtin_amdgcn_s_waitcnt(0);
     const uint64_t t3 = __builtin_amdgcn_s_memtime(), r3 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
-      uint64_t* d = g.dbg + 6 * ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
+      uint64_t* d = g.dbg + 9 * ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave);
       d[0] = dbg_t1 - dbg_t0; d[1] = dbg_t2 - dbg_t1; d[2] = t3 - dbg_t2; d[3] = r3 - dbg_r0; d[4] = dbg_r0; d[5] = r3;
+      d[6] = dbg_s[1] - dbg_s[0]; d[7] = dbg_s[2] - dbg_s[1]; d[8] = dbg_s[3] - dbg_s[2];   // stage 10: pre-barrier, barrier wait, post-barrier
     }
   }
 #endif
@@ -329,7 +389,7 @@ inline int64_t group_stride(int Kpacked) { return (int64_t)(Kpacked / 16) * SUBT
 extern "C" {
 
 #ifdef PATHS_X6_DEBUG
-// development hook (tools/x6_stages.py, debug build only): buffer of 6 uint64 per wave, or NULL
+// development hook (tools/x6_stages.py, debug build only): buffer of 9 uint64 per wave, or NULL
 void paths_x6_debug_buffer(uint64_t* p) { g_x6_dbg = p; }
 #endif
 

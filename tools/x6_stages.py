@@ -11,14 +11,14 @@ DBG = os.path.join(ROOT, "tools", "_bin", "libpaths_hip_dbg.so")
 if not os.path.exists(DBG) or "--rebuild" in sys.argv:
     os.makedirs(os.path.dirname(DBG), exist_ok=True)
     srcs = [os.path.join(ROOT, "paths_amd", "csrc", f) for f in sorted(os.listdir(os.path.join(ROOT, "paths_amd", "csrc"))) if f.endswith(".hip")]
-    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-DPATHS_X6_DEBUG", "-o", DBG] + srcs)
+    subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-DPATHS_X6_DEBUG"] + [a for a in sys.argv if a.startswith("-D")] + ["-o", DBG] + srcs)
     if "--build-only" in sys.argv:
         sys.exit(0)
 os.environ["PATHS_HIP_LIB"] = DBG
 sys.path.insert(0, ROOT)
 import torch
 from paths_amd import _lib, ops
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+args = [a for a in sys.argv[1:] if not a.startswith("-")]
 M = int(args[0]) if len(args) > 0 else 14746
 MP = int(args[1]) if len(args) > 1 else 4096
 D, Hc, G = 1024, 256, 1792
@@ -72,11 +72,11 @@ for name, fn, blocks, stages, floor, flop in CASES:
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
-    dbg = torch.zeros(blocks * 4 * 6, device=dev, dtype=torch.int64)
+    dbg = torch.zeros(blocks * 4 * 9, device=dev, dtype=torch.int64)
     lib.paths_x6_debug_buffer(dbg.data_ptr())
     fn(); torch.cuda.synchronize()
     lib.paths_x6_debug_buffer(None)
-    d = dbg.view(-1, 6).double()
+    d = dbg.view(-1, 9).double()
     d = d[d[:, 3] > 0]
     t_first, t_last = d[:, 4].min().item(), d[:, 5].max().item()
     starts = (d[:, 4] - t_first) / 100.0        # us
@@ -87,4 +87,5 @@ for name, fn, blocks, stages, floor, flop in CASES:
     print(f"{name}: {us:7.1f} us {flop / us / 1e6:6.1f} TF | blocks {blocks:4d} | init {med[0]:8.0f} loop {med[1]:8.0f} epi {med[2]:8.0f} cyc | "
           f"{med[1] / stages:6.0f} cyc/stage (MFMA floor {floor}) | {ghz:.2f} GHz\n"
           f"      in-kernel span {(t_last - t_first) / 100.0:6.1f} us; wave start p50 {starts.median().item():5.1f} max {starts.max().item():5.1f} us; "
-          f"wave life p50 {life.median().item():6.1f} max {life.max().item():6.1f} us", flush=True)
+          f"wave life p50 {life.median().item():6.1f} max {life.max().item():6.1f} us\n"
+          f"      stage 10: pre-barrier {d[:, 6].median().item():6.0f}  barrier wait {d[:, 7].median().item():6.0f}  post-barrier {d[:, 8].median().item():6.0f} cycles", flush=True)
