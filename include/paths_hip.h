@@ -65,32 +65,41 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const 
                           float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
                           int skip_padding, paths_stream_t stream);
 
-/* ---- split-bf16 ("x6") variants of the three GEMM entry points above: same arithmetic contract (fp32 in, fp32 out,
- * error not larger than an fp32 FMA chain's), computed on the bf16 matrix cores: every fp32 operand is the exact sum of three
- * bf16 (hi+mid+lo) and six of the nine partial products are accumulated in fp32 (csrc/gemm_x6.hip).  Activations stay
- * fp32 in HBM; WEIGHTS are passed as the packed image produced once by paths_x6_pack_weights:
- *   [Npad/32][K/16][plane hi|mid|lo][k-half][32 rows][8 bf16]   (paths_x6_packed_bytes(Npad, K) = 6 Npad K bytes).
+/* ---- split-operand variants of the three GEMM entry points above: same arithmetic contract (fp32 in, fp32 out, fp32
+ * accumulation, error of the order of an fp32 FMA chain's), computed on the 16-bit matrix cores (csrc/gemm_x6.hip).
+ *   planes = 3 ("x6"): every fp32 operand is the exact sum of three bf16 (hi+mid+lo); six of the nine partial products are
+ *                      kept (dropped: <= 2^-25 |a w|); 6 bf16 MFMAs per product block.  No range restrictions; scales must be 1.
+ *   planes = 2 ("h3"): operands are split into two fp16 (hi+lo, 22 significant bits); hi*hi + hi*lo + lo*hi are kept (dropped:
+ *                      <= 2^-22 |a w|); 3 fp16 MFMAs per product block.  fp16's exponent range is narrow, so operands are
+ *                      pre-scaled by powers of two: weights by w_scale when packed (max|w| w_scale < 65504), activations by
+ *                      a_scale inside the kernel (|activation| a_scale < 65504; below 0.125 / a_scale the lo plane is
+ *                      subnormal: absolute error 2^-25 / a_scale per element).  Accumulators are un-scaled in the epilogues.
+ * Activations stay fp32 in HBM; WEIGHTS are passed as the image produced once by paths_x6_pack_weights:
+ *   [Npad/32][K/16][plane][k-half][32 rows][8 x 16 bit]   (paths_x6_packed_bytes(Npad, K, planes) = 2 planes Npad K bytes).
  * They replace the same reference code as their f32 twins (model/interface.py:31-58, model/paths.py:78-98,119-124). */
-int64_t paths_x6_packed_bytes(int Npad, int K);
-int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, paths_stream_t stream);
-/* w_gates_x6 = pack of the PACKED gate matrix [3Hc+D, 2D] of paths_lstm_cell; w_mem_x6 = pack of [D, Hc]; D % 256 == 0 */
+int64_t paths_x6_packed_bytes(int Npad, int K, int planes);
+int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int planes, float w_scale,
+                          paths_stream_t stream);
+/* w_gates_x6 = pack of the PACKED gate matrix [3Hc+D, 2D] of paths_lstm_cell (scale wg_scale); w_mem_x6 = pack of [D, Hc]
+ * (scale wm_scale); D % 256 == 0; y may be NULL (Y = X + h1 not materialised) */
 int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                        const void* w_gates_x6, const float* b_gates, const void* w_mem_x6, const float* b_mem,
                        float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
                        const float* hp, const int* hp_row,
-                       int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases, paths_stream_t stream);
-/* w_ip_x6 = pack of [256, D]; y_add (optional): GEMM input = y + y_add summed in fp32 while staging, so that the caller can
- * pass (x, h1) and skip materialising Y = X + h1 (paths_lstm_cell_x6 accepts y = NULL for that) */
+                       int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases,
+                       int planes, float wg_scale, float wm_scale, float a_scale, paths_stream_t stream);
+/* w_ip_x6 = pack of [256, D] (rows interleaved as for paths_importance_proj); y_add (optional): GEMM input = y + y_add summed
+ * in fp32 while staging, so that the caller can pass (x, h1) and skip materialising Y = X + h1 */
 int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows,
                              const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                              float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
-                             int skip_padding, paths_stream_t stream);
+                             int skip_padding, int planes, float w_scale, float a_scale, paths_stream_t stream);
 /* out (+)= maskop(act(a W[:, k0:k0+K]^T + b)) + residual, W = pack of an [Npad, Kpacked] weight; Npad % 256 == 0 */
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
-                     int64_t ldm, int accumulate, paths_stream_t stream);
+                     int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, paths_stream_t stream);
 
 /* ---- backward-pass building blocks (reference: autograd of train.py:65 loss.backward()) --------------------------
  * paths_gemm_nt_f32: out (+)= maskop(act(a W^T + b)) + residual; with W = a transposed weight copy this is dX = dY W.

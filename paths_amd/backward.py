@@ -49,12 +49,12 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
     rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
     mp = None if mask is None else (mask if isinstance(mask, int) else mask.data_ptr())
     ldw = ldw if ldw is not None else K
-    if ops.GEMM_MODE == "x6" and N % 256 == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
+    if ops.GEMM_MODE != "f32" and N % 256 == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
             and wt.shape[0] >= N and wt.stride(0) == ldw and wt.stride(1) == 1:
         # split-bf16 GEMM: the (transposed) weight is re-imaged per call - 6 N K bytes, microseconds next to an M >= 1024 product
-        wx = ops.x6_pack(wt[:N, :K])
+        wx, wx_s = ops.x6_pack(wt[:N, :K])
         _lib.call("paths_gemm_nt_x6", ap, lda, P(wx), K, 0, P(bias), op, ldo, M, N, N, K, act, rp, ldr, mp, ldm,
-                  1 if accumulate else 0, _lib.stream())
+                  1 if accumulate else 0, ops.split_planes(), wx_s, ops.a_scale(), _lib.stream())
         return
     _lib.call("paths_gemm_nt_f32", ap, lda, P(wt), ldw, P(bias), op, ldo, M, N, N, K, act, rp, ldr,
               mp, ldm, 1 if accumulate else 0, _lib.stream())
@@ -108,10 +108,15 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
     else:
         ld, h0, c0 = 0, None, None
     x6 = ops.use_x6(D, Hc)        # forward GEMMs on the split-bf16 path (weight images are re-packed when the optimizer steps)
-    _lib.call("paths_lstm_cell_x6" if x6 else "paths_lstm_cell", P(fts), D, h0, ld, c0, ld,
-              P(ops._x6_of(lstm_pack, "w_gates") if x6 else lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
-              P(ops._x6_of(lstm_pack, "w_mem") if x6 else lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp,
-              P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
+    if x6:
+        (wg, wg_s), (wm, wm_s) = ops._x6_of(lstm_pack, "w_gates"), ops._x6_of(lstm_pack, "w_mem")
+        _lib.call("paths_lstm_cell_x6", P(fts), D, h0, ld, c0, ld, P(wg), P(lstm_pack["b_gates"]), P(wm), P(lstm_pack["b_mem"]),
+                  P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7,
+                  ops.split_planes(), wg_s, wm_s, ops.a_scale(), st)
+    else:
+        _lib.call("paths_lstm_cell", P(fts), D, h0, ld, c0, ld, P(lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
+                  P(lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp,
+                  P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
     sv["importance"] = torch.empty((B, N), **f32)
     sv["tokens"] = torch.empty((B, T, d), **f32)
     sv["hid"] = torch.empty((B, N, 128), **f32)
@@ -122,7 +127,8 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
             P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
             P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)
     if x6:
-        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, 0, P(ops._x6_of(lvl_pack, "w_ip_fwd")), *tail)
+        wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd")
+        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, 0, P(wip), *tail[:-1], ops.split_planes(), wip_s, ops.a_scale(), tail[-1])
     else:
         _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), *tail)
     return sv

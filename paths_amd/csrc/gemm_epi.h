@@ -64,9 +64,11 @@ struct EpiLstmC {
   float* c1; int64_t ldc1;         // state_out + D
   float* frm; int64_t ldfrm;       // optional (training): post-activation f|r|m in the packed column order
   const float* hp; int64_t ldhp; const int* hp_row;   // optional: once-per-parent partial pre-activations h_parent Wh^T
+  float acc_scale = 1.0f;          // accumulators hold (true value) / acc_scale (fp16-split GEMM: operands are pre-scaled by powers of two)
   template <int WTM, int WTN>
   __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
     const int jj = lane & 31;
+    const float seed = 1.0f / acc_scale;
     if (hp == nullptr) {
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
@@ -93,7 +95,7 @@ struct EpiLstmC {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool has = pr[i][r] >= 0;
-        acc[i][0][r] = has ? t[0][r] : 0.f; acc[i][1][r] = has ? t[1][r] : 0.f; acc[i][2][r] = has ? t[2][r] : 0.f;
+        acc[i][0][r] = has ? t[0][r] * seed : 0.f; acc[i][1][r] = has ? t[1][r] * seed : 0.f; acc[i][2][r] = has ? t[2][r] * seed : 0.f;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -113,9 +115,9 @@ struct EpiLstmC {
       for (int r = 0; r < 16; ++r) cp[r] = c0 ? *tile_elem_o<FULL>(c0v, o0, trow, tcol, r, lane, M) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float f = sigmoid_acc(acc[i][0][r] + bf);
-        const float rg = sigmoid_acc(acc[i][1][r] + br);
-        const float mp = tanh_acc(acc[i][2][r] + bm);
+        const float f = sigmoid_acc(fmaf(acc[i][0][r], acc_scale, bf));
+        const float rg = sigmoid_acc(fmaf(acc[i][1][r], acc_scale, br));
+        const float mp = tanh_acc(fmaf(acc[i][2][r], acc_scale, bm));
         const float v = cp[r] * f + rg * mp;
         if (tile_row_ok<FULL>(trow, r, lane, M)) {
           *tile_elem_o<FULL>(c1v, o1, trow, tcol, r, lane, M) = v;
@@ -146,8 +148,10 @@ struct EpiLstmC {
 struct EpiLstmO {
   const float* bias; float* o; int64_t ldo; int N;   // N % 32 == 0
   const float* hp; int64_t ldhp; const int* hp_row; int hp_col0;   // optional parent partials (columns hp_col0 + col)
+  float acc_scale = 1.0f;          // see EpiLstmC
   template <int WTM, int WTN>
   __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
+    const float seed = 1.0f / acc_scale;
     if (hp == nullptr) {
 #pragma unroll
       for (int i = 0; i < WTM; ++i)
@@ -177,7 +181,7 @@ struct EpiLstmO {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j][r] = pr[i][r] >= 0 ? t[j][r] : 0.f;
+        for (int j = 0; j < WTN; ++j) acc[i][j][r] = pr[i][r] >= 0 ? t[j][r] * seed : 0.f;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -192,7 +196,7 @@ struct EpiLstmO {
         char* origin = ov.tile(trow, tcol);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = sigmoid_acc(acc[i][j][r] + b);
+          const float v = sigmoid_acc(fmaf(acc[i][j][r], acc_scale, b));
           if (tile_row_ok<FULL>(trow, r, lane, M)) *tile_elem_o<FULL>(ov, origin, trow, tcol, r, lane, M) = v;
         }
       }
@@ -221,6 +225,7 @@ struct EpiLstmH {
   const float* bias; const float* o; int64_t ldo; const float* x; int64_t ldx;
   float* h1; int64_t ldh; float* y; int64_t ldy; int N;      // N % 32 == 0; y optional (Y = X + h1 not materialised)
   float* tc_out;                   // optional (training): tanh(Wc c1 + bc), [M, N]
+  float acc_scale = 1.0f;          // see EpiLstmC
   template <bool FULL, int WTM, int WTN>
   __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
     // tile-pipelined: the loads of tiles t+1 .. t+PD are in flight while tile t is computed and stored (PD+1 register
@@ -254,7 +259,7 @@ struct EpiLstmH {
         char* th = hv.tile(trow, tcol); char* ty = yv.tile(trow, tcol); char* tt = tv.tile(trow, tcol);
         static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
           constexpr int r = decltype(rc)::value;
-          const float tcv = tanh_acc(acc[i][j][r] + b);
+          const float tcv = tanh_acc(fmaf(acc[i][j][r], acc_scale, b));
           const float h = ov[s][r] * tcv;
           if constexpr (FULL) {
             if constexpr (WITH_TC) *tv.elem(tt, r) = tcv;
@@ -292,6 +297,7 @@ struct EpiBias {
 
   const float* bias; float* out; int64_t ldo; int N; int act;
   const float* residual; int64_t ldr; const float* mask; int64_t ldm; int accumulate;
+  float acc_scale = 1.0f;          // see EpiLstmC
   template <bool FULL, int WTM, int WTN>
   __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
     constexpr int NT = WTM * WTN;
@@ -321,7 +327,7 @@ struct EpiBias {
       if (tcol < N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + b;
+          float v = fmaf(acc[i][j][r], acc_scale, b);
           if (act == 1) v = fmaxf(v, 0.f);
           if (any_load) {
             if (!(mv[s][r] > 0.f)) v = 0.f;
@@ -383,6 +389,7 @@ struct EpiImpProj {
   float* hid_out;                  // optional (training): relu(Y W1^T + b1) [M,128]
   float* pproj_out;                // optional (training): Y Wp^T (before alpha / bias / PE) [M,128]
   const float* pe_table; int pe_rows;   // PE_TAB: paths_pe_table output (same sinf/cosf values, read instead of recomputed)
+  float acc_scale = 1.0f;               // see EpiLstmC
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int wm, int wn, int M, float* smem) const {
     static_assert(WTN == 4 && WGN == 2, "imp/proj epilogue layout: one block spans the 128 hidden + 128 projected columns");
@@ -403,7 +410,7 @@ struct EpiImpProj {
         const float b = b1[u], w = w2[u];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float hv = fmaxf(acc[i][j][r] + b, 0.f);
+          const float hv = fmaxf(fmaf(acc[i][j][r], acc_scale, b), 0.f);
           part[r] += hv * w;
           const int row = row0 + 32 * i + c32_row(r, lane);
           if (hid_out && row < M) hid_out[(int64_t)row * 128 + u] = hv;
@@ -472,8 +479,9 @@ struct EpiImpProj {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int c = u0 + 32 * j + (lane & 31);
-            trow[c] = av[r] * acc[i][2 + j][r] + bpv[j] + pev[r][j];
-            if (pproj_out) pproj_out[(int64_t)row * 128 + c] = acc[i][2 + j][r];
+            const float pj = acc[i][2 + j][r] * acc_scale;
+            trow[c] = av[r] * pj + bpv[j] + pev[r][j];
+            if (pproj_out) pproj_out[(int64_t)row * 128 + c] = pj;
             if (first[r]) trow[c - d] = special[c];
           }
         }

@@ -33,6 +33,8 @@ namespace {
 using namespace paths_epi;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -45,8 +47,17 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {      // v_cvt_pk
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
-constexpr int FRAG = 1024;         // bytes of one 32-row x 16-k fragment of one plane
-constexpr int SUBT = 3 * FRAG;     // one 32-row x 16-k sub-tile: hi | mid | lo
+// fp16 twin of the bf16 helpers (NP == 2 split, see below)
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {       // v_cvt_pk_f16_f32 / 2 x v_cvt_f16_f32: round to nearest even
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ float h_lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float h_hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+
+constexpr int FRAG = 1024;         // bytes of one 32-row x 16-k fragment of one plane (16-bit elements either way)
+// NP = planes per operand: 3 = bf16 hi|mid|lo, 6 MFMAs per product block ("x6"); 2 = fp16 hi|lo, 3 MFMAs ("h3")
+template <int NP> constexpr int subt() { return NP * FRAG; }    // one 32-row x 16-k sub-tile
 
 struct X6Operands {
   const float* A0; int64_t lda0; int K0;
@@ -57,6 +68,7 @@ struct X6Operands {
   int M;
   const int64_t* num_ims;          // optional padding skip
   int rows_per_slide;
+  float a_scale;                   // NP == 2: activations are multiplied by this power of two before the fp16 split
 #ifdef PATHS_X6_DEBUG
   uint64_t* dbg;                   // tools/x6_stages.py only: per-wave {init, loop, epilogue} shader-clock ticks, 100 MHz ticks, start/end 100 MHz stamps
 #endif
@@ -67,14 +79,17 @@ uint64_t* g_x6_dbg = nullptr;
 
 // PF = how many stages ahead of its LDS write a stage is loaded into registers (1 or 2 register sets).  Stages of the
 // 128-row tiles are only ~1,500 cycles long, shorter than a loaded-L2 round trip, so those run two stages ahead.
-template <int WTM, int WTN, int PF, bool ADD, class Epi>
+template <int NP, int WTM, int WTN, int PF, bool ADD, class Epi>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_x6_kernel(X6Operands g, Epi epi) {
+  static_assert(NP == 2 || NP == 3, "two fp16 planes or three bf16 planes");
+  constexpr int SUBT = subt<NP>();
+  constexpr int NPROD = NP == 3 ? 6 : 3;               // partial products kept per operand pair
   constexpr int BM = WTM * 64, BN = WTN * 64;
   constexpr int SA = 2 * WTM, SB = 2 * WTN;            // 32-row sub-tiles per block
   constexpr int STAGE = (SA + SB) * SUBT;
   constexpr int NA = BM / 64;                          // fp32 A chunks (4 floats) per thread per stage
-  constexpr int NPB = SB * 3, NB = (NPB + 3) / 4;      // 1-KiB W pieces per stage, per wave
+  constexpr int NPB = SB * NP, NB = (NPB + 3) / 4;     // 1-KiB W pieces per stage, per wave
   static_assert(WTM % 2 == 0, "A fragment register slots alternate per accumulator row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -118,13 +133,13 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   for (int i = 0; i < NB; ++i) {
     int pc = wave + 4 * i;
     if (pc >= NPB) pc -= 4;                            // re-stage this wave's previous piece (same bytes, same slot)
-    const int sub = pc / 3, pl = pc % 3;
+    const int sub = pc / NP, pl = pc % NP;
     bbase[i] = g.Wt + ((int64_t)(n0 >> 5) + sub) * g.w_group_stride + pl * FRAG;
     bwr[i] = (SA + sub) * SUBT + pl * FRAG + lane * 16;
   }
   static_assert(PF == 1 || PF == 2, "one or two register sets");
   f32x4 sa[PF][NA], sadd[ADD ? PF : 1][ADD ? NA : 1]; u32x4 sbr[PF][NB];
-  uint32_t hi[NA][2], mid[NA][2], lo[NA][2];
+  uint32_t hi[NA][2], mid[NP == 3 ? NA : 1][2], lo[NA][2];
   // Loads go through buffer descriptors: a wave-uniform base (SGPRs), a scalar byte offset (stage, panel, W piece) and ONE
   // per-lane 32-bit offset computed once.  As 64-bit pointers hipcc strength-reduced each load's address into a VGPR pair it
   // then bumped with 3-4 VALU instructions per load; packed into the MFMA gaps of the 128-row tiles that stretched the first
@@ -157,7 +172,8 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // Split of one staged A chunk in NS micro-steps of at most 2 VALU instructions (the last one: the three LDS writes).  A gap
   // between two 32-cycle MFMAs hides about 24 cycles of other issue; the first version used 7 steps of 4 VALU + waits, every
   // such gap overflowed by ~15 cycles and idle gaps cannot win that back: ~500 cycles per stage (tools/x6_stages.py).
-  constexpr int NS = ADD ? 13 : 12;
+  //   NP == 3 (bf16): 12 micro-steps (+1 for the ADD sum);  NP == 2 (fp16): scale, hi, residuals, lo, writes = 8 (+1).
+  constexpr int NS = (NP == 3 ? 12 : 8) + (ADD ? 1 : 0);
   float tf[NA][2];
   auto a_step = [&](int set, int q, int st0, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[set][q];
@@ -165,22 +181,37 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     if constexpr (ADD) {
       if (st0 == 0) v += sadd[set][q];                 // the fp32 sum the reference materialises (Y = X + h1)
     }
-    if (st == 0) { hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]); }
-    if (st == 1) { tf[q][0] = bf_lo(hi[q][0]); tf[q][1] = bf_hi(hi[q][0]); }
-    if (st == 2) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
-    if (st == 3) { tf[q][0] = bf_lo(hi[q][1]); tf[q][1] = bf_hi(hi[q][1]); }
-    if (st == 4) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
-    if (st == 5) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
-    if (st == 6) { tf[q][0] = bf_lo(mid[q][0]); tf[q][1] = bf_hi(mid[q][0]); }
-    if (st == 7) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
-    if (st == 8) { tf[q][0] = bf_lo(mid[q][1]); tf[q][1] = bf_hi(mid[q][1]); }
-    if (st == 9) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
-    if (st == 10) { lo[q][0] = pk_bf16(v[0], v[1]); lo[q][1] = pk_bf16(v[2], v[3]); }
-    if (st == 11) {
-      char* d = smem + buf * STAGE + awr[q];
-      *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
-      *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
-      *reinterpret_cast<u32x2*>(d + 2 * FRAG) = u32x2{lo[q][0], lo[q][1]};
+    if constexpr (NP == 3) {
+      if (st == 0) { hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]); }
+      if (st == 1) { tf[q][0] = bf_lo(hi[q][0]); tf[q][1] = bf_hi(hi[q][0]); }
+      if (st == 2) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
+      if (st == 3) { tf[q][0] = bf_lo(hi[q][1]); tf[q][1] = bf_hi(hi[q][1]); }
+      if (st == 4) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
+      if (st == 5) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
+      if (st == 6) { tf[q][0] = bf_lo(mid[q][0]); tf[q][1] = bf_hi(mid[q][0]); }
+      if (st == 7) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
+      if (st == 8) { tf[q][0] = bf_lo(mid[q][1]); tf[q][1] = bf_hi(mid[q][1]); }
+      if (st == 9) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
+      if (st == 10) { lo[q][0] = pk_bf16(v[0], v[1]); lo[q][1] = pk_bf16(v[2], v[3]); }
+      if (st == 11) {
+        char* d = smem + buf * STAGE + awr[q];
+        *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
+        *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
+        *reinterpret_cast<u32x2*>(d + 2 * FRAG) = u32x2{lo[q][0], lo[q][1]};
+      }
+    } else {
+      if (st == 0) v *= g.a_scale;                      // power of two: exact
+      if (st == 1) { hi[q][0] = pk_f16(v[0], v[1]); hi[q][1] = pk_f16(v[2], v[3]); }
+      if (st == 2) { tf[q][0] = h_lo(hi[q][0]); tf[q][1] = h_hi(hi[q][0]); }
+      if (st == 3) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
+      if (st == 4) { tf[q][0] = h_lo(hi[q][1]); tf[q][1] = h_hi(hi[q][1]); }
+      if (st == 5) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
+      if (st == 6) { lo[q][0] = pk_f16(v[0], v[1]); lo[q][1] = pk_f16(v[2], v[3]); }
+      if (st == 7) {
+        char* d = smem + buf * STAGE + awr[q];
+        *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
+        *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{lo[q][0], lo[q][1]};
+      }
     }
   };
   auto swrite_b = [&](int set, int q, int buf) { *reinterpret_cast<u32x4*>(smem + buf * STAGE + bwr[q]) = sbr[set][q]; };
@@ -191,42 +222,60 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
 
   const char* sA = smem + (wm * WTM) * SUBT + lane * 16;
   const char* sB = smem + (SA + wn * WTN) * SUBT + lane * 16;
-  bf16x8 fa[2][3], fb[2][WTN][3];
-  auto read_a = [&](int buf, int i, int slot, int p) { fa[slot][p] = *reinterpret_cast<const bf16x8*>(sA + buf * STAGE + i * SUBT + p * FRAG); };
-  auto read_b = [&](int buf, int j, int slot, int p) { fb[slot][j][p] = *reinterpret_cast<const bf16x8*>(sB + buf * STAGE + j * SUBT + p * FRAG); };
-  constexpr int RG = WTN * 6;                          // MFMA gaps per accumulator row
+  u32x4 fa[2][NP], fb[2][WTN][NP];                     // 8 x 16-bit per lane and plane
+  auto read_a = [&](int buf, int i, int slot, int p) { fa[slot][p] = *reinterpret_cast<const u32x4*>(sA + buf * STAGE + i * SUBT + p * FRAG); };
+  auto read_b = [&](int buf, int j, int slot, int p) { fb[slot][j][p] = *reinterpret_cast<const u32x4*>(sB + buf * STAGE + j * SUBT + p * FRAG); };
+  constexpr int RG = WTN * NPROD;                      // MFMA gaps per accumulator row
   auto one_mfma = [&](int gq, int sb) __attribute__((always_inline)) {
-    const int i = gq / RG, j = (gq % RG) / 6, t = gq % 6, sl = i & 1;
-    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sl][PA_[t]], fb[sb][j][PB_[t]], acc[i][j], 0, 0, 0);
+    const int i = gq / RG, j = (gq % RG) / NPROD, t = gq % NPROD, sl = i & 1;
+    if constexpr (NP == 3) {
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][PA_[t]]), __builtin_bit_cast(bf16x8, fb[sb][j][PB_[t]]), acc[i][j], 0, 0, 0);
+    } else {
+      constexpr int PA_[3] = {1, 0, 0}, PB_[3] = {0, 1, 0};                     // lo*hi, hi*lo, hi*hi
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[sl][PA_[t]]), __builtin_bit_cast(f16x8, fb[sb][j][PB_[t]]), acc[i][j], 0, 0, 0);
+    }
   };
-  // Staging slots, one MFMA gap each.
-  //   PF == 1: A chunk q owns gaps NS q .. NS q + NS-1 (its micro-steps; its reload with stage kt+2 shares the last one, so
-  //            the load has a full stage), W piece q gap NS NA + q (LDS write + reload).
-  //   PF == 2 (128-row tiles: only one accumulator row precedes the barrier): two micro-steps per gap, then the W writes -
-  //            everything that must precede the barrier - then the NA + NB reloads, which need not.
+  // Staging slots, one MFMA gap each, SPG micro-steps to a gap (the smallest SPG that fits before the barrier).
+  //   PF == 1: A chunk q owns GPC consecutive gaps (its micro-steps; its reload with stage kt+2 shares the last one, so
+  //            the load has a full stage), then W piece q one gap (LDS write + reload).
+  //   PF == 2 (128-row tiles: only one accumulator row precedes the barrier): all micro-steps packed SPG to a gap, then the
+  //            W writes - everything that must precede the barrier - then the NA + NB reloads, which need not.
   constexpr int AG = (WTM - 1) * RG;
-  constexpr int GA2 = (NS * NA + 1) / 2;
-  constexpr int TS = PF == 1 ? NS * NA + NB : GA2 + NB + NA + NB;
-  static_assert((PF == 1 ? TS : GA2 + NB) <= AG && TS <= WTM * RG, "staging does not fit");
+  constexpr auto fits = [](int spg) constexpr {
+    return PF == 1 ? ((NS + spg - 1) / spg) * NA + NB <= AG : (NS * NA + spg - 1) / spg + NB <= AG;
+  };
+  constexpr int SPG = fits(1) ? 1 : fits(2) ? 2 : fits(3) ? 3 : 4;
+  static_assert(fits(SPG), "staging does not fit before the barrier");
+  constexpr int GPC = (NS + SPG - 1) / SPG;            // PF == 1: gaps per A chunk
+  constexpr int GA2 = (NS * NA + SPG - 1) / SPG;       // PF == 2: gaps of all A micro-steps
+  constexpr int TS = PF == 1 ? GPC * NA + NB : GA2 + NB + NA + NB;
+  static_assert(TS <= WTM * RG, "staging does not fit in a stage");
   constexpr int AR0 = RG / 2;                          // gaps AR0 .. AR0+2 of row i: fragment reads of A row i+1
   auto staging_slot = [&](auto sc, int kt, auto bufc, auto m1c, auto m2c) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value, buf = decltype(bufc)::value;
     constexpr bool more1 = decltype(m1c)::value, more2 = decltype(m2c)::value;
     constexpr int set = PF == 2 ? (buf ^ 1) : 0;       // register set holding stage kt+1 (reloaded with stage kt+1+PF)
     if constexpr (PF == 1) {
-      if constexpr (s < NS * NA) {
-        if constexpr (more1) a_step(set, s / NS, s % NS, buf ^ 1);
-        if constexpr (more2 && s % NS == NS - 1) gload_a(set, s / NS, kt + 1 + PF);
+      if constexpr (s < GPC * NA) {
+        constexpr int q = s / GPC, g0 = s % GPC;
+        if constexpr (more1) {
+          static_for<g0 * SPG, (g0 + 1) * SPG < NS ? (g0 + 1) * SPG : NS>([&](auto mc) __attribute__((always_inline)) {
+            a_step(set, q, decltype(mc)::value, buf ^ 1);
+          });
+        }
+        if constexpr (more2 && g0 == GPC - 1) gload_a(set, q, kt + 1 + PF);
       } else if constexpr (s < TS) {
-        if constexpr (more1) swrite_b(set, s - NS * NA, buf ^ 1);
-        if constexpr (more2) gload_b(set, s - NS * NA, kt + 1 + PF);
+        if constexpr (more1) swrite_b(set, s - GPC * NA, buf ^ 1);
+        if constexpr (more2) gload_b(set, s - GPC * NA, kt + 1 + PF);
       }
     } else {
       if constexpr (s < GA2) {
         if constexpr (more1) {
-          a_step(set, (2 * s) / NS, (2 * s) % NS, buf ^ 1);
-          if constexpr (2 * s + 1 < NS * NA) a_step(set, (2 * s + 1) / NS, (2 * s + 1) % NS, buf ^ 1);
+          static_for<s * SPG, (s + 1) * SPG < NS * NA ? (s + 1) * SPG : NS * NA>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            a_step(set, m / NS, m % NS, buf ^ 1);
+          });
         }
       } else if constexpr (s < GA2 + NB) {
         if constexpr (more1) swrite_b(set, s - GA2, buf ^ 1);
@@ -247,7 +296,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     static_for<0, AG>([&](auto gc) __attribute__((always_inline)) {
       constexpr int gq = decltype(gc)::value, i = gq / RG, gr = gq % RG;
       one_mfma(gq, sb);
-      if constexpr (gr >= AR0 && gr < AR0 + 3) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
+      if constexpr (gr >= AR0 && gr < AR0 + NP) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
       staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -265,8 +314,8 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
       if constexpr (more1) {
         static_for<2 * gr, 2 * gr + 2>([&](auto fc) __attribute__((always_inline)) {
           constexpr int f = decltype(fc)::value;
-          if constexpr (f < 3) read_a(buf ^ 1, 0, 0, f);
-          else if constexpr (f < 3 + 3 * WTN) read_b(buf ^ 1, (f - 3) / 3, sb ^ 1, (f - 3) % 3);
+          if constexpr (f < NP) read_a(buf ^ 1, 0, 0, f);
+          else if constexpr (f < NP + NP * WTN) read_b(buf ^ 1, (f - NP) / NP, sb ^ 1, (f - NP) % NP);
         });
       }
       staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);   // (reload slots of the PF == 2 layout)
@@ -301,11 +350,11 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   }
   __syncthreads();
 #pragma unroll
-  for (int p = 0; p < 3; ++p) read_a(0, 0, 0, p);
+  for (int p = 0; p < NP; ++p) read_a(0, 0, 0, p);
 #pragma unroll
   for (int j = 0; j < WTN; ++j)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) read_b(0, j, 0, p);
+    for (int p = 0; p < NP; ++p) read_b(0, j, 0, p);
 #ifdef PATHS_X6_DEBUG
   dbg_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -338,23 +387,30 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
 #endif
 }
 
-// fp32 [N, K] (row stride ldw) -> split tiled image, rows >= N zero
-__global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, __bf16* __restrict__ out, int N, int Npad, int K) {
+// fp32 [N, K] (row stride ldw) -> split tiled image, rows >= N zero.  NP == 2: values are multiplied by wscale (a power of two) first.
+template <int NP>
+__global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, uint16_t* __restrict__ out, int N, int Npad, int K, float wscale) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= (int64_t)Npad * K) return;
   const int n = (int)(i / K), k = (int)(i % K);
-  const float v = n < N ? w[(int64_t)n * ldw + k] : 0.f;
-  const __bf16 h = (__bf16)v; const float r1 = v - (float)h;
-  const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
-  const __bf16 l = (__bf16)r2;
-  __bf16* o = out + ((int64_t)(n >> 5) * (K >> 4) + (k >> 4)) * (SUBT / 2) + ((k >> 3) & 1) * 256 + (n & 31) * 8 + (k & 7);
-  o[0] = h; o[FRAG / 2] = m; o[FRAG] = l;
+  const float v = n < N ? w[(int64_t)n * ldw + k] * wscale : 0.f;
+  uint16_t* o = out + ((int64_t)(n >> 5) * (K >> 4) + (k >> 4)) * (subt<NP>() / 2) + ((k >> 3) & 1) * 256 + (n & 31) * 8 + (k & 7);
+  if constexpr (NP == 3) {
+    const __bf16 h = (__bf16)v; const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    o[0] = __builtin_bit_cast(uint16_t, h); o[FRAG / 2] = __builtin_bit_cast(uint16_t, m); o[FRAG] = __builtin_bit_cast(uint16_t, l);
+  } else {
+    const _Float16 h = (_Float16)v; const float r1 = v - (float)h;
+    const _Float16 l = (_Float16)r1;
+    o[0] = __builtin_bit_cast(uint16_t, h); o[FRAG / 2] = __builtin_bit_cast(uint16_t, l);
+  }
 }
 
-template <int WTM, int WTN, int PF, bool ADD, class Epi>
-int launch_x6(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
+template <int NP, int WTM, int WTN, int PF, bool ADD, class Epi>
+int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
   constexpr int BM = WTM * 64, BN = WTN * 64;
-  constexpr size_t lds = 2ull * (2 * WTM + 2 * WTN) * SUBT;
+  constexpr size_t lds = 2ull * (2 * WTM + 2 * WTN) * subt<NP>();
   const int K = g.K0 + g.K1;
   PATHS_REQUIRE(g.M > 0, "%s: M must be > 0", name);
   PATHS_REQUIRE(g.K0 > 0 && g.K0 % 16 == 0 && g.K1 % 16 == 0 && K % 32 == 0 && K >= 128, "%s: K panels (%d,%d): multiples of 16, total a multiple of 32, >= 128", name, g.K0, g.K1);
@@ -362,7 +418,7 @@ int launch_x6(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream,
   PATHS_REQUIRE(g.lda0 % 4 == 0 && g.lda1 % 4 == 0, "%s: leading dims must be multiples of 4 floats", name);
   PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Wt % 16 == 0), "%s: operands must be 16-byte aligned", name);
   PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? (g.lda0 > g.ldadd ? g.lda0 : g.ldadd) : (g.lda1 > g.ldadd ? g.lda1 : g.ldadd)) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
-  auto kern = gemm_x6_kernel<WTM, WTN, PF, ADD, Epi>;
+  auto kern = gemm_x6_kernel<NP, WTM, WTN, PF, ADD, Epi>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -379,7 +435,16 @@ int launch_x6(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream,
   return PATHS_OK;
 }
 
-inline int64_t group_stride(int Kpacked) { return (int64_t)(Kpacked / 16) * SUBT; }
+// planes = 3: bf16 x6; planes = 2: fp16 x3 (operands pre-scaled by powers of two, undone through Epi::acc_scale)
+template <int WTM, int WTN, int PF, bool ADD, class Epi>
+int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
+  if (planes == 3) return launch_x6_np<3, WTM, WTN, PF, ADD>(g, Npad, epi, stream, name);
+  if (planes == 2) return launch_x6_np<2, WTM, WTN, PF, ADD>(g, Npad, epi, stream, name);
+  return paths_set_error(PATHS_EINVAL, "%s: planes must be 3 (bf16 x6) or 2 (fp16 x3), got %d", name, planes);
+}
+
+inline int64_t group_stride(int planes, int Kpacked) { return (int64_t)(Kpacked / 16) * planes * FRAG; }
+inline bool pow2(float x) { int e; return x > 0.f && frexpf(x, &e) == 0.5f; }
 
 }  // namespace
 
@@ -393,99 +458,114 @@ extern "C" {
 void paths_x6_debug_buffer(uint64_t* p) { g_x6_dbg = p; }
 #endif
 
-// bytes of the packed image of an [Npad, K] weight
-int64_t paths_x6_packed_bytes(int Npad, int K) { return (int64_t)Npad * K * 6; }
+// bytes of the packed image of an [Npad, K] weight: planes x 2 bytes per element
+int64_t paths_x6_packed_bytes(int Npad, int K, int planes) { return (int64_t)Npad * K * 2 * planes; }
 
-// w [N, K] fp32 (row stride ldw) -> out (paths_x6_packed_bytes(Npad, K) bytes); Npad % 32 == 0, K % 16 == 0
-int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, hipStream_t stream) {
+// w [N, K] fp32 (row stride ldw) -> out (paths_x6_packed_bytes bytes); Npad % 32 == 0, K % 16 == 0.
+// planes 3: exact bf16 hi|mid|lo (w_scale must be 1); planes 2: fp16 hi|lo of w * w_scale (w_scale a power of two chosen by
+// the caller so that max|w| * w_scale < 65504; the same w_scale is passed to every kernel that consumes the image).
+int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int planes, float w_scale, hipStream_t stream) {
   PATHS_REQUIRE(N > 0 && Npad >= N && Npad % 32 == 0 && K % 16 == 0, "x6_pack_weights: bad shape N=%d Npad=%d K=%d", N, Npad, K);
   PATHS_REQUIRE((uintptr_t)out % 16 == 0, "x6_pack_weights: out must be 16-byte aligned");
+  PATHS_REQUIRE((planes == 3 && w_scale == 1.0f) || (planes == 2 && pow2(w_scale)), "x6_pack_weights: planes 3 with w_scale 1, or planes 2 with a power-of-two w_scale");
   const int64_t n = (int64_t)Npad * K;
-  hipLaunchKernelGGL(x6_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, ldw, reinterpret_cast<__bf16*>(out), N, Npad, K);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (planes == 3) hipLaunchKernelGGL(x6_pack_kernel<3>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, 1.0f);
+  else hipLaunchKernelGGL(x6_pack_kernel<2>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, w_scale);
   PATHS_LAUNCH_CHECK("x6_pack_weights");
   return PATHS_OK;
 }
 
-// paths_lstm_cell with the gate / mem_to_out weights given as x6-packed images:
+// paths_lstm_cell with the gate / mem_to_out weights given as split images (planes, scales as in paths_x6_pack_weights;
+// a_scale: power of two applied to the fp32 activations before the fp16 split - |activation| * a_scale must stay < 65504):
 //   w_gates_x6 = pack([3Hc + D, 2D] packed gate rows, see paths_lstm_cell), w_mem_x6 = pack([D, Hc])
 int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                        const void* w_gates_x6, const float* b_gates, const void* w_mem_x6, const float* b_mem,
                        float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
                        const float* hp, const int* hp_row, int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide,
-                       int phases, hipStream_t stream) {
+                       int phases, int planes, float wg_scale, float wm_scale, float a_scale, hipStream_t stream) {
   PATHS_REQUIRE(D % 256 == 0 && Hc % 64 == 0, "lstm_cell_x6: D (%d) must be a multiple of 256 and Hc (%d) of 64", D, Hc);
   PATHS_REQUIRE(hp != nullptr || (h0 == nullptr) == (c0 == nullptr), "lstm_cell_x6: h0 and c0 must both be given or both be null");
   PATHS_REQUIRE((hp == nullptr) == (hp_row == nullptr) && (hp == nullptr || h0 == nullptr),
                 "lstm_cell_x6: hp/hp_row come together and replace h0 (the h half of the gate GEMM was done per parent)");
+  PATHS_REQUIRE(planes == 3 || (pow2(wg_scale) && pow2(wm_scale) && pow2(a_scale)), "lstm_cell_x6: scales must be powers of two");
+  if (planes == 3) wg_scale = wm_scale = a_scale = 1.0f;
   const char* wg = reinterpret_cast<const char*>(w_gates_x6);
-  const int64_t gs = group_stride(2 * D);
-  X6Operands g{x, ldx, D, h0, h0 ? ldh0 : 0, h0 ? D : 0, nullptr, 0, wg, gs, M, num_ims, rows_per_slide};
+  const int64_t gs = group_stride(planes, 2 * D);
+  const float sg = 1.0f / (wg_scale * a_scale), sm = 1.0f / (wm_scale * a_scale);
+  X6Operands g{x, ldx, D, h0, h0 ? ldh0 : 0, h0 ? D : 0, nullptr, 0, wg, gs, M, num_ims, rows_per_slide, a_scale};
   if (phases & 1) {   // c-part: N = 3Hc, block 256 x 192
-    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row};
-    int rc = launch_x6<4, 3, 1, false>(g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
+    EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row, sg};
+    int rc = launch_x6<4, 3, 1, false>(planes, g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
     if (rc) return rc;
   }
   if (phases & 2) {   // o gate: N = D, block 256 x 256
     X6Operands go = g;
     go.Wt = wg + (int64_t)(3 * Hc / 32) * gs;
-    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc};
-    int rc = launch_x6<4, 4, 1, false>(go, D, e, stream, "lstm_cell_x6(o)");
+    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc, sg};
+    int rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o)");
     if (rc) return rc;
   }
   if (phases & 4) {   // h1 = o * tanh(Wc c1 + bc), Y = X + h1
-    X6Operands gh{state_out + D, ldso, Hc, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(Hc), M, num_ims, rows_per_slide};
+    X6Operands gh{state_out + D, ldso, Hc, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(planes, Hc), M, num_ims, rows_per_slide, a_scale};
     int rc;
     PATHS_REQUIRE(save_tc == nullptr || y != nullptr, "lstm_cell_x6: save_tc (training) needs y");
     if (save_tc != nullptr) {
-      EpiLstmH<true, true> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc};
-      rc = launch_x6<4, 4, 1, false>(gh, D, e, stream, "lstm_cell_x6(h, save)");
+      EpiLstmH<true, true> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc, sm};
+      rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, save)");
     } else if (y != nullptr) {
-      EpiLstmH<true, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, nullptr};
-      rc = launch_x6<4, 4, 1, false>(gh, D, e, stream, "lstm_cell_x6(h)");
+      EpiLstmH<true, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, nullptr, sm};
+      rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h)");
     } else {
-      EpiLstmH<false, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, nullptr, 0, D, nullptr};
-      rc = launch_x6<4, 4, 1, false>(gh, D, e, stream, "lstm_cell_x6(h, no y)");
+      EpiLstmH<false, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, nullptr, 0, D, nullptr, sm};
+      rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, no y)");
     }
     if (rc) return rc;
   }
   return PATHS_OK;
 }
 
-// paths_importance_proj with w_ip_x6 = pack([W1 ; Wp] = [256, D]).  y_add (optional): the GEMM input is y + y_add, summed in
-// fp32 while staging - the caller passes (x, h1) and never materialises Y = X + h1 (paths_lstm_cell_x6 with y = NULL)
+// paths_importance_proj with w_ip_x6 = pack([256, D], rows interleaved as paths_importance_proj documents).  y_add (optional): the
+// GEMM input is y + y_add, summed in fp32 while staging - the caller passes (x, h1) and never materialises Y = X + h1
+// (paths_lstm_cell_x6 with y = NULL)
 int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                              float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
-                             int skip_padding, hipStream_t stream) {
+                             int skip_padding, int planes, float w_scale, float a_scale, hipStream_t stream) {
   PATHS_REQUIRE(Hi == 128 && d == 128, "importance_proj_x6: this build supports importance_mlp_hidden_dim=128, trans_dim=128 (got %d, %d)", Hi, d);
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj_x6: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj_x6: 2d positional encoding needs locs");
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj_x6: bad slide layout");
   PATHS_REQUIRE(y_add == nullptr || (ldya % 4 == 0 && (uintptr_t)y_add % 16 == 0), "importance_proj_x6: y_add must be 16-byte aligned with ldya %% 4 == 0");
-  X6Operands g{y, ldy, D, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(D), M, skip_padding ? num_ims : nullptr, rows_per_slide};
+  PATHS_REQUIRE(planes == 3 || (pow2(w_scale) && pow2(a_scale)), "importance_proj_x6: scales must be powers of two");
+  if (planes == 3) w_scale = a_scale = 1.0f;
+  const float sc = 1.0f / (w_scale * a_scale);
+  X6Operands g{y, ldy, D, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(planes, D), M, skip_padding ? num_ims : nullptr, rows_per_slide, a_scale};
   if (pe_table != nullptr) {
     PATHS_REQUIRE(pe_rows > 0, "importance_proj_x6: pe_rows must be > 0 with a pe_table");
     EpiImpProj<true> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-                       save_hid, save_pproj, pe_table, pe_rows};
-    if (y_add != nullptr) return launch_x6<2, 4, 2, true>(g, 256, e, stream, "importance_proj_x6(sum, table)");
-    return launch_x6<2, 4, 2, false>(g, 256, e, stream, "importance_proj_x6(table)");
+                       save_hid, save_pproj, pe_table, pe_rows, sc};
+    if (y_add != nullptr) return launch_x6<2, 4, 2, true>(planes, g, 256, e, stream, "importance_proj_x6(sum, table)");
+    return launch_x6<2, 4, 2, false>(planes, g, 256, e, stream, "importance_proj_x6(table)");
   }
   EpiImpProj<false> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-                      save_hid, save_pproj, nullptr, 0};
-  if (y_add != nullptr) return launch_x6<2, 4, 2, true>(g, 256, e, stream, "importance_proj_x6(sum)");
-  return launch_x6<2, 4, 2, false>(g, 256, e, stream, "importance_proj_x6");
+                      save_hid, save_pproj, nullptr, 0, sc};
+  if (y_add != nullptr) return launch_x6<2, 4, 2, true>(planes, g, 256, e, stream, "importance_proj_x6(sum)");
+  return launch_x6<2, 4, 2, false>(planes, g, 256, e, stream, "importance_proj_x6");
 }
 
-// out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual with W given as the x6-packed image of an [Npad, Kpacked]
+// out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual with W given as the split image of an [Npad, Kpacked]
 // weight; k0 selects the column window [k0, k0 + K) of it (k0 % 16 == 0), Npad % 256 == 0.
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
-                     int64_t ldm, int accumulate, hipStream_t stream) {
+                     int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, hipStream_t stream) {
   PATHS_REQUIRE(k0 % 16 == 0 && k0 >= 0 && k0 + K <= Kpacked, "gemm_nt_x6: bad k window");
-  X6Operands g{a, lda, K, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * SUBT, group_stride(Kpacked), M, nullptr, 0};
-  EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate};
-  return launch_x6<2, 4, 2, false>(g, Npad, e, stream, "gemm_nt_x6");
+  PATHS_REQUIRE(planes == 3 || (planes == 2 && pow2(w_scale) && pow2(a_scale)), "gemm_nt_x6: planes 3, or planes 2 with power-of-two scales");
+  if (planes == 3) w_scale = a_scale = 1.0f;
+  X6Operands g{a, lda, K, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * planes * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
+  EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate, 1.0f / (w_scale * a_scale)};
+  return launch_x6<2, 4, 2, false>(planes, g, Npad, e, stream, "gemm_nt_x6");
 }
 
 }  // extern "C"

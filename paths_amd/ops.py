@@ -24,25 +24,47 @@ from . import _lib
 
 LOG2E = 1.4426950408889634
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
-# Which matrix pipe the big GEMMs of the selection chain use (both are HIP kernels of libpaths_hip.so, both fp32-accurate):
-#   "x6"  : split-bf16 GEMM (csrc/gemm_x6.hip, 6 bf16 MFMAs per fp32 product block)  - default
-#   "f32" : f32-input MFMA GEMM (csrc/gemm_f32.hip)
-GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "x6")
+# Which matrix pipe the big products (selection-chain GEMMs, attention) use.  All are HIP kernels of libpaths_hip.so with fp32
+# inputs, outputs and accumulation:
+#   "h3"  : operands split into TWO fp16 planes, 3 MFMAs per product block (csrc/gemm_x6.hip, NP = 2)            - default
+#           weights are pre-scaled per tensor by a power of two, activations by A_SCALE (|activation| must stay < 65504 / A_SCALE)
+#   "x6"  : operands split into THREE bf16 planes, 6 MFMAs per product block (same kernels, NP = 3; no range limits)
+#   "f32" : f32-input MFMA (csrc/gemm_f32.hip, csrc/attn_f32.hip)
+GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "h3")
+A_SCALE = 16.0
 
 
-def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None) -> torch.Tensor:
-    """fp32 [N, K] device weight -> its split-bf16 tiled image (paths_x6_pack_weights), as a byte tensor."""
+def split_planes() -> int:
+    if GEMM_MODE not in ("h3", "x6", "f32"):
+        raise ValueError(f"PATHS_GEMM_MODE must be 'h3', 'x6' or 'f32' (got {GEMM_MODE!r})")
+    return 2 if GEMM_MODE == "h3" else 3
+
+
+def a_scale() -> float:
+    return A_SCALE if GEMM_MODE == "h3" else 1.0
+
+
+def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] = None):
+    """fp32 [N, K] device weight -> (split tiled image as a byte tensor, w_scale)  (paths_x6_pack_weights).
+    planes 3: exact bf16 hi|mid|lo, w_scale 1.  planes 2: fp16 hi|lo of w * w_scale, w_scale = the power of two that puts
+    max|w| into [8192, 16384) (one host sync per weight version)."""
     assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1
+    planes = split_planes() if planes is None else planes
     N, K = w.shape
     n_pad = N if n_pad is None else n_pad
-    out = torch.empty((n_pad * K * 6,), device=w.device, dtype=torch.uint8)
-    _lib.call("paths_x6_pack_weights", _lib.ptr(w), w.stride(0), _lib.ptr(out), N, n_pad, K, _lib.stream())
-    return out
+    w_scale = 1.0
+    if planes == 2:
+        amax = float(w.abs().max())
+        w_scale = 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax)))) if amax > 0 and math.isfinite(amax) else 1.0
+    out = torch.empty((n_pad * K * 2 * planes,), device=w.device, dtype=torch.uint8)
+    _lib.call("paths_x6_pack_weights", _lib.ptr(w), w.stride(0), _lib.ptr(out), N, n_pad, K, planes, w_scale, _lib.stream())
+    return out, w_scale
 
 
-def _x6_of(pack: Dict[str, object], key: str) -> torch.Tensor:
-    """Packed image of pack[key], built on first use and cached beside it (the pack dict is rebuilt when weights change)."""
-    k6 = key + "_x6"
+def _x6_of(pack: Dict[str, object], key: str):
+    """(image, w_scale) of pack[key] for the current split mode, built on first use and cached beside it (the pack dict is
+    rebuilt when weights change)."""
+    k6 = f"{key}_split{split_planes()}"
     if k6 not in pack:
         pack[k6] = x6_pack(pack[key])
     return pack[k6]
@@ -62,9 +84,9 @@ def pe_table(lvl_pack: Dict[str, object], pe_mode: int, d: int, rows: int) -> to
 
 
 def use_x6(D: int, Hc: int = 64) -> bool:
-    if GEMM_MODE not in ("x6", "f32"):
-        raise ValueError(f"PATHS_GEMM_MODE must be 'x6' or 'f32' (got {GEMM_MODE!r})")
-    return GEMM_MODE == "x6" and D % 256 == 0 and Hc % 64 == 0
+    """Split-operand GEMMs (either split) are used for this shape."""
+    split_planes()
+    return GEMM_MODE != "f32" and D % 256 == 0 and Hc % 64 == 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -221,8 +243,9 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                   p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), None, None,
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
         if x6:
+            wip, wip_s = _x6_of(lvl_pack, "w_ip_fwd")
             _lib.call("paths_importance_proj_x6", p(src), D, p(add), add.stride(1) if add is not None else 0,
-                      p(_x6_of(lvl_pack, "w_ip_fwd")), *common)
+                      p(wip), *common[:-1], split_planes(), wip_s, a_scale(), common[-1])
         else:
             assert add is None
             _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip_fwd"]), *common)
@@ -250,17 +273,22 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             ld, h0, c0 = 0, None, None
 
         def lstm(phases):
-            _lib.call("paths_lstm_cell_x6" if x6 else "paths_lstm_cell", p(fts), D, h0, ld, c0, ld,
-                      p(_x6_of(lstm_pack, "w_gates") if x6 else lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
-                      p(_x6_of(lstm_pack, "w_mem") if x6 else lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D,
-                      p(ws_o), None, None, hp, hp_row, M, D, Hc, nim, N, phases, st)
+            if x6:
+                (wg, wg_s), (wm, wm_s) = _x6_of(lstm_pack, "w_gates"), _x6_of(lstm_pack, "w_mem")
+                _lib.call("paths_lstm_cell_x6", p(fts), D, h0, ld, c0, ld, p(wg), p(lstm_pack["b_gates"]), p(wm), p(lstm_pack["b_mem"]),
+                          p(state_out), Dp, p(y), D, p(ws_o), None, None, hp, hp_row, M, D, Hc, nim, N, phases,
+                          split_planes(), wg_s, wm_s, a_scale(), st)
+            else:
+                _lib.call("paths_lstm_cell", p(fts), D, h0, ld, c0, ld, p(lstm_pack["w_gates"]), p(lstm_pack["b_gates"]),
+                          p(lstm_pack["w_mem"]), p(lstm_pack["b_mem"]), p(state_out), Dp, p(y), D,
+                          p(ws_o), None, None, hp, hp_row, M, D, Hc, nim, N, phases, st)
 
         if KERNEL_TIMER is None:
             lstm(7)
         else:                   # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
             lstm(1)
             KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D,
-                                                          "parent_partials": parent is not None, "x6": x6})
+                                                          "parent_partials": parent is not None, "x6": x6, "planes": split_planes() if x6 else 0})
             lstm(4)
         if x6:
             importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out)
@@ -305,8 +333,9 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
     _lib.call("paths_gather_kept_rows", p(state_out), N, Dp, p(keep_idx), cap, p(keep_count), D, B, p(hk), st)
     hp = torch.empty((B * cap, G), **f32)
     if use_x6(D, Hc) and G % 256 == 0:
-        _lib.call("paths_gemm_nt_x6", p(hk), D, p(_x6_of(lstm_pack, "w_gates")), 2 * D, D, None, p(hp), G, B * cap, G, G, D, 0,
-                  None, 0, None, 0, 0, st)
+        wg, wg_s = _x6_of(lstm_pack, "w_gates")
+        _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg), 2 * D, D, None, p(hp), G, B * cap, G, G, D, 0,
+                  None, 0, None, 0, 0, split_planes(), wg_s, a_scale(), st)
     else:
         _lib.call("paths_gemm_nt_f32", p(hk), D, lstm_pack["w_gates"].data_ptr() + 4 * D, 2 * D, None, p(hp), G, B * cap, G, G, D, 0,
                   None, 0, None, 0, 0, st)
@@ -350,7 +379,7 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     token_layer(xa, None, None, layers[0])
     attn_ws = None
     for l in range(L - 1):
-        if GEMM_MODE == "x6":
+        if GEMM_MODE != "f32":
             if attn_ws is None:
                 attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd)),), device=tokens.device, dtype=torch.uint8)
             _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), st)

@@ -390,26 +390,28 @@ def test_heatmap_export_from_trace(dev):
 # ---------------------------------------------------------------------------------------------
 # split-bf16 ("x6") GEMM: the claim is "fp32 in, fp32 out, error not larger than an fp32 FMA chain's"
 # ---------------------------------------------------------------------------------------------
-def _x6_gemm(a, w, n_pad, k0=0, K=None, bias=None, act=0, residual=None, accumulate_into=None):
+def _x6_gemm(a, w, n_pad, k0=0, K=None, bias=None, act=0, residual=None, accumulate_into=None, planes=3, a_scale=1.0):
     from paths_amd import _lib, ops
     p, st = _lib.ptr, _lib.stream()
     M = a.shape[0]
     N, Kp = w.shape
     K = Kp - k0 if K is None else K
-    wx = ops.x6_pack(w, n_pad)
+    wx, w_scale = ops.x6_pack(w, n_pad, planes=planes)
     out = accumulate_into if accumulate_into is not None else torch.empty((M, N), device=a.device, dtype=torch.float32)
     _lib.call("paths_gemm_nt_x6", p(a), a.stride(0), p(wx), Kp, k0, p(bias), p(out), N, M, N, n_pad, K, act,
-              p(residual), N if residual is not None else 0, None, 0, 1 if accumulate_into is not None else 0, st)
+              p(residual), N if residual is not None else 0, None, 0, 1 if accumulate_into is not None else 0,
+              planes, w_scale, a_scale if planes == 2 else 1.0, st)
     return out
 
 
+@pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("M,N,K", [(1000, 512, 1024), (4096, 1792, 1024), (131, 256, 128), (2500, 300, 256)])
-def test_x6_gemm_matches_fp64(dev, M, N, K):
+def test_x6_gemm_matches_fp64(dev, M, N, K, planes):
     g = torch.Generator(device=dev); g.manual_seed(M + N + K)
     a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1) * 1.7
     w = (torch.rand(N, K, device=dev, generator=g) * 2 - 1) / 32
     n_pad = (N + 255) // 256 * 256
-    out = _x6_gemm(a, w, n_pad)
+    out = _x6_gemm(a, w, n_pad, planes=planes, a_scale=16.0)
     ref = a.double() @ w.double().T
     scale = (a.double().abs() @ w.double().abs().T)                  # sum_k |a w|: the natural error scale of a dot product
     err = ((out.double() - ref).abs() / scale).max().item()
@@ -418,18 +420,19 @@ def test_x6_gemm_matches_fp64(dev, M, N, K):
     assert err < 4 * err32 + 1e-7, (err, err32)
 
 
-def test_x6_gemm_window_bias_relu_residual_accumulate(dev):
+@pytest.mark.parametrize("planes", [3, 2])
+def test_x6_gemm_window_bias_relu_residual_accumulate(dev, planes):
     g = torch.Generator(device=dev); g.manual_seed(5)
     M, N, Kp = 777, 256, 512
     a = torch.rand(M, 256, device=dev, generator=g) - 0.5
     w = (torch.rand(N, Kp, device=dev, generator=g) - 0.5) / 8
     bias = torch.rand(N, device=dev, generator=g) - 0.5
     res = torch.rand(M, N, device=dev, generator=g)
-    out = _x6_gemm(a, w, 256, k0=256, K=256, bias=bias, act=1, residual=res)
+    out = _x6_gemm(a, w, 256, k0=256, K=256, bias=bias, act=1, residual=res, planes=planes, a_scale=16.0)
     ref = torch.relu(a.double() @ w[:, 256:].double().T + bias.double()) + res.double()
     assert (out.double() - ref).abs().max().item() < 2e-6
     acc = out.clone()
-    out2 = _x6_gemm(a, w, 256, k0=0, K=256, accumulate_into=acc)
+    out2 = _x6_gemm(a, w, 256, k0=0, K=256, accumulate_into=acc, planes=planes, a_scale=16.0)
     ref2 = ref + a.double() @ w[:, :256].double().T
     assert (out2.double() - ref2).abs().max().item() < 3e-6
 
@@ -439,21 +442,22 @@ def test_x6_split_is_exact(dev):
     from paths_amd import ops
     g = torch.Generator(device=dev); g.manual_seed(9)
     w = (torch.rand(64, 64, device=dev, generator=g) * 2 - 1) * torch.logspace(-20, 20, 64, device=dev)[:, None]
-    img = ops.x6_pack(w).view(torch.bfloat16).view(2, 4, 3, 2, 32, 8).float()          # [n/32][k/16][plane][half][n%32][8]
+    img = ops.x6_pack(w, planes=3)[0].view(torch.bfloat16).view(2, 4, 3, 2, 32, 8).float()   # [n/32][k/16][plane][half][n%32][8]
     rec = (img[:, :, 0] + img[:, :, 1]) + img[:, :, 2]                                   # [2,4,2,32,8]
     rec = rec.permute(0, 3, 1, 2, 4).reshape(64, 64)
     assert torch.equal(rec, w)
 
 
-def test_f32_gemm_mode_matches_default(dev, monkeypatch):
-    """PATHS_GEMM_MODE=f32 (f32-input MFMA GEMMs) and the default split-bf16 GEMMs agree to rounding on a whole level."""
+@pytest.mark.parametrize("mode", ["f32", "x6"])
+def test_other_gemm_modes_match_default(dev, monkeypatch, mode):
+    """PATHS_GEMM_MODE=f32 (f32-input MFMA) / x6 (3 bf16 planes) and the default (2 fp16 planes) agree to rounding on a whole level."""
     from paths_amd import ops
-    g, info, out_x6 = run_single(dev, "g1_level0_b2_k256")
-    monkeypatch.setattr(ops, "GEMM_MODE", "f32")
-    _, _, out_f32 = run_single(dev, "g1_level0_b2_k256")
-    np.testing.assert_allclose(out_f32["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
-    np.testing.assert_allclose(out_f32["importance"].numpy(), out_x6["importance"].numpy(), atol=2e-6, rtol=0)
-    np.testing.assert_allclose(out_f32["ctx_patch"].numpy(), out_x6["ctx_patch"].numpy(), atol=5e-6, rtol=0)
+    g, info, out_def = run_single(dev, "g1_level0_b2_k256")
+    monkeypatch.setattr(ops, "GEMM_MODE", mode)
+    _, _, out_m = run_single(dev, "g1_level0_b2_k256")
+    np.testing.assert_allclose(out_m["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out_m["importance"].numpy(), out_def["importance"].numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(out_m["ctx_patch"].numpy(), out_def["ctx_patch"].numpy(), atol=5e-6, rtol=0)
 
 
 @pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37]), (65, [64, 65])])

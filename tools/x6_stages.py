@@ -27,9 +27,10 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 rnd = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
 x, c0 = rnd(M, D), rnd(M, Hc)
 wg, bg, wm, bm = rnd(G, 2 * D) / 45, rnd(G), rnd(D, Hc) / 16, rnd(D)
-wg6, wm6 = ops.x6_pack(wg), ops.x6_pack(wm)
+(wg6, wgs), (wm6, wms) = ops.x6_pack(wg), ops.x6_pack(wm)
+PL, AS = ops.split_planes(), ops.a_scale()
 wip, wip6 = rnd(256, D) / 32, None
-wip6 = ops.x6_pack(wip)
+wip6, wips = ops.x6_pack(wip)
 hk = rnd(MP, D)
 hp = torch.empty(MP, G, device=dev)
 hp_row = (torch.arange(M, device=dev, dtype=torch.int32) // 4) % MP
@@ -48,21 +49,22 @@ lib.paths_x6_debug_buffer.argtypes = [C.c_void_p]; lib.paths_x6_debug_buffer.res
 
 def lstm(ph):
     _lib.call("paths_lstm_cell_x6", p(x), D, None, 0, p(c0), Hc, p(wg6), p(bg), p(wm6), p(bm), p(so), D + Hc, None, D, p(ws), None, None,
-              p(hp), p(hp_row), M, D, Hc, None, 1, ph, st())
+              p(hp), p(hp_row), M, D, Hc, None, 1, ph, PL, wgs, wms, AS, st())
 def parent():
-    _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg6), 2 * D, D, None, p(hp), G, MP, G, G, D, 0, None, 0, None, 0, 0, st())
+    _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg6), 2 * D, D, None, p(hp), G, MP, G, G, D, 0, None, 0, None, 0, 0, PL, wgs, AS, st())
 def impproj():
     _lib.call("paths_importance_proj_x6", p(yi), D, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
-              p(imp), p(tok), None, None, Mi, D, 128, 128, 1, st())
+              p(imp), p(tok), None, None, Mi, D, 128, 128, 1, PL, wips, AS, st())
 
 USE_TAB = True
 USE_ADD = True
 yadd = rnd(Mi, D)
-CASES = [("parent partials  <2,4> K=1024", parent, (MP + 127) // 128 * 7, 64, 2 * 4 * 6 * 32, 2.0 * MP * G * D),
-         ("gate c-part      <4,3> K=1024", lambda: lstm(1), (M + 255) // 256 * 4, 64, 4 * 3 * 6 * 32, 2.0 * M * 768 * D),
-         ("gate o-part      <4,4> K=1024", lambda: lstm(2), (M + 255) // 256 * 4, 64, 4 * 4 * 6 * 32, 2.0 * M * D * D),
-         ("mem_to_out       <4,4> K=256 ", lambda: lstm(4), (M + 255) // 256 * 4, 16, 4 * 4 * 6 * 32, 2.0 * M * D * Hc),
-         ("importance+proj  <2,4> K=1024", impproj, (Mi + 127) // 128, 64, 2 * 4 * 6 * 32, 2.0 * Mi * 256 * D)]
+NPR = 6 if PL == 3 else 3
+CASES = [("parent partials  <2,4> K=1024", parent, (MP + 127) // 128 * 7, 64, 2 * 4 * NPR * 32, 2.0 * MP * G * D),
+         ("gate c-part      <4,3> K=1024", lambda: lstm(1), (M + 255) // 256 * 4, 64, 4 * 3 * NPR * 32, 2.0 * M * 768 * D),
+         ("gate o-part      <4,4> K=1024", lambda: lstm(2), (M + 255) // 256 * 4, 64, 4 * 4 * NPR * 32, 2.0 * M * D * D),
+         ("mem_to_out       <4,4> K=256 ", lambda: lstm(4), (M + 255) // 256 * 4, 16, 4 * 4 * NPR * 32, 2.0 * M * D * Hc),
+         ("importance+proj  <2,4> K=1024", impproj, (Mi + 127) // 128, 64, 2 * 4 * NPR * 32, 2.0 * Mi * 256 * D)]
 for name, fn, blocks, stages, floor, flop in CASES:
     lib.paths_x6_debug_buffer(None)
     for _ in range(3): fn()
