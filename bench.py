@@ -13,9 +13,10 @@ collectives are the barriers around the timed region and a MAX-reduce of the ela
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     dominant kernel (output-gate GEMM of the LSTM cell) timed live with events on the launch stream inside
-               the timed region; achieved = algorithmic FLOP (2 M N K) / measured duration.  Default build: the GEMM runs
-               fp32-accurately on the bf16 matrix cores with 6 MFMAs per product block (csrc/gemm_x6.hip), so its ceiling
-               is the dense bf16 MFMA peak / 6; PATHS_GEMM_MODE=f32 runs the f32-input MFMA kernel (peak 157.3 TFLOP/s).
+               the timed region; achieved = algorithmic FLOP (2 M N K) / measured duration.  Default build
+               (PATHS_GEMM_MODE=h3): the GEMM multiplies fp32 operands as 2 fp16 planes with 3 MFMAs per product block
+               (csrc/gemm_x6.hip), so its ceiling is the dense 16-bit MFMA peak / 3; "x6": 3 bf16 planes, 6 MFMAs, peak / 6;
+               "f32": the f32-input MFMA kernel (peak 157.3 TFLOP/s).
   cpu_baseline the oracle (oracle/paths_oracle.py, plain torch CPU ops) timed on this box's host cores on a bounded
                sample of the same workload (rank 0, N=1 only).
 """
@@ -35,7 +36,7 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)" (measured 155)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
-X6_MFMA_PER_PRODUCT = 6           # bf16 MFMAs issued per fp32 product block by the split-bf16 GEMM
+MFMA_PER_PRODUCT = {3: 6, 2: 3}   # 16-bit MFMAs issued per fp32 product block: 3 bf16 planes ("x6") / 2 fp16 planes ("h3")
 BASE_SHAPES = {2048: (32, 64), 1024: (32, 32), 256: (16, 16)}
 
 
@@ -245,21 +246,26 @@ def main():
     n_launch = max(1, len(events))
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     x6 = bool(events and events[0][3].get("x6"))
+    planes = int(events[0][3].get("planes", 3)) if x6 else 0
     traffic = None            # HBM-side bytes per launch from the committed PMC passes (separate --pmc runs, profiles/)
+    prof = {2: "r01f_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json" if x6 else "r01_pmc_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", prof)) as fh:
             traffic = json.load(fh)["kernels"]["EpiLstmO"]["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     if x6:
-        peak = PEAK_BF16_MFMA_TFLOPS / X6_MFMA_PER_PRODUCT
+        nprod = MFMA_PER_PRODUCT[planes]
+        peak = PEAK_BF16_MFMA_TFLOPS / nprod
+        what = ("2 fp16 planes (hi + lo), hi*hi + hi*lo + lo*hi = 3 x v_mfma_f32_32x32x16_f16" if planes == 2 else
+                "3 bf16 planes (hi + mid + lo), 6 x v_mfma_f32_32x32x16_bf16")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
-                    "kernel": "gemm_x6_kernel<4,4,1,EpiLstmO> (LSTM output-gate GEMM, fp32 operands split 3-way into bf16, "
-                              "6 x v_mfma_f32_32x32x16_bf16 per product block, fp32 accumulate)",
-                    "peak_basis": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per fp32 product block; achieved counts "
-                                  "ALGORITHMIC flops 2MNK, so frac == bf16 MFMA flops issued / 2500",
-                    "mfma_issue_tflops": round(achieved * X6_MFMA_PER_PRODUCT, 1),
+                    "kernel": f"gemm_x6_kernel<{planes},4,4,1,EpiLstmO> (LSTM output-gate GEMM, fp32 operands split into {what} "
+                              "per product block, fp32 accumulate)",
+                    "peak_basis": f"dense 16-bit MFMA peak 2500 TFLOP/s / {nprod} MFMAs per fp32 product block; achieved counts "
+                                  "ALGORITHMIC flops 2MNK, so frac == 16-bit MFMA flops issued / 2500",
+                    "mfma_issue_tflops": round(achieved * nprod, 1),
                     "vs_f32_matrix_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
                     "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": len(events),
                     "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
@@ -282,7 +288,10 @@ def main():
                                    f"features, trans_dim 128 x 4 heads x 2 layers, LSTM ctx 256; {spg} HBM-resident slides per GPU",
                        "slides_per_gpu": spg, "global_batch": spg * world, "levels": cfg.num_levels,
                        "parallelism": f"slide-sharded x{world} (no data-path collective)",
-                       "gemm_mode": ("bf16x6: fp32 operands split exactly into 3 bf16, 6 bf16 MFMAs per product block, fp32 "
+                       "gemm_mode": ("h3: GEMM and attention operands split into 2 fp16 planes (22 bits), 3 fp16 MFMAs per product block, "
+                                     "fp32 accumulate, power-of-two scaling of the GEMM operands (error of the order of an fp32 FMA "
+                                     "chain's); everything else fp32") if planes == 2 else
+                                    ("x6: operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product block, fp32 "
                                      "accumulate (error <= an fp32 FMA chain's); everything else fp32") if x6 else "f32 MFMA"},
             "roofline": roofline,
         }

@@ -156,13 +156,14 @@ int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b
 int paths_attention_f32(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims,
                         int B, int T, int H, int head_dim, int max_queries, paths_stream_t stream);
 
-/* paths_attention_f32 on the bf16 matrix cores with fp32 accuracy (csrc/attn_x6.hip): q, k, v are first re-written as exact
- * 3-way bf16 splits in MFMA-fragment order (workspace of paths_attention_x6_workspace(B, T, H, head_dim) bytes, caller-owned),
- * then S^T = K Q^T and O^T += V^T P^T run as 6 bf16 MFMAs per product block with fp32 accumulation; P is split in registers.
+/* paths_attention_f32 on the 16-bit matrix cores with fp32 accuracy (csrc/attn_x6.hip): q, k, v are first re-written as
+ * split operands in MFMA-fragment order (planes = 3: exact bf16 hi|mid|lo, 6 MFMAs per product block; planes = 2: fp16 hi|lo,
+ * 3 MFMAs, |q|, |k|, |v| < 65504; workspace of paths_attention_x6_workspace(B, T, H, head_dim, planes) bytes, caller-owned),
+ * then S^T = K Q^T and O^T += V^T P^T run with fp32 accumulation; P is split in registers.
  * Same arguments and results (to fp32 rounding) as paths_attention_f32. */
-int64_t paths_attention_x6_workspace(int B, int T, int H, int head_dim);
+int64_t paths_attention_x6_workspace(int B, int T, int H, int head_dim, int planes);
 int paths_attention_x6(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims,
-                       int B, int T, int H, int head_dim, int max_queries, void* workspace, paths_stream_t stream);
+                       int B, int T, int H, int head_dim, int max_queries, void* workspace, int planes, paths_stream_t stream);
 
 /* Token-row chain of one post-LN decoder layer with empty memory + the next in_proj (same call site):
  *   do_post: x_out = norm3(x' + ffn(x')), x' = norm2(norm1(x_in + out_proj(attn)) + cross_attn_bias)

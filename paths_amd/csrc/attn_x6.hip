@@ -24,14 +24,17 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HD = 32;
 constexpr int FRAG = 1024;                 // bytes of one fragment (64 lanes x 8 bf16)
 constexpr int KSTEP = 64;                  // keys staged per LDS buffer
-// per 64 keys: K = 4 key tiles x 3 planes, V^T = 2 key groups x 2 dv tiles x 3 planes -> 24 fragments = 24 KiB
-constexpr int STEP_BYTES = 24 * FRAG;
+// per 64 keys: K = 4 key tiles x NP planes, V^T = 2 key groups x 2 dv tiles x NP planes -> 8 NP fragments of 1 KiB
+// NP = 3: bf16 hi|mid|lo, 6 MFMAs per product (x6);  NP = 2: fp16 hi|lo, 3 MFMAs (h3; q, k, v and P are O(1): no scaling)
+template <int NP> constexpr int step_bytes() { return 8 * NP * FRAG; }
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
   f32x2 v = {a, b};
@@ -40,6 +43,23 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// 8 fp32 -> two planes of 8 fp16 (hi, lo): 22 significant bits
+__device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const uint32_t h = pk_f16(a, b);
+    const f16x2 hv = __builtin_bit_cast(f16x2, h);
+    hi[i] = h; lo[i] = pk_f16(a - (float)hv[0], b - (float)hv[1]);
+  }
+}
+// planes[0..NP) of 8 values
+template <int NP>
+__device__ __forceinline__ void split_planes(const float (&x)[8], u32x4 (&pl)[NP]);
 // 8 fp32 -> three planes of 8 bf16 (hi, mid, lo), exact
 __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mid, u32x4& lo) {
 #pragma unroll
@@ -53,9 +73,13 @@ __device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& mi
   }
 }
 
+template <> __device__ __forceinline__ void split_planes<3>(const float (&x)[8], u32x4 (&pl)[3]) { split8(x, pl[0], pl[1], pl[2]); }
+template <> __device__ __forceinline__ void split_planes<2>(const float (&x)[8], u32x4 (&pl)[2]) { split8h(x, pl[0], pl[1]); }
+
 // Fragment images (per (slide, head), Tp = T rounded up to 64):
 //   Q6 / K6 : [Tp/16 tiles][3 planes][64 lanes][8 bf16]        lane (r = l&15, g = l>>4): token 16 tile + r, dims 8g .. 8g+7
 //   V6      : [Tp/32 groups][2 dv tiles][3 planes][64 lanes][8] lane (dv = l&15, g):      dim 16 dvt + dv, keys 32 grp + kappa(g, j)
+template <int NP>
 __global__ void __launch_bounds__(256)
 attn_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                     char* __restrict__ q6, char* __restrict__ k6, char* __restrict__ v6,
@@ -65,7 +89,7 @@ attn_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, co
   const int len = min((int)num_ims[b] + 1, T);
   const int tid = threadIdx.x;
   const int64_t base = ((int64_t)b * H + head) * T * HD;
-  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 6;     // bytes of one (slide, head) image
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * NP;     // bytes of one (slide, head) image
   // ---- Q and K: thread = (token t0 + tid/4, dims 8 (tid%4) ..)
   {
     const int tl = tid >> 2, g = tid & 3, tok = t0 + tl;
@@ -76,12 +100,14 @@ attn_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, co
       xk[i] = kvalid ? k[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
       xq[i] = qvalid ? q[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
     }
-    u32x4 h, m, l;
-    const int64_t off = ibase + ((int64_t)(tok >> 4) * 3) * FRAG + ((tok & 15) + 16 * g) * 16;
-    split8(xk, h, m, l);
-    *reinterpret_cast<u32x4*>(k6 + off) = h; *reinterpret_cast<u32x4*>(k6 + off + FRAG) = m; *reinterpret_cast<u32x4*>(k6 + off + 2 * FRAG) = l;
-    split8(xq, h, m, l);
-    *reinterpret_cast<u32x4*>(q6 + off) = h; *reinterpret_cast<u32x4*>(q6 + off + FRAG) = m; *reinterpret_cast<u32x4*>(q6 + off + 2 * FRAG) = l;
+    u32x4 pl[NP];
+    const int64_t off = ibase + ((int64_t)(tok >> 4) * NP) * FRAG + ((tok & 15) + 16 * g) * 16;
+    split_planes<NP>(xk, pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(k6 + off + p * FRAG) = pl[p];
+    split_planes<NP>(xq, pl);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(q6 + off + p * FRAG) = pl[p];
   }
   // ---- V^T: through LDS (coalesced rows in, transposed + key-permuted fragments out)
 #pragma unroll
@@ -95,16 +121,22 @@ attn_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, co
     float xv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) xv[j] = sv[32 * kg + 4 * g + (j & 3) + 16 * (j >> 2)][16 * dvt + dv];
-    u32x4 h, m, lo;
-    split8(xv, h, m, lo);
-    const int64_t off = ibase + ((int64_t)(((t0 >> 5) + kg) * 2 + dvt) * 3) * FRAG + l * 16;
-    *reinterpret_cast<u32x4*>(v6 + off) = h; *reinterpret_cast<u32x4*>(v6 + off + FRAG) = m; *reinterpret_cast<u32x4*>(v6 + off + 2 * FRAG) = lo;
+    u32x4 pl[NP];
+    split_planes<NP>(xv, pl);
+    const int64_t off = ibase + ((int64_t)(((t0 >> 5) + kg) * 2 + dvt) * NP) * FRAG + l * 16;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(v6 + off + p * FRAG) = pl[p];
   }
 }
 
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-// acc += A * B with A = (a[0] hi, a[1] mid, a[2] lo), B alike: the six largest partial products, smallest first
-__device__ __forceinline__ f32x4 mfma_x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c) {
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// acc += A * B from split operands, smallest partial products first
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {   // hi, mid, lo: six largest of nine
   c = mfma_bf16(a[2], b[0], c);
   c = mfma_bf16(a[0], b[2], c);
   c = mfma_bf16(a[1], b[1], c);
@@ -113,10 +145,18 @@ __device__ __forceinline__ f32x4 mfma_x6(const bf16x8 (&a)[3], const bf16x8 (&b)
   c = mfma_bf16(a[0], b[0], c);
   return c;
 }
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x4 c) {   // hi, lo: all but lo*lo
+  c = mfma_f16(a[1], b[0], c);
+  c = mfma_f16(a[0], b[1], c);
+  c = mfma_f16(a[0], b[0], c);
+  return c;
+}
 
+template <int NP>
 __global__ void __launch_bounds__(256)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
+  constexpr int STEP_BYTES = step_bytes<NP>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];          // 2 x STEP_BYTES (+ occupancy padding, see the launcher)
   char (*smem)[STEP_BYTES] = reinterpret_cast<char (*)[STEP_BYTES]>(smem_raw);
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
@@ -124,16 +164,16 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   if (q0 >= len) return;                                // every query of this block is padding
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 15, g4 = lane >> 4;
-  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 6;
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * NP;
   const int qw = q0 + wave * 32;                        // this wave's first query
 
   // Q fragments (B operand of S^T): two 16-query tiles x 3 planes, kept in registers
-  bf16x8 qf[2][3];
+  u32x4 qf[2][NP];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      qf[qt][p] = *reinterpret_cast<const bf16x8*>(q6 + ibase + ((int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * 3 + p) * FRAG + lane * 16);
+    for (int p = 0; p < NP; ++p)
+      qf[qt][p] = *reinterpret_cast<const u32x4*>(q6 + ibase + ((int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * NP + p) * FRAG + lane * 16);
 
   f32x4 oacc[2][2];                                     // [dv tile][query tile]: rows = dims 4 g4 .. +3, col = query ql
 #pragma unroll
@@ -142,21 +182,21 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-  // staging: one 64-key step = 12 KiB of K fragments + 12 KiB of V^T fragments, both contiguous in their images
+  // staging: one 64-key step = 4 NP KiB of K fragments + 4 NP KiB of V^T fragments, both contiguous in their images
   const int nkt = (len + KSTEP - 1) / KSTEP;
-  u32x4 st[6];
+  u32x4 st[2 * NP];
   auto gload = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      st[i] = *reinterpret_cast<const u32x4*>(k6 + ibase + (int64_t)kt * 12 * FRAG + (tid + 256 * i) * 16);
-      st[3 + i] = *reinterpret_cast<const u32x4*>(v6 + ibase + (int64_t)kt * 12 * FRAG + (tid + 256 * i) * 16);
+    for (int i = 0; i < NP; ++i) {
+      st[i] = *reinterpret_cast<const u32x4*>(k6 + ibase + (int64_t)kt * 4 * NP * FRAG + (tid + 256 * i) * 16);
+      st[NP + i] = *reinterpret_cast<const u32x4*>(v6 + ibase + (int64_t)kt * 4 * NP * FRAG + (tid + 256 * i) * 16);
     }
   };
   auto swrite = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NP; ++i) {
       *reinterpret_cast<u32x4*>(smem[buf] + (tid + 256 * i) * 16) = st[i];
-      *reinterpret_cast<u32x4*>(smem[buf] + 12 * FRAG + (tid + 256 * i) * 16) = st[3 + i];
+      *reinterpret_cast<u32x4*>(smem[buf] + 4 * NP * FRAG + (tid + 256 * i) * 16) = st[NP + i];
     }
   };
   gload(0);
@@ -166,20 +206,20 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) gload(kt + 1);
     const char* sK = smem[buf] + lane * 16;
-    const char* sV = smem[buf] + 12 * FRAG + lane * 16;
+    const char* sV = smem[buf] + 4 * NP * FRAG + lane * 16;
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       // ---- S^T = K Q^T: key tiles 2 kg, 2 kg + 1 of this step
       f32x4 s[2][2];                                    // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
-      bf16x8 kf[2][3];
+      u32x4 kf[2][NP];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) kf[t][p] = *reinterpret_cast<const bf16x8*>(sK + ((2 * kg + t) * 3 + p) * FRAG);
+        for (int p = 0; p < NP; ++p) kf[t][p] = *reinterpret_cast<const u32x4*>(sK + ((2 * kg + t) * NP + p) * FRAG);
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) s[qt][t] = mfma_x6(kf[t], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < 2; ++t) s[qt][t] = mfma_split(kf[t], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
       // ---- mask (last step only) + online softmax (lane: query ql of each tile; keys 16 t + 4 g4 + r)
       if (kt == nkt - 1) {
         const int kbase = kt * KSTEP + 32 * kg + 4 * g4;
@@ -191,7 +231,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
             for (int r = 0; r < 4; ++r)
               if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
       }
-      bf16x8 pf[2][3];
+      u32x4 pf[2][NP];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         float mx = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
@@ -210,18 +250,16 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
         m_run[qt] = m_new;
         oacc[0][qt] *= alpha;
         oacc[1][qt] *= alpha;
-        u32x4 h, m, l;
-        split8(pv, h, m, l);
-        pf[qt][0] = __builtin_bit_cast(bf16x8, h); pf[qt][1] = __builtin_bit_cast(bf16x8, m); pf[qt][2] = __builtin_bit_cast(bf16x8, l);
+        split_planes<NP>(pv, pf[qt]);
       }
       // ---- O^T += V^T P^T
 #pragma unroll
       for (int dvt = 0; dvt < 2; ++dvt) {
-        bf16x8 vf[3];
+        u32x4 vf[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8*>(sV + ((kg * 2 + dvt) * 3 + p) * FRAG);
+        for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + ((kg * 2 + dvt) * NP + p) * FRAG);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oacc[dvt][qt] = mfma_x6(vf, pf[qt], oacc[dvt][qt]);
+        for (int qt = 0; qt < 2; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt], oacc[dvt][qt]);
       }
     }
     if (kt + 1 < nkt) swrite(buf ^ 1);
@@ -244,44 +282,53 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   }
 }
 
-}  // namespace
-
-extern "C" {
-
-// bytes of the workspace paths_attention_x6 needs (three fragment images)
-int64_t paths_attention_x6_workspace(int B, int T, int H, int head_dim) {
-  const int64_t Tp = ((int64_t)T + KSTEP - 1) / KSTEP * KSTEP;
-  return 3 * (int64_t)B * H * Tp * head_dim * 6;
-}
-
-int paths_attention_x6(const float* q, const float* k, const float* v, float* o, float* lse /*[B,H,T] or null*/,
-                       const int64_t* num_ims, int B, int T, int H, int head_dim, int max_queries, void* workspace,
-                       hipStream_t stream) {
-  PATHS_REQUIRE(head_dim == HD, "attention_x6: head_dim must be %d (got %d)", HD, head_dim);
-  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && num_ims != nullptr && workspace != nullptr, "attention_x6: bad arguments B=%d T=%d H=%d", B, T, H);
-  PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_x6: buffers must be 16-byte aligned");
+template <int NP>
+int attention_split(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B, int T,
+                           int H, int max_queries, void* workspace, hipStream_t stream) {
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
-  const int64_t img = (int64_t)B * H * Tp * HD * 6;
+  const int64_t img = (int64_t)B * H * Tp * HD * 2 * NP;
   char* q6 = reinterpret_cast<char*>(workspace);
   char* k6 = q6 + img;
   char* v6 = k6 + img;
   const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
-  hipLaunchKernelGGL(attn_x6_prep_kernel, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
+  hipLaunchKernelGGL(attn_x6_prep_kernel<NP>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
   PATHS_LAUNCH_CHECK("attention_x6(prep)");
-  // Workgroups per CU: registers allow 2 (170 VGPRs; capping them at 168 for 3 cost more than it gave), LDS would allow 3.
-  // The dispatcher fills a CU to its limit before it moves on, so small grids ask for more LDS than needed to spread out:
-  // depth = ceil(grid / 256).
+  // Workgroups per CU: registers allow 2, LDS would allow more.  The dispatcher fills a CU to its limit before it moves on, so
+  // small grids ask for more LDS than needed to spread out: depth = ceil(grid / 256).
   const int nblk = ((nq + 127) / 128) * H * B;
   const int depth = nblk <= 256 ? 1 : nblk <= 512 ? 2 : 3;
-  const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * STEP_BYTES;
+  const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_x6_kernel, dim3((nq + 127) / 128, H, B), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H);
+  hipLaunchKernelGGL(attn_x6_kernel<NP>, dim3((nq + 127) / 128, H, B), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H);
   PATHS_LAUNCH_CHECK("attention_x6");
   return PATHS_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the workspace paths_attention_x6 needs (three fragment images of `planes` 16-bit planes)
+int64_t paths_attention_x6_workspace(int B, int T, int H, int head_dim, int planes) {
+  const int64_t Tp = ((int64_t)T + KSTEP - 1) / KSTEP * KSTEP;
+  return 3 * (int64_t)B * H * Tp * head_dim * 2 * planes;
+}
+
+// planes 3: bf16 hi|mid|lo, 6 MFMAs per product block; planes 2: fp16 hi|lo, 3 MFMAs (q, k, v must stay below 65504 in magnitude)
+int paths_attention_x6(const float* q, const float* k, const float* v, float* o, float* lse /*[B,H,T] or null*/,
+                       const int64_t* num_ims, int B, int T, int H, int head_dim, int max_queries, void* workspace, int planes,
+                       hipStream_t stream) {
+  PATHS_REQUIRE(head_dim == HD, "attention_x6: head_dim must be %d (got %d)", HD, head_dim);
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && num_ims != nullptr && workspace != nullptr, "attention_x6: bad arguments B=%d T=%d H=%d", B, T, H);
+  PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_x6: buffers must be 16-byte aligned");
+  PATHS_REQUIRE(planes == 2 || planes == 3, "attention_x6: planes must be 3 (bf16 x6) or 2 (fp16 x3)");
+  return planes == 3 ? attention_split<3>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, stream)
+                     : attention_split<2>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, stream);
 }
 
 }  // extern "C"

@@ -381,8 +381,9 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     for l in range(L - 1):
         if GEMM_MODE != "f32":
             if attn_ws is None:
-                attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd)),), device=tokens.device, dtype=torch.uint8)
-            _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), st)
+                attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, split_planes())),),
+                                      device=tokens.device, dtype=torch.uint8)
+            _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), split_planes(), st)
         else:
             _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st)
         token_layer(xa, xb, layers[l], layers[l + 1])

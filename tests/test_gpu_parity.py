@@ -460,8 +460,9 @@ def test_other_gemm_modes_match_default(dev, monkeypatch, mode):
     np.testing.assert_allclose(out_m["ctx_patch"].numpy(), out_def["ctx_patch"].numpy(), atol=5e-6, rtol=0)
 
 
+@pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37]), (65, [64, 65])])
-def test_attention_x6_matches_fp64(dev, T, lens):
+def test_attention_x6_matches_fp64(dev, T, lens, planes):
     """Split-bf16 attention against an fp64 softmax(q k^T) v and against the f32-MFMA kernel."""
     from paths_amd import _lib
     B, H, hd = len(lens), 4, 32
@@ -471,11 +472,11 @@ def test_attention_x6_matches_fp64(dev, T, lens):
     v = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1)
     num_ims = torch.tensor([n - 1 for n in lens], device=dev, dtype=torch.int64)
     p, st = _lib.ptr, _lib.stream()
-    ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8)
+    ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, planes)),), device=dev, dtype=torch.uint8)
     o6 = torch.full((B, T, H * hd), float("nan"), device=dev)
     o32 = torch.full((B, T, H * hd), float("nan"), device=dev)
     lse6 = torch.empty((B, H, T), device=dev)
-    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o6), p(lse6), p(num_ims), B, T, H, hd, 0, p(ws), st)
+    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o6), p(lse6), p(num_ims), B, T, H, hd, 0, p(ws), planes, st)
     _lib.call("paths_attention_f32", p(q), p(k), p(v), p(o32), None, p(num_ims), B, T, H, hd, 0, st)
     for b, n in enumerate(lens):
         s = (q[b, :, :n].double() @ k[b, :, :n].double().transpose(1, 2)) * np.log(2.0)      # kernels use exp2 of pre-scaled q
