@@ -52,9 +52,9 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
     if ops.GEMM_MODE != "f32" and N % 256 == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
             and wt.shape[0] >= N and wt.stride(0) == ldw and wt.stride(1) == 1:
         # split-bf16 GEMM: the (transposed) weight is re-imaged per call - 6 N K bytes, microseconds next to an M >= 1024 product
-        wx, wx_s = ops.x6_pack(wt[:N, :K])
+        wx, wx_s = ops.x6_pack(wt[:N, :K], planes=ops.TRAIN_PLANES)
         _lib.call("paths_gemm_nt_x6", ap, lda, P(wx), K, 0, P(bias), op, ldo, M, N, N, K, act, rp, ldr, mp, ldm,
-                  1 if accumulate else 0, ops.split_planes(), wx_s, ops.a_scale(), _lib.stream())
+                  1 if accumulate else 0, ops.TRAIN_PLANES, wx_s, 1.0, _lib.stream())
         return
     _lib.call("paths_gemm_nt_f32", ap, lda, P(wt), ldw, P(bias), op, ldo, M, N, N, K, act, rp, ldr,
               mp, ldm, 1 if accumulate else 0, _lib.stream())
@@ -109,10 +109,11 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
         ld, h0, c0 = 0, None, None
     x6 = ops.use_x6(D, Hc)        # forward GEMMs on the split-bf16 path (weight images are re-packed when the optimizer steps)
     if x6:
-        (wg, wg_s), (wm, wm_s) = ops._x6_of(lstm_pack, "w_gates"), ops._x6_of(lstm_pack, "w_mem")
+        TP = ops.TRAIN_PLANES
+        (wg, wg_s), (wm, wm_s) = ops._x6_of(lstm_pack, "w_gates", TP), ops._x6_of(lstm_pack, "w_mem", TP)
         _lib.call("paths_lstm_cell_x6", P(fts), D, h0, ld, c0, ld, P(wg), P(lstm_pack["b_gates"]), P(wm), P(lstm_pack["b_mem"]),
                   P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7,
-                  ops.split_planes(), wg_s, wm_s, ops.a_scale(), st)
+                  TP, wg_s, wm_s, 1.0, st)
     else:
         _lib.call("paths_lstm_cell", P(fts), D, h0, ld, c0, ld, P(lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
                   P(lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp,
@@ -127,8 +128,8 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
             P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
             P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)
     if x6:
-        wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd")
-        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, 0, P(wip), *tail[:-1], ops.split_planes(), wip_s, ops.a_scale(), tail[-1])
+        wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd", ops.TRAIN_PLANES)
+        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, 0, P(wip), *tail[:-1], ops.TRAIN_PLANES, wip_s, 1.0, tail[-1])
     else:
         _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), *tail)
     return sv

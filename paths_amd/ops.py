@@ -31,7 +31,8 @@ KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set b
 #   "x6"  : operands split into THREE bf16 planes, 6 MFMAs per product block (same kernels, NP = 3; no range limits)
 #   "f32" : f32-input MFMA (csrc/gemm_f32.hip, csrc/attn_f32.hip)
 GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "h3")
-A_SCALE = 16.0
+A_SCALE = float(os.environ.get("PATHS_H3_A_SCALE", "16"))      # a power of two
+TRAIN_PLANES = 3        # training re-images weights every step: the bf16 split needs no scale, i.e. no host sync on max|w|
 
 
 def split_planes() -> int:
@@ -61,12 +62,13 @@ def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] 
     return out, w_scale
 
 
-def _x6_of(pack: Dict[str, object], key: str):
-    """(image, w_scale) of pack[key] for the current split mode, built on first use and cached beside it (the pack dict is
-    rebuilt when weights change)."""
-    k6 = f"{key}_split{split_planes()}"
+def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None):
+    """(image, w_scale) of pack[key] for the given (default: current) split, built on first use and cached beside it (the pack
+    dict is rebuilt when weights change)."""
+    planes = split_planes() if planes is None else planes
+    k6 = f"{key}_split{planes}"
     if k6 not in pack:
-        pack[k6] = x6_pack(pack[key])
+        pack[k6] = x6_pack(pack[key], planes=planes)
     return pack[k6]
 
 
