@@ -11,9 +11,14 @@ import collections, csv, glob, json, re, sys
 def short(name):
     m = re.search(r'gemm_(x6|f32)_kernel<(.*?)(?:paths_epi::)?(Epi\w+)', name)
     if m:
-        tile = ",".join(t.strip() for t in m.group(2).split(",")[:2])
-        return f"gemm_{m.group(1)}<{tile}>{m.group(3)}"
-    m = re.search(r'::(\w+_kernel|\w+)\(', name)
+        args = [t.strip() for t in m.group(2).split(",")]
+        if m.group(1) == "x6":          # <planes, WTM, WTN, PF, ADD, Epi>
+            return f"gemm_{'h3' if args[0] == '2' else 'x6'}<{args[1]},{args[2]}>{m.group(3)}"
+        return f"gemm_f32<{args[0]},{args[1]}>{m.group(3)}"
+    m = re.search(r'::(\w+_kernel)(<\d+>)?\(', name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    m = re.search(r'::(\w+)\(', name)
     return m.group(1) if m else name[:40]
 
 
