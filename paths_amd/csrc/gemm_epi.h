@@ -362,7 +362,7 @@ __device__ __forceinline__ int div_pos(int64_t x, int d, float rd) {      // pix
 // columns and BOTH column halves (wn = 0, 1) own 64 importance hidden units and 64 projected token channels, so the two
 // epilogue phases (importance logit, tokens) are shared by all waves instead of running one after the other on half of them.
 //   alpha = valid ? sigmoid(w2 . relu(acc + b1) + b2) : 0            (importance_mode "mul": token = alpha*acc + bp + PE)
-template <bool PE_TAB>
+template <bool PE_TAB, bool SAVE = false>    // SAVE: training keeps relu(Y W1^T + b1) and Y Wp^T
 struct EpiImpProj {
   template <int WTM, int WTN>
   __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
@@ -413,23 +413,54 @@ struct EpiImpProj {
           const float hv = fmaxf(fmaf(acc[i][j][r], acc_scale, b), 0.f);
           part[r] += hv * w;
           const int row = row0 + 32 * i + c32_row(r, lane);
-          if (hid_out && row < M) hid_out[(int64_t)row * 128 + u] = hv;
+          if constexpr (SAVE) { if (row < M) hid_out[(int64_t)row * 128 + u] = hv; }
         }
       }
+      // Sum over the 32 lanes (= hidden units) of each half-wave, 16 rows at once.  Halving butterfly: at distance 16 a lane
+      // keeps 8 rows and hands the other 8 to its partner, then 4, 2, 1: 8+4+2+1+1 = 16 cross-lane moves instead of 16 x 5.
+      // Afterwards lane l holds the total of row index rho(l) = bits 4..1 of l (both lanes of a pair hold the same value).
+      float p8[8], p4[4], p2[2], p1;
+      {
+        const bool up = (lane & 16) != 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = part[r];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-        if ((lane & 31) == 0) alpha_p[wn * RB + wm * WTM * 32 + 32 * i + c32_row(r, lane)] = v;
+        for (int k = 0; k < 8; ++k) {
+          const float keep = up ? part[8 + k] : part[k], send = up ? part[k] : part[8 + k];
+          p8[k] = keep + __shfl_xor(send, 16);
+        }
       }
+      {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float keep = up ? p8[4 + k] : p8[k], send = up ? p8[k] : p8[4 + k];
+          p4[k] = keep + __shfl_xor(send, 8);
+        }
+      }
+      {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float keep = up ? p4[2 + k] : p4[k], send = up ? p4[k] : p4[2 + k];
+          p2[k] = keep + __shfl_xor(send, 4);
+        }
+      }
+      {
+        const bool up = (lane & 2) != 0;
+        const float keep = up ? p2[1] : p2[0], send = up ? p2[0] : p2[1];
+        p1 = keep + __shfl_xor(send, 2);
+      }
+      p1 += __shfl_xor(p1, 1);
+      const int rho = (lane >> 1) & 15;               // bit4 -> r bit 3, bit3 -> r bit 2, bit2 -> r bit 1, bit1 -> r bit 0
+      if ((lane & 1) == 0) alpha_p[wn * RB + wm * WTM * 32 + 32 * i + c32_row(rho, lane)] = p1;
     }
     __syncthreads();
     // ---- phase B (all waves): alpha of every row (both column halves compute the same value), tokens of this wave's 64 channels
-    float bpv[2], dtv[2];
+    float bpv[2], dtv[2], spv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = u0 + 32 * j + (lane & 31);
       bpv[j] = bp[c];
+      spv[j] = special[c];
       dtv[j] = pe_mode == 2 ? div_term[(c & (d / 2 - 1)) >> 1] : div_term[c >> 1];
     }
 #pragma unroll
@@ -440,29 +471,45 @@ struct EpiImpProj {
         const int rowc = min(row0 + 32 * i + c32_row(r, lane), M - 1);
         lp[r] = pe_mode == 2 ? locs[2 * (int64_t)rowc + wn] : 0;
       }
+      // slide / row-in-slide of this lane's rows: ONE division for the tile's first row, the others follow by counting (a
+      // 32-row tile crosses at most one slide boundary when rows_per_slide >= 32; smaller slides take the division per row)
+      const int trow0 = min(row0 + 32 * i, M - 1);
+      const int b0 = small_rows ? div_u24(trow0, rows_per_slide, rps_inv) : trow0 / rows_per_slide, idx0 = trow0 - b0 * rows_per_slide;
+      const int nslides = M / rows_per_slide;
+      const int nim0 = (int)num_ims[b0], nim1 = (int)num_ims[min(b0 + 1, nslides - 1)];
       int tokrow[16]; float av[16]; bool first[16]; float pev[16][2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lrow = wm * WTM * 32 + 32 * i + c32_row(r, lane);
         const int rowr = row0 + 32 * i + c32_row(r, lane);
-        const int row = min(rowr, M - 1);
-        const int b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide, idx = row - b * rows_per_slide;
+        int b, idx, nim;
+        if (rows_per_slide >= 32) {
+          const int off = min(rowr, M - 1) - trow0;
+          const bool next = idx0 + off >= rows_per_slide;
+          b = b0 + (next ? 1 : 0); idx = idx0 + off - (next ? rows_per_slide : 0); nim = next ? nim1 : nim0;
+        } else {
+          const int row = min(rowr, M - 1);
+          b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide; idx = row - b * rows_per_slide; nim = (int)num_ims[b];
+        }
         float a = 0.f;
-        if (idx < (int)num_ims[b]) a = sigmoid_acc((alpha_p[lrow] + alpha_p[RB + lrow]) + b2);
+        if (idx < nim) a = sigmoid_acc((alpha_p[lrow] + alpha_p[RB + lrow]) + b2);
         if (wn == 0 && (lane & 31) == 0 && rowr < M) importance[rowr] = a;
         av[r] = imp_mul ? a : 1.f;
         tokrow[r] = b * (rows_per_slide + 1) + idx + 1;                   // token row (row 0 of a slide = special token)
         first[r] = idx == 0;                                              // this row also emits its slide's special token
-        const int ipos = pe_mode == 2 ? div_pos(lp[r], patch_size, ps_inv) : idx;
         if constexpr (PE_TAB) {
-          // the caller guarantees positions < pe_rows (paths_amd passes the level's grid size); clamped for memory safety
-          const int tp = min(max(ipos, 0), pe_rows - 1);
+          // the caller guarantees positions < pe_rows (paths_amd passes the level's grid size); clamped for memory safety,
+          // which also makes the division branch-free (no 64-bit fallback)
+          const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
+          const int ipos = pe_mode == 2 ? div_u24(px24, patch_size, ps_inv) : idx;
+          const int tp = min(ipos, pe_rows - 1);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int c = u0 + 32 * j + (lane & 31);
             pev[r][j] = pe_mode == 2 ? pe_table[(int64_t)tp * (d / 2) + (c & (d / 2 - 1))] : pe_table[(int64_t)tp * d + c];
           }
         } else {
+          const int ipos = pe_mode == 2 ? div_pos(lp[r], patch_size, ps_inv) : idx;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int c = u0 + 32 * j + (lane & 31);
@@ -481,8 +528,8 @@ struct EpiImpProj {
             const int c = u0 + 32 * j + (lane & 31);
             const float pj = acc[i][2 + j][r] * acc_scale;
             trow[c] = av[r] * pj + bpv[j] + pev[r][j];
-            if (pproj_out) pproj_out[(int64_t)row * 128 + c] = pj;
-            if (first[r]) trow[c - d] = special[c];
+            if constexpr (SAVE) pproj_out[(int64_t)row * 128 + c] = pj;
+            if (first[r]) trow[c - d] = spv[j];
           }
         }
       }

@@ -262,15 +262,15 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256,
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj: 2d positional encoding needs locs");
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj: bad slide layout");
   GemmOperands g{y, ldy, D, nullptr, 0, 0, w_ip, D, M, skip_padding ? num_ims : nullptr, rows_per_slide};
-  if (pe_table != nullptr) {
-    PATHS_REQUIRE(pe_rows > 0, "importance_proj: pe_rows must be > 0 with a pe_table");
-    EpiImpProj<true> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-                       save_hid, save_pproj, pe_table, pe_rows};
-    return launch_gemm<1, 4, 2, 2>(g, 256, e, stream, "importance_proj(table)");
-  }
-  EpiImpProj<false> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-                      save_hid, save_pproj, nullptr, 0};
-  return launch_gemm<1, 4, 2, 2>(g, 256, e, stream, "importance_proj");
+  PATHS_REQUIRE((save_hid == nullptr) == (save_pproj == nullptr), "importance_proj: save_hid and save_pproj come together");
+  PATHS_REQUIRE(pe_table == nullptr || pe_rows > 0, "importance_proj: pe_rows must be > 0 with a pe_table");
+  auto go = [&](auto epi) {
+    decltype(epi) e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
+                    save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0};
+    return launch_gemm<1, 4, 2, 2>(g, 256, e, stream, "importance_proj");
+  };
+  if (pe_table != nullptr) return save_hid ? go(EpiImpProj<true, true>{}) : go(EpiImpProj<true, false>{});
+  return save_hid ? go(EpiImpProj<false, true>{}) : go(EpiImpProj<false, false>{});
 }
 
 // positional-encoding table for paths_importance_proj(_x6): out [rows, d/2] (pe_mode 2) or [rows, d] (pe_mode 1)

@@ -542,17 +542,16 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, in
   if (planes == 3) w_scale = a_scale = 1.0f;
   const float sc = 1.0f / (w_scale * a_scale);
   X6Operands g{y, ldy, D, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(planes, D), M, skip_padding ? num_ims : nullptr, rows_per_slide, a_scale};
-  if (pe_table != nullptr) {
-    PATHS_REQUIRE(pe_rows > 0, "importance_proj_x6: pe_rows must be > 0 with a pe_table");
-    EpiImpProj<true> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-                       save_hid, save_pproj, pe_table, pe_rows, sc};
-    if (y_add != nullptr) return launch_x6<2, 4, 2, true>(planes, g, 256, e, stream, "importance_proj_x6(sum, table)");
-    return launch_x6<2, 4, 2, false>(planes, g, 256, e, stream, "importance_proj_x6(table)");
-  }
-  EpiImpProj<false> e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
-                      save_hid, save_pproj, nullptr, 0, sc};
-  if (y_add != nullptr) return launch_x6<2, 4, 2, true>(planes, g, 256, e, stream, "importance_proj_x6(sum)");
-  return launch_x6<2, 4, 2, false>(planes, g, 256, e, stream, "importance_proj_x6");
+  PATHS_REQUIRE((save_hid == nullptr) == (save_pproj == nullptr), "importance_proj_x6: save_hid and save_pproj come together");
+  PATHS_REQUIRE(pe_table == nullptr || pe_rows > 0, "importance_proj_x6: pe_rows must be > 0 with a pe_table");
+  auto go = [&](auto epi) {
+    decltype(epi) e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
+                    save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0, sc};
+    if (y_add != nullptr) return launch_x6<2, 4, 2, true>(planes, g, 256, e, stream, "importance_proj_x6(sum)");
+    return launch_x6<2, 4, 2, false>(planes, g, 256, e, stream, "importance_proj_x6");
+  };
+  if (pe_table != nullptr) return save_hid ? go(EpiImpProj<true, true>{}) : go(EpiImpProj<true, false>{});
+  return save_hid ? go(EpiImpProj<false, true>{}) : go(EpiImpProj<false, false>{});
 }
 
 // out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual with W given as the split image of an [Npad, Kpacked]
