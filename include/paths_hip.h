@@ -81,16 +81,18 @@ int64_t paths_x6_packed_bytes(int Npad, int K, int planes);
 int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int planes, float w_scale,
                           paths_stream_t stream);
 /* w_gates_x6 = pack of the PACKED gate matrix [3Hc+D, 2D] of paths_lstm_cell (scale wg_scale); w_mem_x6 = pack of [D, Hc]
- * (scale wm_scale); D % 256 == 0; y may be NULL (Y = X + h1 not materialised) */
-int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
+ * (scale wm_scale); D % 256 == 0; y may be NULL (Y = X + h1 not materialised).  x_rows (optional, planes = 2, needs hp / no
+ * h0, y = NULL): [M] addresses of the feature rows - x is then read in place (paths_gather_rows row_ptrs), x / ldx unused */
+int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                        const void* w_gates_x6, const float* b_gates, const void* w_mem_x6, const float* b_mem,
                        float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
                        const float* hp, const int* hp_row,
                        int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide, int phases,
                        int planes, float wg_scale, float wm_scale, float a_scale, paths_stream_t stream);
 /* w_ip_x6 = pack of [256, D] (rows interleaved as for paths_importance_proj); y_add (optional): GEMM input = y + y_add summed
- * in fp32 while staging, so that the caller can pass (x, h1) and skip materialising Y = X + h1 */
-int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+ * in fp32 while staging, so that the caller can pass (x, h1) and skip materialising Y = X + h1; y_rows (optional, planes = 2):
+ * row addresses of y instead of (y, ldy) */
+int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows,
                              const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
@@ -226,10 +228,14 @@ int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t
 
 /* Gather child features from the next-level grids and parent LSTM state (reference slide.py:318,327-331;
  * zero padding of data_utils/dataset.py:216-227 when zero_pad != 0).  state_cur points at the first state column to copy
- * (row stride ld_state_cur), Dp = number of columns copied into state_out [B, n_next, Dp]. */
+ * (row stride ld_state_cur), Dp = number of columns copied into state_out [B, n_next, Dp].
+ * fts_out may be NULL when row_ptrs [B, n_next] is given: the features are then not copied at all, row_ptrs receives the
+ * ADDRESS of every child's feature row inside its resident grid (padding rows: zero_row, D zeros) and the split-operand
+ * GEMMs read the rows in place (x_rows / y_rows of paths_lstm_cell_x6 / paths_importance_proj_x6). */
 int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,
                       int64_t ld_state_cur, const int* src_row, int Dp, const int64_t* num_out, int B, int64_t n_next,
-                      float* fts_out, float* state_out, int zero_pad, paths_stream_t stream);
+                      float* fts_out, float* state_out, int zero_pad, int64_t* row_ptrs, const float* zero_row,
+                      paths_stream_t stream);
 
 /* Compact table of the kept parents' rows: out[b*ldk + i] = src[b, keep_idx[b,i], 0:D] (zeros beyond keep_count). */
 int paths_gather_kept_rows(const float* src, int64_t n_cur, int64_t ld_src, const int* keep_idx, int64_t ldk, const int* keep_count,

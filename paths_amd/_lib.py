@@ -26,9 +26,9 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_gemm_nt_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp],
     "paths_x6_pack_weights": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
-    "paths_lstm_cell_x6": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+    "paths_lstm_cell_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i32, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
-    "paths_importance_proj_x6": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
+    "paths_importance_proj_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "paths_gemm_nt_x6": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32,
                          _i32, _f32, _f32, _vp],
@@ -54,7 +54,7 @@ SIGNATURES = {
     "paths_gather_kept_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp],
     "paths_gather_rows_bwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp],
     "paths_fallback_all_cells": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp],
+    "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp],
     "paths_scale_add_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],

@@ -115,7 +115,7 @@ class GatherFn(torch.autograd.Function):
         state_next = torch.empty((B, n_next, Dp), **f32)
         p = _lib.ptr
         _lib.call("paths_gather_rows", p(grid_ptrs), p(src_cell), D, p(state_cur), n_cur, Dp, p(src_row), Dp, p(num_next), B,
-                  n_next, p(fts_next), p(state_next), 1, _lib.stream())
+                  n_next, p(fts_next), p(state_next), 1, None, None, _lib.stream())
         ctx.meta = (keep_idx, keep_count, child_pos, n_cur, n_next, Dp, B)
         ctx.mark_non_differentiable(fts_next)
         return fts_next, state_next

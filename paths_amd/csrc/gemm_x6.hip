@@ -61,6 +61,8 @@ template <int NP> constexpr int subt() { return NP * FRAG; }    // one 32-row x 
 
 struct X6Operands {
   const float* A0; int64_t lda0; int K0;
+  const int64_t* A0rows;           // ROWS kernels: address of every row of panel 0 (rows live wherever they are, e.g. in the slides'
+                                   // resident feature grids: no gathered copy); A0 / lda0 unused then
   const float* A1; int64_t lda1; int K1;
   const float* Aadd; int64_t ldadd;   // ADD kernels only: panel 0 is A0 + Aadd, summed in fp32 on the way to the split
   const char* Wt;                  // packed weights, already advanced to the first 32-row group and first k16 step used
@@ -79,7 +81,7 @@ uint64_t* g_x6_dbg = nullptr;
 
 // PF = how many stages ahead of its LDS write a stage is loaded into registers (1 or 2 register sets).  Stages of the
 // 128-row tiles are only ~1,500 cycles long, shorter than a loaded-L2 round trip, so those run two stages ahead.
-template <int NP, int WTM, int WTN, int PF, bool ADD, class Epi>
+template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 gemm_x6_kernel(X6Operands g, Epi epi) {
   static_assert(NP == 2 || NP == 3, "two fp16 planes or three bf16 planes");
@@ -118,11 +120,14 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // against a wave-uniform panel base.  W: wave -> 1-KiB pieces wave + 4 i of the stage's SB x 3 fragments.
   const int arow = tid >> 2, ac = tid & 3;
   uint32_t aoff0[NA], aoff1[NA], aoffs[ADD ? NA : 1]; int awr[NA];
+  typedef const f32x4 __attribute__((address_space(1))) * gptr_f4;
+  gptr_f4 rowp[ROWS ? NA : 1];                         // ROWS: this thread's piece of each of its rows, advanced one stage at a time
 #pragma unroll
   for (int p = 0; p < NA; ++p) {
     const int row = p * 64 + arow;
     const int64_t grow = min(m0 + row, g.M - 1);
-    aoff0[p] = (uint32_t)((grow * g.lda0 + 4 * ac) * 4);
+    aoff0[p] = ROWS ? 0u : (uint32_t)((grow * g.lda0 + 4 * ac) * 4);
+    if constexpr (ROWS) rowp[p] = reinterpret_cast<gptr_f4>(static_cast<uintptr_t>(g.A0rows[grow]) + 16 * ac);
     aoff1[p] = (uint32_t)((grow * g.lda1 + 4 * ac) * 4);
     if constexpr (ADD) aoffs[p] = (uint32_t)((grow * g.ldadd + 4 * ac) * 4);
     awr[p] = (row >> 5) * SUBT + (ac >> 1) * 512 + (row & 31) * 16 + (ac & 1) * 8;
@@ -144,9 +149,10 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // per-lane 32-bit offset computed once.  As 64-bit pointers hipcc strength-reduced each load's address into a VGPR pair it
   // then bumped with 3-4 VALU instructions per load; packed into the MFMA gaps of the 128-row tiles that stretched the first
   // gaps of every stage to ~60 cycles.
-  const auto rsA0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, 0xFFFFFFFFu, 0x00020000);
-  const auto rsA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A1 ? g.A1 : g.A0), 0, 0xFFFFFFFFu, 0x00020000);
-  const auto rsAdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ADD ? g.Aadd : g.A0), 0, 0xFFFFFFFFu, 0x00020000);
+  float* const anyA = const_cast<float*>(ROWS ? reinterpret_cast<const float*>(g.Wt) : g.A0);   // (descriptor placeholder when unused)
+  const auto rsA0 = __builtin_amdgcn_make_buffer_rsrc(anyA, 0, 0xFFFFFFFFu, 0x00020000);
+  const auto rsA1 = __builtin_amdgcn_make_buffer_rsrc(g.A1 ? const_cast<float*>(g.A1) : anyA, 0, 0xFFFFFFFFu, 0x00020000);
+  const auto rsAdd = __builtin_amdgcn_make_buffer_rsrc(ADD ? const_cast<float*>(g.Aadd) : anyA, 0, 0xFFFFFFFFu, 0x00020000);
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.Wt), 0, 0xFFFFFFFFu, 0x00020000);
   const int lane16 = lane * 16;
   int bsoff[NB];                                       // scalar byte offset of W piece i at stage 0
@@ -159,9 +165,13 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
 #else
     const int soff = (first ? kt : kt - nk0) * 64;
 #endif
-    const u32x4 raw = first ? __builtin_amdgcn_raw_buffer_load_b128(rsA0, (int)aoff0[q], soff, 0)
-                            : __builtin_amdgcn_raw_buffer_load_b128(rsA1, (int)aoff1[q], soff, 0);
-    sa[set][q] = __builtin_bit_cast(f32x4, raw);
+    if constexpr (ROWS) {                              // single panel: 64-bit per-lane row address + the stage's 64 bytes
+      sa[set][q] = rowp[q][kt * 4];
+    } else {
+      const u32x4 raw = first ? __builtin_amdgcn_raw_buffer_load_b128(rsA0, (int)aoff0[q], soff, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(rsA1, (int)aoff1[q], soff, 0);
+      sa[set][q] = __builtin_bit_cast(f32x4, raw);
+    }
     if constexpr (ADD) {                               // (ADD kernels have a single panel)
       sadd[set][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsAdd, (int)aoffs[q], kt * 64, 0));
     }
@@ -407,7 +417,7 @@ __global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, uint16_
   }
 }
 
-template <int NP, int WTM, int WTN, int PF, bool ADD, class Epi>
+template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi>
 int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
   constexpr int BM = WTM * 64, BN = WTN * 64;
   constexpr size_t lds = 2ull * (2 * WTM + 2 * WTN) * subt<NP>();
@@ -417,8 +427,9 @@ int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stre
   PATHS_REQUIRE(Npad % BN == 0, "%s: packed N (%d) must be a multiple of %d", name, Npad, BN);
   PATHS_REQUIRE(g.lda0 % 4 == 0 && g.lda1 % 4 == 0, "%s: leading dims must be multiples of 4 floats", name);
   PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Wt % 16 == 0), "%s: operands must be 16-byte aligned", name);
+  PATHS_REQUIRE(ROWS == (g.A0rows != nullptr) && (!ROWS || g.K1 == 0), "%s: row-pointer form is single-panel", name);
   PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? (g.lda0 > g.ldadd ? g.lda0 : g.ldadd) : (g.lda1 > g.ldadd ? g.lda1 : g.ldadd)) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
-  auto kern = gemm_x6_kernel<NP, WTM, WTN, PF, ADD, Epi>;
+  auto kern = gemm_x6_kernel<NP, WTM, WTN, PF, ADD, ROWS, Epi>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -438,8 +449,12 @@ int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stre
 // planes = 3: bf16 x6; planes = 2: fp16 x3 (operands pre-scaled by powers of two, undone through Epi::acc_scale)
 template <int WTM, int WTN, int PF, bool ADD, class Epi>
 int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
-  if (planes == 3) return launch_x6_np<3, WTM, WTN, PF, ADD>(g, Npad, epi, stream, name);
-  if (planes == 2) return launch_x6_np<2, WTM, WTN, PF, ADD>(g, Npad, epi, stream, name);
+  if (g.A0rows != nullptr) {       // row-pointer form: the default (two-plane) split only
+    if (planes == 2) return launch_x6_np<2, WTM, WTN, PF, ADD, true>(g, Npad, epi, stream, name);
+    return paths_set_error(PATHS_EUNSUPPORTED, "%s: row pointers need planes = 2", name);
+  }
+  if (planes == 3) return launch_x6_np<3, WTM, WTN, PF, ADD, false>(g, Npad, epi, stream, name);
+  if (planes == 2) return launch_x6_np<2, WTM, WTN, PF, ADD, false>(g, Npad, epi, stream, name);
   return paths_set_error(PATHS_EINVAL, "%s: planes must be 3 (bf16 x6) or 2 (fp16 x3), got %d", name, planes);
 }
 
@@ -479,7 +494,7 @@ int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npa
 // paths_lstm_cell with the gate / mem_to_out weights given as split images (planes, scales as in paths_x6_pack_weights;
 // a_scale: power of two applied to the fp32 activations before the fp16 split - |activation| * a_scale must stay < 65504):
 //   w_gates_x6 = pack([3Hc + D, 2D] packed gate rows, see paths_lstm_cell), w_mem_x6 = pack([D, Hc])
-int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
+int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                        const void* w_gates_x6, const float* b_gates, const void* w_mem_x6, const float* b_mem,
                        float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,
                        const float* hp, const int* hp_row, int M, int D, int Hc, const int64_t* num_ims, int rows_per_slide,
@@ -489,11 +504,12 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh
   PATHS_REQUIRE((hp == nullptr) == (hp_row == nullptr) && (hp == nullptr || h0 == nullptr),
                 "lstm_cell_x6: hp/hp_row come together and replace h0 (the h half of the gate GEMM was done per parent)");
   PATHS_REQUIRE(planes == 3 || (pow2(wg_scale) && pow2(wm_scale) && pow2(a_scale)), "lstm_cell_x6: scales must be powers of two");
+  PATHS_REQUIRE(x_rows == nullptr || (h0 == nullptr && y == nullptr && save_tc == nullptr), "lstm_cell_x6: x_rows (rows addressed in place) excludes h0, y and the training saves");
   if (planes == 3) wg_scale = wm_scale = a_scale = 1.0f;
   const char* wg = reinterpret_cast<const char*>(w_gates_x6);
   const int64_t gs = group_stride(planes, 2 * D);
   const float sg = 1.0f / (wg_scale * a_scale), sm = 1.0f / (wm_scale * a_scale);
-  X6Operands g{x, ldx, D, h0, h0 ? ldh0 : 0, h0 ? D : 0, nullptr, 0, wg, gs, M, num_ims, rows_per_slide, a_scale};
+  X6Operands g{x, ldx, D, x_rows, h0, h0 ? ldh0 : 0, h0 ? D : 0, nullptr, 0, wg, gs, M, num_ims, rows_per_slide, a_scale};
   if (phases & 1) {   // c-part: N = 3Hc, block 256 x 192
     EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row, sg};
     int rc = launch_x6<4, 3, 1, false>(planes, g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
@@ -507,7 +523,7 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh
     if (rc) return rc;
   }
   if (phases & 4) {   // h1 = o * tanh(Wc c1 + bc), Y = X + h1
-    X6Operands gh{state_out + D, ldso, Hc, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(planes, Hc), M, num_ims, rows_per_slide, a_scale};
+    X6Operands gh{state_out + D, ldso, Hc, nullptr, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_mem_x6), group_stride(planes, Hc), M, num_ims, rows_per_slide, a_scale};
     int rc;
     PATHS_REQUIRE(save_tc == nullptr || y != nullptr, "lstm_cell_x6: save_tc (training) needs y");
     if (save_tc != nullptr) {
@@ -528,7 +544,7 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const float* h0, int64_t ldh
 // paths_importance_proj with w_ip_x6 = pack([256, D], rows interleaved as paths_importance_proj documents).  y_add (optional): the
 // GEMM input is y + y_add, summed in fp32 while staging - the caller passes (x, h1) and never materialises Y = X + h1
 // (paths_lstm_cell_x6 with y = NULL)
-int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                              float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
@@ -541,7 +557,7 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const float* y_add, in
   PATHS_REQUIRE(planes == 3 || (pow2(w_scale) && pow2(a_scale)), "importance_proj_x6: scales must be powers of two");
   if (planes == 3) w_scale = a_scale = 1.0f;
   const float sc = 1.0f / (w_scale * a_scale);
-  X6Operands g{y, ldy, D, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(planes, D), M, skip_padding ? num_ims : nullptr, rows_per_slide, a_scale};
+  X6Operands g{y, ldy, D, y_rows, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(planes, D), M, skip_padding ? num_ims : nullptr, rows_per_slide, a_scale};
   PATHS_REQUIRE((save_hid == nullptr) == (save_pproj == nullptr), "importance_proj_x6: save_hid and save_pproj come together");
   PATHS_REQUIRE(pe_table == nullptr || pe_rows > 0, "importance_proj_x6: pe_rows must be > 0 with a pe_table");
   auto go = [&](auto epi) {
@@ -562,7 +578,7 @@ int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked,
   PATHS_REQUIRE(k0 % 16 == 0 && k0 >= 0 && k0 + K <= Kpacked, "gemm_nt_x6: bad k window");
   PATHS_REQUIRE(planes == 3 || (planes == 2 && pow2(w_scale) && pow2(a_scale)), "gemm_nt_x6: planes 3, or planes 2 with power-of-two scales");
   if (planes == 3) w_scale = a_scale = 1.0f;
-  X6Operands g{a, lda, K, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * planes * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
+  X6Operands g{a, lda, K, nullptr, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * planes * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
   EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate, 1.0f / (w_scale * a_scale)};
   return launch_x6<2, 4, 2, false>(planes, g, Npad, e, stream, "gemm_nt_x6");
 }

@@ -195,16 +195,18 @@ __global__ void __launch_bounds__(256)
 gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src_cell, int D,
               const float* __restrict__ state_cur /*already offset to the first copied column*/, int64_t n_cur, int64_t ld_state_cur,
               const int* __restrict__ src_row, int Dp /*columns copied*/, const int64_t* __restrict__ num_out, int64_t n_next,
-              float* __restrict__ fts_out, float* __restrict__ state_out, int zero_pad) {
+              float* __restrict__ fts_out, float* __restrict__ state_out, int zero_pad,
+              int64_t* __restrict__ row_ptrs, const float* __restrict__ zero_row) {
   const int b = blockIdx.y;
   const int64_t j = blockIdx.x;
   const int64_t o = (int64_t)b * n_next + j;
   const int tid = threadIdx.x;
-  f32x4* fo = reinterpret_cast<f32x4*>(fts_out + o * D);
+  f32x4* fo = fts_out ? reinterpret_cast<f32x4*>(fts_out + o * D) : nullptr;
   f32x4* so = state_out ? reinterpret_cast<f32x4*>(state_out + o * Dp) : nullptr;
   if (j < num_out[b]) {
     const f32x4* fi = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(grid_ptrs[b]) + (int64_t)src_cell[o] * D);
-    for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
+    if (row_ptrs && tid == 0) row_ptrs[o] = (int64_t)reinterpret_cast<uintptr_t>(fi);     // consumers read the row where it lives
+    if (fo) for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
     if (so) {
       const int sr = src_row[o];
       if (sr >= 0) {
@@ -215,10 +217,13 @@ gather_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ src
         for (int i = tid; i < Dp / 4; i += 256) so[i] = z;
       }
     }
-  } else if (zero_pad) {
-    const f32x4 z{0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < D / 4; i += 256) fo[i] = z;
-    if (so) for (int i = tid; i < Dp / 4; i += 256) so[i] = z;
+  } else {
+    if (row_ptrs && tid == 0) row_ptrs[o] = (int64_t)reinterpret_cast<uintptr_t>(zero_row);   // padding rows: a row of zeros
+    if (zero_pad) {
+      const f32x4 z{0.f, 0.f, 0.f, 0.f};
+      if (fo) for (int i = tid; i < D / 4; i += 256) fo[i] = z;
+      if (so) for (int i = tid; i < Dp / 4; i += 256) so[i] = z;
+    }
   }
 }
 
@@ -380,11 +385,14 @@ int paths_fallback_all_cells(const int* next_x, const int* next_y, const int64_t
 
 int paths_gather_rows(const int64_t* grid_ptrs, const int* src_cell, int D, const float* state_cur, int64_t n_cur,
                       int64_t ld_state_cur, const int* src_row, int Dp, const int64_t* num_out, int B, int64_t n_next,
-                      float* fts_out, float* state_out, int zero_pad, hipStream_t stream) {
+                      float* fts_out, float* state_out, int zero_pad, int64_t* row_ptrs, const float* zero_row,
+                      hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && n_next > 0 && D % 4 == 0 && Dp % 4 == 0 && ld_state_cur % 4 == 0, "gather_rows: bad shape");
+  PATHS_REQUIRE(fts_out != nullptr || row_ptrs != nullptr, "gather_rows: features must go somewhere (a copy or row pointers)");
+  PATHS_REQUIRE(row_ptrs == nullptr || zero_row != nullptr, "gather_rows: row_ptrs needs a zero row for padding");
   PATHS_REQUIRE((state_cur == nullptr) == (state_out == nullptr), "gather_rows: state in/out must both be given or null");
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)n_next, B), dim3(256), 0, stream, grid_ptrs, src_cell, D, state_cur,
-                     n_cur, ld_state_cur, src_row, Dp, num_out, n_next, fts_out, state_out, zero_pad);
+                     n_cur, ld_state_cur, src_row, Dp, num_out, n_next, fts_out, state_out, zero_pad, row_ptrs, zero_row);
   PATHS_LAUNCH_CHECK("gather_rows");
   return PATHS_OK;
 }

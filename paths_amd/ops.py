@@ -206,26 +206,33 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
 
 def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool,
-                      parent=None, max_pos: int = 0) -> Dict[str, torch.Tensor]:
+                      parent=None, max_pos: int = 0, x_rows=None, feat_dim: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
     (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims.
 
     ``max_pos`` (optional): an upper bound (exclusive) of ``locs // patch_size`` known to the caller (the grid size of the level);
     positional-encoding values are then read from a cached table instead of evaluated per token element.
 
+    ``x_rows`` (device recursion only, default split mode): [B, N] int64 ADDRESSES of the feature rows (paths_gather_rows
+    ``row_ptrs``); ``fts`` is then None, ``feat_dim`` = D, and the GEMMs read the rows where they live (no gathered copy).
+
     ``parent`` (device recursion only) = {"hp": [rows, 3Hc+D], "hp_row": [B,N] int32, "c0": [B,N,Hc]}: the up-to-4 children
     of a kept patch share the parent's h, so the h half of the gate GEMM is computed once per kept PARENT
     (:func:`parent_partials`) and added in the children's epilogue; ``state_prev`` is then None."""
-    _lib.require_cuda(fts, locs, num_ims, state_prev)
-    B, N, D = fts.shape
+    _lib.require_cuda(fts, locs, num_ims, state_prev, x_rows)
+    if x_rows is not None:
+        assert fts is None and feat_dim is not None and parent is not None and x_rows.dtype == torch.int64 and x_rows.is_contiguous()
+        (B, N), D = x_rows.shape, int(feat_dim)
+    else:
+        B, N, D = fts.shape
     d, H, L = mc.trans_dim, mc.trans_heads, mc.trans_layers
     T = N + 1
     M = B * N
-    dev = fts.device
+    dev = locs.device
     st = _lib.stream()
     p = _lib.ptr
     f32 = dict(device=dev, dtype=torch.float32)
-    assert fts.is_contiguous() and fts.dtype == torch.float32
+    assert fts is None or (fts.is_contiguous() and fts.dtype == torch.float32)
     locs = locs.contiguous()
     num_ims = num_ims.contiguous()
     assert locs.dtype == torch.int64 and num_ims.dtype == torch.int64
@@ -234,6 +241,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     tokens = torch.empty((B, T, d), **f32)
 
     x6 = use_x6(D, lstm_pack["Hc"] if mc.lstm else 64)
+    assert x_rows is None or (x6 and split_planes() == 2 and mc.lstm), "row pointers need the default split mode and lstm=true"
     pe_rows = N if pe_mode == 1 else int(max_pos)
     pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
 
@@ -246,7 +254,8 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
         if x6:
             wip, wip_s = _x6_of(lvl_pack, "w_ip_fwd")
-            _lib.call("paths_importance_proj_x6", p(src), D, p(add), add.stride(1) if add is not None else 0,
+            _lib.call("paths_importance_proj_x6", p(src), D, p(x_rows) if src is None else None, p(add),
+                      add.stride(1) if add is not None else 0,
                       p(wip), *common[:-1], split_planes(), wip_s, a_scale(), common[-1])
         else:
             assert add is None
@@ -277,7 +286,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         def lstm(phases):
             if x6:
                 (wg, wg_s), (wm, wm_s) = _x6_of(lstm_pack, "w_gates"), _x6_of(lstm_pack, "w_mem")
-                _lib.call("paths_lstm_cell_x6", p(fts), D, h0, ld, c0, ld, p(wg), p(lstm_pack["b_gates"]), p(wm), p(lstm_pack["b_mem"]),
+                _lib.call("paths_lstm_cell_x6", p(fts), D, p(x_rows), h0, ld, c0, ld, p(wg), p(lstm_pack["b_gates"]), p(wm), p(lstm_pack["b_mem"]),
                           p(state_out), Dp, p(y), D, p(ws_o), None, None, hp, hp_row, M, D, Hc, nim, N, phases,
                           split_planes(), wg_s, wm_s, a_scale(), st)
             else:

@@ -54,6 +54,7 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
 
 
 OVERLAP_AGGREGATOR = os.environ.get("PATHS_OVERLAP_AGGREGATOR", "1") != "0"
+ROWS_IN_PLACE = os.environ.get("PATHS_ROWS_IN_PLACE", "1") != "0"
 _STREAMS: Dict[int, tuple] = {}
 
 
@@ -117,6 +118,10 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     out = None
     lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
     share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
+    # default split mode: children's feature rows are read in place (row-pointer GEMM operands) instead of being gathered
+    rows_in_place = share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE
+    zero_row = torch.zeros((D,), **f32) if rows_in_place else None
+    x_rows = None
     # The aggregator of level i (attention, token chain, classifier) feeds nothing of level i+1 except the slide context, so
     # it runs on a second HIP stream beside the selection chain of level i+1 (top-K, expansion, gathers, gate GEMMs).  Several
     # of those kernels cannot fill 256 CUs alone (116-232 workgroups, one per CU); the other chain's waves take the idle CUs.
@@ -128,7 +133,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         proc = model.procs[i]
         lvl_pack = ops.pack_level(proc)
         sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
-                                    max_pos=batch.max_dim[i])
+                                    max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D)
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
@@ -179,22 +184,31 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
                 _lib.call("paths_fallback_all_cells", p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), mc.patch_size, B, Nn,
                           p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status),
                           p(hp_row) if share_parent else None, st)
-        fts_next = torch.empty((B, Nn, D), **f32)
+        x_rows_next = None
         if share_parent:
             # children only need their parent's c row (h enters through the per-parent partials below)
             Hc = Dp - D
             state_next = torch.empty((B, Nn, Hc), **f32)
-            _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
-                      p(src_row), Hc, p(num_next), B, Nn, p(fts_next), p(state_next), 0, st)
+            if rows_in_place:
+                # ... and their feature rows are not copied either: the GEMMs of the next level read them in the resident grids
+                fts_next = None
+                x_rows_next = torch.empty((B, Nn), **i64)
+                _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
+                          p(src_row), Hc, p(num_next), B, Nn, None, p(state_next), 0, p(x_rows_next), p(zero_row), st)
+            else:
+                fts_next = torch.empty((B, Nn, D), **f32)
+                _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
+                          p(src_row), Hc, p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st)
             parent = {"hp": ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count), "hp_row": hp_row, "c0": state_next}
             state_next = None
         else:
+            fts_next = torch.empty((B, Nn, D), **f32)
             state_next = torch.empty((B, Nn, Dp), **f32)
             _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
-                      p(num_next), B, Nn, p(fts_next), p(state_next), 0, st)
+                      p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st)
         if rec is not None:
             rec["keep_idx"], rec["keep_count"] = keep_idx, keep_count
-        fts, locs, parent_inds, num_ims, state_prev, N = fts_next, locs_next, parent_next, num_next, state_next, Nn
+        fts, x_rows, locs, parent_inds, num_ims, state_prev, N = fts_next, x_rows_next, locs_next, parent_next, num_next, state_next, Nn
     if overlap:
         main_stream.wait_stream(side_stream)
         keepalive.clear()

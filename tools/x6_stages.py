@@ -48,12 +48,12 @@ lib = _lib.load()
 lib.paths_x6_debug_buffer.argtypes = [C.c_void_p]; lib.paths_x6_debug_buffer.restype = None
 
 def lstm(ph):
-    _lib.call("paths_lstm_cell_x6", p(x), D, None, 0, p(c0), Hc, p(wg6), p(bg), p(wm6), p(bm), p(so), D + Hc, None, D, p(ws), None, None,
+    _lib.call("paths_lstm_cell_x6", p(x), D, None, None, 0, p(c0), Hc, p(wg6), p(bg), p(wm6), p(bm), p(so), D + Hc, None, D, p(ws), None, None,
               p(hp), p(hp_row), M, D, Hc, None, 1, ph, PL, wgs, wms, AS, st())
 def parent():
     _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg6), 2 * D, D, None, p(hp), G, MP, G, G, D, 0, None, 0, None, 0, 0, PL, wgs, AS, st())
 def impproj():
-    _lib.call("paths_importance_proj_x6", p(yi), D, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
+    _lib.call("paths_importance_proj_x6", p(yi), D, None, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
               p(imp), p(tok), None, None, Mi, D, 128, 128, 1, PL, wips, AS, st())
 
 USE_TAB = True
