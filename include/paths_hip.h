@@ -179,6 +179,21 @@ int paths_token_layer_f32(const float* x_in, const float* attn, float* x_out,
                           int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens,
                           paths_stream_t stream);
 
+/* paths_token_layer_f32 on the fp16 matrix cores with fp32 accuracy (csrc/tlayer_h3.hip; two-plane operand split as in the
+ * planes = 2 GEMMs, 3 x v_mfma_f32_16x16x32_f16 per product block, activations split in registers).  Weights are passed as
+ * images built once per weight version by paths_tlayer_pack_h3: part 0 = (out_proj, linear1, linear2) of THIS layer with
+ * power-of-two scales (s_wo, s_w1, s_w2), part 1 = in_proj of the NEXT layer with s_wqkv (max|w| * scale < 65504).
+ * Same arguments otherwise, same results to fp32 rounding. */
+int64_t paths_tlayer_h3_image_bytes(int part);
+int paths_tlayer_pack_h3(int part, const float* wa, const float* wb, const float* wc, float s_a, float s_b, float s_c, void* out,
+                         paths_stream_t stream);
+int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, const void* w_post, const void* w_qkv,
+                         const float* bo, const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                         const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
+                         float s_wo, float s_w1, float s_w2, float s_wqkv,
+                         float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
+                         int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens, paths_stream_t stream);
+
 /* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
  * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only
  * out[:, 0] of the final layer is read: it needs K/V of every token (q,k,v as written by paths_token_layer_f32 for

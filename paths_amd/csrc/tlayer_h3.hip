@@ -1,0 +1,340 @@
+// Token-row chain of one post-LN nn.TransformerDecoderLayer (+ the next layer's QKV projection) on the fp16 matrix cores
+// with fp32 accuracy: the two-plane operand split ("h3") of gemm_x6.hip applied to tlayer_f32.hip.
+//
+// Same math and same call site as paths_token_layer_f32 (reference model/aggregator.py:25-33, 70-72):
+//   x  = norm1(x + out_proj(attn)) ; x = norm2(x + multihead_attn.out_proj.bias) ; x = norm3(x + linear2(relu(linear1(x))))
+//   q,k,v = in_proj(x) of the NEXT layer, q pre-scaled for the exp2 softmax
+//
+// Every product is still computed transposed, Y^T[out][token] = W[out][:] . X^T[:][token], one wave = 16 tokens, activations
+// live in registers for the whole chain.  What changes:
+//   * MFMA = v_mfma_f32_16x16x32_f16: one instruction contracts 32 k.  The accumulators of two 16-feature tiles of a product,
+//     taken in k-slot order (g, j) <-> feature 4g + (j&3) + 16 (j>>2), are the B operand of the next product once split into
+//     fp16 hi | lo planes (11 + 11 bits) in registers; the weights are packed in that same k order.
+//   * hi*hi + hi*lo + lo*hi, smallest first, fp32 accumulate: 3 MFMAs of 16 cycles per 16x16x32 block against 8 of 32 cycles
+//     (v_mfma_f32_16x16x4_f32): 5.3x fewer matrix-pipe cycles.
+//   * Weights are pre-packed once per weight version (paths_tlayer_pack_h3) as a stream of 32-KiB chunks of MFMA fragments
+//     (lane l owns bytes [16 l, 16 l + 16) of every 1-KiB fragment), scaled per tensor by a power of two so that fp16 holds
+//     them; a chunk is staged global -> LDS as a plain linear copy, fragment reads are lane-linear (conflict-free).
+//   * LayerNorm'd activations and relu outputs are O(1): no activation scaling (|activation| < 65504; below 0.125 the lo
+//     plane is subnormal: absolute error 2^-25 per element).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DM = 128;            // trans_dim
+constexpr int DFF = 512;           // dim_feedforward = 4 * trans_dim
+constexpr int FRAG = 1024;         // bytes of one 16-row x 32-k fragment of one plane
+constexpr int CHUNK = 32 * FRAG;   // one staged chunk: [64 out rows][128 k] or [128 out rows][64 k], 2 planes
+constexpr int N_POST = 18;         // chunks of the post-attention part: 0-1 Wo | 2+2h W1 rows 64h | 3+2h W2[:, 64h:64h+64]
+constexpr int N_QKV = 6;           // chunks of in_proj: rows 64 c
+
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// 8 fp32 -> hi | lo planes of 8 fp16 (22 significant bits)
+__device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const uint32_t h = pk_f16(a, b);
+    const f16x2 hv = __builtin_bit_cast(f16x2, h);
+    hi[i] = h; lo[i] = pk_f16(a - (float)hv[0], b - (float)hv[1]);
+  }
+}
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+struct TLayerH3Params {
+  const float* x_in; const float* attn; float* x_out;
+  const char* w_post;              // 18 chunks (Wo, W1, W2 of this layer), or null
+  const char* w_qkv;               // 6 chunks (in_proj of the next layer), or null
+  const float *bo, *ln1g, *ln1b, *cab, *ln2g, *ln2b, *b1, *b2, *ln3g, *ln3b, *bqkv;
+  float inv_wo, inv_w1, inv_w2, inv_wqkv;      // 1 / (power-of-two scale of the packed tensor)
+  float *q, *k, *v;
+  const int64_t* num_ims;
+  int T, H; int do_post, do_qkv, skip_padding; float qscale, eps;
+};
+
+typedef f32x4 act_t[8];            // 128 features of 16 tokens: tile t, reg r, lane group g -> feature 16t + 4g + r
+typedef u32x4 split_t[4][2];       // the same as MFMA B operands: [k32 block][hi | lo]
+
+__device__ __forceinline__ void layernorm_t(act_t& x, const float* gamma, const float* beta, int g4, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.0f / DM);
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float c = x[t][r] - mean; v += c * c; }
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  const float rstd = 1.0f / sqrtf(v * (1.0f / DM) + eps);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * t + 4 * g4);
+    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * t + 4 * g4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[t][r] = (x[t][r] - mean) * rstd * gm[r] + bt[r];
+  }
+}
+
+// NT2 pairs of 16-feature tiles -> NT2 k32 blocks of B operand (k-slot (g, j) = feature 4g + (j&3) + 16 (j>>2) of the pair)
+template <int NT2>
+__device__ __forceinline__ void split_act(const f32x4* x, u32x4 (*xs)[2]) {
+#pragma unroll
+  for (int kb = 0; kb < NT2; ++kb) {
+    const float v[8] = {x[2 * kb][0], x[2 * kb][1], x[2 * kb][2], x[2 * kb][3], x[2 * kb + 1][0], x[2 * kb + 1][1], x[2 * kb + 1][2], x[2 * kb + 1][3]};
+    split8h(v, xs[kb][0], xs[kb][1]);
+  }
+}
+
+// acc[ot] += W_chunk[16 ot + row][32 kb + slot] * x[kb][slot]   (NOT out tiles, NKB k32 blocks), fragments of the chunk:
+// ((ot * NKB + kb) * 2 + plane) KiB
+template <int NOT, int NKB>
+__device__ __forceinline__ void mm_chunk(const char* sW, f32x4 (&acc)[NOT], const u32x4 (*xs)[2], int lane) {
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    u32x4 ah[NOT], al[NOT];
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) {
+      ah[ot] = *reinterpret_cast<const u32x4*>(sW + ((ot * NKB + kb) * 2) * FRAG + lane * 16);
+      al[ot] = *reinterpret_cast<const u32x4*>(sW + ((ot * NKB + kb) * 2 + 1) * FRAG + lane * 16);
+    }
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma_f16(al[ot], xs[kb][0], acc[ot]);      // lo * hi
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma_f16(ah[ot], xs[kb][1], acc[ot]);      // hi * lo
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) acc[ot] = mfma_f16(ah[ot], xs[kb][0], acc[ot]);      // hi * hi
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+tlayer_h3_kernel(TLayerH3Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK] + in-loop biases [512 + 384] floats
+  float* s_b1 = reinterpret_cast<float*>(smem + 2 * CHUNK);
+  float* s_bqkv = s_b1 + DFF;
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  if (p.skip_padding && t0 >= (int)p.num_ims[b] + 1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
+  const int tok = t0 + wave * 16 + ql;
+  const int tokc = min(tok, p.T - 1);
+  const int64_t rowoff = ((int64_t)b * p.T + tokc) * DM;
+
+  // ---- weight chunk stream: ids 0-17 from w_post, 18-23 from w_qkv; a chunk is 32 KiB of fragments, copied linearly
+  const int c_first = p.do_post ? 0 : N_POST, c_last = p.do_qkv ? N_POST + N_QKV : N_POST;
+  u32x4 rs[8];
+  auto stage_load = [&](int c) {
+    const char* src = c < N_POST ? p.w_post + (int64_t)c * CHUNK : p.w_qkv + (int64_t)(c - N_POST) * CHUNK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rs[i] = *reinterpret_cast<const u32x4*>(src + (tid + i * 256) * 16);
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(smem + buf * CHUNK + (tid + i * 256) * 16) = rs[i];
+  };
+  act_t x;      // activations first (oldest loads), then biases, then the first weight chunk
+#pragma unroll
+  for (int t = 0; t < 8; ++t) x[t] = *reinterpret_cast<const f32x4*>(p.x_in + rowoff + 16 * t + 4 * g4);
+  if (p.do_post) for (int i = threadIdx.x; i < DFF; i += 256) s_b1[i] = p.b1[i];
+  if (p.do_qkv) for (int i = threadIdx.x; i < 3 * DM; i += 256) s_bqkv[i] = p.bqkv[i];
+  int buf = 0, c = c_first;
+  stage_load(c);
+  stage_store(0);
+  __syncthreads();
+  // begin(): start fetching the chunk after the current one; end(): publish it and flip buffers
+  auto begin = [&]() { if (c + 1 < c_last) stage_load(c + 1); };
+  auto end = [&]() { if (c + 1 < c_last) stage_store(buf ^ 1); __syncthreads(); buf ^= 1; ++c; };
+
+  split_t xs;
+  if (p.do_post) {
+    // ---- out_proj(attn) + residual -> norm1 -> + cross-attn bias -> norm2
+    act_t y;
+    {
+      act_t at;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) at[t] = *reinterpret_cast<const f32x4*>(p.attn + rowoff + 16 * t + 4 * g4);
+      split_act<4>(at, xs);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      begin();
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm_chunk<4, 4>(smem + buf * CHUNK, acc, xs, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[4 * half + i] = acc[i];
+      end();
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bo + 16 * t + 4 * g4);
+      x[t] = x[t] + (y[t] * p.inv_wo + bo);
+    }
+    layernorm_t(x, p.ln1g, p.ln1b, g4, p.eps);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = x[t] + *reinterpret_cast<const f32x4*>(p.cab + 16 * t + 4 * g4);
+    layernorm_t(x, p.ln2g, p.ln2b, g4, p.eps);
+    split_act<4>(x, xs);
+
+    // ---- feed-forward: 8 hidden chunks of 64; y accumulates linear2 (in units of 1 / inv_w2)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int hc = 0; hc < 8; ++hc) {
+      f32x4 hid[4], b1v[4];
+      begin();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b1v[i] = *reinterpret_cast<const f32x4*>(s_b1 + 64 * hc + 16 * i + 4 * g4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) hid[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm_chunk<4, 4>(smem + buf * CHUNK, hid, xs, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hid[i][r] = fmaxf(fmaf(hid[i][r], p.inv_w1, b1v[i][r]), 0.f);
+      u32x4 hs[2][2];
+      split_act<2>(hid, hs);
+      end();
+      begin();
+      mm_chunk<8, 2>(smem + buf * CHUNK, y, hs, lane);
+      end();
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + 16 * t + 4 * g4);
+      x[t] = x[t] + (y[t] * p.inv_w2 + b2);
+    }
+    layernorm_t(x, p.ln3g, p.ln3b, g4, p.eps);
+    if (tok < p.T) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4*>(p.x_out + rowoff + 16 * t + 4 * g4) = x[t];
+    }
+  }
+
+  if (p.do_qkv) {
+    split_act<4>(x, xs);
+    // ---- in_proj: 6 chunks of 64 output rows: q(0,1) k(2,3) v(4,5); head = feature >> 5
+#pragma unroll 1
+    for (int qc = 0; qc < 6; ++qc) {
+      f32x4 bb[4];
+      begin();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bb[i] = *reinterpret_cast<const f32x4*>(s_bqkv + 128 * (qc >> 1) + 64 * (qc & 1) + 16 * i + 4 * g4);
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mm_chunk<4, 4>(smem + buf * CHUNK, acc, xs, lane);
+      float* dst = qc < 2 ? p.q : qc < 4 ? p.k : p.v;
+      const float sc = qc < 2 ? p.qscale : 1.0f;
+      if (tok < p.T) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 64 * (qc & 1) + 16 * i + 4 * g4;          // feature within q / k / v
+          const int head = f >> 5, dd = f & 31;
+          *reinterpret_cast<f32x4*>(dst + (((int64_t)b * p.H + head) * p.T + tok) * 32 + dd) = (acc[i] * p.inv_wqkv + bb[i]) * sc;
+        }
+      }
+      end();
+    }
+  }
+}
+
+// One chunk per workgroup.  kind 0: rows [row0, row0+64) x k [0,128) of w (ld = ldw)  -> 4 out tiles x 4 k32 blocks
+//                           kind 1: rows [0,128) x k [k0, k0+64)                      -> 8 out tiles x 2 k32 blocks
+struct PackJob { const float* w; int ldw; int row0; int k0; int kind; float scale; };
+struct PackJobs { PackJob j[24]; };
+
+__global__ void __launch_bounds__(256)
+tlayer_pack_h3_kernel(PackJobs jobs, char* __restrict__ out) {
+  const PackJob jb = jobs.j[blockIdx.x];
+  const int nkb = jb.kind == 0 ? 4 : 2;
+  char* dst = out + (int64_t)blockIdx.x * CHUNK;
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const int piece = threadIdx.x + 256 * i;          // 2048 lane pieces of 16 bytes
+    const int f = piece >> 6, lane = piece & 63, plane = f & 1, fk = f >> 1;
+    const int ot = fk / nkb, kb = fk % nkb, ql = lane & 15, g = lane >> 4;
+    const float* src = jb.w + (int64_t)(jb.row0 + 16 * ot + ql) * jb.ldw + jb.k0 + 32 * kb;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[4 * g + (j & 3) + 16 * (j >> 2)] * jb.scale;
+    u32x4 hi, lo;
+    split8h(v, hi, lo);
+    *reinterpret_cast<u32x4*>(dst + f * FRAG + lane * 16) = plane == 0 ? hi : lo;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the two weight images of paths_token_layer_h3
+int64_t paths_tlayer_h3_image_bytes(int part /*0: post (Wo, W1, W2), 1: in_proj*/) { return (int64_t)(part == 0 ? N_POST : N_QKV) * CHUNK; }
+
+// Pack one part: part 0 = (wo [128,128], w1 [512,128], w2 [128,512]) with scales s_a, s_b, s_c; part 1 = wqkv [384,128] with s_a.
+// Scales are powers of two chosen by the caller (max|w| * scale < 65504).
+int paths_tlayer_pack_h3(int part, const float* wa, const float* wb, const float* wc, float s_a, float s_b, float s_c, void* out,
+                         hipStream_t stream) {
+  PATHS_REQUIRE((part == 0 && wa && wb && wc) || (part == 1 && wa), "tlayer_pack_h3: bad arguments");
+  PATHS_REQUIRE(out != nullptr && (uintptr_t)out % 16 == 0, "tlayer_pack_h3: out must be 16-byte aligned");
+  PackJobs jobs;
+  int n = 0;
+  if (part == 0) {
+    for (int c = 0; c < 2; ++c) jobs.j[n++] = PackJob{wa, DM, 64 * c, 0, 0, s_a};
+    for (int h = 0; h < 8; ++h) {
+      jobs.j[n++] = PackJob{wb, DM, 64 * h, 0, 0, s_b};
+      jobs.j[n++] = PackJob{wc, DFF, 0, 64 * h, 1, s_c};
+    }
+  } else {
+    for (int c = 0; c < 6; ++c) jobs.j[n++] = PackJob{wa, DM, 64 * c, 0, 0, s_a};
+  }
+  hipLaunchKernelGGL(tlayer_pack_h3_kernel, dim3(n), dim3(256), 0, stream, jobs, reinterpret_cast<char*>(out));
+  PATHS_LAUNCH_CHECK("tlayer_pack_h3");
+  return PATHS_OK;
+}
+
+// paths_token_layer_f32 with the weights given as packed images (w_post: paths_tlayer_pack_h3 part 0 of THIS layer with scales
+// s_wo, s_w1, s_w2; w_qkv: part 1 of the NEXT layer with scale s_wqkv)
+int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, const void* w_post, const void* w_qkv,
+                         const float* bo, const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                         const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
+                         float s_wo, float s_w1, float s_w2, float s_wqkv,
+                         float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
+                         int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens, hipStream_t stream) {
+  PATHS_REQUIRE(d == DM && H == 4, "token_layer_h3: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
+  PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer_h3: nothing to do");
+  PATHS_REQUIRE(!skip_padding || num_ims, "token_layer_h3: skip_padding needs num_ims");
+  PATHS_REQUIRE(x_in && (!do_post || (attn && x_out && w_post)) && (!do_qkv || (w_qkv && q && k && v)), "token_layer_h3: null operand");
+  TLayerH3Params p{x_in, attn, x_out, reinterpret_cast<const char*>(w_post), reinterpret_cast<const char*>(w_qkv),
+                   bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, bqkv,
+                   do_post ? 1.0f / s_wo : 1.0f, do_post ? 1.0f / s_w1 : 1.0f, do_post ? 1.0f / s_w2 : 1.0f, do_qkv ? 1.0f / s_wqkv : 1.0f,
+                   q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps};
+  constexpr size_t lds_min = 2ull * CHUNK + (DFF + 3 * DM) * sizeof(float);              // 69,120 B: two workgroups per CU
+  constexpr size_t lds_solo = 84 * 1024;                                                 // > 80 KiB: one workgroup per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solo);
+    attr_set = true;
+  }
+  const int nt = max_tokens > 0 && max_tokens < T ? max_tokens : T;
+  const int nblk = ((nt + 63) / 64) * B;
+  const size_t lds = nblk <= 2 * 256 ? lds_solo : lds_min;      // spread small grids one workgroup per CU (see tlayer_f32.hip)
+  hipLaunchKernelGGL(tlayer_h3_kernel, dim3((nt + 63) / 64, B), dim3(256), lds, stream, p);
+  PATHS_LAUNCH_CHECK("token_layer_h3");
+  return PATHS_OK;
+}
+
+}  // extern "C"

@@ -55,11 +55,32 @@ def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] 
     n_pad = N if n_pad is None else n_pad
     w_scale = 1.0
     if planes == 2:
-        amax = float(w.abs().max())
-        w_scale = 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax)))) if amax > 0 and math.isfinite(amax) else 1.0
+        w_scale = _pow2_scale(w)
     out = torch.empty((n_pad * K * 2 * planes,), device=w.device, dtype=torch.uint8)
     _lib.call("paths_x6_pack_weights", _lib.ptr(w), w.stride(0), _lib.ptr(out), N, n_pad, K, planes, w_scale, _lib.stream())
     return out, w_scale
+
+
+def _pow2_scale(w: torch.Tensor) -> float:
+    """The power of two that puts max|w| into [8192, 16384) (fp16 operand scaling; one host sync)."""
+    amax = float(w.abs().max())
+    return 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax)))) if amax > 0 and math.isfinite(amax) else 1.0
+
+
+def tlayer_h3_images(layer: Dict[str, object], part: int):
+    """(image, scales) of a decoder layer's weights for paths_token_layer_h3: part 0 = (wo, w1, w2), part 1 = wqkv.
+    Built on first use and cached in the layer's pack dict (rebuilt when weights change)."""
+    key = f"h3_image_{part}"
+    if key not in layer:
+        ws = [layer["wo"], layer["w1"], layer["w2"]] if part == 0 else [layer["wqkv"]]
+        scales = tuple(_pow2_scale(w) for w in ws)
+        nbytes = int(_lib.load().paths_tlayer_h3_image_bytes(part))
+        img = torch.empty((nbytes,), device=ws[0].device, dtype=torch.uint8)
+        pw = [_lib.ptr(w) for w in ws] + [None] * (3 - len(ws))
+        sc = list(scales) + [1.0] * (3 - len(scales))
+        _lib.call("paths_tlayer_pack_h3", part, pw[0], pw[1], pw[2], sc[0], sc[1], sc[2], _lib.ptr(img), _lib.stream())
+        layer[key] = (img, scales)
+    return layer[key]
 
 
 def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None):
@@ -374,6 +395,15 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     def token_layer(x_in, x_out, post, nxt, max_tokens=0):
         w = post or nxt
         g = lambda dct, key: p(dct[key]) if dct is not None else None
+        if GEMM_MODE == "h3":
+            ip, sp = tlayer_h3_images(post, 0) if post is not None else (None, (1.0, 1.0, 1.0))
+            iq, sq = tlayer_h3_images(nxt, 1) if nxt is not None else (None, (1.0,))
+            _lib.call("paths_token_layer_h3", p(x_in), p(attn) if post else None, p(x_out) if post else None, p(ip), p(iq),
+                      g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
+                      g(post, "b1"), g(post, "b2"), g(post, "ln3g"), g(post, "ln3b"), g(nxt, "bqkv"),
+                      sp[0], sp[1], sp[2], sq[0], p(q), p(k), p(v), p(num_ims), B, T, d, H,
+                      1 if post else 0, 1 if nxt else 0, 1, qscale, w["eps"], max_tokens, st)
+            return
         _lib.call("paths_token_layer_f32", p(x_in), p(attn) if post else None, p(x_out) if post else None,
                   g(post, "wo"), g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
                   g(post, "w1"), g(post, "b1"), g(post, "w2"), g(post, "b2"), g(post, "ln3g"), g(post, "ln3b"),
