@@ -487,3 +487,26 @@ def test_attention_x6_matches_fp64(dev, T, lens, planes):
         assert e6 < 3 * e32 + 3e-7, (b, e6, e32)
         lse_ref = torch.logsumexp(s, dim=-1) / np.log(2.0)
         assert (lse6[b, :, :n].double() - lse_ref).abs().max().item() < 1e-4
+
+
+def test_token_layer_h3_matches_f32_kernel(dev):
+    """The fp16-split token-layer chain against the f32-MFMA one on the same random layer (both paths of one level)."""
+    from paths_amd import ops
+    g, info, out_h3 = run_single(dev, "g2_level2_b2_k256")
+    import paths_amd.ops as O
+    calls = []
+    orig = O._lib.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+
+    O._lib.call = spy
+    try:
+        _, _, out_again = run_single(dev, "g2_level2_b2_k256")
+    finally:
+        O._lib.call = orig
+    assert "paths_token_layer_h3" in calls and "paths_token_layer_f32" not in calls
+    np.testing.assert_allclose(out_again["logits"].numpy(), out_h3["logits"].numpy(), atol=0, rtol=0)      # deterministic
+    np.testing.assert_allclose(out_h3["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out_h3["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
