@@ -248,7 +248,7 @@ def main():
     x6 = bool(events and events[0][3].get("x6"))
     planes = int(events[0][3].get("planes", 3)) if x6 else 0
     traffic = None            # HBM-side bytes per launch from the committed PMC passes (separate --pmc runs, profiles/)
-    prof = {2: "r01f_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
+    prof = {2: "r01g_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
     try:
         with open(os.path.join(ROOT, "profiles", prof)) as fh:
             traffic = json.load(fh)["kernels"]["EpiLstmO"]["traffic_bytes_per_launch"]
@@ -288,9 +288,9 @@ def main():
                                    f"features, trans_dim 128 x 4 heads x 2 layers, LSTM ctx 256; {spg} HBM-resident slides per GPU",
                        "slides_per_gpu": spg, "global_batch": spg * world, "levels": cfg.num_levels,
                        "parallelism": f"slide-sharded x{world} (no data-path collective)",
-                       "gemm_mode": ("h3: GEMM and attention operands split into 2 fp16 planes (22 bits), 3 fp16 MFMAs per product block, "
-                                     "fp32 accumulate, power-of-two scaling of the GEMM operands (error of the order of an fp32 FMA "
-                                     "chain's); everything else fp32") if planes == 2 else
+                       "gemm_mode": ("h3: GEMM, attention and token-layer operands split into 2 fp16 planes (22 bits), 3 fp16 MFMAs per "
+                                     "product block, fp32 accumulate, power-of-two scaling of weights / GEMM activations (error of the "
+                                     "order of an fp32 FMA chain's); everything else fp32") if planes == 2 else
                                     ("x6: operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product block, fp32 "
                                      "accumulate (error <= an fp32 FMA chain's); everything else fp32") if x6 else "f32 MFMA"},
             "roofline": roofline,
