@@ -207,61 +207,66 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     if (kt + 1 < nkt) gload(kt + 1);
     const char* sK = smem[buf] + lane * 16;
     const char* sV = smem[buf] + 4 * NP * FRAG + lane * 16;
+    // ---- S^T = K Q^T for the 4 key tiles of this 64-key step (all scores first: ONE running-max update, one rescale of the
+    // output tile and 2 cross-lane swaps per query tile and step instead of two of each, and 4 independent chains for the
+    // scheduler to interleave)
+    f32x4 s[2][4];                                      // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      // ---- S^T = K Q^T: key tiles 2 kg, 2 kg + 1 of this step
-      f32x4 s[2][2];                                    // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
-      u32x4 kf[2][NP];
+    for (int t = 0; t < 4; ++t) {
+      u32x4 kf[NP];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const u32x4*>(sK + (t * NP + p) * FRAG);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) kf[t][p] = *reinterpret_cast<const u32x4*>(sK + ((2 * kg + t) * NP + p) * FRAG);
+      for (int qt = 0; qt < 2; ++qt) s[qt][t] = mfma_split(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    // ---- mask (last step only) + online softmax (lane: query ql of each tile; keys 16 t + 4 g4 + r)
+    if (kt == nkt - 1) {
+      const int kbase = kt * KSTEP + 4 * g4;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) s[qt][t] = mfma_split(kf[t], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-      // ---- mask (last step only) + online softmax (lane: query ql of each tile; keys 16 t + 4 g4 + r)
-      if (kt == nkt - 1) {
-        const int kbase = kt * KSTEP + 32 * kg + 4 * g4;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+          for (int r = 0; r < 4; ++r)
+            if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
+    }
+    u32x4 pf[2][2][NP];                                 // [query tile][32-key group][plane]
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
-      }
-      u32x4 pf[2][NP];
+      for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[qt][t][0], s[qt][t][1]), fmaxf(s[qt][t][2], s[qt][t][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qt], mx);         // finite: key 0 (special token) is always valid
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+      float psum = 0.f;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        float mx = fmaxf(fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), fmaxf(s[qt][0][2], s[qt][0][3])),
-                         fmaxf(fmaxf(s[qt][1][0], s[qt][1][1]), fmaxf(s[qt][1][2], s[qt][1][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run[qt], mx);       // finite: key 0 (special token) is always valid
-        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-        float pv[8], psum = 0.f;
+      for (int kg = 0; kg < 2; ++kg) {
+        float pv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) of the PV product = key 4 g4 + (j&3) + 16 (j>>2)
-          pv[j] = __builtin_amdgcn_exp2f(s[qt][j >> 2][j & 3] - m_new);
+        for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) of the PV product = key 4 g4 + (j&3) + 16 (j>>2) of the group
+          pv[j] = __builtin_amdgcn_exp2f(s[qt][2 * kg + (j >> 2)][j & 3] - m_new);
           psum += pv[j];
         }
-        l_run[qt] = l_run[qt] * alpha + psum;
-        m_run[qt] = m_new;
-        oacc[0][qt] *= alpha;
-        oacc[1][qt] *= alpha;
-        split_planes<NP>(pv, pf[qt]);
+        split_planes<NP>(pv, pf[qt][kg]);
       }
-      // ---- O^T += V^T P^T
+      l_run[qt] = l_run[qt] * alpha + psum;
+      m_run[qt] = m_new;
+      oacc[0][qt] *= alpha;
+      oacc[1][qt] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
       for (int dvt = 0; dvt < 2; ++dvt) {
         u32x4 vf[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + ((kg * 2 + dvt) * NP + p) * FRAG);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt], oacc[dvt][qt]);
+        for (int qt = 0; qt < 2; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
       }
-    }
     if (kt + 1 < nkt) swrite(buf ^ 1);
     __syncthreads();
     buf ^= 1;
