@@ -263,7 +263,8 @@ int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_coun
 
 /* Level-0 batch: every grid cell in row-major order (reference data_utils/slide.py:257-269,362-381). */
 int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,
-                       float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, paths_stream_t stream);
+                       float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, int64_t* row_ptrs,
+                       const float* zero_row, paths_stream_t stream);
 
 /* z = alpha * x (+ h on valid rows): importance scaling and the non-LSTM hierarchical-context add
  * (reference model/paths.py:96-109). */

@@ -57,7 +57,7 @@ SIGNATURES = {
     "paths_gather_rows_bwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp],
     "paths_fallback_all_cells": [_vp, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp],
-    "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp],
+    "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_scale_add_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],

@@ -278,22 +278,29 @@ gather_bwd_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __re
 __global__ void __launch_bounds__(256)
 level0_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ gx, const int* __restrict__ gy, int D,
               int patch_size, int64_t n0, float* __restrict__ fts, int64_t* __restrict__ locs,
-              int64_t* __restrict__ parent, int64_t* __restrict__ num_ims, int zero_pad) {
+              int64_t* __restrict__ parent, int64_t* __restrict__ num_ims, int zero_pad,
+              int64_t* __restrict__ row_ptrs, const float* __restrict__ zero_row) {
   const int b = blockIdx.y;
   const int64_t j = blockIdx.x;
   const int X = gx[b], Y = gy[b];
   const int64_t n = (int64_t)X * Y;
   const int64_t o = (int64_t)b * n0 + j;
   const int tid = threadIdx.x;
-  f32x4* fo = reinterpret_cast<f32x4*>(fts + o * D);
+  f32x4* fo = fts ? reinterpret_cast<f32x4*>(fts + o * D) : nullptr;
   if (j == 0 && tid == 0) num_ims[b] = n;
   if (j < n) {
     const f32x4* fi = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(grid_ptrs[b]) + j * D);
-    for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
-    if (tid == 0) { locs[2 * o] = (j / Y) * patch_size; locs[2 * o + 1] = (j % Y) * patch_size; parent[o] = j; }
+    if (fo) for (int i = tid; i < D / 4; i += 256) fo[i] = fi[i];
+    if (tid == 0) {
+      locs[2 * o] = (j / Y) * patch_size; locs[2 * o + 1] = (j % Y) * patch_size; parent[o] = j;
+      if (row_ptrs) row_ptrs[o] = (int64_t)reinterpret_cast<uintptr_t>(fi);
+    }
   } else {
-    if (zero_pad) { const f32x4 z{0.f, 0.f, 0.f, 0.f}; for (int i = tid; i < D / 4; i += 256) fo[i] = z; }
-    if (tid == 0) { locs[2 * o] = 0; locs[2 * o + 1] = 0; parent[o] = 0; }
+    if (fo && zero_pad) { const f32x4 z{0.f, 0.f, 0.f, 0.f}; for (int i = tid; i < D / 4; i += 256) fo[i] = z; }
+    if (tid == 0) {
+      locs[2 * o] = 0; locs[2 * o + 1] = 0; parent[o] = 0;
+      if (row_ptrs) row_ptrs[o] = (int64_t)reinterpret_cast<uintptr_t>(zero_row);
+    }
   }
 }
 
@@ -421,10 +428,12 @@ int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_coun
 }
 
 int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,
-                       float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, hipStream_t stream) {
+                       float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, int64_t* row_ptrs,
+                       const float* zero_row, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && n0 > 0 && D % 4 == 0, "level0_batch: bad shape");
+  PATHS_REQUIRE((fts != nullptr || row_ptrs != nullptr) && (row_ptrs == nullptr || zero_row != nullptr), "level0_batch: features need a destination (copy or row pointers + zero row)");
   hipLaunchKernelGGL(level0_kernel, dim3((unsigned)n0, B), dim3(256), 0, stream, grid_ptrs, gx, gy, D, patch_size, n0,
-                     fts, locs, parent, num_ims, zero_pad);
+                     fts, locs, parent, num_ims, zero_pad, row_ptrs, zero_row);
   PATHS_LAUNCH_CHECK("level0_batch");
   return PATHS_OK;
 }

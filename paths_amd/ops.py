@@ -242,7 +242,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     (:func:`parent_partials`) and added in the children's epilogue; ``state_prev`` is then None."""
     _lib.require_cuda(fts, locs, num_ims, state_prev, x_rows)
     if x_rows is not None:
-        assert fts is None and feat_dim is not None and parent is not None and x_rows.dtype == torch.int64 and x_rows.is_contiguous()
+        assert fts is None and feat_dim is not None and state_prev is None and x_rows.dtype == torch.int64 and x_rows.is_contiguous()
         (B, N), D = x_rows.shape, int(feat_dim)
     else:
         B, N, D = fts.shape

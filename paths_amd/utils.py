@@ -108,20 +108,21 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     status = torch.zeros(1, **i32)
 
     N = batch.n0
-    fts = torch.empty((B, N, D), **f32)
+    lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
+    share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
+    # default split mode: feature rows are read in place in the resident grids (row-pointer GEMM operands) instead of being
+    # copied (level 0) or gathered (children)
+    rows_in_place = share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE
+    zero_row = torch.zeros((D,), **f32) if rows_in_place else None
+    fts = None if rows_in_place else torch.empty((B, N, D), **f32)
+    x_rows = torch.empty((B, N), **i64) if rows_in_place else None
     locs = torch.empty((B, N, 2), **i64)
     parent_inds = torch.empty((B, N), **i64)
     num_ims = torch.empty((B,), **i64)
     _lib.call("paths_level0_batch", p(grid_ptrs[0]), p(gx[0]), p(gy[0]), B, D, mc.patch_size, N,
-              p(fts), p(locs), p(parent_inds), p(num_ims), 0, st)
+              p(fts), p(locs), p(parent_inds), p(num_ims), 0, p(x_rows), p(zero_row), st)
     state_prev, ctx_hist, parent = None, [], None
     out = None
-    lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
-    share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
-    # default split mode: children's feature rows are read in place (row-pointer GEMM operands) instead of being gathered
-    rows_in_place = share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE
-    zero_row = torch.zeros((D,), **f32) if rows_in_place else None
-    x_rows = None
     # The aggregator of level i (attention, token chain, classifier) feeds nothing of level i+1 except the slide context, so
     # it runs on a second HIP stream beside the selection chain of level i+1 (top-K, expansion, gathers, gate GEMMs).  Several
     # of those kernels cannot fill 256 CUs alone (116-232 workgroups, one per CU); the other chain's waves take the idle CUs.
@@ -239,7 +240,7 @@ def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int) -
     parent = torch.empty((B, N), **i64)
     num_ims = torch.empty((B,), **i64)
     _lib.call("paths_level0_batch", p(batch.grid_ptrs[0]), p(batch.gx[0]), p(batch.gy[0]), B, D, mc.patch_size, N,
-              p(fts), p(locs), p(parent), p(num_ims), 1, st)
+              p(fts), p(locs), p(parent), p(num_ims), 1, None, None, st)
     state_prev, ctx_prev = None, None
     logits = None
     for i in range(num_levels):
