@@ -58,9 +58,20 @@ def dead_params(model) -> List[torch.nn.Parameter]:
 
 
 def fill_dead_grads(model):
-    for p in dead_params(model):
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
+    """Zero gradients for the dead parameters.  They are views of ONE zero buffer kept on the model (160 tensors per step
+    would otherwise cost 160 fill launches); nothing downstream writes a non-zero into a gradient that is exactly zero
+    (AdamW only reads it, an all-reduce / clipping of zeros yields zeros)."""
+    dead = dead_params(model)
+    todo = [p for p in dead if p.grad is None]
+    if not todo:
+        return
+    need = max(p.numel() for p in dead)
+    zero = getattr(model, "_paths_dead_zero", None)
+    if zero is None or zero.numel() < need or zero.device != todo[0].device:
+        zero = torch.zeros((need,), device=todo[0].device, dtype=torch.float32)
+        object.__setattr__(model, "_paths_dead_zero", zero)
+    for p in todo:
+        p.grad = zero[:p.numel()].view_as(p)
 
 
 class LevelFn(torch.autograd.Function):

@@ -76,7 +76,7 @@ def colsum(a, lda, M, N, out=None, accumulate=False):
     dev = a.device if not isinstance(a, int) else out.device
     if out is None:
         out = torch.empty((N,), **_f32(dev))
-    splits = max(1, min(64, M // 128))
+    splits = max(1, min(256, M // 64))
     ws = torch.empty((splits * N,), **_f32(dev))
     ap = a if isinstance(a, int) else a.data_ptr()
     _lib.call("paths_colsum_f32", ap, lda, M, N, P(out), splits, 1 if accumulate else 0, P(ws), _lib.stream())
@@ -161,10 +161,8 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     grads["special"] = colsum(d_tokens, T * 128, B, 128)
     # proj_in.bias: sum of token gradients over the valid patch rows = colsum of dP / alpha is not usable (alpha may
     # be 0), so sum d_tokens rows 1..N directly; padded token rows carry exact zeros (masked keys, unused queries)
-    dbp = torch.zeros((128,), **f32)
-    for b in range(B):
-        colsum(d_tokens.data_ptr() + 4 * (b * T + 1) * 128, 128, N, 128, out=dbp, accumulate=True)
-    grads["bp"] = dbp
+    # = (sum over all B*T token rows) - (sum over the B special-token rows): two launches instead of 2 B
+    grads["bp"] = colsum(d_tokens, 128, B * T, 128) - grads["special"]
     grads["w_ip"] = torch.empty((256, D), **f32)
     gemm_tn(du, 256, sv["y"], D, grads["w_ip"], M, 256, D)
     dy = torch.empty((M, D), **f32)
@@ -297,6 +295,18 @@ def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: floa
     return g
 
 
+def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries):
+    """Masked self-attention forward (+ log2-domain lse for the backward kernels): split-bf16 MFMA kernel (exact fp32
+    products) unless PATHS_GEMM_MODE=f32."""
+    st = _lib.stream()
+    if ops.GEMM_MODE != "f32":
+        TP = ops.TRAIN_PLANES
+        ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, TP)),), device=q.device, dtype=torch.uint8)
+        _lib.call("paths_attention_x6", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP, st)
+    else:
+        _lib.call("paths_attention_f32", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, st)
+
+
 def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev):
     """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output)."""
     B, T, d = tokens.shape
@@ -323,7 +333,7 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev):
     for l in range(L - 1):
         attn = torch.zeros((B, T, d), **f32)
         lse = torch.zeros((B, H, T), **f32)
-        _lib.call("paths_attention_f32", P(q), P(k), P(v), P(attn), P(lse), P(num_ims), B, T, H, hd, 0, st)
+        attention(q, k, v, attn, lse, num_ims, B, T, H, hd, 0)
         x_out = torch.empty((B, T, d), **f32)
         q2, k2, v2 = (torch.empty((B, H, T, hd), **f32) for _ in range(3))
         token_layer(x, x_out, layers[l], layers[l + 1], attn, q2, k2, v2)
@@ -366,7 +376,7 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     x_last = last["x_in"]
     # recompute token 0 of the last layer up to x3 (its attention output first)
     attn0 = torch.zeros((B, T, d), **f32)
-    _lib.call("paths_attention_f32", P(last["q"]), P(last["k"]), P(last["v"]), P(attn0), None, P(num_ims), B, T, H, hd, 1, st)
+    attention(last["q"], last["k"], last["v"], attn0, None, num_ims, B, T, H, hd, 1)
     u1 = torch.empty((B, 128), **f32)
     gemm_nt(attn0.data_ptr(), T * d, wl["wo"], u1, 128, B, 128, 128, bias=wl["bo"], residual=x_last.data_ptr(), ldr=T * d)
     n1, _, _ = _ln_fwd(u1, None, wl["ln1g"], wl["ln1b"], B, wl["eps"])
