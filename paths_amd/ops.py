@@ -227,7 +227,8 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
 
 def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool,
-                      parent=None, max_pos: int = 0, x_rows=None, feat_dim: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                      parent=None, max_pos: int = 0, x_rows=None, feat_dim: Optional[int] = None,
+                      importance_out: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
     (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims.
 
@@ -282,7 +283,11 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             assert add is None
             _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip_fwd"]), *common)
 
-    importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
+    if importance_out is not None:          # caller's buffer, already zero where padding rows must read 0
+        assert importance_out.shape == (B, N) and importance_out.is_contiguous() and importance_out.dtype == torch.float32
+        importance = importance_out
+    else:
+        importance = torch.zeros((B, N), **f32) if skip_padding else torch.empty((B, N), **f32)
     if mc.lstm:
         Hc = lstm_pack["Hc"]
         Dp = D + Hc

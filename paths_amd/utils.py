@@ -59,11 +59,12 @@ _STREAMS: Dict[int, tuple] = {}
 
 
 def _streams(dev):
-    """(selection-chain stream, aggregator stream) of a device.  The selection chain is the critical path of the recursion,
+    """(selection-chain stream, aggregator stream, parent-partials stream) of a device.  The selection chain is the critical path of the recursion,
     so it gets the high-priority queue: its workgroups are dispatched first and the aggregator fills what is left."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _STREAMS:
-        _STREAMS[idx] = (torch.cuda.Stream(device=idx, priority=-1), torch.cuda.Stream(device=idx, priority=0))
+        _STREAMS[idx] = (torch.cuda.Stream(device=idx, priority=-1), torch.cuda.Stream(device=idx, priority=0),
+                         torch.cuda.Stream(device=idx, priority=-1))
     return _STREAMS[idx]
 
 
@@ -71,19 +72,20 @@ def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
              trace: Optional[list] = None, careful: bool = False) -> Dict[str, torch.Tensor]:
     batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
     if not (OVERLAP_AGGREGATOR and batch.device.type == "cuda"):
-        return _recurse_body(model, batch, keep_patches, num_levels, trace, careful, None)
+        return _recurse_body(model, batch, keep_patches, num_levels, trace, careful, None, None)
     caller = torch.cuda.current_stream(batch.device)
-    sel_stream, agg_stream = _streams(batch.device)
+    sel_stream, agg_stream, par_stream = _streams(batch.device)
     sel_stream.wait_stream(caller)
     agg_stream.wait_stream(caller)
+    par_stream.wait_stream(caller)
     with torch.cuda.stream(sel_stream):
-        out = _recurse_body(model, batch, keep_patches, num_levels, trace, careful, agg_stream)
+        out = _recurse_body(model, batch, keep_patches, num_levels, trace, careful, agg_stream, par_stream)
     caller.wait_stream(sel_stream)          # (the body has already joined agg_stream into sel_stream)
     return out
 
 
 def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
-                  trace: Optional[list], careful: bool, agg_stream) -> Dict[str, torch.Tensor]:
+                  trace: Optional[list], careful: bool, agg_stream, par_stream=None) -> Dict[str, torch.Tensor]:
     """Run all levels for a batch of HBM-resident slides (a list of DeviceSlide, or a DeviceSlideBatch built once
     and re-used across calls).  Returns the last level's output dict (+ "status").
 
@@ -129,12 +131,27 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     overlap = agg_stream is not None
     main_stream = torch.cuda.current_stream(dev) if overlap else None
     side_stream = agg_stream
-    keepalive = []                         # main-stream tensors read on the side stream: kept until the streams join
+    keepalive = []                         # tensors read on a stream other than the one that allocated them: kept until the streams join
+    # importance of padded rows is 0 (reference utils.py:106-115): ONE zero fill for all levels (sizes are known up front
+    # unless the careful path has to grow a level)
+    sizes, n_l = [], N
+    for i in range(num_levels):
+        sizes.append(n_l)
+        if i < num_levels - 1:
+            keep = int(keep_patches[i])
+            n_l = 4 * (n_l if keep < 0 else min(n_l, keep))
+    imp_all = torch.zeros((B * sum(sizes),), **f32)
+    imp_off = [B * sum(sizes[:i]) for i in range(num_levels)]
+    hp_pending = None
     for i in range(num_levels):
         proc = model.procs[i]
         lvl_pack = ops.pack_level(proc)
+        if hp_pending is not None:
+            main_stream.wait_stream(par_stream)           # parent partials of this level are ready
+            hp_pending = None
+        imp_buf = imp_all[imp_off[i]:imp_off[i] + B * N].view(B, N) if N == sizes[i] else None
         sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
-                                    max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D)
+                                    max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf)
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
@@ -162,6 +179,18 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         keep_count = torch.empty((B,), **i32)
         _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
         Nn = 4 * cap_keep
+        hp = None
+        if share_parent:
+            # The kept parents' h-partials need only the top-K indices: their GEMM runs on a third stream beside the child
+            # expansion and the gathers (tiny latency-bound kernels) instead of after them.
+            if overlap and par_stream is not None:
+                par_stream.wait_stream(main_stream)
+                with torch.cuda.stream(par_stream):
+                    hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count)
+                keepalive.append(hp)
+                hp_pending = hp
+            else:
+                hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count)
         def expand(cap):
             bufs = (torch.empty((B,), **i64), torch.empty((B, cap, 2), **i64), torch.empty((B, cap), **i64),
                     torch.empty((B, cap), **i32), torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
@@ -200,7 +229,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
                 fts_next = torch.empty((B, Nn, D), **f32)
                 _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
                           p(src_row), Hc, p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st)
-            parent = {"hp": ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count), "hp_row": hp_row, "c0": state_next}
+            parent = {"hp": hp, "hp_row": hp_row, "c0": state_next}
             state_next = None
         else:
             fts_next = torch.empty((B, Nn, D), **f32)
@@ -212,6 +241,8 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         fts, x_rows, locs, parent_inds, num_ims, state_prev, N = fts_next, x_rows_next, locs_next, parent_next, num_next, state_next, Nn
     if overlap:
         main_stream.wait_stream(side_stream)
+        if par_stream is not None:
+            main_stream.wait_stream(par_stream)
         keepalive.clear()
     out = dict(out)
     out["status"] = status
