@@ -12,6 +12,7 @@ from __future__ import annotations
 import os
 from typing import Dict, List, Optional, Sequence
 
+import contextlib
 import torch
 import torch.nn.functional as F
 
@@ -142,13 +143,13 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
             n_l = 4 * (n_l if keep < 0 else min(n_l, keep))
     imp_all = torch.zeros((B * sum(sizes),), **f32)
     imp_off = [B * sum(sizes[:i]) for i in range(num_levels)]
-    hp_pending = None
+    fork_pending = False
     for i in range(num_levels):
         proc = model.procs[i]
         lvl_pack = ops.pack_level(proc)
-        if hp_pending is not None:
-            main_stream.wait_stream(par_stream)           # parent partials of this level are ready
-            hp_pending = None
+        if fork_pending:
+            main_stream.wait_stream(par_stream)           # this level's rows / bookkeeping from the expansion branch are ready
+            fork_pending = False
         imp_buf = imp_all[imp_off[i]:imp_off[i] + B * N].view(B, N) if N == sizes[i] else None
         sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
                                     max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf)
@@ -179,63 +180,63 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         keep_count = torch.empty((B,), **i32)
         _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
         Nn = 4 * cap_keep
-        hp = None
-        if share_parent:
-            # The kept parents' h-partials need only the top-K indices: their GEMM runs on a third stream beside the child
-            # expansion and the gathers (tiny latency-bound kernels) instead of after them.
-            if overlap and par_stream is not None:
-                par_stream.wait_stream(main_stream)
-                with torch.cuda.stream(par_stream):
-                    hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count)
-                keepalive.append(hp)
-                hp_pending = hp
-            else:
-                hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count)
-        def expand(cap):
-            bufs = (torch.empty((B,), **i64), torch.empty((B, cap, 2), **i64), torch.empty((B, cap), **i64),
-                    torch.empty((B, cap), **i32), torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
-            _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
-                      p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, cap, p(bufs[0]), p(bufs[1]), p(bufs[2]),
-                      p(bufs[3]), p(bufs[4]), p(status), None, p(bufs[5]) if share_parent else None, st)
-            return bufs
+        # After the top-K the chain forks: the kept parents' h-partials (gather + GEMM, the longer branch) stay on this stream,
+        # the child expansion and the row gathers (tiny latency-bound kernels) run beside them on a third stream and are joined
+        # before the next level's gate GEMMs.
+        forked = overlap and par_stream is not None and share_parent
+        if forked:
+            par_stream.wait_stream(main_stream)            # top-K indices are ready
+        hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count) if share_parent else None
+        st2 = par_stream.cuda_stream if forked else st
+        with (torch.cuda.stream(par_stream) if forked else contextlib.nullcontext()):
+            def expand(cap):
+                bufs = (torch.empty((B,), **i64), torch.empty((B, cap, 2), **i64), torch.empty((B, cap), **i64),
+                        torch.empty((B, cap), **i32), torch.empty((B, cap), **i32), torch.empty((B, cap), **i32))
+                _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
+                          p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), B, cap, p(bufs[0]), p(bufs[1]), p(bufs[2]),
+                          p(bufs[3]), p(bufs[4]), p(status), None, p(bufs[5]) if share_parent else None, st2)
+                return bufs
 
-        num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
-        if careful:
-            empty = (num_next == 0).cpu()                      # per-level sync: slow path only
-            if bool(empty.any()):
-                need = Nn
-                for b in torch.nonzero(empty).flatten().tolist():
-                    tissue = int(batch.slides[b].masks[i + 1].sum().item())
-                    X, Y = batch.slides[b].shape(i + 1)
-                    need = max(need, tissue if tissue > 0 else X * Y)
-                if need > Nn:
-                    Nn = need
-                    num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
-                _lib.call("paths_fallback_all_cells", p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), mc.patch_size, B, Nn,
-                          p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status),
-                          p(hp_row) if share_parent else None, st)
-        x_rows_next = None
-        if share_parent:
-            # children only need their parent's c row (h enters through the per-parent partials below)
-            Hc = Dp - D
-            state_next = torch.empty((B, Nn, Hc), **f32)
-            if rows_in_place:
-                # ... and their feature rows are not copied either: the GEMMs of the next level read them in the resident grids
-                fts_next = None
-                x_rows_next = torch.empty((B, Nn), **i64)
-                _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
-                          p(src_row), Hc, p(num_next), B, Nn, None, p(state_next), 0, p(x_rows_next), p(zero_row), st)
+            num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
+            if careful:
+                empty = (num_next == 0).cpu()                      # per-level sync: slow path only
+                if bool(empty.any()):
+                    need = Nn
+                    for b in torch.nonzero(empty).flatten().tolist():
+                        tissue = int(batch.slides[b].masks[i + 1].sum().item())
+                        X, Y = batch.slides[b].shape(i + 1)
+                        need = max(need, tissue if tissue > 0 else X * Y)
+                    if need > Nn:
+                        Nn = need
+                        num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
+                    _lib.call("paths_fallback_all_cells", p(gx[i + 1]), p(gy[i + 1]), p(mask_ptrs[i + 1]), mc.patch_size, B, Nn,
+                              p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status),
+                              p(hp_row) if share_parent else None, st2)
+            x_rows_next = None
+            if share_parent:
+                # children only need their parent's c row (h enters through the per-parent partials below)
+                Hc = Dp - D
+                state_next = torch.empty((B, Nn, Hc), **f32)
+                if rows_in_place:
+                    # ... and their feature rows are not copied either: the GEMMs of the next level read them in the resident grids
+                    fts_next = None
+                    x_rows_next = torch.empty((B, Nn), **i64)
+                    _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
+                              p(src_row), Hc, p(num_next), B, Nn, None, p(state_next), 0, p(x_rows_next), p(zero_row), st2)
+                else:
+                    fts_next = torch.empty((B, Nn, D), **f32)
+                    _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
+                              p(src_row), Hc, p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st2)
+                parent = {"hp": hp, "hp_row": hp_row, "c0": state_next}
+                state_next = None
             else:
                 fts_next = torch.empty((B, Nn, D), **f32)
-                _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
-                          p(src_row), Hc, p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st)
-            parent = {"hp": hp, "hp_row": hp_row, "c0": state_next}
-            state_next = None
-        else:
-            fts_next = torch.empty((B, Nn, D), **f32)
-            state_next = torch.empty((B, Nn, Dp), **f32)
-            _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
-                      p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st)
+                state_next = torch.empty((B, Nn, Dp), **f32)
+                _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, p(out["ctx_patch"]), N, Dp, p(src_row), Dp,
+                          p(num_next), B, Nn, p(fts_next), p(state_next), 0, None, None, st2)
+            if forked:
+                fork_pending = True
+                keepalive.append((num_next, locs_next, parent_next, src_row, src_cell, hp_row, parent, fts_next, x_rows_next))
         if rec is not None:
             rec["keep_idx"], rec["keep_count"] = keep_idx, keep_count
         fts, x_rows, locs, parent_inds, num_ims, state_prev, N = fts_next, x_rows_next, locs_next, parent_next, num_next, state_next, Nn
