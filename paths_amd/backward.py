@@ -129,7 +129,7 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
             P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)
     if x6:
         wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd", ops.TRAIN_PLANES)
-        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, None, 0, P(wip), *tail[:-1], ops.TRAIN_PLANES, wip_s, 1.0, tail[-1])
+        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, None, 0, P(wip), *tail[:-1], ops.TRAIN_PLANES, wip_s, 1.0, None, tail[-1])
     else:
         _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), *tail)
     return sv

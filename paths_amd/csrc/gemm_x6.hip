@@ -71,6 +71,7 @@ struct X6Operands {
   const int64_t* num_ims;          // optional padding skip
   int rows_per_slide;
   float a_scale;                   // NP == 2: activations are multiplied by this power of two before the fp16 split
+  int ksplit = 1;                  // > 1 (single-panel launches only): blockIdx.z owns the k window [z K0/ksplit, (z+1) K0/ksplit)
 #ifdef PATHS_X6_DEBUG
   uint64_t* dbg;                   // tools/x6_stages.py only: per-wave {init, loop, epilogue} shader-clock ticks, 100 MHz ticks, start/end 100 MHz stamps
 #endif
@@ -132,7 +133,18 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     if constexpr (ADD) aoffs[p] = (uint32_t)((grow * g.ldadd + 4 * ac) * 4);
     awr[p] = (row >> 5) * SUBT + (ac >> 1) * 512 + (row & 31) * 16 + (ac & 1) * 8;
   }
-  const int nk0 = g.K0 >> 4, nk = (g.K0 + g.K1) >> 4;
+  // split-K launches: this block's k window of the single panel (A columns, Aadd columns, W stages all start kofs floats in)
+  const int K0w = g.ksplit > 1 ? g.K0 / g.ksplit : g.K0;
+  const int kofs = g.ksplit > 1 ? (int)blockIdx.z * K0w : 0;
+  if (kofs != 0) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      aoff0[p] += (uint32_t)kofs * 4u;
+      if constexpr (ROWS) rowp[p] += kofs >> 2;
+      if constexpr (ADD) aoffs[p] += (uint32_t)kofs * 4u;
+    }
+  }
+  const int nk0 = K0w >> 4, nk = (K0w + g.K1) >> 4;
   const char* bbase[NB]; int bwr[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -157,7 +169,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   const int lane16 = lane * 16;
   int bsoff[NB];                                       // scalar byte offset of W piece i at stage 0
 #pragma unroll
-  for (int i = 0; i < NB; ++i) bsoff[i] = (int)(bbase[i] - g.Wt);
+  for (int i = 0; i < NB; ++i) bsoff[i] = (int)(bbase[i] - g.Wt) + (kofs >> 4) * SUBT;
   auto gload_a = [&](int set, int q, int kt) {
     const bool first = kt < nk0;                       // wave-uniform panel select
 #ifdef PATHS_X6_EXP_HOTA
@@ -435,7 +447,8 @@ int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stre
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(Npad / BN, (g.M + BM - 1) / BM);
+  PATHS_REQUIRE(g.ksplit == 1 || (g.ksplit > 1 && g.K1 == 0 && g.K0 % (32 * g.ksplit) == 0 && g.K0 / g.ksplit >= 128), "%s: split-K needs a single panel and k windows that are multiples of 32, >= 128", name);
+  dim3 grid(Npad / BN, (g.M + BM - 1) / BM, g.ksplit);
 #ifdef PATHS_X6_DEBUG
   X6Operands gd = g; gd.dbg = g_x6_dbg;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, gd, epi);
@@ -444,6 +457,58 @@ int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stre
 #endif
   PATHS_LAUNCH_CHECK(name);
   return PATHS_OK;
+}
+
+// ---- split-K in two launches.  A GEMM whose tile grid covers half the chip (importance/proj: M/128 x 1 blocks) runs its k loop
+// as ksplit x as many blocks, each storing its RAW accumulators (EpiRaw: one [4][64 lanes][4] slab per 32x32 tile, the register
+// layout itself, so stores and loads are 16 bytes per lane and fully coalesced); x6_finish_kernel then sums the ksplit slabs
+// into registers and runs the real epilogue on 64-row blocks (2x the blocks again).  No inter-block waiting anywhere.
+struct EpiRaw {
+  float* ws; int64_t zstride; int ntn;       // ws [ksplit][M_pad/32][ntn = N_pad/32][1024] floats
+  template <int WTM, int WTN>
+  __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  template <int WTM, int WTN, int WGM, int WGN>
+  __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int, float*) const {
+    float* base = ws + (int64_t)blockIdx.z * zstride;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        f32x4* t = reinterpret_cast<f32x4*>(base + ((int64_t)((row0 >> 5) + i) * ntn + (col0 >> 5) + j) * 1024) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[64 * q] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      }
+  }
+};
+
+template <int NZ, class Epi>
+__global__ void __launch_bounds__(256)
+x6_finish_kernel(const float* __restrict__ ws, int64_t zstride, int ntn, int M, const int64_t* __restrict__ num_ims, int rows_per_slide, Epi epi) {
+  __shared__ float smem[256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 64;
+  if (block_all_padding(num_ims, rows_per_slide, m0, 64, M)) return;
+  const int row0 = m0 + wm * 32, col0 = wn * 128;
+  f32x16 acc[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4* t = reinterpret_cast<const f32x4*>(ws + ((int64_t)(row0 >> 5) * ntn + (col0 >> 5) + j) * 1024) + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = t[64 * q];
+#pragma unroll
+      for (int z = 1; z < NZ; ++z) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * zstride);
+      acc[0][j][4 * q] = v[0]; acc[0][j][4 * q + 1] = v[1]; acc[0][j][4 * q + 2] = v[2]; acc[0][j][4 * q + 3] = v[3];
+    }
+  }
+  epi.template run<1, 4, 2, 2>(acc, row0, col0, lane, wm, wn, M, smem);
 }
 
 // planes = 3: bf16 x6; planes = 2: fp16 x3 (operands pre-scaled by powers of two, undone through Epi::acc_scale)
@@ -544,11 +609,14 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
 // paths_importance_proj with w_ip_x6 = pack([256, D], rows interleaved as paths_importance_proj documents).  y_add (optional): the
 // GEMM input is y + y_add, summed in fp32 while staging - the caller passes (x, h1) and never materialises Y = X + h1
 // (paths_lstm_cell_x6 with y = NULL)
+// bytes of the optional split-K workspace of paths_importance_proj_x6 (two k halves of raw [M_pad, 256] accumulators)
+int64_t paths_importance_proj_x6_workspace(int M) { return 2ll * ((M + 127) / 128 * 4) * 8 * 1024 * 4; }
+
 int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                              float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
-                             int skip_padding, int planes, float w_scale, float a_scale, hipStream_t stream) {
+                             int skip_padding, int planes, float w_scale, float a_scale, float* splitk_ws, hipStream_t stream) {
   PATHS_REQUIRE(Hi == 128 && d == 128, "importance_proj_x6: this build supports importance_mlp_hidden_dim=128, trans_dim=128 (got %d, %d)", Hi, d);
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj_x6: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj_x6: 2d positional encoding needs locs");
@@ -563,6 +631,22 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
   auto go = [&](auto epi) {
     decltype(epi) e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
                     save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0, sc};
+    if constexpr (!std::is_same<decltype(epi), EpiImpProj<true, true>>::value && !std::is_same<decltype(epi), EpiImpProj<false, true>>::value) {
+      // two-launch split-K (inference, default split, Y = X + h1 form): k halves on 2 x the blocks, epilogue on 64-row blocks
+      if (splitk_ws != nullptr && planes == 2 && y_add != nullptr && D % 64 == 0 && D >= 256) {
+        const int mt = (M + 127) / 128 * 4;                         // 32-row tiles, padded to the GEMM's 128-row blocks
+        const int64_t zstride = (int64_t)mt * 8 * 1024;
+        X6Operands gs = g; gs.ksplit = 2;
+        EpiRaw raw{splitk_ws, zstride, 8};
+        int rc = y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(gs, 256, raw, stream, "importance_proj_x6(split-k)")
+                        : launch_x6_np<2, 2, 4, 2, true, false>(gs, 256, raw, stream, "importance_proj_x6(split-k)");
+        if (rc != PATHS_OK) return rc;
+        hipLaunchKernelGGL((x6_finish_kernel<2, decltype(epi)>), dim3((M + 63) / 64), dim3(256), 0, stream, splitk_ws, zstride, 8, M,
+                           skip_padding ? num_ims : nullptr, rows_per_slide, e);
+        PATHS_LAUNCH_CHECK("importance_proj_x6(finish)");
+        return PATHS_OK;
+      }
+    }
     if (y_add != nullptr) return launch_x6<2, 4, 2, true>(planes, g, 256, e, stream, "importance_proj_x6(sum)");
     return launch_x6<2, 4, 2, false>(planes, g, 256, e, stream, "importance_proj_x6");
   };

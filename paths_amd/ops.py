@@ -23,6 +23,7 @@ import torch
 from . import _lib
 
 LOG2E = 1.4426950408889634
+SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 # Which matrix pipe the big products (selection-chain GEMMs, attention) use.  All are HIP kernels of libpaths_hip.so with fp32
 # inputs, outputs and accumulation:
@@ -276,9 +277,13 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
         if x6:
             wip, wip_s = _x6_of(lvl_pack, "w_ip_fwd")
+            # M/128 blocks fill half the chip at K = 2048 x 8 slides: two k halves on twice the blocks + an epilogue launch
+            splitk_ws = None
+            if SPLITK_IMPORTANCE and add is not None and split_planes() == 2 and (M + 127) // 128 <= 160:
+                splitk_ws = torch.empty((int(_lib.load().paths_importance_proj_x6_workspace(M)),), device=dev, dtype=torch.uint8)
             _lib.call("paths_importance_proj_x6", p(src), D, p(x_rows) if src is None else None, p(add),
                       add.stride(1) if add is not None else 0,
-                      p(wip), *common[:-1], split_planes(), wip_s, a_scale(), common[-1])
+                      p(wip), *common[:-1], split_planes(), wip_s, a_scale(), p(splitk_ws), common[-1])
         else:
             assert add is None
             _lib.call("paths_importance_proj", p(src), D, p(lvl_pack["w_ip_fwd"]), *common)

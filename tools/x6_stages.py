@@ -54,7 +54,7 @@ def parent():
     _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg6), 2 * D, D, None, p(hp), G, MP, G, G, D, 0, None, 0, None, 0, 0, PL, wgs, AS, st())
 def impproj():
     _lib.call("paths_importance_proj_x6", p(yi), D, None, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
-              p(imp), p(tok), None, None, Mi, D, 128, 128, 1, PL, wips, AS, st())
+              p(imp), p(tok), None, None, Mi, D, 128, 128, 1, PL, wips, AS, None, st())
 
 USE_TAB = True
 USE_ADD = True
