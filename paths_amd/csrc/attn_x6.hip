@@ -299,9 +299,9 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   hipLaunchKernelGGL(attn_x6_prep_kernel<NP>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
   PATHS_LAUNCH_CHECK("attention_x6(prep)");
   // Workgroups per CU: registers allow 2, LDS would allow more.  The dispatcher fills a CU to its limit before it moves on, so
-  // small grids ask for more LDS than needed to spread out: depth = ceil(grid / 256).
+  // small grids ask for more LDS than needed to spread out: depth ~ grid / 256.
   const int nblk = ((nq + 127) / 128) * H * B;
-  const int depth = nblk <= 256 ? 1 : nblk <= 512 ? 2 : 3;
+  const int depth = nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
   const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
   static bool attr_set = false;
   if (!attr_set) {
