@@ -296,7 +296,11 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   char* k6 = q6 + img;
   char* v6 = k6 + img;
   const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
-  hipLaunchKernelGGL(attn_x6_prep_kernel<NP>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
+  // (the dispatcher packs a CU to its limit before it moves on: pad the LDS request so that the grid covers all 256 CUs)
+  const int nprep = (Tp / KSTEP) * H * B;
+  const int pdepth = (nprep + 255) / 256;
+  const int plds = pdepth >= 8 ? 0 : (160 * 1024 / pdepth - 9 * 1024) / 1024 * 1024 < 55 * 1024 ? (160 * 1024 / pdepth - 9 * 1024) / 1024 * 1024 : 55 * 1024;
+  hipLaunchKernelGGL(attn_x6_prep_kernel<NP>, dim3(Tp / KSTEP, H, B), dim3(256), plds, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
   PATHS_LAUNCH_CHECK("attention_x6(prep)");
   // Workgroups per CU: registers allow 2, LDS would allow more.  The dispatcher fills a CU to its limit before it moves on, so
   // small grids ask for more LDS than needed to spread out: depth ~ grid / 256.

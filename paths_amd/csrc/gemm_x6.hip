@@ -491,7 +491,7 @@ struct EpiRaw {
 template <int NZ, class Epi>
 __global__ void __launch_bounds__(256)
 x6_finish_kernel(const float* __restrict__ ws, int64_t zstride, int ntn, int M, const int64_t* __restrict__ num_ims, int rows_per_slide, Epi epi) {
-  __shared__ float smem[256];
+  extern __shared__ __attribute__((aligned(16))) char smem[];       // 1 KiB used; the launcher pads the request (one workgroup per CU)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * 64;
   if (block_all_padding(num_ims, rows_per_slide, m0, 64, M)) return;
@@ -508,7 +508,7 @@ x6_finish_kernel(const float* __restrict__ ws, int64_t zstride, int ntn, int M, 
       acc[0][j][4 * q] = v[0]; acc[0][j][4 * q + 1] = v[1]; acc[0][j][4 * q + 2] = v[2]; acc[0][j][4 * q + 3] = v[3];
     }
   }
-  epi.template run<1, 4, 2, 2>(acc, row0, col0, lane, wm, wn, M, smem);
+  epi.template run<1, 4, 2, 2>(acc, row0, col0, lane, wm, wn, M, reinterpret_cast<float*>(smem));
 }
 
 // planes = 3: bf16 x6; planes = 2: fp16 x3 (operands pre-scaled by powers of two, undone through Epi::acc_scale)
@@ -641,7 +641,16 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
         int rc = y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(gs, 256, raw, stream, "importance_proj_x6(split-k)")
                         : launch_x6_np<2, 2, 4, 2, true, false>(gs, 256, raw, stream, "importance_proj_x6(split-k)");
         if (rc != PATHS_OK) return rc;
-        hipLaunchKernelGGL((x6_finish_kernel<2, decltype(epi)>), dim3((M + 63) / 64), dim3(256), 0, stream, splitk_ws, zstride, 8, M,
+        // the dispatcher packs a CU to its limit before it moves on: ask for LDS that spreads the blocks over all CUs
+        const int fblk = (M + 63) / 64, fdepth = (fblk + 255) / 256;
+        const int flds = fdepth == 1 ? 84 * 1024 : fdepth == 2 ? 54 * 1024 : fdepth == 3 ? 41 * 1024 : 1024;
+        auto fk = x6_finish_kernel<2, decltype(epi)>;
+        static bool fattr = false;
+        if (!fattr) {
+          hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
+          fattr = true;
+        }
+        hipLaunchKernelGGL(fk, dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
                            skip_padding ? num_ims : nullptr, rows_per_slide, e);
         PATHS_LAUNCH_CHECK("importance_proj_x6(finish)");
         return PATHS_OK;
