@@ -460,6 +460,21 @@ def test_other_gemm_modes_match_default(dev, monkeypatch, mode):
     np.testing.assert_allclose(out_m["ctx_patch"].numpy(), out_def["ctx_patch"].numpy(), atol=5e-6, rtol=0)
 
 
+@pytest.mark.parametrize("name", ["g2_level2_b2_k256", "g9_level1_b2_k2048"])
+def test_split_k_importance_matches_single_launch(dev, monkeypatch, name):
+    """The importance/proj GEMM as two k halves + epilogue launch (default) against the single launch: same products, one
+    extra fp32 addition per output (tokens / importance agree to rounding; downstream outputs within the golden tolerance)."""
+    from paths_amd import ops
+    assert ops.SPLITK_IMPORTANCE and ops.GEMM_MODE == "h3"
+    g, info, out_split = run_single(dev, name)
+    monkeypatch.setattr(ops, "SPLITK_IMPORTANCE", False)
+    _, _, out_one = run_single(dev, name)
+    np.testing.assert_allclose(out_split["importance"].numpy(), out_one["importance"].numpy(), atol=5e-7, rtol=0)
+    np.testing.assert_allclose(out_split["logits"].numpy(), out_one["logits"].numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out_split["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    assert torch.equal(out_split["ctx_patch"], out_one["ctx_patch"])          # the LSTM state does not pass through this GEMM
+
+
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37]), (65, [64, 65])])
 def test_attention_x6_matches_fp64(dev, T, lens, planes):
