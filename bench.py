@@ -248,10 +248,13 @@ def main():
     x6 = bool(events and events[0][3].get("x6"))
     planes = int(events[0][3].get("planes", 3)) if x6 else 0
     traffic = None            # HBM-side bytes per launch from the committed PMC passes (separate --pmc runs, profiles/)
-    prof = {2: "r01g_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
+    prof = {2: "r01i_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
+    serialized_us = None      # the same kernel with nothing beside it (those passes serialise the streams)
     try:
         with open(os.path.join(ROOT, "profiles", prof)) as fh:
-            traffic = json.load(fh)["kernels"]["EpiLstmO"]["traffic_bytes_per_launch"]
+            kstat = json.load(fh)["kernels"]["EpiLstmO"]
+        traffic = kstat["traffic_bytes_per_launch"]
+        serialized_us = kstat.get("avg_us")
     except (OSError, KeyError, ValueError):
         pass
     if x6:
@@ -269,6 +272,10 @@ def main():
                     "vs_f32_matrix_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
                     "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": len(events),
                     "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
+        if serialized_us:
+            # context only (not live): `achieved` above is the kernel sharing the chip with the aggregator stream's kernels
+            roofline["serialized_us_from_profile"] = serialized_us
+            roofline["serialized_frac_from_profile"] = round(flop / n_launch / (serialized_us * 1e-6) / 1e12 / peak, 4)
     else:
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
