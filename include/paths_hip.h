@@ -169,7 +169,10 @@ int paths_attention_f32(const float* q, const float* k, const float* v, float* o
  * Same arguments and results (to fp32 rounding) as paths_attention_f32. */
 int64_t paths_attention_x6_workspace(int B, int T, int H, int head_dim, int planes);
 int paths_attention_x6(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims,
-                       int B, int T, int H, int head_dim, int max_queries, void* workspace, int planes, paths_stream_t stream);
+                       int B, int T, int H, int head_dim, int max_queries, void* workspace, int planes, int images_ready,
+                       paths_stream_t stream);
+/* images_ready != 0 (planes = 2): the workspace already holds the operand images (paths_token_layer_h3 wrote them through its
+ * qkv_images argument); q, k, v are not read and the re-write launch is skipped. */
 
 /* Token-row chain of one post-LN decoder layer with empty memory + the next in_proj (same call site):
  *   do_post: x_out = norm3(x' + ffn(x')), x' = norm2(norm1(x_in + out_proj(attn)) + cross_attn_bias)
@@ -196,7 +199,10 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
                          const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
                          float s_wo, float s_w1, float s_w2, float s_wqkv,
                          float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
-                         int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens, paths_stream_t stream);
+                         int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens, void* qkv_images,
+                         paths_stream_t stream);
+/* qkv_images (optional, max_tokens = 0): a paths_attention_x6_workspace(B, T, H, 32, 2) buffer; the in_proj outputs are written
+ * as the two-plane operand images of paths_attention_x6 (masked keys zeroed) instead of fp32 q, k, v (which may then be null). */
 
 /* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
  * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only

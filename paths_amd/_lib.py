@@ -44,9 +44,9 @@ SIGNATURES = {
     "paths_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "paths_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_attention_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "paths_attention_x6": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
+    "paths_attention_x6": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "paths_tlayer_pack_h3": [_i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp],
-    "paths_token_layer_h3": [_vp] * 16 + [_f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
+    "paths_token_layer_h3": [_vp] * 16 + [_f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp],
     "paths_token_layer_f32": [_vp] * 21 + [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "paths_token0_tail": [_vp] * 20 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "paths_final_head": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],

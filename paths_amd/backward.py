@@ -302,7 +302,7 @@ def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries):
     if ops.GEMM_MODE != "f32":
         TP = ops.TRAIN_PLANES
         ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, TP)),), device=q.device, dtype=torch.uint8)
-        _lib.call("paths_attention_x6", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP, st)
+        _lib.call("paths_attention_x6", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP, 0, st)
     else:
         _lib.call("paths_attention_f32", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, st)
 

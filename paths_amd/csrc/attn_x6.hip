@@ -289,19 +289,21 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 
 template <int NP>
 int attention_split(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B, int T,
-                           int H, int max_queries, void* workspace, hipStream_t stream) {
+                           int H, int max_queries, void* workspace, int images_ready, hipStream_t stream) {
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
   const int64_t img = (int64_t)B * H * Tp * HD * 2 * NP;
   char* q6 = reinterpret_cast<char*>(workspace);
   char* k6 = q6 + img;
   char* v6 = k6 + img;
   const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
+  if (!images_ready) {
   // (the dispatcher packs a CU to its limit before it moves on: pad the LDS request so that the grid covers all 256 CUs)
   const int nprep = (Tp / KSTEP) * H * B;
   const int pdepth = (nprep + 255) / 256;
   const int plds = pdepth >= 8 ? 0 : (160 * 1024 / pdepth - 9 * 1024) / 1024 * 1024 < 55 * 1024 ? (160 * 1024 / pdepth - 9 * 1024) / 1024 * 1024 : 55 * 1024;
   hipLaunchKernelGGL(attn_x6_prep_kernel<NP>, dim3(Tp / KSTEP, H, B), dim3(256), plds, stream, q, k, v, q6, k6, v6, num_ims, T, Tp, H, nq);
   PATHS_LAUNCH_CHECK("attention_x6(prep)");
+  }
   // Workgroups per CU: registers allow 2, LDS would allow more.  The dispatcher fills a CU to its limit before it moves on, so
   // small grids ask for more LDS than needed to spread out: depth ~ grid / 256.
   const int nblk = ((nq + 127) / 128) * H * B;
@@ -331,13 +333,15 @@ int64_t paths_attention_x6_workspace(int B, int T, int H, int head_dim, int plan
 // planes 3: bf16 hi|mid|lo, 6 MFMAs per product block; planes 2: fp16 hi|lo, 3 MFMAs (q, k, v must stay below 65504 in magnitude)
 int paths_attention_x6(const float* q, const float* k, const float* v, float* o, float* lse /*[B,H,T] or null*/,
                        const int64_t* num_ims, int B, int T, int H, int head_dim, int max_queries, void* workspace, int planes,
-                       hipStream_t stream) {
+                       int images_ready, hipStream_t stream) {
   PATHS_REQUIRE(head_dim == HD, "attention_x6: head_dim must be %d (got %d)", HD, head_dim);
+  PATHS_REQUIRE(!images_ready || planes == 2, "attention_x6: images_ready (workspace filled by paths_token_layer_h3) is the two-plane form");
+  PATHS_REQUIRE(images_ready || (q && k && v), "attention_x6: q, k, v are required unless images_ready");
   PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && num_ims != nullptr && workspace != nullptr, "attention_x6: bad arguments B=%d T=%d H=%d", B, T, H);
   PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_x6: buffers must be 16-byte aligned");
   PATHS_REQUIRE(planes == 2 || planes == 3, "attention_x6: planes must be 3 (bf16 x6) or 2 (fp16 x3)");
-  return planes == 3 ? attention_split<3>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, stream)
-                     : attention_split<2>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, stream);
+  return planes == 3 ? attention_split<3>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, 0, stream)
+                     : attention_split<2>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, images_ready, stream);
 }
 
 }  // extern "C"

@@ -37,6 +37,9 @@ __device__ __forceinline__ uint32_t pk_f16(float a, float b) {
   f32x2 v = {a, b};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
+__device__ __forceinline__ float h_lo(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float h_hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // 8 fp32 -> hi | lo planes of 8 fp16 (22 significant bits)
 __device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
@@ -60,6 +63,8 @@ struct TLayerH3Params {
   float *q, *k, *v;
   const int64_t* num_ims;
   int T, H; int do_post, do_qkv, skip_padding; float qscale, eps;
+  char* qkv_img = nullptr;         // instead of q, k, v: the two-plane fragment images attn_x6_kernel<2> reads (attn_x6.hip), Q | K | V
+  int Tp = 0;                      // T rounded up to 64 (image rows per (slide, head))
 };
 
 typedef f32x4 act_t[8];            // 128 features of 16 tokens: tile t, reg r, lane group g -> feature 16t + 4g + r
@@ -239,7 +244,48 @@ tlayer_h3_kernel(TLayerH3Params p) {
       mm_chunk<4, 4>(smem + buf * CHUNK, acc, xs, lane);
       float* dst = qc < 2 ? p.q : qc < 4 ? p.k : p.v;
       const float sc = qc < 2 ? p.qscale : 1.0f;
-      if (tok < p.T) {
+      if (p.qkv_img != nullptr) {
+        // Straight into the attention kernel's operand images (what attn_x6_prep_kernel<2> would build from q, k, v): this
+        // lane owns 4 consecutive dims of one token, and both image layouts keep the token (Q, K) or the dim (V^T, after a
+        // 4x4 exchange inside the lane quad) on lane & 15, so every piece is one 8-byte store per plane.
+        const int which = qc >> 1;
+        const int len = p.num_ims ? min((int)p.num_ims[b] + 1, p.T) : p.T;
+        const bool live = which == 0 ? tok < p.T : tok < len;          // masked keys: K = 0, V = 0 (0 * garbage would poison O)
+        const int64_t img = (int64_t)gridDim.y * p.H * p.Tp * 128;     // bytes of one of the three images (32 dims x 2 planes x 2 B)
+        const int tokb = t0 + wave * 16;                               // first token of this wave's tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int head = 2 * (qc & 1) + (i >> 1);
+          char* base = p.qkv_img + which * img + ((int64_t)b * p.H + head) * p.Tp * 128;
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) w[r] = live ? (acc[i][r] * p.inv_wqkv + bb[i][r]) * sc : 0.f;
+          int64_t off;
+          if (which < 2) {           // Q6 / K6: [tile of 16 tokens][plane][lane = token + 16 (dim / 8)][8 dims]
+            off = (int64_t)(tokb >> 4) * 2 * FRAG + (ql + 16 * (2 * (i & 1) + (g4 >> 1))) * 16 + (g4 & 1) * 8;
+          } else {                   // V6: [32 keys][dim tile][plane][lane = dim + 16 (key quad)][8 keys in kappa order]
+            const int m = ql & 3;
+#pragma unroll
+            for (int pq = 0; pq < 4; pq += 2) {                       // exchange with lane ^ 1: register bit 0 <-> lane bit 0
+              const float a = w[pq], c2 = w[pq + 1];
+              const float recv = __shfl_xor((m & 1) ? a : c2, 1);
+              w[pq] = (m & 1) ? recv : a; w[pq + 1] = (m & 1) ? c2 : recv;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                             // exchange with lane ^ 2: register bit 1 <-> lane bit 1
+              const float a = w[e], c2 = w[e + 2];
+              const float recv = __shfl_xor((m & 2) ? a : c2, 2);
+              w[e] = (m & 2) ? recv : a; w[e + 2] = (m & 2) ? c2 : recv;
+            }
+            // now w[n] = dim 16 (i & 1) + 4 g4 + m of token 4 (ql >> 2) + n
+            off = (int64_t)((tokb >> 5) * 2 + (i & 1)) * 2 * FRAG + ((4 * g4 + m) + 16 * (ql >> 2)) * 16 + (wave & 1) * 8;
+          }
+          const uint32_t h0 = pk_f16(w[0], w[1]), h1 = pk_f16(w[2], w[3]);
+          const uint32_t l0 = pk_f16(w[0] - h_lo(h0), w[1] - h_hi(h0)), l1 = pk_f16(w[2] - h_lo(h1), w[3] - h_hi(h1));
+          *reinterpret_cast<u32x2*>(base + off) = u32x2{h0, h1};
+          *reinterpret_cast<u32x2*>(base + off + FRAG) = u32x2{l0, l1};
+        }
+      } else if (tok < p.T) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int f = 64 * (qc & 1) + 16 * i + 4 * g4;          // feature within q / k / v
@@ -313,15 +359,17 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
                          const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
                          float s_wo, float s_w1, float s_w2, float s_wqkv,
                          float* q, float* k, float* v, const int64_t* num_ims, int B, int T, int d, int H,
-                         int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens, hipStream_t stream) {
+                         int do_post, int do_qkv, int skip_padding, float qscale, float eps, int max_tokens, void* qkv_images,
+                         hipStream_t stream) {
   PATHS_REQUIRE(d == DM && H == 4, "token_layer_h3: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer_h3: nothing to do");
   PATHS_REQUIRE(!skip_padding || num_ims, "token_layer_h3: skip_padding needs num_ims");
-  PATHS_REQUIRE(x_in && (!do_post || (attn && x_out && w_post)) && (!do_qkv || (w_qkv && q && k && v)), "token_layer_h3: null operand");
+  PATHS_REQUIRE(x_in && (!do_post || (attn && x_out && w_post)) && (!do_qkv || (w_qkv && ((q && k && v) || qkv_images))), "token_layer_h3: null operand");
+  PATHS_REQUIRE(qkv_images == nullptr || (do_qkv && max_tokens == 0), "token_layer_h3: qkv_images needs do_qkv over all tokens");
   TLayerH3Params p{x_in, attn, x_out, reinterpret_cast<const char*>(w_post), reinterpret_cast<const char*>(w_qkv),
                    bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, bqkv,
                    do_post ? 1.0f / s_wo : 1.0f, do_post ? 1.0f / s_w1 : 1.0f, do_post ? 1.0f / s_w2 : 1.0f, do_qkv ? 1.0f / s_wqkv : 1.0f,
-                   q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps};
+                   q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps, reinterpret_cast<char*>(qkv_images), (T + 63) / 64 * 64};
   constexpr size_t lds_min = 2ull * CHUNK + (DFF + 3 * DM) * sizeof(float);              // 69,120 B: two workgroups per CU
   constexpr size_t lds_solo = 84 * 1024;                                                 // > 80 KiB: one workgroup per CU
   static bool attr_set = false;

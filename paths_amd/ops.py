@@ -23,6 +23,7 @@ import torch
 from . import _lib
 
 LOG2E = 1.4426950408889634
+QKV_IMAGES = os.environ.get("PATHS_QKV_IMAGES", "1") != "0"
 SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 # Which matrix pipe the big products (selection-chain GEMMs, attention) use.  All are HIP kernels of libpaths_hip.so with fp32
@@ -402,7 +403,7 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     qscale = LOG2E / math.sqrt(hd)
     layers = lvl_pack["layers"]
 
-    def token_layer(x_in, x_out, post, nxt, max_tokens=0):
+    def token_layer(x_in, x_out, post, nxt, max_tokens=0, qkv_images=None):
         w = post or nxt
         g = lambda dct, key: p(dct[key]) if dct is not None else None
         if GEMM_MODE == "h3":
@@ -412,7 +413,7 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
                       g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
                       g(post, "b1"), g(post, "b2"), g(post, "ln3g"), g(post, "ln3b"), g(nxt, "bqkv"),
                       sp[0], sp[1], sp[2], sq[0], p(q), p(k), p(v), p(num_ims), B, T, d, H,
-                      1 if post else 0, 1 if nxt else 0, 1, qscale, w["eps"], max_tokens, st)
+                      1 if post else 0, 1 if nxt else 0, 1, qscale, w["eps"], max_tokens, p(qkv_images), st)
             return
         _lib.call("paths_token_layer_f32", p(x_in), p(attn) if post else None, p(x_out) if post else None,
                   g(post, "wo"), g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
@@ -427,17 +428,21 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     cat = ctx_all.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_all is not None and ctx_all.shape[1] > 0) else None
     depth = cat.shape[1] if cat is not None else 0
 
-    token_layer(xa, None, None, layers[0])
     attn_ws = None
+    if GEMM_MODE != "f32" and L > 1:
+        attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, split_planes())),),
+                              device=tokens.device, dtype=torch.uint8)
+    # default mode: the in_proj of a layer that feeds the full attention writes the attention kernel's operand images itself
+    # (no fp32 q, k, v round trip, no re-write launch); the last layer's q, k, v stay fp32 for the token-0 tail
+    direct = GEMM_MODE == "h3" and attn_ws is not None and QKV_IMAGES
+    token_layer(xa, None, None, layers[0], qkv_images=attn_ws if direct else None)
     for l in range(L - 1):
         if GEMM_MODE != "f32":
-            if attn_ws is None:
-                attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, split_planes())),),
-                                      device=tokens.device, dtype=torch.uint8)
-            _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), split_planes(), st)
+            _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), split_planes(),
+                      1 if direct else 0, st)
         else:
             _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st)
-        token_layer(xa, xb, layers[l], layers[l + 1])
+        token_layer(xa, xb, layers[l], layers[l + 1], qkv_images=attn_ws if (direct and l + 1 < L - 1) else None)
         xa, xb = xb, xa
     # Last layer: only token 0 of its output is read (aggregator.py:75) -> one fused launch per level computes the
     # single-query attention, the row chain, decoder.norm, the slide-context residual and the classifier.

@@ -491,7 +491,7 @@ def test_attention_x6_matches_fp64(dev, T, lens, planes):
     o6 = torch.full((B, T, H * hd), float("nan"), device=dev)
     o32 = torch.full((B, T, H * hd), float("nan"), device=dev)
     lse6 = torch.empty((B, H, T), device=dev)
-    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o6), p(lse6), p(num_ims), B, T, H, hd, 0, p(ws), planes, st)
+    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o6), p(lse6), p(num_ims), B, T, H, hd, 0, p(ws), planes, 0, st)
     _lib.call("paths_attention_f32", p(q), p(k), p(v), p(o32), None, p(num_ims), B, T, H, hd, 0, st)
     for b, n in enumerate(lens):
         s = (q[b, :, :n].double() @ k[b, :, :n].double().transpose(1, 2)) * np.log(2.0)      # kernels use exp2 of pre-scaled q
@@ -525,3 +525,18 @@ def test_token_layer_h3_matches_f32_kernel(dev):
     np.testing.assert_allclose(out_again["logits"].numpy(), out_h3["logits"].numpy(), atol=0, rtol=0)      # deterministic
     np.testing.assert_allclose(out_h3["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out_h3["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["g2_level2_b2_k256", "g9_level1_b2_k2048"])
+def test_qkv_images_written_by_token_layer_equal_the_rewrite(dev, monkeypatch, name):
+    """Default mode: the in_proj kernel writes the attention operand images itself.  They hold the same fp32 values split the
+    same way as the q, k, v re-write launch produces, so a level's outputs are bit-identical either way (ragged slides included:
+    masked keys must be zero in both)."""
+    from paths_amd import ops
+    assert ops.QKV_IMAGES and ops.GEMM_MODE == "h3"
+    g, info, out_direct = run_single(dev, name)
+    monkeypatch.setattr(ops, "QKV_IMAGES", False)
+    _, _, out_rewrite = run_single(dev, name)
+    for key in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        assert torch.equal(out_direct[key], out_rewrite[key]), key
+    np.testing.assert_allclose(out_direct["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
