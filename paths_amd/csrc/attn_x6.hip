@@ -53,8 +53,9 @@ __device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& l
   for (int i = 0; i < 4; ++i) {
     const float a = x[2 * i], b = x[2 * i + 1];
     const uint32_t h = pk_f16(a, b);
-    const f16x2 hv = __builtin_bit_cast(f16x2, h);
-    hi[i] = h; lo[i] = pk_f16(a - (float)hv[0], b - (float)hv[1]);
+    float ra, rb;
+    f16_pair_residuals(h, a, b, ra, rb);
+    hi[i] = h; lo[i] = pk_f16(ra, rb);
   }
 }
 // planes[0..NP) of 8 values
@@ -235,7 +236,10 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     for (int qt = 0; qt < 2; ++qt) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[qt][t][0], s[qt][t][1]), fmaxf(s[qt][t][2], s[qt][t][3])));
+      for (int t = 0; t < 4; ++t) {                     // two v_max3_f32 per key tile
+        mx = fmaxf(fmaxf(mx, s[qt][t][0]), s[qt][t][1]);
+        mx = fmaxf(fmaxf(mx, s[qt][t][2]), s[qt][t][3]);
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run[qt], mx);         // finite: key 0 (special token) is always valid
@@ -245,9 +249,11 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
       for (int kg = 0; kg < 2; ++kg) {
         float pv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) of the PV product = key 4 g4 + (j&3) + 16 (j>>2) of the group
-          pv[j] = __builtin_amdgcn_exp2f(s[qt][2 * kg + (j >> 2)][j & 3] - m_new);
-          psum += pv[j];
+        for (int j = 0; j < 8; j += 2) {                // k-slot (g4, j) of the PV product = key 4 g4 + (j&3) + 16 (j>>2) of the group
+          const f32x2 d = f32x2{s[qt][2 * kg + (j >> 2)][j & 3], s[qt][2 * kg + (j >> 2)][(j & 3) + 1]} - f32x2{m_new, m_new};   // v_pk_add_f32
+          pv[j] = __builtin_amdgcn_exp2f(d[0]);
+          pv[j + 1] = __builtin_amdgcn_exp2f(d[1]);
+          psum += pv[j] + pv[j + 1];
         }
         split_planes<NP>(pv, pf[qt][kg]);
       }

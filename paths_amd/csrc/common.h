@@ -29,6 +29,14 @@ int paths_set_error(int code, const char* fmt, ...);
   } while (0)
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - indices stay constants without relying on the unroller
+// Residuals of a packed fp16 pair: ra = a - (float)h.lo, rb = b - (float)h.hi, one v_fma_mix_f32 each (the mixed-precision FMA reads
+// the half straight out of the packed register; written as a - (float)h hipcc emits v_cvt_f32_f16 + v_sub_f32, and turns an
+// fmaf(h, -1, a) back into that).  Exact either way: the same fp32 subtraction.
+__device__ __forceinline__ void f16_pair_residuals(uint32_t h, float a, float b, float& ra, float& rb) {
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {

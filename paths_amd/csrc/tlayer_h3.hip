@@ -46,8 +46,9 @@ __device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& l
   for (int i = 0; i < 4; ++i) {
     const float a = x[2 * i], b = x[2 * i + 1];
     const uint32_t h = pk_f16(a, b);
-    const f16x2 hv = __builtin_bit_cast(f16x2, h);
-    hi[i] = h; lo[i] = pk_f16(a - (float)hv[0], b - (float)hv[1]);
+    float ra, rb;
+    f16_pair_residuals(h, a, b, ra, rb);
+    hi[i] = h; lo[i] = pk_f16(ra, rb);
   }
 }
 __device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
@@ -281,7 +282,10 @@ tlayer_h3_kernel(TLayerH3Params p) {
             off = (int64_t)((tokb >> 5) * 2 + (i & 1)) * 2 * FRAG + ((4 * g4 + m) + 16 * (ql >> 2)) * 16 + (wave & 1) * 8;
           }
           const uint32_t h0 = pk_f16(w[0], w[1]), h1 = pk_f16(w[2], w[3]);
-          const uint32_t l0 = pk_f16(w[0] - h_lo(h0), w[1] - h_hi(h0)), l1 = pk_f16(w[2] - h_lo(h1), w[3] - h_hi(h1));
+          float r0, r1, r2, r3;
+          f16_pair_residuals(h0, w[0], w[1], r0, r1);
+          f16_pair_residuals(h1, w[2], w[3], r2, r3);
+          const uint32_t l0 = pk_f16(r0, r1), l1 = pk_f16(r2, r3);
           *reinterpret_cast<u32x2*>(base + off) = u32x2{h0, h1};
           *reinterpret_cast<u32x2*>(base + off + FRAG) = u32x2{l0, l1};
         }
