@@ -194,8 +194,8 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // Split of one staged A chunk in NS micro-steps of at most 2 VALU instructions (the last one: the three LDS writes).  A gap
   // between two 32-cycle MFMAs hides about 24 cycles of other issue; the first version used 7 steps of 4 VALU + waits, every
   // such gap overflowed by ~15 cycles and idle gaps cannot win that back: ~500 cycles per stage (tools/x6_stages.py).
-  //   NP == 3 (bf16): 12 micro-steps (+1 for the ADD sum);  NP == 2 (fp16): scale, hi, residuals, lo, writes = 8 (+1).
-  constexpr int NS = (NP == 3 ? 12 : 8) + (ADD ? 1 : 0);
+  //   NP == 3 (bf16): 12 micro-steps (+1 for the ADD sum);  NP == 2 (fp16): scale, hi, 2 x residuals (v_fma_mix), lo, writes = 6 (+1).
+  constexpr int NS = (NP == 3 ? 12 : 6) + (ADD ? 1 : 0);
   float tf[NA][2];
   auto a_step = [&](int set, int q, int st0, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[set][q];
@@ -224,12 +224,10 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     } else {
       if (st == 0) v *= g.a_scale;                      // power of two: exact
       if (st == 1) { hi[q][0] = pk_f16(v[0], v[1]); hi[q][1] = pk_f16(v[2], v[3]); }
-      if (st == 2) { tf[q][0] = h_lo(hi[q][0]); tf[q][1] = h_hi(hi[q][0]); }
-      if (st == 3) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
-      if (st == 4) { tf[q][0] = h_lo(hi[q][1]); tf[q][1] = h_hi(hi[q][1]); }
-      if (st == 5) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
-      if (st == 6) { lo[q][0] = pk_f16(v[0], v[1]); lo[q][1] = pk_f16(v[2], v[3]); }
-      if (st == 7) {
+      if (st == 2) f16_pair_residuals(hi[q][0], v[0], v[1], tf[q][0], tf[q][1]);   // 2 x v_fma_mix_f32 (was cvt, cvt | sub, sub)
+      if (st == 3) { float r2, r3; f16_pair_residuals(hi[q][1], v[2], v[3], r2, r3); v[2] = r2; v[3] = r3; }
+      if (st == 4) { lo[q][0] = pk_f16(tf[q][0], tf[q][1]); lo[q][1] = pk_f16(v[2], v[3]); }
+      if (st == 5) {
         char* d = smem + buf * STAGE + awr[q];
         *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
         *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{lo[q][0], lo[q][1]};
