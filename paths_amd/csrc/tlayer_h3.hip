@@ -128,9 +128,12 @@ __device__ __forceinline__ void mm_chunk(const char* sW, f32x4 (&acc)[NOT], cons
 
 __global__ void __launch_bounds__(256, 2)
 tlayer_h3_kernel(TLayerH3Params p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK] + in-loop biases [512 + 384] floats
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK] + biases / LayerNorm vectors [512 + 384 + 9 x 128] floats
   float* s_b1 = reinterpret_cast<float*>(smem + 2 * CHUNK);
   float* s_bqkv = s_b1 + DFF;
+  // the nine 128-float vectors of the post part (bo, ln1 g/b, cab, ln2 g/b, b2, ln3 g/b): read from HBM/L2 at their point of use
+  // each was a ~1 us round trip with nothing to hide it (one wave per SIMD); staged here they ride under the first chunk load
+  float* s_vec = s_bqkv + 3 * DM;
   const int b = blockIdx.y, t0 = blockIdx.x * 64;
   if (p.skip_padding && t0 >= (int)p.num_ims[b] + 1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
@@ -153,7 +156,12 @@ tlayer_h3_kernel(TLayerH3Params p) {
   act_t x;      // activations first (oldest loads), then biases, then the first weight chunk
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *reinterpret_cast<const f32x4*>(p.x_in + rowoff + 16 * t + 4 * g4);
-  if (p.do_post) for (int i = threadIdx.x; i < DFF; i += 256) s_b1[i] = p.b1[i];
+  if (p.do_post) {
+    for (int i = threadIdx.x; i < DFF; i += 256) s_b1[i] = p.b1[i];
+    const float* const vecs[9] = {p.bo, p.ln1g, p.ln1b, p.cab, p.ln2g, p.ln2b, p.b2, p.ln3g, p.ln3b};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) if (threadIdx.x < DM) s_vec[j * DM + threadIdx.x] = vecs[j][threadIdx.x];
+  }
   if (p.do_qkv) for (int i = threadIdx.x; i < 3 * DM; i += 256) s_bqkv[i] = p.bqkv[i];
   int buf = 0, c = c_first;
   stage_load(c);
@@ -186,13 +194,13 @@ tlayer_h3_kernel(TLayerH3Params p) {
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const f32x4 bo = *reinterpret_cast<const f32x4*>(p.bo + 16 * t + 4 * g4);
+      const f32x4 bo = *reinterpret_cast<const f32x4*>(s_vec + 16 * t + 4 * g4);
       x[t] = x[t] + (y[t] * p.inv_wo + bo);
     }
-    layernorm_t(x, p.ln1g, p.ln1b, g4, p.eps);
+    layernorm_t(x, s_vec + DM, s_vec + 2 * DM, g4, p.eps);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = x[t] + *reinterpret_cast<const f32x4*>(p.cab + 16 * t + 4 * g4);
-    layernorm_t(x, p.ln2g, p.ln2b, g4, p.eps);
+    for (int t = 0; t < 8; ++t) x[t] = x[t] + *reinterpret_cast<const f32x4*>(s_vec + 3 * DM + 16 * t + 4 * g4);
+    layernorm_t(x, s_vec + 4 * DM, s_vec + 5 * DM, g4, p.eps);
     split_act<4>(x, xs);
 
     // ---- feed-forward: 8 hidden chunks of 64; y accumulates linear2 (in units of 1 / inv_w2)
@@ -220,10 +228,10 @@ tlayer_h3_kernel(TLayerH3Params p) {
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + 16 * t + 4 * g4);
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(s_vec + 6 * DM + 16 * t + 4 * g4);
       x[t] = x[t] + (y[t] * p.inv_w2 + b2);
     }
-    layernorm_t(x, p.ln3g, p.ln3b, g4, p.eps);
+    layernorm_t(x, s_vec + 7 * DM, s_vec + 8 * DM, g4, p.eps);
     if (tok < p.T) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) *reinterpret_cast<f32x4*>(p.x_out + rowoff + 16 * t + 4 * g4) = x[t];
@@ -374,7 +382,7 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
                    bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, bqkv,
                    do_post ? 1.0f / s_wo : 1.0f, do_post ? 1.0f / s_w1 : 1.0f, do_post ? 1.0f / s_w2 : 1.0f, do_qkv ? 1.0f / s_wqkv : 1.0f,
                    q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps, reinterpret_cast<char*>(qkv_images), (T + 63) / 64 * 64};
-  constexpr size_t lds_min = 2ull * CHUNK + (DFF + 3 * DM) * sizeof(float);              // 69,120 B: two workgroups per CU
+  constexpr size_t lds_min = 2ull * CHUNK + (DFF + 3 * DM + 9 * DM) * sizeof(float);     // 73,728 B: two workgroups per CU
   constexpr size_t lds_solo = 84 * 1024;                                                 // > 80 KiB: one workgroup per CU
   static bool attr_set = false;
   if (!attr_set) {
