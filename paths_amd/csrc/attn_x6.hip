@@ -159,7 +159,6 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
   constexpr int STEP_BYTES = step_bytes<NP>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];          // 2 x STEP_BYTES (+ occupancy padding, see the launcher)
-  char (*smem)[STEP_BYTES] = reinterpret_cast<char (*)[STEP_BYTES]>(smem_raw);
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
   const int len = min((int)num_ims[b] + 1, T);          // valid keys = special token + patches
   if (q0 >= len) return;                                // every query of this block is padding
@@ -183,35 +182,33 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 
-  // staging: one 64-key step = 4 NP KiB of K fragments + 4 NP KiB of V^T fragments, both contiguous in their images
+  // staging: one 64-key step = 4 NP KiB of K fragments + 4 NP KiB of V^T fragments, both contiguous in their images.
+  // Software pipeline: S(k+1) = K(k+1) Q^T is issued BEFORE the softmax of S(k), so one wave's MFMAs run under its own VALU work
+  // (as one block, QK^T -> softmax -> PV, a wave ran them strictly one after the other and only the SIMD's second wave overlapped
+  // them).  K therefore runs one step ahead of V in LDS: K(k+1), K(k+2 being written) | V(k), V(k+1 being written).
   const int nkt = (len + KSTEP - 1) / KSTEP;
+  constexpr int HALF = 4 * NP * FRAG;                   // bytes of the K (or V) fragments of one step
+  char* const sKb = smem_raw;                           // [2][HALF]
+  char* const sVb = smem_raw + 2 * HALF;                // [2][HALF]
   u32x4 st[2 * NP];
-  auto gload = [&](int kt) {
+  auto gload_k = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      st[i] = *reinterpret_cast<const u32x4*>(k6 + ibase + (int64_t)kt * 4 * NP * FRAG + (tid + 256 * i) * 16);
-      st[NP + i] = *reinterpret_cast<const u32x4*>(v6 + ibase + (int64_t)kt * 4 * NP * FRAG + (tid + 256 * i) * 16);
-    }
+    for (int i = 0; i < NP; ++i) st[i] = *reinterpret_cast<const u32x4*>(k6 + ibase + (int64_t)kt * HALF + (tid + 256 * i) * 16);
   };
-  auto swrite = [&](int buf) {
+  auto gload_v = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      *reinterpret_cast<u32x4*>(smem[buf] + (tid + 256 * i) * 16) = st[i];
-      *reinterpret_cast<u32x4*>(smem[buf] + 4 * NP * FRAG + (tid + 256 * i) * 16) = st[NP + i];
-    }
+    for (int i = 0; i < NP; ++i) st[NP + i] = *reinterpret_cast<const u32x4*>(v6 + ibase + (int64_t)kt * HALF + (tid + 256 * i) * 16);
   };
-  gload(0);
-  swrite(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) gload(kt + 1);
-    const char* sK = smem[buf] + lane * 16;
-    const char* sV = smem[buf] + 4 * NP * FRAG + lane * 16;
-    // ---- S^T = K Q^T for the 4 key tiles of this 64-key step (all scores first: ONE running-max update, one rescale of the
-    // output tile and 2 cross-lane swaps per query tile and step instead of two of each, and 4 independent chains for the
-    // scheduler to interleave)
-    f32x4 s[2][4];                                      // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
+  auto swrite_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sKb + (kt & 1) * HALF + (tid + 256 * i) * 16) = st[i];
+  };
+  auto swrite_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sVb + (kt & 1) * HALF + (tid + 256 * i) * 16) = st[NP + i];
+  };
+  auto qk = [&](int kt, f32x4 (&s)[2][4]) __attribute__((always_inline)) {      // S^T = K Q^T for the 4 key tiles of step kt
+    const char* sK = sKb + (kt & 1) * HALF + lane * 16;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       u32x4 kf[NP];
@@ -220,6 +217,18 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) s[qt][t] = mfma_split(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
     }
+  };
+  gload_k(0); gload_v(0);
+  swrite_k(0); swrite_v(0);
+  if (nkt > 1) { gload_k(1); swrite_k(1); }
+  __syncthreads();
+  f32x4 sA[2][4], sB[2][4];                             // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
+  qk(0, sA);
+  // one step: s = S(kt) (ready), sn receives S(kt+1)
+  auto step = [&](int kt, f32x4 (&s)[2][4], f32x4 (&sn)[2][4]) __attribute__((always_inline)) {
+    if (kt + 2 < nkt) gload_k(kt + 2);
+    if (kt + 1 < nkt) gload_v(kt + 1);
+    const char* sV = sVb + (kt & 1) * HALF + lane * 16;
     // ---- mask (last step only) + online softmax (lane: query ql of each tile; keys 16 t + 4 g4 + r)
     if (kt == nkt - 1) {
       const int kbase = kt * KSTEP + 4 * g4;
@@ -231,6 +240,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
           for (int r = 0; r < 4; ++r)
             if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
     }
+    qk(kt + 1, sn);                                     // (past the end: stale K fragments, finite garbage nobody reads)
     u32x4 pf[2][2][NP];                                 // [query tile][32-key group][plane]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -273,9 +283,13 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
       }
-    if (kt + 1 < nkt) swrite(buf ^ 1);
+    if (kt + 2 < nkt) swrite_k(kt + 2);                 // over K(kt): read one step ago
+    if (kt + 1 < nkt) swrite_v(kt + 1);                 // over V(kt-1)
     __syncthreads();
-    buf ^= 1;
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, sA, sB);
+    if (kt + 1 < nkt) step(kt + 1, sB, sA);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
