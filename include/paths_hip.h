@@ -106,6 +106,9 @@ int64_t paths_importance_proj_x6_workspace(int M);
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                      int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, paths_stream_t stream);
+/* The same product without bias / activation, A given as row ADDRESSES (planes = 2 only): row m = the K floats at a_rows[m]. */
+int paths_gemm_rows_nt_x6(const int64_t* a_rows, const void* w_x6, int Kpacked, int k0, float* out, int64_t ldo,
+                          int M, int Npad, int K, int planes, float w_scale, float a_scale, paths_stream_t stream);
 
 /* ---- backward-pass building blocks (reference: autograd of train.py:65 loss.backward()) --------------------------
  * paths_gemm_nt_f32: out (+)= maskop(act(a W^T + b)) + residual; with W = a transposed weight copy this is dX = dY W.
@@ -233,6 +236,11 @@ int paths_layernorm_f32(const float* x, const float* gamma, const float* beta, f
  * Order: score descending, ties by index ascending.  keep = -1 keeps every patch in original order. */
 int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, int n_max, int keep,
                int* keep_idx, int64_t ldk, int* keep_count, paths_stream_t stream);
+/* paths_topk + kept_rows[b, i] = address of row_base[b, keep_idx[b, i], 0] of a row-major [B, slide_rows, row_ld] float table
+ * (entries beyond keep_count[b] = zero_row): lets paths_gemm_rows_nt_x6 read the kept parents' rows in place. */
+int paths_topk_rows(const float* scores, int64_t ld, const int64_t* num_ims, int B, int n_max, int keep,
+                    int* keep_idx, int64_t ldk, int* keep_count, const float* row_base, int64_t row_ld, int64_t slide_rows,
+                    int64_t* kept_rows, const float* zero_row, paths_stream_t stream);
 
 /* 4-child expansion, bounds + background filter, stable compaction (reference data_utils/slide.py:303-331).
  *   mask_ptrs[b] -> uint8 [X*Y] tissue mask of the NEXT level (1 = row sum != 0).  status bit0: a slide

@@ -52,6 +52,8 @@ SIGNATURES = {
     "paths_final_head": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
     "paths_layernorm_f32": [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "paths_topk": [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp],
+    "paths_topk_rows": [_vp, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp],
+    "paths_gemm_rows_nt_x6": [_vp, _vp, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "paths_expand_children": [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "paths_gather_kept_rows": [_vp, _i64, _i64, _vp, _i64, _vp, _i32, _i32, _vp, _vp],
     "paths_gather_rows_bwd": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp],

@@ -674,4 +674,16 @@ int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked,
   return launch_x6<2, 4, 2, false>(planes, g, Npad, e, stream, "gemm_nt_x6");
 }
 
+// paths_gemm_nt_x6 without bias / activation, with the A operand given as row ADDRESSES (planes = 2): out[M, Npad] = A W^T where
+// row m of A is the K floats at a_rows[m] (16-byte aligned; e.g. kept parents' h rows inside the level's state tensor)
+int paths_gemm_rows_nt_x6(const int64_t* a_rows, const void* w_x6, int Kpacked, int k0, float* out, int64_t ldo,
+                          int M, int Npad, int K, int planes, float w_scale, float a_scale, hipStream_t stream) {
+  PATHS_REQUIRE(a_rows != nullptr && planes == 2 && pow2(w_scale) && pow2(a_scale), "gemm_rows_nt_x6: row addresses need planes = 2 with power-of-two scales");
+  PATHS_REQUIRE(k0 % 16 == 0 && k0 >= 0 && k0 + K <= Kpacked, "gemm_rows_nt_x6: bad k window");
+  X6Operands g{nullptr, K, K, a_rows, nullptr, 0, 0, nullptr, 0,
+               reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * planes * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
+  EpiBias e{nullptr, out, ldo, Npad, 0, nullptr, 0, nullptr, 0, 0, 1.0f / (w_scale * a_scale)};
+  return launch_x6<2, 4, 2, false>(planes, g, Npad, e, stream, "gemm_rows_nt_x6");
+}
+
 }  // extern "C"

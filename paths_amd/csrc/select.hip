@@ -24,14 +24,19 @@ constexpr int TOPK_MAX = 8192;
 
 __global__ void __launch_bounds__(1024)
 topk_kernel(const float* __restrict__ scores, int64_t ld, const int64_t* __restrict__ num_ims, int keep,
-            int* __restrict__ keep_idx, int64_t ldk, int* __restrict__ keep_count) {
+            int* __restrict__ keep_idx, int64_t ldk, int* __restrict__ keep_count,
+            const float* __restrict__ row_base, int64_t row_ld, int64_t slide_rows,        // optional: kept_rows[b, i] = address of
+            int64_t* __restrict__ kept_rows, const float* __restrict__ zero_row) {          // row_base[b, keep_idx[b, i], :] (zero_row beyond count)
   __shared__ unsigned long long keys[TOPK_MAX];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = (int)num_ims[b];
   const int count = keep < 0 ? n : min(n, keep);
   if (tid == 0) keep_count[b] = count;
+  auto row_addr = [&](int idx) { return (int64_t)reinterpret_cast<uintptr_t>(row_base + ((int64_t)b * slide_rows + idx) * row_ld); };
   if (keep < 0) {                                     // keep all, original order (slide.py:294 not taken)
     for (int i = tid; i < n; i += 1024) keep_idx[(int64_t)b * ldk + i] = i;
+    if (kept_rows)
+      for (int i = tid; i < ldk; i += 1024) kept_rows[(int64_t)b * ldk + i] = i < n ? row_addr(i) : (int64_t)reinterpret_cast<uintptr_t>(zero_row);
     return;
   }
   int np = 1;
@@ -66,6 +71,9 @@ topk_kernel(const float* __restrict__ scores, int64_t ld, const int64_t* __restr
   }
   __syncthreads();
   for (int i = tid; i < count; i += 1024) keep_idx[(int64_t)b * ldk + i] = (int)(uint32_t)keys[i];
+  if (kept_rows)
+    for (int i = tid; i < ldk; i += 1024)
+      kept_rows[(int64_t)b * ldk + i] = i < count ? row_addr((int)(uint32_t)keys[i]) : (int64_t)reinterpret_cast<uintptr_t>(zero_row);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,8 +377,24 @@ int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, i
   PATHS_REQUIRE(B > 0 && n_max > 0 && n_max <= TOPK_MAX, "topk: n_max (%d) must be in [1, %d]", n_max, TOPK_MAX);
   PATHS_REQUIRE(keep == -1 || keep > 0, "topk: keep must be -1 (all) or > 0");
   PATHS_REQUIRE(ldk >= (keep < 0 ? n_max : (keep < n_max ? keep : n_max)), "topk: keep_idx row too short");
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, stream, scores, ld, num_ims, keep, keep_idx, ldk, keep_count);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, stream, scores, ld, num_ims, keep, keep_idx, ldk, keep_count,
+                     (const float*)nullptr, (int64_t)0, (int64_t)0, (int64_t*)nullptr, (const float*)nullptr);
   PATHS_LAUNCH_CHECK("topk");
+  return PATHS_OK;
+}
+
+// paths_topk + the ADDRESS of every kept row of a row-major [B, slide_rows, row_ld] table (kept_rows [B, ldk]; entries beyond a
+// slide's keep_count point at zero_row): the once-per-parent GEMM reads the kept parents' h rows through them, in place.
+int paths_topk_rows(const float* scores, int64_t ld, const int64_t* num_ims, int B, int n_max, int keep,
+                    int* keep_idx, int64_t ldk, int* keep_count, const float* row_base, int64_t row_ld, int64_t slide_rows,
+                    int64_t* kept_rows, const float* zero_row, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && n_max > 0 && n_max <= TOPK_MAX, "topk_rows: n_max (%d) must be in [1, %d]", n_max, TOPK_MAX);
+  PATHS_REQUIRE(keep == -1 || keep > 0, "topk_rows: keep must be -1 (all) or > 0");
+  PATHS_REQUIRE(ldk >= (keep < 0 ? n_max : (keep < n_max ? keep : n_max)), "topk_rows: keep_idx row too short");
+  PATHS_REQUIRE(row_base && kept_rows && zero_row && row_ld > 0 && slide_rows >= n_max, "topk_rows: row table arguments");
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, stream, scores, ld, num_ims, keep, keep_idx, ldk, keep_count,
+                     row_base, row_ld, slide_rows, kept_rows, zero_row);
+  PATHS_LAUNCH_CHECK("topk_rows");
   return PATHS_OK;
 }
 

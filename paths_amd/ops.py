@@ -361,7 +361,8 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     return {"ctx_patch": state_out, "importance": importance, "tokens": tokens, "num_ims": num_ims}
 
 
-def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, keep_count: torch.Tensor) -> torch.Tensor:
+def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, keep_count: torch.Tensor,
+                    kept_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """HP[b*cap + i] = h1[b, keep_idx[b,i]] @ W_gates[:, D:2D]^T  (no bias) for the kept parents of every slide:
     [B*cap, 3Hc+D] in the packed gate-column order.  ~4x fewer rows than the children that will consume it."""
     B, N, Dp = state_out.shape
@@ -372,9 +373,15 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
     f32 = dict(device=state_out.device, dtype=torch.float32)
     st = _lib.stream()
     p = _lib.ptr
+    hp = torch.empty((B * cap, G), **f32)
+    if kept_rows is not None:
+        # default split mode: the GEMM reads the kept parents' h rows where they are (addresses from paths_topk_rows)
+        assert use_x6(D, Hc) and G % 256 == 0 and split_planes() == 2 and kept_rows.shape == (B, cap) and kept_rows.dtype == torch.int64
+        wg, wg_s = _x6_of(lstm_pack, "w_gates")
+        _lib.call("paths_gemm_rows_nt_x6", p(kept_rows), p(wg), 2 * D, D, p(hp), G, B * cap, G, D, 2, wg_s, a_scale(), st)
+        return hp
     hk = torch.empty((B * cap, D), **f32)
     _lib.call("paths_gather_kept_rows", p(state_out), N, Dp, p(keep_idx), cap, p(keep_count), D, B, p(hk), st)
-    hp = torch.empty((B * cap, G), **f32)
     if use_x6(D, Hc) and G % 256 == 0:
         wg, wg_s = _x6_of(lstm_pack, "w_gates")
         _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg), 2 * D, D, None, p(hp), G, B * cap, G, G, D, 0,

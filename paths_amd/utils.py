@@ -178,7 +178,14 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         cap_keep = N if keep < 0 else min(N, keep)
         keep_idx = torch.empty((B, cap_keep), **i32)
         keep_count = torch.empty((B,), **i32)
-        _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
+        kept_rows = None
+        if rows_in_place:
+            # ... with the addresses of the kept parents' h rows (row b, i -> ctx_patch[b, keep_idx[b, i], :D]) for the parent GEMM
+            kept_rows = torch.empty((B, cap_keep), **i64)
+            _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count),
+                      p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st)
+        else:
+            _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
         Nn = 4 * cap_keep
         # After the top-K the chain forks: the kept parents' h-partials (gather + GEMM, the longer branch) stay on this stream,
         # the child expansion and the row gathers (tiny latency-bound kernels) run beside them on a third stream and are joined
@@ -186,7 +193,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         forked = overlap and par_stream is not None and share_parent
         if forked:
             par_stream.wait_stream(main_stream)            # top-K indices are ready
-        hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count) if share_parent else None
+        hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count, kept_rows) if share_parent else None
         st2 = par_stream.cuda_stream if forked else st
         with (torch.cuda.stream(par_stream) if forked else contextlib.nullcontext()):
             def expand(cap):

@@ -540,3 +540,42 @@ def test_qkv_images_written_by_token_layer_equal_the_rewrite(dev, monkeypatch, n
     for key in ("logits", "ctx_slide", "importance", "ctx_patch"):
         assert torch.equal(out_direct[key], out_rewrite[key]), key
     np.testing.assert_allclose(out_direct["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+
+
+def test_topk_rows_and_row_addressed_gemm(dev):
+    """paths_topk_rows returns paths_topk's indices plus the address of every kept row (zero row beyond the count), and the GEMM
+    that reads its A operand through those addresses equals the one fed with a gathered copy, bit for bit."""
+    from paths_amd import _lib, ops
+    B, N, D, Dp, keep, G = 3, 700, 1024, 1280, 96, 512
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    scores = torch.rand(B, N, device=dev, generator=g)
+    state = (torch.rand(B, N, Dp, device=dev, generator=g) * 2 - 1) * 3
+    num_ims = torch.tensor([700, 50, 311], device=dev, dtype=torch.int64)
+    p, st = _lib.ptr, _lib.stream()
+    ki0 = torch.empty(B, keep, device=dev, dtype=torch.int32); kc0 = torch.empty(B, device=dev, dtype=torch.int32)
+    ki1 = torch.full((B, keep), -7, device=dev, dtype=torch.int32); kc1 = torch.empty(B, device=dev, dtype=torch.int32)
+    rows = torch.empty(B, keep, device=dev, dtype=torch.int64)
+    zero_row = torch.zeros(D, device=dev)
+    _lib.call("paths_topk", p(scores), N, p(num_ims), B, N, keep, p(ki0), keep, p(kc0), st)
+    _lib.call("paths_topk_rows", p(scores), N, p(num_ims), B, N, keep, p(ki1), keep, p(kc1), p(state), Dp, N, p(rows), p(zero_row), st)
+    torch.cuda.synchronize()
+    assert torch.equal(kc0, kc1)
+    for b in range(B):
+        c = int(kc0[b])
+        assert c == min(keep, int(num_ims[b])) and torch.equal(ki0[b, :c], ki1[b, :c])
+        want = state.data_ptr() + (b * N + ki0[b, :c].long()) * Dp * 4
+        assert torch.equal(rows[b, :c], want) and bool((rows[b, c:] == zero_row.data_ptr()).all())
+    w = (torch.rand(G, D, device=dev, generator=g) * 2 - 1) / 32
+    img, ws = ops.x6_pack(w, planes=2)
+    gathered = torch.zeros(B * keep, D, device=dev)
+    for b in range(B):
+        c = int(kc0[b])
+        gathered[b * keep:b * keep + c] = state[b, ki0[b, :c].long(), :D]
+    out_rows = torch.empty(B * keep, G, device=dev); out_copy = torch.empty(B * keep, G, device=dev)
+    _lib.call("paths_gemm_rows_nt_x6", p(rows), p(img), D, 0, p(out_rows), G, B * keep, G, D, 2, ws, ops.a_scale(), st)
+    _lib.call("paths_gemm_nt_x6", p(gathered), D, p(img), D, 0, None, p(out_copy), G, B * keep, G, G, D, 0, None, 0, None, 0, 0, 2, ws,
+              ops.a_scale(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out_rows, out_copy)
+    ref = gathered.double() @ w.double().t()
+    assert (out_rows.double() - ref).abs().max().item() < 2e-5
