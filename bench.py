@@ -248,7 +248,7 @@ def main():
     x6 = bool(events and events[0][3].get("x6"))
     planes = int(events[0][3].get("planes", 3)) if x6 else 0
     traffic = None            # HBM-side bytes per launch from the committed PMC passes (separate --pmc runs, profiles/)
-    prof = {2: "r01l_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
+    prof = {2: "r01m_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
     serialized_us = None      # the same kernel with nothing beside it (those passes serialise the streams)
     try:
         with open(os.path.join(ROOT, "profiles", prof)) as fh:
