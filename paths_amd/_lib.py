@@ -42,6 +42,8 @@ SIGNATURES = {
     "paths_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "paths_attention_token0_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "paths_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "paths_layernorm_bwd_sums": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "paths_reduce_slabs_f32": [_vp, _i32, _i32, _vp, _i32, _vp],
     "paths_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_attention_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_attention_x6": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],

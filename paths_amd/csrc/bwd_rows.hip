@@ -141,6 +141,40 @@ ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, cons
   *reinterpret_cast<float2*>(dyxhat + row * 128 + 2 * lane) = float2{d.x * xh.x, d.y * xh.y};
 }
 
+// ln_bwd_kernel + the column sums the affine gradients need, in one pass: a workgroup owns rows_per_block rows (wave w takes
+// rows w, w+4, ...), keeps sum(dy * xhat) (-> dgamma) and sum(dy) (-> dbeta) of its rows in registers and writes one 256-float
+// slab per workgroup (fixed order: deterministic); paths_reduce_slabs_f32 adds the slabs.  Replaces the dy*xhat tensor (written,
+// then read back by a column-sum launch) and two column-sum launch pairs per LayerNorm.
+__global__ void __launch_bounds__(256)
+ln_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                   const float* __restrict__ g, float* __restrict__ dx, float* __restrict__ slabs, int64_t rows, int rows_per_block) {
+  __shared__ float2 pg[4][64], pb[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
+  const float g0 = g[2 * lane], g1 = g[2 * lane + 1];
+  float2 sg{0.f, 0.f}, sb{0.f, 0.f};
+  for (int64_t row = row0 + wave; row < row1; row += 4) {
+    const float2 d = *reinterpret_cast<const float2*>(dy + row * 128 + 2 * lane);
+    const float2 xh = *reinterpret_cast<const float2*>(xhat + row * 128 + 2 * lane);
+    const float2 dg = {d.x * g0, d.y * g1};
+    const float m1 = wave_sum(dg.x + dg.y) * (1.0f / 128);
+    const float m2 = wave_sum(dg.x * xh.x + dg.y * xh.y) * (1.0f / 128);
+    const float rs = rstd[row];
+    *reinterpret_cast<float2*>(dx + row * 128 + 2 * lane) = float2{rs * (dg.x - m1 - xh.x * m2), rs * (dg.y - m1 - xh.y * m2)};
+    sg.x += d.x * xh.x; sg.y += d.y * xh.y;
+    sb.x += d.x; sb.y += d.y;
+  }
+  pg[wave][lane] = sg; pb[wave][lane] = sb;
+  __syncthreads();
+  if (wave == 0) {
+    float* o = slabs + (int64_t)blockIdx.x * 256;
+    const float2 a = pg[0][lane], b = pg[1][lane], c = pg[2][lane], d = pg[3][lane];
+    *reinterpret_cast<float2*>(o + 2 * lane) = float2{(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y)};
+    const float2 e = pb[0][lane], f = pb[1][lane], h = pb[2][lane], k = pb[3][lane];
+    *reinterpret_cast<float2*>(o + 128 + 2 * lane) = float2{(e.x + f.x) + (h.x + k.x), (e.y + f.y) + (h.y + k.y)};
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -185,6 +219,16 @@ int paths_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, c
   PATHS_REQUIRE(rows > 0 && d == 128 && dy && xhat && rstd && gamma && dx && dyxhat, "layernorm_bwd: bad arguments");
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dy, xhat, rstd, gamma, dx, dyxhat, rows);
   PATHS_LAUNCH_CHECK("layernorm_bwd");
+  return PATHS_OK;
+}
+
+// LayerNorm backward with the affine-gradient partial sums: slabs [ceil(rows / rows_per_block)][256] = sum(dy * xhat) | sum(dy)
+int paths_layernorm_bwd_sums(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* slabs,
+                             int64_t rows, int d, int rows_per_block, hipStream_t stream) {
+  PATHS_REQUIRE(rows > 0 && d == 128 && rows_per_block >= 4 && dy && xhat && rstd && gamma && dx && slabs, "layernorm_bwd_sums: bad arguments");
+  hipLaunchKernelGGL(ln_bwd_sums_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0, stream,
+                     dy, xhat, rstd, gamma, dx, slabs, rows, rows_per_block);
+  PATHS_LAUNCH_CHECK("layernorm_bwd_sums");
   return PATHS_OK;
 }
 

@@ -300,6 +300,15 @@ int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int 
   return PATHS_OK;
 }
 
+// out[n] (+)= sum over `splits` slabs of n floats each, fixed order (the second half of paths_colsum_f32, for producers that write
+// their own slabs: paths_layernorm_bwd_sums)
+int paths_reduce_slabs_f32(const float* slabs, int splits, int n, float* out, int accumulate, hipStream_t stream) {
+  PATHS_REQUIRE(slabs && out && splits > 0 && n > 0, "reduce_slabs: bad arguments");
+  hipLaunchKernelGGL(reduce_slabs_small_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, slabs, splits, n, out, accumulate);
+  PATHS_LAUNCH_CHECK("reduce_slabs");
+  return PATHS_OK;
+}
+
 int paths_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, hipStream_t stream) {
   PATHS_REQUIRE(R > 0 && C > 0 && in && out && ldi >= C && ldo >= R, "transpose: bad arguments");
   hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, in, ldi, R, C, out, ldo);
