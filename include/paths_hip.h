@@ -142,8 +142,9 @@ int paths_layernorm_fwd_stats(const float* x, const float* add, const float* gam
                               float* rstd, int64_t rows, int d, float eps, paths_stream_t stream);
 int paths_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* dyxhat,
                         int64_t rows, int d, paths_stream_t stream);
-/* paths_layernorm_bwd without the dy*xhat tensor: every workgroup of rows_per_block rows also writes one 256-float slab
- * sum(dy * xhat) | sum(dy) of its rows; paths_reduce_slabs_f32 over the ceil(rows / rows_per_block) slabs gives dgamma | dbeta. */
+/* paths_layernorm_bwd without the dy*xhat tensor: every workgroup of rows_per_block rows also writes one 384-float slab
+ * sum(dy * xhat) | sum(dy) | sum(dx) of its rows; paths_reduce_slabs_f32 over the ceil(rows / rows_per_block) slabs gives
+ * dgamma | dbeta | column sums of dx (the gradient of a bias added in front of the LayerNorm). */
 int paths_layernorm_bwd_sums(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* slabs,
                              int64_t rows, int d, int rows_per_block, paths_stream_t stream);
 int paths_reduce_slabs_f32(const float* slabs, int splits, int n, float* out, int accumulate, paths_stream_t stream);

@@ -238,16 +238,16 @@ def _ln_bwd(dy, xh, rs, g, rows):
 
 
 def _ln_bwd_sums(dy, xh, rs, g, rows):
-    """LayerNorm backward + affine gradients in two launches: (dx, dgamma, dbeta)."""
+    """LayerNorm backward + affine gradients + column sums of dx in two launches: (dx, dgamma, dbeta, colsum(dx))."""
     f32 = _f32(dy.device)
     dx = torch.empty((rows, 128), **f32)
     rpb = 64
     nblk = (rows + rpb - 1) // rpb
-    slabs = torch.empty((nblk, 256), **f32)
+    slabs = torch.empty((nblk, 384), **f32)
     _lib.call("paths_layernorm_bwd_sums", P(dy), P(xh), P(rs), P(g), P(dx), P(slabs), rows, 128, rpb, _lib.stream())
-    gb = torch.empty((256,), **f32)
-    _lib.call("paths_reduce_slabs_f32", P(slabs), nblk, 256, P(gb), 0, _lib.stream())
-    return dx, gb[:128], gb[128:]
+    gb = torch.empty((384,), **f32)
+    _lib.call("paths_reduce_slabs_f32", P(slabs), nblk, 384, P(gb), 0, _lib.stream())
+    return dx, gb[:128], gb[128:256], gb[256:]
 
 
 def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dx_out: torch.Tensor, dev):
@@ -268,8 +268,7 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
     gemm_nt(hid, 512, w["w2"], u3, 128, M, 128, 512, bias=w["b2"], residual=n2, ldr=128)
     _, xh3, rs3 = _ln_fwd(u3, None, w["ln3g"], w["ln3b"], M, eps, want_y=False)
     # ---- backward
-    du3, g["ln3g"], g["ln3b"] = _ln_bwd_sums(dx_out, xh3, rs3, w["ln3g"], M)
-    g["b2"] = colsum(du3, 128, M, 128)
+    du3, g["ln3g"], g["ln3b"], g["b2"] = _ln_bwd_sums(dx_out, xh3, rs3, w["ln3g"], M)
     dhid = torch.empty((M, 512), **f32)
     gemm_nt(du3, 128, transpose(w["w2"], 128, 512), dhid, 512, M, 512, 128, mask=hid, ldm=512)
     g["w2"] = torch.empty((128, 512), **f32)
@@ -279,10 +278,8 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
     g["w1"] = torch.empty((512, 128), **f32)
     gemm_tn(dhid, 512, n2, 128, g["w1"], M, 512, 128)
     g["b1"] = colsum(dhid, 512, M, 512)
-    du2, g["ln2g"], g["ln2b"] = _ln_bwd_sums(dn2, xh2, rs2, w["ln2g"], M)
-    g["cab"] = colsum(du2, 128, M, 128)
-    du1, g["ln1g"], g["ln1b"] = _ln_bwd_sums(du2, xh1, rs1, w["ln1g"], M)
-    g["bo"] = colsum(du1, 128, M, 128)
+    du2, g["ln2g"], g["ln2b"], g["cab"] = _ln_bwd_sums(dn2, xh2, rs2, w["ln2g"], M)
+    du1, g["ln1g"], g["ln1b"], g["bo"] = _ln_bwd_sums(du2, xh1, rs1, w["ln1g"], M)
     dattn = torch.empty((M, 128), **f32)
     gemm_nt(du1, 128, transpose(w["wo"], 128, 128), dattn, 128, M, 128, 128)
     g["wo"] = torch.empty((128, 128), **f32)

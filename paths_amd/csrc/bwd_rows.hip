@@ -142,17 +142,17 @@ ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, cons
 }
 
 // ln_bwd_kernel + the column sums the affine gradients need, in one pass: a workgroup owns rows_per_block rows (wave w takes
-// rows w, w+4, ...), keeps sum(dy * xhat) (-> dgamma) and sum(dy) (-> dbeta) of its rows in registers and writes one 256-float
-// slab per workgroup (fixed order: deterministic); paths_reduce_slabs_f32 adds the slabs.  Replaces the dy*xhat tensor (written,
+// rows w, w+4, ...), keeps sum(dy * xhat) (-> dgamma), sum(dy) (-> dbeta) and sum(dx) (-> the bias in front of this LayerNorm) of its rows in
+// registers and writes one 384-float slab per workgroup (fixed order: deterministic); paths_reduce_slabs_f32 adds the slabs.  Replaces the dy*xhat tensor (written,
 // then read back by a column-sum launch) and two column-sum launch pairs per LayerNorm.
 __global__ void __launch_bounds__(256)
 ln_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
                    const float* __restrict__ g, float* __restrict__ dx, float* __restrict__ slabs, int64_t rows, int rows_per_block) {
-  __shared__ float2 pg[4][64], pb[4][64];
+  __shared__ float2 pg[4][64], pb[4][64], px[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * rows_per_block, row1 = min(rows, row0 + rows_per_block);
   const float g0 = g[2 * lane], g1 = g[2 * lane + 1];
-  float2 sg{0.f, 0.f}, sb{0.f, 0.f};
+  float2 sg{0.f, 0.f}, sb{0.f, 0.f}, sx{0.f, 0.f};
   for (int64_t row = row0 + wave; row < row1; row += 4) {
     const float2 d = *reinterpret_cast<const float2*>(dy + row * 128 + 2 * lane);
     const float2 xh = *reinterpret_cast<const float2*>(xhat + row * 128 + 2 * lane);
@@ -160,18 +160,22 @@ ln_bwd_sums_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
     const float m1 = wave_sum(dg.x + dg.y) * (1.0f / 128);
     const float m2 = wave_sum(dg.x * xh.x + dg.y * xh.y) * (1.0f / 128);
     const float rs = rstd[row];
-    *reinterpret_cast<float2*>(dx + row * 128 + 2 * lane) = float2{rs * (dg.x - m1 - xh.x * m2), rs * (dg.y - m1 - xh.y * m2)};
+    const float2 o2{rs * (dg.x - m1 - xh.x * m2), rs * (dg.y - m1 - xh.y * m2)};
+    *reinterpret_cast<float2*>(dx + row * 128 + 2 * lane) = o2;
     sg.x += d.x * xh.x; sg.y += d.y * xh.y;
     sb.x += d.x; sb.y += d.y;
+    sx.x += o2.x; sx.y += o2.y;
   }
-  pg[wave][lane] = sg; pb[wave][lane] = sb;
+  pg[wave][lane] = sg; pb[wave][lane] = sb; px[wave][lane] = sx;
   __syncthreads();
   if (wave == 0) {
-    float* o = slabs + (int64_t)blockIdx.x * 256;
+    float* o = slabs + (int64_t)blockIdx.x * 384;
     const float2 a = pg[0][lane], b = pg[1][lane], c = pg[2][lane], d = pg[3][lane];
     *reinterpret_cast<float2*>(o + 2 * lane) = float2{(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y)};
     const float2 e = pb[0][lane], f = pb[1][lane], h = pb[2][lane], k = pb[3][lane];
     *reinterpret_cast<float2*>(o + 128 + 2 * lane) = float2{(e.x + f.x) + (h.x + k.x), (e.y + f.y) + (h.y + k.y)};
+    const float2 q0 = px[0][lane], q1 = px[1][lane], q2 = px[2][lane], q3 = px[3][lane];
+    *reinterpret_cast<float2*>(o + 256 + 2 * lane) = float2{(q0.x + q1.x) + (q2.x + q3.x), (q0.y + q1.y) + (q2.y + q3.y)};
   }
 }
 
@@ -222,7 +226,7 @@ int paths_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, c
   return PATHS_OK;
 }
 
-// LayerNorm backward with the affine-gradient partial sums: slabs [ceil(rows / rows_per_block)][256] = sum(dy * xhat) | sum(dy)
+// LayerNorm backward with the affine-gradient partial sums: slabs [ceil(rows / rows_per_block)][384] = sum(dy * xhat) | sum(dy) | sum(dx)
 int paths_layernorm_bwd_sums(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* slabs,
                              int64_t rows, int d, int rows_per_block, hipStream_t stream) {
   PATHS_REQUIRE(rows > 0 && d == 128 && rows_per_block >= 4 && dy && xhat && rstd && gamma && dx && slabs, "layernorm_bwd_sums: bad arguments");
