@@ -12,6 +12,7 @@ plus the row-wise derivative kernels of csrc/bwd_rows.hip and the attention back
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -19,6 +20,7 @@ import torch
 from . import _lib, ops
 
 P = _lib.ptr
+TN_SPLIT2 = int(os.environ.get("PATHS_TN_SPLIT2", "2"))
 
 
 def _f32(dev):
@@ -28,7 +30,9 @@ def _f32(dev):
 def _splits(M: int, n_tiles: int) -> int:
     """Split the row reduction so that about 2 x 256 workgroups are in flight, each with >= 256 rows."""
     if n_tiles >= 192:
-        return 1                      # already about one workgroup per CU: no split, result written in place
+        # about one workgroup per CU: TN_SPLIT2 = two half-height workgroups per CU instead (they hide each other's barrier and
+        # load stalls), at the price of one slab reduction
+        return TN_SPLIT2 if (TN_SPLIT2 > 1 and n_tiles <= 256 and M >= 4096) else 1
     return max(1, min(64, (512 + n_tiles - 1) // n_tiles, M // 256 if M >= 256 else 1))
 
 
