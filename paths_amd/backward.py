@@ -113,11 +113,12 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
         ld, h0, c0 = 0, None, None
     x6 = ops.use_x6(D, Hc)        # forward GEMMs on the split-bf16 path (weight images are re-packed when the optimizer steps)
     if x6:
-        TP = ops.TRAIN_PLANES
-        (wg, wg_s), (wm, wm_s) = ops._x6_of(lstm_pack, "w_gates", TP), ops._x6_of(lstm_pack, "w_mem", TP)
+        TP = ops.TRAIN_FWD_PLANES
+        asc = ops.A_SCALE if TP == 2 else 1.0
+        (wg, wg_s), (wm, wm_s) = ops._x6_of(lstm_pack, "w_gates", TP, lagged=True), ops._x6_of(lstm_pack, "w_mem", TP, lagged=True)
         _lib.call("paths_lstm_cell_x6", P(fts), D, None, h0, ld, c0, ld, P(wg), P(lstm_pack["b_gates"]), P(wm), P(lstm_pack["b_mem"]),
                   P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7,
-                  TP, wg_s, wm_s, 1.0, st)
+                  TP, wg_s, wm_s, asc, st)
     else:
         _lib.call("paths_lstm_cell", P(fts), D, h0, ld, c0, ld, P(lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
                   P(lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp,
@@ -132,8 +133,9 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
             P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
             P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)
     if x6:
-        wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd", ops.TRAIN_PLANES)
-        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, None, 0, P(wip), *tail[:-1], ops.TRAIN_PLANES, wip_s, 1.0, None, tail[-1])
+        TP = ops.TRAIN_FWD_PLANES
+        wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd", TP, lagged=True)
+        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, None, 0, P(wip), *tail[:-1], TP, wip_s, ops.A_SCALE if TP == 2 else 1.0, None, tail[-1])
     else:
         _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), *tail)
     return sv
@@ -311,7 +313,7 @@ def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries):
     products) unless PATHS_GEMM_MODE=f32."""
     st = _lib.stream()
     if ops.GEMM_MODE != "f32":
-        TP = ops.TRAIN_PLANES
+        TP = ops.TRAIN_FWD_PLANES
         ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, TP)),), device=q.device, dtype=torch.uint8)
         _lib.call("paths_attention_x6", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP, 0, st)
     else:

@@ -35,6 +35,8 @@ KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set b
 GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "h3")
 A_SCALE = float(os.environ.get("PATHS_H3_A_SCALE", "16"))      # a power of two
 TRAIN_PLANES = 3        # training re-images weights every step: the bf16 split needs no scale, i.e. no host sync on max|w|
+# forward GEMMs / attention of the TRAINING step: 2 = the inference split (fp16 planes) with lagged weight scales, 3 = exact bf16
+TRAIN_FWD_PLANES = int(os.environ.get("PATHS_TRAIN_FWD_PLANES", "2"))
 
 
 def split_planes() -> int:
@@ -47,7 +49,7 @@ def a_scale() -> float:
     return A_SCALE if GEMM_MODE == "h3" else 1.0
 
 
-def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] = None):
+def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] = None, w_scale: Optional[float] = None):
     """fp32 [N, K] device weight -> (split tiled image as a byte tensor, w_scale)  (paths_x6_pack_weights).
     planes 3: exact bf16 hi|mid|lo, w_scale 1.  planes 2: fp16 hi|lo of w * w_scale, w_scale = the power of two that puts
     max|w| into [8192, 16384) (one host sync per weight version)."""
@@ -55,8 +57,9 @@ def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] 
     planes = split_planes() if planes is None else planes
     N, K = w.shape
     n_pad = N if n_pad is None else n_pad
-    w_scale = 1.0
-    if planes == 2:
+    if planes != 2:
+        w_scale = 1.0
+    elif w_scale is None:
         w_scale = _pow2_scale(w)
     out = torch.empty((n_pad * K * 2 * planes,), device=w.device, dtype=torch.uint8)
     _lib.call("paths_x6_pack_weights", _lib.ptr(w), w.stride(0), _lib.ptr(out), N, n_pad, K, planes, w_scale, _lib.stream())
@@ -67,6 +70,30 @@ def _pow2_scale(w: torch.Tensor) -> float:
     """The power of two that puts max|w| into [8192, 16384) (fp16 operand scaling; one host sync)."""
     amax = float(w.abs().max())
     return 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax)))) if amax > 0 and math.isfinite(amax) else 1.0
+
+
+_LAGGED_SCALES: Dict[object, list] = {}
+
+
+def _pow2_scale_lagged(w: torch.Tensor, key) -> float:
+    """:func:`_pow2_scale` without a host sync after the first call per ``key``: training re-images its weights every step, so
+    the scale in use is the one computed from an EARLIER version of the same weight (its max|w| is reduced on the device, copied
+    to pinned memory asynchronously and picked up once the copy has landed).  The scale leaves a factor 4 of fp16 headroom above
+    max|w|, which no optimizer step at the reference's learning rates can cross between two refreshes."""
+    ent = _LAGGED_SCALES.get(key)
+    if ent is None:
+        ent = _LAGGED_SCALES[key] = [_pow2_scale(w), None, torch.empty((1,), dtype=torch.float32).pin_memory()]
+    elif ent[1] is not None and ent[1].query():
+        amax = float(ent[2][0])
+        if amax > 0 and math.isfinite(amax):
+            ent[0] = 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax))))
+        ent[1] = None
+    if ent[1] is None:
+        ent[2].copy_(w.detach().abs().max().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[1] = ev
+    return ent[0]
 
 
 def tlayer_h3_images(layer: Dict[str, object], part: int):
@@ -85,13 +112,14 @@ def tlayer_h3_images(layer: Dict[str, object], part: int):
     return layer[key]
 
 
-def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None):
+def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None, lagged: bool = False):
     """(image, w_scale) of pack[key] for the given (default: current) split, built on first use and cached beside it (the pack
-    dict is rebuilt when weights change)."""
+    dict is rebuilt when weights change).  ``lagged`` (training, two-plane split): see :func:`_pow2_scale_lagged`."""
     planes = split_planes() if planes is None else planes
     k6 = f"{key}_split{planes}"
     if k6 not in pack:
-        pack[k6] = x6_pack(pack[key], planes=planes)
+        ws = _pow2_scale_lagged(pack[key], (pack.get("_owner"), key)) if (lagged and planes == 2) else None
+        pack[k6] = x6_pack(pack[key], planes=planes, w_scale=ws)
     return pack[k6]
 
 
@@ -141,6 +169,7 @@ def pack_lstm(lstm) -> Dict[str, torch.Tensor]:
             "w_mem": mo.weight.detach().float().contiguous(),
             "b_mem": mo.bias.detach().float().contiguous(),
             "Hc": Hc,
+            "_owner": id(lstm),
         }
     lstm._paths_pack = (key, packed)
     return packed
@@ -192,6 +221,7 @@ def pack_level(proc) -> Dict[str, object]:
             "lnfg": c(agg.transformer.decoder.norm.weight), "lnfb": c(agg.transformer.decoder.norm.bias),
             "lnf_eps": float(agg.transformer.decoder.norm.eps),
             "wcls": c(proc.classification_layer.weight), "bcls": c(proc.classification_layer.bias),
+            "_owner": id(proc),
         }
         if hasattr(proc, "hctx_mlp"):      # lstm=false: RNN hierarchical context (reference model/paths.py:49-54)
             packed.update({"wh1": c(proc.hctx_mlp[0].weight), "bh1": c(proc.hctx_mlp[0].bias),
