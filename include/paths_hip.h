@@ -58,7 +58,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
  *   evaluating them).  The caller guarantees 0 <= locs / patch_size < pe_rows (paths_amd passes the level's grid size);
  *   positions are clamped into the table for memory safety only. */
 int paths_pe_table(const float* div_term, int pe_mode, int d, int rows, float* out, paths_stream_t stream);
-int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const float* b1, const float* w2, float b2,
+int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const float* b1, const float* w2, const float* b2 /* device scalar */,
                           const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows,
                           const int64_t* locs,
                           const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
@@ -92,7 +92,7 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
 /* w_ip_x6 = pack of [256, D] (rows interleaved as for paths_importance_proj); y_add (optional): GEMM input = y + y_add summed
  * in fp32 while staging, so that the caller can pass (x, h1) and skip materialising Y = X + h1; y_rows (optional, planes = 2):
  * row addresses of y instead of (y, ldy) */
-int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, const float* b2 /* device scalar */,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows,
                              const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,

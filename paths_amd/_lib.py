@@ -22,13 +22,13 @@ SIGNATURES = {
     "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                         _i32, _i32, _i32, _vp, _i32, _i32, _vp],
     "paths_pe_table": [_vp, _i32, _i32, _i32, _vp, _vp],
-    "paths_importance_proj": [_vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
+    "paths_importance_proj": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                               _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_gemm_nt_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp],
     "paths_x6_pack_weights": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "paths_lstm_cell_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i32, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
-    "paths_importance_proj_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
+    "paths_importance_proj_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp],
     "paths_gemm_nt_x6": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32,
                          _i32, _f32, _f32, _vp],

@@ -128,7 +128,7 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
     sv["hid"] = torch.empty((B, N, 128), **f32)
     sv["pproj"] = torch.empty((B, N, 128), **f32)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
-    tail = (P(lvl_pack["b1"]), P(lvl_pack["w2"]), lvl_pack["b2"],
+    tail = (P(lvl_pack["b1"]), P(lvl_pack["w2"]), P(lvl_pack["b2"]),
             P(lvl_pack["bp"]), P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), None, 0, P(locs),
             P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
             P(sv["tokens"]), P(sv["hid"]), P(sv["pproj"]), M, D, mc.importance_mlp_hidden_dim, d, 0, st)

@@ -374,7 +374,7 @@ struct EpiImpProj {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  const float* b1; const float* w2; float b2;
+  const float* b1; const float* w2; const float* b2;   // b2: device pointer to the scalar bias of the importance MLP's last layer
   const float* bp;                 // proj_in bias [d]
   const float* special;            // special token [d]
   const float* div_term;           // 2d: [d/4] ; 1d: [d/2]   (host: torch.exp(arange * -ln(1e4)/d), utils.py:18,56)
@@ -455,6 +455,7 @@ struct EpiImpProj {
     }
     __syncthreads();
     // ---- phase B (all waves): alpha of every row (both column halves compute the same value), tokens of this wave's 64 channels
+    const float b2v = *b2;
     float bpv[2], dtv[2], spv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -492,7 +493,7 @@ struct EpiImpProj {
           b = small_rows ? div_u24(row, rows_per_slide, rps_inv) : row / rows_per_slide; idx = row - b * rows_per_slide; nim = (int)num_ims[b];
         }
         float a = 0.f;
-        if (idx < nim) a = sigmoid_acc((alpha_p[lrow] + alpha_p[RB + lrow]) + b2);
+        if (idx < nim) a = sigmoid_acc((alpha_p[lrow] + alpha_p[RB + lrow]) + b2v);
         if (wn == 0 && (lane & 31) == 0 && rowr < M) importance[rowr] = a;
         av[r] = imp_mul ? a : 1.f;
         tokrow[r] = b * (rows_per_slide + 1) + idx + 1;                   // token row (row 0 of a slide = special token)

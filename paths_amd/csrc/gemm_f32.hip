@@ -252,7 +252,7 @@ int paths_lstm_cell(const float* x, int64_t ldx, const float* h0, int64_t ldh0, 
 }
 
 int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256, D]: W1 ; Wp*/,
-                          const float* b1, const float* w2, float b2, const float* bp, const float* special,
+                          const float* b1, const float* w2, const float* b2, const float* bp, const float* special,
                           const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims,
                           int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                           float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
@@ -261,6 +261,7 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip /*[256,
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj: 2d positional encoding needs locs");
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj: bad slide layout");
+  PATHS_REQUIRE(b1 != nullptr && w2 != nullptr && b2 != nullptr, "importance_proj: b1, w2 and b2 (device scalar) are required");
   GemmOperands g{y, ldy, D, nullptr, 0, 0, w_ip, D, M, skip_padding ? num_ims : nullptr, rows_per_slide};
   PATHS_REQUIRE((save_hid == nullptr) == (save_pproj == nullptr), "importance_proj: save_hid and save_pproj come together");
   PATHS_REQUIRE(pe_table == nullptr || pe_rows > 0, "importance_proj: pe_rows must be > 0 with a pe_table");

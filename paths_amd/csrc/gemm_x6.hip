@@ -610,7 +610,7 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
 // bytes of the optional split-K workspace of paths_importance_proj_x6 (two k halves of raw [M_pad, 256] accumulators)
 int64_t paths_importance_proj_x6_workspace(int M) { return 2ll * ((M + 127) / 128 * 4) * 8 * 1024 * 4; }
 
-int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, float b2,
+int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6, const float* b1, const float* w2, const float* b2,
                              const float* bp, const float* special, const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs,
                              const int64_t* num_ims, int rows_per_slide, int patch_size, int pe_mode, int imp_mul,
                              float* importance, float* tokens, float* save_hid, float* save_pproj, int M, int D, int Hi, int d,
@@ -619,6 +619,7 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_proj_x6: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_mode == 1 || locs != nullptr, "importance_proj_x6: 2d positional encoding needs locs");
   PATHS_REQUIRE(num_ims != nullptr && rows_per_slide > 0 && M % rows_per_slide == 0, "importance_proj_x6: bad slide layout");
+  PATHS_REQUIRE(b1 != nullptr && w2 != nullptr && b2 != nullptr, "importance_proj_x6: b1, w2 and b2 (device scalar) are required");
   PATHS_REQUIRE(y_add == nullptr || (ldya % 4 == 0 && (uintptr_t)y_add % 16 == 0), "importance_proj_x6: y_add must be 16-byte aligned with ldya %% 4 == 0");
   PATHS_REQUIRE(planes == 3 || (pow2(w_scale) && pow2(a_scale)), "importance_proj_x6: scales must be powers of two");
   if (planes == 3) w_scale = a_scale = 1.0f;

@@ -212,7 +212,7 @@ def pack_level(proc) -> Dict[str, object]:
             "w_ip_fwd": torch.cat([proc.importance_mlp[0].weight[:64], agg.proj_in.weight[:64],
                                    proc.importance_mlp[0].weight[64:], agg.proj_in.weight[64:]], dim=0).float().contiguous(),
             "b1": c(proc.importance_mlp[0].bias), "w2": c(proc.importance_mlp[2].weight.view(-1)),
-            "b2": float(proc.importance_mlp[2].bias.item()),
+            "b2": c(proc.importance_mlp[2].bias.view(-1)),        # read on the device (a .item() here was a host sync per re-pack)
             "bp": c(agg.proj_in.bias), "special": c(agg.special_token),
             # same expressions as reference utils.py:18 / :56, evaluated on the CPU like the CPU reference
             "div_1d": torch.exp(torch.arange(0, d, 2) * (-math.log(k) / d)).float().to(dev),
@@ -301,7 +301,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
 
     def importance_proj(src, imp_mul, imp_out, add=None):
         """tokens / importance from ``src`` (+ ``add``: x6 only, the GEMM input is src + add, row stride of add arbitrary)."""
-        common = (p(lvl_pack["b1"]), p(lvl_pack["w2"]), lvl_pack["b2"],
+        common = (p(lvl_pack["b1"]), p(lvl_pack["w2"]), p(lvl_pack["b2"]),
                   p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]),
                   p(pe_tab), pe_tab.shape[0] if pe_tab is not None else 0, p(locs),
                   p(num_ims), N, mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), None, None,

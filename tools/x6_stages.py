@@ -43,6 +43,7 @@ locs = torch.randint(0, 1024, (Mi, 2), device=dev, dtype=torch.int64, generator=
 petab = ops.pe_table({"div_2d": (torch.rand(32, device=dev, generator=g))}, 2, 128, 1024)
 imp, tok = torch.empty(Mi, device=dev), torch.empty(B, N + 1, 128, device=dev)
 b1, w2, bp, sp, div = rnd(128), rnd(128), rnd(128), rnd(128), rnd(32)
+b2s = torch.full((1,), 0.1, device=dev)
 p, st = _lib.ptr, _lib.stream
 lib = _lib.load()
 lib.paths_x6_debug_buffer.argtypes = [C.c_void_p]; lib.paths_x6_debug_buffer.restype = None
@@ -53,7 +54,7 @@ def lstm(ph):
 def parent():
     _lib.call("paths_gemm_nt_x6", p(hk), D, p(wg6), 2 * D, D, None, p(hp), G, MP, G, G, D, 0, None, 0, None, 0, 0, PL, wgs, AS, st())
 def impproj():
-    _lib.call("paths_importance_proj_x6", p(yi), D, None, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), 0.1, p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
+    _lib.call("paths_importance_proj_x6", p(yi), D, None, p(yadd) if USE_ADD else None, D, p(wip6), p(b1), p(w2), p(b2s), p(bp), p(sp), p(div), p(petab) if USE_TAB else None, petab.shape[0] if USE_TAB else 0, p(locs), p(num_ims), N, 256, 2, 1,
               p(imp), p(tok), None, None, Mi, D, 128, 128, 1, PL, wips, AS, None, st())
 
 USE_TAB = True
