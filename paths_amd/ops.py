@@ -85,7 +85,13 @@ def _pow2_scale_lagged(w: torch.Tensor, key) -> float:
         ent = _LAGGED_SCALES[key] = [_pow2_scale(w), None, torch.empty((1,), dtype=torch.float32).pin_memory()]
     elif ent[1] is not None and ent[1].query():
         amax = float(ent[2][0])
-        if amax > 0 and math.isfinite(amax):
+        if not math.isfinite(amax) or amax * ent[0] >= 65504.0:
+            # the scale used since the last refresh was too large for this weight (or the weight is not finite): the fp16 planes
+            # built with it overflowed.  Loud, if late; weights replaced wholesale must call reset_lagged_scales() (load_state does)
+            _LAGGED_SCALES.pop(key, None)
+            raise _lib.PathsHipError(f"weight {key!r}: max|w| = {amax} left the fp16 range of its lagged scale {ent[0]}; "
+                                     "call paths_amd.ops.reset_lagged_scales() after replacing weights")
+        if amax > 0:
             ent[0] = 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax))))
         ent[1] = None
     if ent[1] is None:
@@ -94,6 +100,12 @@ def _pow2_scale_lagged(w: torch.Tensor, key) -> float:
         ev.record()
         ent[1] = ev
     return ent[0]
+
+
+def reset_lagged_scales():
+    """Forget the lagged weight scales (next use recomputes them with a host sync): call after loading a checkpoint or any other
+    wholesale replacement of the weights of a model that is being trained."""
+    _LAGGED_SCALES.clear()
 
 
 def tlayer_h3_images(layer: Dict[str, object], part: int):

@@ -37,6 +37,8 @@ def load_state(root_path: str, model, map_location=None) -> Dict:
     stats_path = os.path.join(root_path, "train_stats.pkl")
     if os.path.isfile(model_path):
         model.load_state_dict(torch.load(model_path, map_location=map_location))
+        from . import ops
+        ops.reset_lagged_scales()          # the training forward's fp16 weight scales lag one step behind the weights
     if not os.path.isfile(stats_path):
         return {"epoch": 1}
     with open(stats_path, "rb") as fh:

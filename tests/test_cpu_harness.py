@@ -103,3 +103,11 @@ def test_importance_map_weighting():
     np.testing.assert_allclose(m[2, 0], 0.8 + 1e-4 + 0.5 * (0.5 + 1e-4))
     np.testing.assert_allclose(m[3, 1], 0.8 + 1e-4 + 0.5 * (0.1 + 1e-4))
     np.testing.assert_allclose(m[2, 1], 0.8 + 1e-4)                                  # child filtered out (background)
+
+
+def test_lagged_scale_registry_resets():
+    """The training forward's lagged fp16 weight scales are dropped when weights are replaced wholesale."""
+    from paths_amd import ops
+    ops._LAGGED_SCALES[("x", "w")] = [2.0, None, None]
+    ops.reset_lagged_scales()
+    assert not ops._LAGGED_SCALES
