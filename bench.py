@@ -224,10 +224,11 @@ def main():
     out = None
     for _ in range(args.steps):
         out = step()
+    t_enqueued = time.perf_counter() - t0          # host side done (diagnostic: is the Python launch path ahead of the GPU?)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
-    log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
+    log(f"timed region: {args.steps} steps in {elapsed:.4f} s (all launches enqueued after {t_enqueued:.4f} s)")
     status = int(out["status"].item())
     assert status == 0, f"recursion status {status}"
     elapsed = pdist.max_over_ranks(elapsed, dev_reduce)
