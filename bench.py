@@ -38,6 +38,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)" (me
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 MFMA_PER_PRODUCT = {3: 6, 2: 3}   # 16-bit MFMAs issued per fp32 product block: 3 bf16 planes ("x6") / 2 fp16 planes ("h3")
 BASE_SHAPES = {2048: (32, 64), 1024: (32, 32), 256: (16, 16)}
+CPU_DSEED = 1234
+# slide ids of the cpu_baseline / parity sample: screened here with the oracle so that every level's top-K boundary gap
+# (score[k-1] - score[k]) is >= 1e-5 with the bench weights (seed 0) - the reference's own selection is thread-count
+# dependent below ~1e-6 (hard part 1); id 10001 at K=2048 has a 2.4e-7 gap at level 0 and is left out
+CPU_SLIDE_IDS = {2048: [10003, 10004, 10005, 10002], 1024: [10000, 10001, 10003, 10002], 256: [10000, 10001, 10002, 10003]}
 
 
 def log(msg):
@@ -93,10 +98,13 @@ def cpu_baseline(cfg, sd, K: int, n_slides: int, reps: int):
     log(f"cpu_baseline: {threads} threads (os.cpu_count()={os.cpu_count()}), {n_slides} slides x {reps} reps")
     ocfg = orc.OracleConfig(top_k_patches=list(cfg.top_k_patches))
     params = {k: torch.from_numpy(v) for k, v in sd.items()}
-    grids = [CachedGrids(syn.SyntheticSlide(1234, 10_000 + i, BASE_SHAPES[K])) for i in range(n_slides)]
+    ids = CPU_SLIDE_IDS[K][:n_slides]
+    assert len(ids) == n_slides, f"at most {len(CPU_SLIDE_IDS[K])} screened cpu slides"
+    grids = [CachedGrids(syn.SyntheticSlide(CPU_DSEED, i, BASE_SHAPES[K])) for i in ids]
+    otrace = []
     with torch.no_grad():
         t0 = time.perf_counter()
-        orc.inference_end2end(params, ocfg, grids)           # warm-up + fills the row cache
+        ohz, _ = orc.inference_end2end(params, ocfg, grids, None, otrace)     # warm-up + fills the row cache; kept for the parity check
         log(f"cpu_baseline: warm-up pass {time.perf_counter() - t0:.1f} s")
         times = []
         for _ in range(reps):
@@ -108,7 +116,26 @@ def cpu_baseline(cfg, sd, K: int, n_slides: int, reps: int):
     med = times[len(times) // 2]
     return {"value": n_slides / med, "unit": "slides/s", "cores": threads, "kind": "port",
             "sample": f"{n_slides} slides x {reps} timed repetitions (median) of the same 5-level K={K} recursion, "
-                      f"fp32 torch CPU ops, {threads} threads, inputs cached"}
+                      f"fp32 torch CPU ops, {threads} threads, inputs cached"}, ids, otrace, ohz
+
+
+def parity_check(cfg, model, K, ids, otrace, ohz, dev):
+    """The cpu_baseline leg's oracle outputs against the HIP recursion on the SAME slides (outside the timed region): per
+    level num_ims, location sets, kept (top-K) sets, (child -> parent) pairs bit-exact, importance and final hazards within
+    tolerance (oracle/compare.py)."""
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    sl = DeviceSlideBatch([DeviceSlide.synthetic(CPU_DSEED, i, BASE_SHAPES[K], device=dev) for i in ids])
+    trace = []
+    with torch.no_grad():
+        out = putils.recurse(model, sl, cfg.top_k_patches, cfg.num_levels, trace=trace)
+    torch.cuda.synchronize()
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), ohz, raise_on_mismatch=False)
+    res["slide_ids"] = list(ids)
+    if res["problems"]:
+        log("PARITY MISMATCH vs oracle: " + "; ".join(res["problems"][:6]))
+    return res
 
 
 def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unused):
@@ -190,6 +217,7 @@ def main():
     slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)])
     torch.cuda.synchronize()
     log(f"model + {spg} slides resident ({torch.cuda.memory_allocated() / 2**30:.1f} GiB)")
+    print(f"[bench rank {rank}/{world}] slide ids {[rank * spg + i for i in range(spg)]}", file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -304,7 +332,8 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, K, args.cpu_slides, args.cpu_reps)
+            line["cpu_baseline"], ids, otrace, ohz = cpu_baseline(cfg, sd, K, args.cpu_slides, args.cpu_reps)
+            line["parity_checked"] = parity_check(cfg, model, K, ids, otrace, ohz, dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

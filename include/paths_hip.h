@@ -13,7 +13,14 @@
  *   - all floating-point buffers are fp32, row-major, 16-byte aligned, leading dimensions in elements
  *     and multiples of 4; integer fields follow the reference's dtypes (int64 locs / num_ims /
  *     parent_inds);
- *   - arithmetic: exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32), fp32 accumulate.
+ *   - arithmetic: fp32 inputs, outputs and accumulation everywhere.  The *_x6 / *_h3 entry points multiply SPLIT operands on
+ *     the 16-bit matrix cores: planes = 2 -> x = hi + lo as two fp16 planes (22 significant bits; 3 x
+ *     v_mfma_f32_32x32x16_f16 per product block; operands pre-scaled by powers of two, w_scale / a_scale arguments, and
+ *     |activation| * a_scale must stay below 65504: the Python host checks max|x| of every resident grid / input batch
+ *     (paths_tissue_mask_absmax) and runs out-of-range data on planes = 3); planes = 3 -> x = hi + mid + lo EXACTLY as three
+ *     bf16 planes (6 x v_mfma_f32_32x32x16_bf16, no range limits).  The entry points without suffix use the f32-input
+ *     matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4_f32: a k-ordered fp32 FMA chain).  Measured error of all three vs
+ *     fp64 is that of an fp32 FMA chain.
  */
 #ifndef PATHS_HIP_H
 #define PATHS_HIP_H
@@ -297,6 +304,11 @@ int paths_scale_add_rows(const float* x, const float* alpha, const float* h, con
 
 /* Tissue mask of a preprocessed grid [cells, D]: 1 iff fp32 row sum != 0 (reference slide.py:324). */
 int paths_tissue_mask(const float* grid, int64_t cells, int D, uint8_t* mask, paths_stream_t stream);
+
+/* The same pass (mask may be NULL) + *absmax_bits = max(*absmax_bits, fp32 bit pattern of max|x| over the grid): non-negative
+ * floats order like their bit patterns, a NaN reads back above +inf.  Guards the fp16-split range contract of the default mode
+ * (replaces nothing in the reference; its fp32 CPU path has no such limit). */
+int paths_tissue_mask_absmax(const float* grid, int64_t cells, int D, uint8_t* mask, uint32_t* absmax_bits, paths_stream_t stream);
 
 /* Counter-based synthetic grid (paths_amd/synthetic.py). */
 int paths_synth_grid(float* grid, int X, int Y, int D, uint32_t slide_level_key, int level, uint64_t bg_threshold,

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PATHS_HIP_LIB") or os.path.join(_HERE, "libpaths_hip.
 
 _i64, _i32, _f32, _vp, _u32, _u64 = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint64
 
-# name -> argtypes (mirrors include/paths_hip.h; tests/test_abi.py checks both against the .so exports)
+# name -> argtypes (mirrors include/paths_hip.h; tests/test_cpu_surface.py::test_library_exports_every_declared_symbol checks both against the .so exports)
 SIGNATURES = {
     "paths_lstm_cell": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                         _i32, _i32, _i32, _vp, _i32, _i32, _vp],
@@ -64,6 +64,7 @@ SIGNATURES = {
     "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_scale_add_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
+    "paths_tissue_mask_absmax": [_vp, _i64, _i32, _vp, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],
 }
 _PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, [])}
@@ -114,3 +115,20 @@ def require_cuda(*tensors: torch.Tensor):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise PathsHipError("paths_amd runs on the GPU only: got a CPU tensor (no CPU fallback)")
+
+
+def float_from_bits(bits: int) -> float:
+    """fp32 value of a bit pattern written by paths_tissue_mask_absmax; any NaN pattern (above +inf) reads as inf."""
+    import struct
+    bits &= 0xFFFFFFFF
+    return float("inf") if bits >= 0x7F800000 else struct.unpack("<f", struct.pack("<I", bits))[0]
+
+
+def absmax(t: torch.Tensor) -> float:
+    """max|x| of a contiguous fp32 device tensor (inf if not finite) through the same kernel; one host sync."""
+    require_cuda(t)
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 4 == 0
+    bits = torch.zeros((1,), dtype=torch.int32, device=t.device)
+    D = t.shape[-1] if (t.dim() > 1 and t.shape[-1] % 4 == 0) else 4
+    call("paths_tissue_mask_absmax", t.data_ptr(), t.numel() // D, D, None, bits.data_ptr(), stream())
+    return float_from_bits(int(bits.item()))

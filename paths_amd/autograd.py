@@ -57,6 +57,29 @@ def dead_params(model) -> List[torch.nn.Parameter]:
     return out
 
 
+def live_grad_params(model, num_levels: Optional[int] = None) -> List[torch.nn.Parameter]:
+    """The parameters that receive a real gradient from one training step, in a FIXED order that is the same on every
+    rank whatever slides it holds: the shared LSTM + the live parameters of levels 0..num_levels-1, without the classifiers
+    of the non-final levels (their logits are unused: grad stays None, reference SURVEY 3.2).  This is the list the gradient
+    all-reduce walks (paths_amd/distributed.py) and the list a rank without slides fills with zeros."""
+    L = len(model.procs) if num_levels is None else min(int(num_levels), len(model.procs))
+    out = list(lstm_params(model.lstm)) if model.use_lstm else []
+    for i in range(L):
+        lp = level_params(model.procs[i])
+        out += lp if i == L - 1 else lp[:-2]
+    return out
+
+
+def zero_live_grads(model, num_levels: Optional[int] = None):
+    """A rank that holds no slide of a (short) global batch: exactly the gradient set of an active rank, all zeros."""
+    for p in live_grad_params(model, num_levels):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        else:
+            p.grad.zero_()
+    fill_dead_grads(model)
+
+
 def fill_dead_grads(model):
     """Zero gradients for the dead parameters.  They are views of ONE zero buffer kept on the model (160 tensors per step
     would otherwise cost 160 fill launches); nothing downstream writes a non-zero into a gradient that is exactly zero
@@ -74,12 +97,24 @@ def fill_dead_grads(model):
         p.grad = zero[:p.numel()].view_as(p)
 
 
+def check_dropout_supported(proc):
+    """Every entry to the differentiable path passes here (LevelFn.forward): a config with dropout > 0 in train mode is
+    never silently run with its five dropout sites per layer as identity (reference model/aggregator.py:25-33)."""
+    if proc.training and proc.config.dropout > 0 and not DROPOUT_IMPLEMENTED:
+        raise NotImplementedError("dropout > 0 in train mode is not implemented on the HIP path: set model_config.dropout = 0 "
+                                  "or call model.eval()")
+
+
+DROPOUT_IMPLEMENTED = False
+
+
 class LevelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, proc, lstm, fts, locs, num_ims, state_prev, ctx_prev, *params):
         mc = proc.config
         if mc.slide_ctx_mode == "concat":
             raise NotImplementedError("training with slide_ctx_mode='concat' is not implemented on the HIP path")
+        check_dropout_supported(proc)
         lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
         sel = bw.selection_forward_train(mc, lp, vp, fts, locs.contiguous(), num_ims.contiguous(), state_prev)
         res = ctx_prev if mc.slide_ctx_mode == "residual" else None

@@ -327,6 +327,32 @@ tissue_mask_kernel(const float* __restrict__ grid, int64_t cells, int D, uint8_t
 }
 
 
+// The same pass + max|x| of the whole grid (fp16-split range contract of the default GEMM mode: |x| * a_scale must stay a finite
+// fp16).  absmax_bits holds the fp32 BIT PATTERN of the running maximum: non-negative floats order like their bit patterns and a
+// NaN's pattern is above +inf's, so a NaN anywhere reads back as "not finite".  The atomic is only issued by waves that beat the
+// value they last saw, i.e. a handful of times per grid.
+__global__ void __launch_bounds__(256)
+tissue_mask_absmax_kernel(const float* __restrict__ grid, int64_t cells, int D, uint8_t* __restrict__ mask, unsigned* __restrict__ absmax_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cell >= cells) return;
+  const f32x4* row = reinterpret_cast<const f32x4*>(grid + cell * D);
+  float s = 0.f;
+  unsigned m = 0;
+  for (int i = lane; i < D / 4; i += 64) {
+    const f32x4 v = row[i];
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { s += __shfl_xor(s, o); m = max(m, (unsigned)__shfl_xor((int)m, o)); }
+  if (lane == 0) {
+    if (mask) mask[cell] = s != 0.f ? 1 : 0;
+    if (m > __hip_atomic_load(absmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(absmax_bits, m);
+  }
+}
+
 // Z[row] = alpha[row] * X[row] (+ H[row] on valid rows): the non-LSTM hierarchical-context update
 // (reference model/paths.py:96-109: Z = Y * alpha; Z += apply_to_non_padded(hctx_mlp, prev Z)).
 __global__ void __launch_bounds__(256)
@@ -474,6 +500,13 @@ int paths_tissue_mask(const float* grid, int64_t cells, int D, uint8_t* mask, hi
   PATHS_REQUIRE(cells > 0 && D % 4 == 0, "tissue_mask: bad shape");
   hipLaunchKernelGGL(tissue_mask_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, stream, grid, cells, D, mask);
   PATHS_LAUNCH_CHECK("tissue_mask");
+  return PATHS_OK;
+}
+
+int paths_tissue_mask_absmax(const float* grid, int64_t cells, int D, uint8_t* mask, uint32_t* absmax_bits, hipStream_t stream) {
+  PATHS_REQUIRE(cells > 0 && D % 4 == 0 && absmax_bits != nullptr, "tissue_mask_absmax: bad arguments");
+  hipLaunchKernelGGL(tissue_mask_absmax_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, stream, grid, cells, D, mask, absmax_bits);
+  PATHS_LAUNCH_CHECK("tissue_mask_absmax");
   return PATHS_OK;
 }
 

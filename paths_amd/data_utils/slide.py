@@ -25,15 +25,26 @@ class DeviceSlide:
         self.subtype = subtype
         self.grids: List[torch.Tensor] = []
         self.masks: List[torch.Tensor] = []
+        self._absmax_bits = None          # fp32 bit pattern of max|feature| over all levels, written by the mask pass
+        self._absmax: Optional[float] = None
         for g in grids:
             _lib.require_cuda(g)
             assert g.dim() == 3 and g.dtype == torch.float32
             g = g.contiguous()
             X, Y, D = g.shape
             m = torch.empty((X, Y), dtype=torch.uint8, device=g.device)
-            _lib.call("paths_tissue_mask", g.data_ptr(), X * Y, D, m.data_ptr(), _lib.stream())
+            if self._absmax_bits is None:
+                self._absmax_bits = torch.zeros((1,), dtype=torch.int32, device=g.device)
+            _lib.call("paths_tissue_mask_absmax", g.data_ptr(), X * Y, D, m.data_ptr(), self._absmax_bits.data_ptr(), _lib.stream())
             self.grids.append(g)
             self.masks.append(m)
+
+    def feature_absmax(self) -> float:
+        """max|x| over every grid of the slide (inf if any element is inf or NaN): the operand-range check of the default
+        fp16-split GEMM mode (paths_amd/ops.py:h3_in_range).  One host sync on first use, cached."""
+        if self._absmax is None:
+            self._absmax = _lib.float_from_bits(int(self._absmax_bits.item()))
+        return self._absmax
 
     @property
     def num_levels(self) -> int:
@@ -108,6 +119,7 @@ class DeviceSlideBatch:
         self.gx = table(lambda s, l: s.shape(l)[0], torch.int32)
         self.gy = table(lambda s, l: s.shape(l)[1], torch.int32)
         self.n0 = max(s.shape(0)[0] * s.shape(0)[1] for s in self.slides)
+        self.feat_absmax = max(s.feature_absmax() for s in self.slides)
         self.max_dim = [max(max(s.shape(l)) for s in self.slides) for l in range(L)]   # bound of locs // patch_size per level
 
     def __len__(self):

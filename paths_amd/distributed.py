@@ -63,15 +63,23 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([bufs[r][: len(shard_range(n_total, r, world))] for r in range(world)], dim=0)
 
 
-def allreduce_gradients(model, average: bool = False):
-    """ONE flat-bucket all-reduce(sum) of every existing gradient (RCCL over xGMI with backend "nccl").
+def allreduce_gradients(model, average: bool = False, num_levels: Optional[int] = None):
+    """ONE flat-bucket all-reduce(sum) of the live gradients (RCCL over xGMI with backend "nccl").
     The loss of each rank is already scaled by local_batch / global_batch (paths_amd.utils.loss_from_logits), so the sum
-    of the shards' gradients IS the gradient of the global-batch mean loss; parameters whose grad is None (the unused
-    classifiers of the non-final levels) are None on every rank and are skipped consistently."""
+    of the shards' gradients IS the gradient of the global-batch mean loss.  The bucket walks a FIXED parameter list
+    (paths_amd.autograd.live_grad_params: identical on every rank, whatever slides a rank holds), so the message has the
+    same element count everywhere; a missing gradient in that list counts as zeros.  The dead parameters (nn.Transformer
+    encoder, cross-attention matrices: zero gradients on every rank) are not sent: 7.2 M fp32 = 29 MB per step instead of
+    39.5 MB.  The classifiers of the non-final levels have grad None on every rank and stay None."""
     if not dist.is_initialized():
         return
-    grads = [p.grad for p in model.parameters() if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])          # 9.9 M fp32 = 39.5 MB: one message per step
+    from . import autograd as pag
+    params = pag.live_grad_params(model, num_levels)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    grads = [p.grad for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])          # one message per step
     if dist.get_backend() == "gloo" and flat.is_cuda:         # CPU-collective rehearsal path (tests / 1-GPU boxes)
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)

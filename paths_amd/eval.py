@@ -64,6 +64,11 @@ def _gather_np(a: np.ndarray) -> np.ndarray:
     return np.concatenate(objs)
 
 
+def _cat(chunks, tail=()) -> np.ndarray:
+    """np.concatenate that also works on a rank that registered nothing (it still has to take part in the gather)."""
+    return np.concatenate(chunks) if chunks else np.zeros((0,) + tuple(tail), np.float64)
+
+
 class Evaluator(ABC):
     def __init__(self, split: str):
         self.losses, self.weights = [], []
@@ -115,8 +120,8 @@ class SurvivalEvaluator(Evaluator):
         self.times.append(torch.as_tensor(batch["survival"]).cpu().numpy())
 
     def calculate(self, train_stats=None, epoch=None):
-        event = (1 - _gather_np(np.concatenate(self.cens))).astype(bool)
-        times, risks = _gather_np(np.concatenate(self.times)), _gather_np(np.concatenate(self.risks))
+        event = (1 - _gather_np(_cat(self.cens))).astype(bool)
+        times, risks = _gather_np(_cat(self.times)), _gather_np(_cat(self.risks))
         if event.sum() <= 1:
             c_index = 0.5
         else:
@@ -145,7 +150,7 @@ class SubtypeClassificationEvaluator(Evaluator):
         self.labels.append(torch.as_tensor(batch["subtype"]).cpu().numpy())
 
     def calculate(self, train_stats=None, epoch=None):
-        preds, labels = _gather_np(np.concatenate(self.preds)), _gather_np(np.concatenate(self.labels))
+        preds, labels = _gather_np(_cat(self.preds, (self.nclasses,))), _gather_np(_cat(self.labels))
         aucs = [binary_auroc(preds[:, i], labels == i) for i in range(self.nclasses)]
         out = {f"{self.split}_loss": self._mean_loss(), f"{self.split}_AUC": float(sum(aucs) / len(aucs))}
         self._add_to_train_stats(epoch, out, train_stats)

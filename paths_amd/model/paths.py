@@ -18,6 +18,15 @@ from .aggregator import TransformerAggregator
 from .interface import Processor
 
 
+def _lib_absmax(fts: torch.Tensor, state_prev) -> float:
+    from .. import _lib
+    m = _lib.absmax(fts)
+    if state_prev is not None and state_prev.numel():
+        sp = state_prev.detach().float().contiguous()
+        m = max(m, _lib.absmax(sp))
+    return m
+
+
 class PATHSProcessor(nn.Module, Processor):
     def __init__(self, config, train_config, depth: int):
         super().__init__()
@@ -45,6 +54,17 @@ class PATHSProcessor(nn.Module, Processor):
         assert lstm is not None or not mc.lstm, "lstm=True needs the shared LSTMCell (RecursiveModel passes it)"
         if self.training and mc.dropout > 0:
             raise NotImplementedError("paths_amd round 1: dropout (train mode) is not implemented on the HIP path")
+        if mc.patch_embed_dim % 4 == 0 and (ops.GEMM_MODE == "h3" or ops.TRAIN_FWD_PLANES == 2):
+            # drop-in batches come from the caller: reduce max|x| on entry (one host sync; the reference's own PatchBatch
+            # constructor syncs on num_ims.max(), data_utils/patch_batch.py:50) and keep out-of-range data off the fp16 split
+            f32 = data.fts if (data.fts.dtype == torch.float32 and data.fts.is_contiguous()) else data.fts.float().contiguous()
+            amax = _lib_absmax(f32, data.ctx_patch[:, :, -1] if self.depth > 0 else None)
+            with ops.range_guard(amax):
+                return self._process(data, lstm, skip_padding)
+        return self._process(data, lstm, skip_padding)
+
+    def _process(self, data, lstm, skip_padding: bool) -> Dict[str, torch.Tensor]:
+        mc = self.config
         if torch.is_grad_enabled():
             # differentiable path (training): same kernels + saved activations, backward in HIP (paths_amd/autograd.py)
             if not mc.lstm:

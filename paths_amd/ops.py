@@ -39,6 +39,44 @@ TRAIN_PLANES = 3        # training re-images weights every step: the bf16 split 
 TRAIN_FWD_PLANES = int(os.environ.get("PATHS_TRAIN_FWD_PLANES", "2"))
 
 
+H3_STATE_MARGIN = 8.0   # |h1| <= 1 and |c1| <= depth + 1 by construction (sigmoid * tanh, interface.py:52-56): x + h1, c stay inside
+
+
+def h3_in_range(feat_absmax: float) -> bool:
+    """The fp16-split operands of the default mode hold |activation| * A_SCALE: features up to (65504 / A_SCALE) - margin."""
+    return math.isfinite(feat_absmax) and (feat_absmax + H3_STATE_MARGIN) * A_SCALE < 65504.0
+
+
+RANGE_FALLBACKS = [0]    # how often a batch left the fp16 range and ran on the bf16 split (diagnostic / tests)
+
+
+class range_guard:
+    """``with range_guard(max|feature|):`` — the range contract of the default fp16-split mode, enforced where data enters the
+    path (every resident grid's max|x| comes with its tissue-mask pass, drop-in batches are reduced on entry): inside the block
+    an out-of-range batch runs on the exact three-plane bf16 kernels (PATHS_GEMM_MODE semantics "x6": same entry points, no
+    range limits, ~1.6x slower) instead of silently producing inf/NaN planes; non-finite features raise."""
+
+    def __init__(self, feat_absmax: float):
+        self.amax = float(feat_absmax)
+        self.saved = None
+
+    def __enter__(self):
+        global GEMM_MODE, TRAIN_FWD_PLANES
+        if not math.isfinite(self.amax):
+            raise _lib.PathsHipError("input features contain inf or NaN")
+        if not h3_in_range(self.amax) and (GEMM_MODE == "h3" or TRAIN_FWD_PLANES == 2):
+            self.saved = (GEMM_MODE, TRAIN_FWD_PLANES)
+            RANGE_FALLBACKS[0] += 1
+            GEMM_MODE, TRAIN_FWD_PLANES = ("x6" if GEMM_MODE == "h3" else GEMM_MODE), 3
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_MODE, TRAIN_FWD_PLANES
+        if self.saved is not None:
+            GEMM_MODE, TRAIN_FWD_PLANES = self.saved
+        return False
+
+
 def split_planes() -> int:
     if GEMM_MODE not in ("h3", "x6", "f32"):
         raise ValueError(f"PATHS_GEMM_MODE must be 'h3', 'x6' or 'f32' (got {GEMM_MODE!r})")
@@ -72,23 +110,34 @@ def _pow2_scale(w: torch.Tensor) -> float:
     return 2.0 ** max(-14, min(24, math.floor(math.log2(16384.0 / amax)))) if amax > 0 and math.isfinite(amax) else 1.0
 
 
-_LAGGED_SCALES: Dict[object, list] = {}
+_LAGGED_EPOCH = [0]      # bumped by reset_lagged_scales(): every per-module store older than this is discarded on next use
 
 
-def _pow2_scale_lagged(w: torch.Tensor, key) -> float:
+def _lagged_store(owner) -> Dict[object, list]:
+    """The lagged-scale entries of one module live ON the module (not in a table keyed by id(), which Python may hand to
+    another module after this one is collected)."""
+    st = owner.__dict__.get("_paths_lagged")
+    if st is None or st.get("_epoch") != _LAGGED_EPOCH[0]:
+        st = {"_epoch": _LAGGED_EPOCH[0]}
+        object.__setattr__(owner, "_paths_lagged", st)
+    return st
+
+
+def _pow2_scale_lagged(w: torch.Tensor, owner, key) -> float:
     """:func:`_pow2_scale` without a host sync after the first call per ``key``: training re-images its weights every step, so
     the scale in use is the one computed from an EARLIER version of the same weight (its max|w| is reduced on the device, copied
     to pinned memory asynchronously and picked up once the copy has landed).  The scale leaves a factor 4 of fp16 headroom above
     max|w|, which no optimizer step at the reference's learning rates can cross between two refreshes."""
-    ent = _LAGGED_SCALES.get(key)
+    store = _lagged_store(owner)
+    ent = store.get(key)
     if ent is None:
-        ent = _LAGGED_SCALES[key] = [_pow2_scale(w), None, torch.empty((1,), dtype=torch.float32).pin_memory()]
+        ent = store[key] = [_pow2_scale(w), None, torch.empty((1,), dtype=torch.float32).pin_memory()]
     elif ent[1] is not None and ent[1].query():
         amax = float(ent[2][0])
         if not math.isfinite(amax) or amax * ent[0] >= 65504.0:
             # the scale used since the last refresh was too large for this weight (or the weight is not finite): the fp16 planes
             # built with it overflowed.  Loud, if late; weights replaced wholesale must call reset_lagged_scales() (load_state does)
-            _LAGGED_SCALES.pop(key, None)
+            store.pop(key, None)
             raise _lib.PathsHipError(f"weight {key!r}: max|w| = {amax} left the fp16 range of its lagged scale {ent[0]}; "
                                      "call paths_amd.ops.reset_lagged_scales() after replacing weights")
         if amax > 0:
@@ -105,7 +154,7 @@ def _pow2_scale_lagged(w: torch.Tensor, key) -> float:
 def reset_lagged_scales():
     """Forget the lagged weight scales (next use recomputes them with a host sync): call after loading a checkpoint or any other
     wholesale replacement of the weights of a model that is being trained."""
-    _LAGGED_SCALES.clear()
+    _LAGGED_EPOCH[0] += 1
 
 
 def tlayer_h3_images(layer: Dict[str, object], part: int):
@@ -130,7 +179,7 @@ def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None, lagg
     planes = split_planes() if planes is None else planes
     k6 = f"{key}_split{planes}"
     if k6 not in pack:
-        ws = _pow2_scale_lagged(pack[key], (pack.get("_owner"), key)) if (lagged and planes == 2) else None
+        ws = _pow2_scale_lagged(pack[key], pack["_owner"], key) if (lagged and planes == 2) else None
         pack[k6] = x6_pack(pack[key], planes=planes, w_scale=ws)
     return pack[k6]
 
@@ -181,7 +230,7 @@ def pack_lstm(lstm) -> Dict[str, torch.Tensor]:
             "w_mem": mo.weight.detach().float().contiguous(),
             "b_mem": mo.bias.detach().float().contiguous(),
             "Hc": Hc,
-            "_owner": id(lstm),
+            "_owner": lstm,
         }
     lstm._paths_pack = (key, packed)
     return packed
@@ -233,7 +282,7 @@ def pack_level(proc) -> Dict[str, object]:
             "lnfg": c(agg.transformer.decoder.norm.weight), "lnfb": c(agg.transformer.decoder.norm.bias),
             "lnf_eps": float(agg.transformer.decoder.norm.eps),
             "wcls": c(proc.classification_layer.weight), "bcls": c(proc.classification_layer.bias),
-            "_owner": id(proc),
+            "_owner": proc,
         }
         if hasattr(proc, "hctx_mlp"):      # lstm=false: RNN hierarchical context (reference model/paths.py:49-54)
             packed.update({"wh1": c(proc.hctx_mlp[0].weight), "bh1": c(proc.hctx_mlp[0].bias),

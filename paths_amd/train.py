@@ -108,25 +108,15 @@ def train_loop(model, train_ds, val_ds, test_ds, config, model_dir: str, log=Non
     model.train()
     for e in range(start_epoch, config.num_epochs + 1):
         for batch, gb in iterate_batches(train_ds, config.batch_size[0], True, rank, world):
-            if batch is None:                                  # this rank holds no slide of a short last batch
-                opt.zero_grad(set_to_none=True)
-                from . import autograd as pag
-                pag.fill_dead_grads(model)
-                for p in model.parameters():
-                    if p.grad is None and p.requires_grad:
-                        p.grad = torch.zeros_like(p)
-                if ar:
-                    ar(model)
-                opt.step()
+            if batch is None:
+                # this rank holds no slide of a short last batch: zeros for exactly the gradient set of an active rank (the
+                # unused classifiers stay None here too, so AdamW skips them on every rank alike)
+                putils.train_step(model, opt, None, config.num_levels, config.top_k_patches, config.task, gb, ar)
                 continue
             opt.zero_grad(set_to_none=True)
-            out = putils.recurse_train(model, batch["slide"], config.top_k_patches, config.num_levels)
-            outputs, loss = putils.loss_from_logits(out["logits"], batch, config.task, gb)
-            loss.backward()
-            from . import autograd as pag
-            pag.fill_dead_grads(model)
+            outputs, loss = putils.forward_backward(model, batch, config.num_levels, config.top_k_patches, config.task, gb)
             if ar:
-                ar(model)
+                ar(model, num_levels=config.num_levels)
             opt.step()
             n_local = len(batch["slide"])
             train_eval.register(batch, outputs, float(loss.detach()) * gb / n_local, weight=n_local)

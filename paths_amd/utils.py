@@ -72,6 +72,11 @@ def _streams(dev):
 def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
              trace: Optional[list] = None, careful: bool = False) -> Dict[str, torch.Tensor]:
     batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
+    with ops.range_guard(batch.feat_absmax):       # out-of-range features run on the exact bf16 split (no fp16 overflow)
+        return _recurse_streams(model, batch, keep_patches, num_levels, trace, careful)
+
+
+def _recurse_streams(model, batch, keep_patches, num_levels, trace, careful):
     if not (OVERLAP_AGGREGATOR and batch.device.type == "cuda"):
         return _recurse_body(model, batch, keep_patches, num_levels, trace, careful, None, None)
     caller = torch.cuda.current_stream(batch.device)
@@ -257,15 +262,25 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     return out
 
 
-def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int) -> Dict[str, torch.Tensor]:
+def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int, careful: bool = False) -> Dict[str, torch.Tensor]:
     """Differentiable recursion for training: same kernels as :func:`recurse`, but every level goes through
     paths_amd.autograd.LevelFn / GatherFn so that ``loss.backward()`` runs the hand-written backward kernels.
-    Padded rows are zero-filled and computed (no tile skipping) so that every saved activation is finite."""
+    Padded rows are zero-filled and computed (no tile skipping) so that every saved activation is finite.
+
+    Like :func:`recurse` the default pass is optimistic and sync-free; the returned ``status`` word has bit 0 set when some
+    slide's kept patches had no tissue children.  The caller (:func:`forward_backward`) then repeats the step with
+    ``careful=True``: one host sync per level and the reference's fallback to all tissue cells of the next grid with zero
+    parent state (data_utils/slide.py:336-352), handled on the device (paths_fallback_all_cells)."""
+    batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
+    with ops.range_guard(batch.feat_absmax):
+        return _recurse_train_body(model, batch, keep_patches, num_levels, careful)
+
+
+def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
     from . import autograd as pag
     mc = model.procs[0].config
     ops.check_supported(mc)
     assert model.use_lstm, "training on the HIP path needs lstm=true"
-    batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
     B, dev, D = len(batch), batch.device, batch.dim
     st = _lib.stream()
     p = _lib.ptr
@@ -299,9 +314,31 @@ def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int) -
         src_row = torch.empty((B, Nn), **i32)
         src_cell = torch.empty((B, Nn), **i32)
         child_pos = torch.empty((B, 4 * cap_keep), **i32)
-        _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
-                  p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next),
-                  p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), None, st)
+
+        def expand():
+            _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
+                      p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next),
+                      p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), None, st)
+
+        expand()
+        if careful:
+            empty = (num_next == 0).cpu()                      # per-level sync: slow path only
+            if bool(empty.any()):
+                need = Nn
+                for b in torch.nonzero(empty).flatten().tolist():
+                    tissue = int(batch.slides[b].masks[i + 1].sum().item())
+                    X, Y = batch.slides[b].shape(i + 1)
+                    need = max(need, tissue if tissue > 0 else X * Y)
+                if need > Nn:
+                    Nn = need
+                    locs_next = torch.empty((B, Nn, 2), **i64)
+                    parent_next = torch.empty((B, Nn), **i64)
+                    src_row = torch.empty((B, Nn), **i32)
+                    src_cell = torch.empty((B, Nn), **i32)
+                    expand()
+                # fallback rows: src_row = -1 (zero parent state, no gradient to any parent: child_pos of that slide is all -1)
+                _lib.call("paths_fallback_all_cells", p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), mc.patch_size,
+                          B, Nn, p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status), None, st)
         fts, state_prev = pag.GatherFn.apply(state_out, batch.grid_ptrs[i + 1], src_cell, src_row, num_next, keep_idx,
                                              keep_count, child_pos, D, Nn)
         locs, parent, num_ims, N = locs_next, parent_next, num_next, Nn
@@ -323,21 +360,58 @@ def loss_from_logits(logits, batch, task: str, global_batch: Optional[int] = Non
     raise ValueError(task)
 
 
+_STATUS_HOST: Dict[int, torch.Tensor] = {}
+
+
+def forward_backward(model, batch, num_levels, keep_patches, task: str = "survival", global_batch: Optional[int] = None):
+    """Forward recursion + loss + backward of one (local) batch, with the recursion's status word checked BEFORE any gradient
+    leaves the rank (all-reduce / optimizer): the status is copied to pinned memory right after the forward and read once the
+    backward has been enqueued (by then the forward has long finished, so the wait is free).  Bit 0 (a slide without tissue
+    children) repeats forward + backward on the careful path (reference fallback, data_utils/slide.py:336-352); bit 2
+    (capacity) raises.  Gradients must be clear (set to None) on entry.  Returns (outputs, loss)."""
+    from . import autograd as pag
+    out = recurse_train(model, batch["slide"], keep_patches, num_levels)
+    dev = out["status"].device
+    host = _STATUS_HOST.get(dev.index)
+    if host is None:
+        host = _STATUS_HOST[dev.index] = torch.zeros((1,), dtype=torch.int32).pin_memory()
+    host.copy_(out["status"], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    outputs, loss = loss_from_logits(out["logits"], batch, task, global_batch)
+    loss.backward()
+    ev.synchronize()
+    code = int(host[0])
+    if code & 1:
+        model.zero_grad(set_to_none=True)
+        out = recurse_train(model, batch["slide"], keep_patches, num_levels, careful=True)
+        outputs, loss = loss_from_logits(out["logits"], batch, task, global_batch)
+        loss.backward()
+        code = int(out["status"].item()) & ~1
+    if code & 2:
+        raise RecursionError_("child capacity exceeded (internal error)")
+    pag.fill_dead_grads(model)
+    return outputs, loss
+
+
 def train_step(model, optimizer, batch, num_levels, keep_patches, task: str = "survival", global_batch: Optional[int] = None,
                allreduce=None):
     """One optimisation step with the reference's semantics (train.py:59-68): forward recursion, mean loss,
     backward, [gradient all-reduce], optimizer step.  Dead parameters get the reference's zero gradients.
-    Returns the (local share of the) loss as a tensor."""
+    ``batch`` None = this rank holds no slide of a short global batch: it contributes zeros for exactly the gradient set of
+    an active rank.  Returns the (local share of the) loss as a tensor (None for an idle rank)."""
     from . import autograd as pag
     optimizer.zero_grad(set_to_none=True)
-    out = recurse_train(model, batch["slide"], keep_patches, num_levels)
-    _, loss = loss_from_logits(out["logits"], batch, task, global_batch)
-    loss.backward()
-    pag.fill_dead_grads(model)
+    loss = None
+    if batch is None:
+        pag.zero_live_grads(model, num_levels)
+    else:
+        _, loss = forward_backward(model, batch, num_levels, keep_patches, task, global_batch)
+        loss = loss.detach()
     if allreduce is not None:
-        allreduce(model)
+        allreduce(model, num_levels=num_levels)
     optimizer.step()
-    return loss.detach()
+    return loss
 
 
 def inference_end2end(num_levels, keep_patches, model, base_power, batch, task: str):

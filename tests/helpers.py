@@ -71,3 +71,13 @@ def sequence_inversions(keep_a, keep_b, scores):
         return 0.0
     s = np.asarray(scores, dtype=np.float64)
     return float(np.abs(s[keep_a[diff]] - s[keep_b[diff]]).max())
+
+
+def golden_trace(g, B, L):
+    """The reference's per-level records of a recursion fixture (G3/G4) in the oracle's trace format (oracle/compare.py)."""
+    tr = []
+    for l in range(L):
+        tr.append({"num_ims": g[f"L{l}_num_ims"], "locs": g[f"L{l}_locs"], "parent_inds": g[f"L{l}_parent_inds"],
+                   "importance": g[f"L{l}_importance"], "logits": g[f"L{l}_logits"],
+                   "keep_inds": [g[f"L{l}_keep_{j}"] for j in range(B)] if l < L - 1 else []})
+    return tr

@@ -1,0 +1,111 @@
+"""N > 1 rehearsal on ONE GPU: two fresh processes, both on device 0, collectives over gloo
+(RCCL refuses two ranks of one communicator on one device).  Everything except the transport is the production path:
+bench.py's launch contract, slide sharding, the fixed-list flat gradient all-reduce, an idle rank in a short last batch, a rank
+without validation slides.
+
+This file sorts first so that its child processes are started BEFORE anything in the pytest process has touched the GPU
+(the box forbids exec from a process that has initialised the GPU); nothing here calls torch.cuda in the parent.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _spawn(argv, port, extra_env=None, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PATHS_DIST_BACKEND="gloo",
+               PATHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-3000:] for o in outs)
+    return outs
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_two_ranks_one_device(mode):
+    outs = _spawn(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--slides-per-gpu", "2", "--k", "256",
+                   "--no-cpu-baseline", "--mode", mode], 29741 + (mode == "train"))
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # rank 0 prints THE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["config"]["global_batch"] == 4 and rec["unit"] == "slides/s"
+    assert abs(rec["value"] - 4 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 0.01       # whole-job aggregate over both ranks
+    ids = []
+    for r in range(2):
+        tag = [l for l in outs[r][1].splitlines() if l.startswith(f"[bench rank {r}/2] slide ids ")]
+        assert len(tag) == 1
+        ids.append(set(json.loads(tag[0].split("slide ids ")[1])))
+    assert ids[0] == {0, 1} and ids[1] == {2, 3} and not (ids[0] & ids[1])
+    if mode == "infer":
+        assert "roofline" in rec and "cpu_baseline" not in rec        # the CPU leg is rank 0 at N=1 only
+
+
+WORKER = r'''
+import os, sys, json, tempfile
+sys.path.insert(0, os.environ["PATHS_ROOT"])
+import numpy as np, torch
+import torch.distributed as dist
+from paths_amd import distributed as pd, utils as putils, autograd as pag
+from paths_amd.config import Config
+from paths_amd.data_utils.slide import DeviceSlideBatch
+from paths_amd.train import synthetic_dataset, train_loop
+rank, world, _ = pd.env_rank_world()
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+pd.init("gloo")
+cfg = Config.load(os.path.join(os.environ["PATHS_ROOT"], "tests", "golden", "sample"), test_mode=True)
+cfg.model_config.dropout = 0.0
+cfg.num_levels, cfg.top_k_patches, cfg.batch_size = 3, [8, 8], [4, 4, 4]
+cfg.num_epochs, cfg.lr, cfg.early_stopping, cfg.eval_epochs, cfg.min_epochs = 2, 2e-4, True, 1, 0
+torch.manual_seed(0)
+model = cfg.get_model().to(dev).train()
+ds = synthetic_dataset(8, (6, 6), 3, dev, seed=77)
+
+def batch_of(items):
+    return {"slide": DeviceSlideBatch([it["slide"] for it in items]), "survival_bin": torch.as_tensor([it["survival_bin"] for it in items]),
+            "censored": torch.as_tensor([it["censored"] for it in items])}
+
+# (1) 2-rank gradients through the REAL all-reduce == 1-rank gradients of the same global batch of 3 slides (ranks hold 2 + 1)
+glob = ds[:3]
+model.zero_grad(set_to_none=True)
+putils.forward_backward(model, batch_of(glob), 3, cfg.top_k_patches, "survival", 3)
+full = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+mine = [glob[i] for i in pd.shard_range(3, rank, world)]
+model.zero_grad(set_to_none=True)
+putils.forward_backward(model, batch_of(mine), 3, cfg.top_k_patches, "survival", 3)
+pd.allreduce_gradients(model, num_levels=3)
+got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+assert set(got) == set(full), set(got) ^ set(full)
+worst = max(float((got[n] - full[n]).abs().max() / full[n].abs().max().clamp_min(1e-20)) for n in full)
+assert worst < 2e-5, worst
+# (2) the epoch loop: 5 training slides in batches of 4 -> in the last batch rank 1 holds NO slide; 1 validation slide -> rank 1
+# evaluates nothing; both must stay in lock-step through every collective and end with identical replicas
+logs = []
+stats = train_loop(model, ds[3:8], ds[:1], ds[1:3], cfg, os.environ["PATHS_MODEL_DIR"], log=logs.append)   # shared model dir
+digest = float(sum(p.double().sum() for p in model.parameters()))
+objs = [None, None]
+dist.all_gather_object(objs, (digest, stats["train_loss"], stats["val_c-index"]))
+assert objs[0] == objs[1], objs
+assert set(stats["train_loss"]) == {1, 2} and all(np.isfinite(v) for v in stats["train_loss"].values())
+pd.barrier()
+print(json.dumps({"rank": rank, "worst_grad_rel_err": worst, "digest": digest}))
+'''
+
+
+def test_two_rank_training_equals_one_rank_and_survives_idle_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    outs = _spawn([str(script)], 29745, {"PATHS_MODEL_DIR": str(mdir)})
+    recs = [json.loads([l for l in o[0].splitlines() if l.startswith("{")][-1]) for o in outs]
+    assert recs[0]["digest"] == recs[1]["digest"] and max(r["worst_grad_rel_err"] for r in recs) < 2e-5

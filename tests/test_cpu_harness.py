@@ -108,6 +108,8 @@ def test_importance_map_weighting():
 def test_lagged_scale_registry_resets():
     """The training forward's lagged fp16 weight scales are dropped when weights are replaced wholesale."""
     from paths_amd import ops
-    ops._LAGGED_SCALES[("x", "w")] = [2.0, None, None]
+    a, b = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    ops._lagged_store(a)["w"] = [2.0, None, None]
+    assert "w" in ops._lagged_store(a) and "w" not in ops._lagged_store(b)      # kept on the module, not keyed by id()
     ops.reset_lagged_scales()
-    assert not ops._LAGGED_SCALES
+    assert "w" not in ops._lagged_store(a)

@@ -160,13 +160,43 @@ allrows = pd.gather_rows(local, n_total)
 assert allrows.shape == (n_total, 2) and torch.equal(allrows[:, 0], torch.arange(n_total, dtype=torch.float32)), allrows
 t = pd.max_over_ranks(1.0 + rank, torch.device("cpu"))
 assert t == float(world), t
-# flat-bucket gradient all-reduce: params with grad None are skipped consistently, the others are summed
-lin = torch.nn.Linear(3, 2); unused = torch.nn.Linear(2, 2)
-model = torch.nn.ModuleList([lin, unused])
-lin.weight.grad = torch.full((2, 3), float(rank + 1)); lin.bias.grad = torch.tensor([1.0 * rank, 2.0])
-pd.allreduce_gradients(model)
-assert torch.equal(lin.weight.grad, torch.full((2, 3), 3.0)) and torch.equal(lin.bias.grad, torch.tensor([1.0, 4.0]))
-assert unused.weight.grad is None
+# flat-bucket gradient all-reduce over the FIXED live-parameter list: rank 0 is an active rank (real gradients, the unused
+# classifiers of levels 0..3 have grad None), rank 1 holds no slide of the batch (zeros for exactly the same set)
+from paths_amd import autograd as pag
+from paths_amd.config import Config
+cfg = Config.load(os.path.join(os.environ["PATHS_ROOT"], "tests", "golden", "sample"), test_mode=True)
+torch.manual_seed(0)
+model = cfg.get_model()
+live = pag.live_grad_params(model, cfg.num_levels)
+unused = [p for i in range(cfg.num_levels - 1) for p in model.procs[i].classification_layer.parameters()]
+assert len({id(p) for p in live}) == len(live) and not ({id(p) for p in live} & {id(p) for p in unused})
+assert sum(p.numel() for p in live) + sum(p.numel() for p in unused) + sum(p.numel() for p in pag.dead_params(model)) == 9881881
+if rank == 0:
+    for i, p in enumerate(live):
+        p.grad = torch.full_like(p, 1.0 + (i % 3))
+    pag.fill_dead_grads(model)
+else:
+    pag.zero_live_grads(model, cfg.num_levels)
+pd.allreduce_gradients(model, num_levels=cfg.num_levels)
+for i, p in enumerate(live):
+    assert torch.equal(p.grad, torch.full_like(p, 1.0 + (i % 3))), i
+assert all(p.grad is None for p in unused)
+assert all(p.grad is not None and not p.grad.any() for p in pag.dead_params(model))
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+opt.step()
+digest = float(sum(p.double().sum() for p in model.parameters()))
+import torch.distributed as dist
+objs = [None, None]; dist.all_gather_object(objs, digest)
+assert objs[0] == objs[1], objs              # replicas stay identical after the step (same grads, same None set)
+# evaluators on a rank that registered nothing (no val slide on this rank) still take part in the gathers
+from paths_amd.eval import SurvivalEvaluator, SubtypeClassificationEvaluator
+ev = SurvivalEvaluator("val"); ev2 = SubtypeClassificationEvaluator("val", 2)
+if rank == 0:
+    hz = torch.tensor([[0.9, 0.5, 0.5, 0.5], [0.1, 0.1, 0.1, 0.1], [0.5, 0.5, 0.5, 0.5]])
+    ev.register({"censored": torch.tensor([0, 0, 1]), "survival": torch.tensor([1.0, 9.0, 5.0])}, hz, torch.tensor(0.7))
+    ev2.register({"subtype": torch.tensor([0, 1, 1])}, torch.tensor([[2.0, 0.0], [0.0, 1.0], [0.5, 0.6]]), torch.tensor(0.3))
+r1, r2 = ev.calculate(), ev2.calculate()
+assert abs(r1["val_loss"] - 0.7) < 1e-6 and r1["val_c-index"] == 1.0 and r2["val_AUC"] == 1.0, (r1, r2)
 pd.barrier()
 print("rank", rank, "ok", list(mine))
 '''

@@ -206,6 +206,38 @@ def test_recursion_gradients_vs_oracle_autograd(dev):
     assert live > 100
 
 
+def test_training_on_zero_children_slides_takes_the_fallback(dev):
+    """the training path reads the recursion's status word too.  Slides whose kept patches have no tissue children
+    (reference fallback to all cells with zero parent state, data_utils/slide.py:336-352) train through the careful
+    differentiable pass: loss and every live gradient equal torch autograd through the oracle."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, params = build_model(dev, 9, None, top_k_patches=[2] * 4)
+    slides = [DeviceSlide.synthetic(57, sid, (4, 4), p_bg=0.93, device=dev) for sid in range(4)]
+    labels = np.asarray([s.synthetic_spec.label(4) for s in slides], np.int64)
+    batch = {"slide": DeviceSlideBatch(slides), "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
+    model.train()
+    fast = putils.recurse_train(model, batch["slide"], cfg.top_k_patches, 5)
+    assert int(fast["status"].item()) & 1, "test slides should trigger the fallback"
+    model.zero_grad(set_to_none=True)
+    _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(top_k_patches=[2] * 4)
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides],
+                                      {"survival_bin": batch["survival_bin"], "censored": batch["censored"]})
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5
+    sd = dict(model.named_parameters())
+    live = 0
+    for k, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            continue
+        assert sd[k].grad is not None and rel_err(sd[k].grad, ref.grad) < 2e-3, (k, rel_err(sd[k].grad, ref.grad))
+        live += 1
+    assert live > 100
+
+
 def test_three_adamw_steps_match_reference_g6(dev):
     """Reference train-step semantics (train.py:49-50,59-68): losses of 3 AdamW steps vs the fixture captured from the
     reference (G6), dead parameters included in weight decay, unused classifiers left with grad None."""

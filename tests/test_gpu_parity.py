@@ -146,6 +146,10 @@ def test_recursion_vs_reference_golden(dev, name):
         np.testing.assert_allclose(lv["logits"].cpu().numpy(), g[f"L{l}_logits"], atol=LOGIT_TOL, rtol=0)
     hazards = torch.sigmoid(out["logits"]).cpu()
     np.testing.assert_allclose(hazards.numpy(), g["hazards"], atol=LOGIT_TOL, rtol=0)
+    # the same comparison through the shared checker, which also pins parent_inds as (child loc -> parent loc) pairs
+    from oracle.compare import compare_recursion
+    res = compare_recursion(trace, H.golden_trace(g, B, cfg.num_levels), hazards, g["hazards"], imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["index_sets_identical"] and res["parent_pairs_identical"] and not res["near_tie_slides"]
     labels = torch.from_numpy(g["labels"])
     loss = putils.nll_loss(hazards, labels[:, 0], labels[:, 1])
     np.testing.assert_allclose(float(loss), float(g["loss"]), atol=LOGIT_TOL, rtol=0)
@@ -267,6 +271,44 @@ def test_lstm_cell_module(dev):
     np.testing.assert_allclose(c1.cpu().numpy(), rc.numpy(), atol=STATE_TOL, rtol=0)
 
 
+def test_fp16_range_guard_large_features(dev):
+    """ADVICE r1 / VERDICT r1 item 7: the default mode's fp16 planes hold |x| * 16, so features beyond ~4e3 would overflow them.
+    The entry check (max|x| reduced on the device) sends such a batch to the exact bf16 split: results still match the oracle,
+    nothing is inf/NaN; an in-range batch stays on the default path; non-finite features raise."""
+    from oracle import paths_oracle as orc
+    from paths_amd import _lib, ops
+    from paths_amd.data_utils.patch_batch import PatchBatch
+    from paths_amd.data_utils.slide import DeviceSlide
+    g, info = load_golden("g2_level2_b2_k256")
+    cfg, model, params = build_model(dev, info["wseed"], info["cfg_over"])
+    ocfg = H.oracle_config(info["cfg_over"])
+    inp = {k: torch.from_numpy(v) for k, v in H.single_level_inputs(info, ocfg).items()}
+    inp["fts"] = inp["fts"] * 1e4                                    # max|x| = 1.7e4: 16 x that is past fp16's 65504
+    before = ops.RANGE_FALLBACKS[0]
+    with torch.no_grad():
+        out = model(info["depth"], PatchBatch(**{k: v.to(dev) for k, v in inp.items()}))
+        ref = orc.process_level(params, ocfg, info["depth"], inp["fts"], inp["locs"], inp["num_ims"], inp["ctx_slide"], inp["ctx_patch"])
+    assert ops.RANGE_FALLBACKS[0] == before + 1 and ops.GEMM_MODE == "h3"
+    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        assert torch.isfinite(out[k]).all(), k
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["importance"].cpu().numpy(), ref["importance"].numpy(), atol=STATE_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_patch"].cpu().numpy(), ref["ctx_patch"].numpy(), atol=STATE_TOL, rtol=0)
+    run_single(dev, "g2_level2_b2_k256")
+    assert ops.RANGE_FALLBACKS[0] == before + 1                       # in-range data: default path
+    # resident slides carry their max|x| from the tissue-mask pass
+    s = DeviceSlide.synthetic(3, 1, (4, 4), num_levels=2, device=dev)
+    assert abs(s.feature_absmax() - max(float(np.abs(s.synthetic_spec.grid(l)).max()) for l in range(2))) == 0.0
+    big = DeviceSlide([gr * 1e4 for gr in s.grids])
+    assert big.feature_absmax() > 1e4 and not ops.h3_in_range(big.feature_absmax()) and ops.h3_in_range(s.feature_absmax())
+    bad = s.grids[1].clone(); bad[1, 2, 3] = float("nan")
+    nan_slide = DeviceSlide([s.grids[0], bad])
+    assert nan_slide.feature_absmax() == float("inf")
+    from paths_amd import utils as putils
+    with pytest.raises(_lib.PathsHipError):
+        putils.recurse(model, [nan_slide], [4], 2)
+
+
 def test_cpu_tensor_rejected(dev):
     from paths_amd import _lib
     cfg, model, _ = build_model(dev, 8)
@@ -316,6 +358,48 @@ def test_full_size_properties(dev):
                 par = nxt["parent_inds"][j, :n2].cpu().numpy()
                 assert np.array_equal(pl, locs[j][ki[par]])
     assert torch.isfinite(out_pair["logits"]).all()
+
+
+@pytest.mark.parametrize("K,base,ids", [(2048, (32, 64), [10003, 10004]), (1024, (32, 32), [10000, 10001])])
+def test_headline_recursion_vs_oracle(dev, K, base, ids):
+    """BASELINE configs[1] / [2] at full size: the 5-level recursion at K patches/level (top_k K/4, 10 % background), bench
+    weights (seed 0) and the bench's cpu_baseline slides, against the oracle: per level num_ims, location sets, kept sets and
+    (child -> parent) pairs bit-exact; importance <= 5e-6, hazards <= 2e-5 (north-star bars: indices exact, logits 1e-4).
+    The slide ids were screened with the oracle for a top-K boundary gap >= 1e-5 at every level (bench.py CPU_SLIDE_IDS)."""
+    from oracle import paths_oracle as orc
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    cfg, model, params = build_model(dev, 0, None, top_k_patches=[K // 4] * 4)
+    ocfg = H.oracle_config(top_k_patches=[K // 4] * 4)
+    slides = [DeviceSlide.synthetic(1234, sid, base, device=dev) for sid in ids]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["index_sets_identical"] and res["parent_pairs_identical"] and res["near_tie_slides"] == []
+    assert res["min_boundary_gap"] >= 1e-5 and res["kept_indices_compared"] == 2 * 4 * (K // 4)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
+
+
+def test_topk_at_n8192(dev):
+    """paths_topk at its documented size limit (N = 8192 scores per slide, BASELINE configs[4] shape), ragged, with ties."""
+    from paths_amd import _lib
+    g = torch.Generator().manual_seed(11)
+    sc = torch.rand(3, 8192, generator=g)
+    sc[0, 4000:4100] = sc[0, 17]                   # a run of exact ties across the boundary region
+    nim = torch.tensor([8192, 8191, 5000])
+    sc_d, nim_d = sc.to(dev), nim.to(dev)
+    for keep in (2048, 8192):
+        ki = torch.full((3, keep), -1, dtype=torch.int32, device=dev)
+        kc = torch.zeros(3, dtype=torch.int32, device=dev)
+        _lib.call("paths_topk", sc_d.data_ptr(), 8192, nim_d.data_ptr(), 3, 8192, keep, ki.data_ptr(), keep, kc.data_ptr(), _lib.stream())
+        for b in range(3):
+            n = int(nim[b]); c = min(n, keep)
+            order = np.lexsort((np.arange(n), -sc[b, :n].numpy()))[:c]
+            assert int(kc[b]) == c
+            assert np.array_equal(ki[b, :c].cpu().numpy(), order)
 
 
 def test_graft_entry_smoke(dev):

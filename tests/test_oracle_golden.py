@@ -103,3 +103,44 @@ def test_state_dict_surface():
     assert sum(int(np.prod(s)) for s in shapes.values()) == 9_881_881
     assert "procs.0.global_agg.transformer.encoder.layers.0.self_attn.in_proj_weight" in shapes
     assert "lstm.mem_to_out.0.weight" in shapes
+
+
+def test_compare_recursion_checker_detects_differences():
+    """oracle/compare.py (used by the GPU tests and bench.py's parity_checked): the oracle against itself passes; a swapped
+    kept index, a wrong parent index and a hazard shift are each detected."""
+    import copy
+    from oracle import paths_oracle as orc
+    from oracle.compare import compare_recursion
+    from paths_amd import synthetic as syn
+    ocfg = H.oracle_config(top_k_patches=[6] * 4)
+    params = H.oracle_params(ocfg, 3)
+    grids = [orc.LazyGrids(syn.SyntheticSlide(5, s, (5, 6), 1024, 5, 0.1)) for s in range(2)]
+    tr = []
+    with torch.no_grad():
+        hz, _ = orc.inference_end2end(params, ocfg, grids, None, tr)
+
+    def as_gpu(t):          # the HIP trace's field names (paths_amd/utils.py:_recurse_body)
+        out = []
+        for l, lv in enumerate(t):
+            r = {k: lv[k].clone() for k in ("num_ims", "locs", "parent_inds", "importance", "logits")}
+            if lv["keep_inds"]:
+                cap = max(len(k) for k in lv["keep_inds"])
+                ki = torch.zeros((len(lv["keep_inds"]), cap), dtype=torch.int32)
+                for j, k in enumerate(lv["keep_inds"]):
+                    ki[j, :len(k)] = k.to(torch.int32)
+                r["keep_idx"], r["keep_count"] = ki, torch.tensor([len(k) for k in lv["keep_inds"]], dtype=torch.int32)
+            out.append(r)
+        return out
+
+    res = compare_recursion(as_gpu(tr), tr, hz, hz)
+    assert res["index_sets_identical"] and res["parent_pairs_identical"] and res["max_hazard_diff"] == 0 and res["levels"] == 5
+    bad = as_gpu(tr)
+    n0 = int(tr[0]["num_ims"][0])
+    unkept = [i for i in range(n0) if i not in set(tr[0]["keep_inds"][0].tolist())][0]
+    bad[0]["keep_idx"][0, 0] = unkept
+    assert not compare_recursion(bad, tr, hz, hz, raise_on_mismatch=False)["index_sets_identical"]
+    bad = as_gpu(tr)
+    bad[2]["parent_inds"][1, 0] = (bad[2]["parent_inds"][1, 0] + 1) % 6
+    assert not compare_recursion(bad, tr, hz, hz, raise_on_mismatch=False)["parent_pairs_identical"]
+    with pytest.raises(AssertionError):
+        compare_recursion(as_gpu(tr), tr, hz + 1e-3, hz)
