@@ -38,6 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)" (me
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 MFMA_PER_PRODUCT = {3: 6, 2: 3}   # 16-bit MFMAs issued per fp32 product block: 3 bf16 planes ("x6") / 2 fp16 planes ("h3")
 BASE_SHAPES = {2048: (32, 64), 1024: (32, 32), 256: (16, 16)}
+PMC_PROFILE_H3 = "r01m_pmc_traffic.json"     # separate --pmc passes of the default build (tools/refresh_profiles.sh)
 CPU_DSEED = 1234
 # slide ids of the cpu_baseline / parity sample: screened here with the oracle so that every level's top-K boundary gap
 # (score[k-1] - score[k]) is >= 1e-5 with the bench weights (seed 0) - the reference's own selection is thread-count
@@ -189,6 +190,8 @@ def main():
     ap.add_argument("--cpu-slides", type=int, default=2)
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra DVFS-steady loop (0 = skip)")
+    ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer (default, the BASELINE metric) or train: forward + HIP backward + AdamW + gradient all-reduce")
     args = ap.parse_args()
@@ -236,17 +239,18 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
-    # ---- timed region; the dominant kernel is bracketed by events on the launch stream
+    # ---- timed region; the dominant kernel and the aggregator span are bracketed by events on their launch streams
     events = []
 
     def timer(name, launch, meta):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        launch()
+        out_ = launch()
         e1.record()
         events.append((name, e0, e1, meta))
+        return out_
 
-    ops.KERNEL_TIMER = timer
+    ops.KERNEL_TIMER, ops.TIMER_ALL = timer, False
     barrier()
     t0 = time.perf_counter()
     out = None
@@ -260,30 +264,77 @@ def main():
     status = int(out["status"].item())
     assert status == 0, f"recursion status {status}"
     elapsed = pdist.max_over_ranks(elapsed, dev_reduce)
+    live = {}
+    for name, e0, e1, meta in events:
+        live.setdefault(name, []).append((e0.elapsed_time(e1), meta))
+    events.clear()
 
-    # ---- roofline of the dominant kernel: algorithmic FLOP = 2 * valid_rows * K * N per launch
+    # ---- sustained figure: the same step for >= --sustain seconds (DVFS-steady clocks; the 20-step region above lasts ~50 ms)
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-4)) + 1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            out = step()
+        barrier()
+        el2 = pdist.max_over_ranks(time.perf_counter() - t1, dev_reduce)
+        sustained = {"steps": n_sus, "seconds": round(el2, 3), "slides_per_s": round(spg * world * n_sus / el2, 2),
+                     "ms_per_step": round(el2 / n_sus * 1e3, 3)}
+        log(f"sustained: {n_sus} steps in {el2:.3f} s")
+
+    # ---- per-level valid rows / tokens of this rank's batch (the algorithmic work of one step)
     trace = []
     step(trace)
     torch.cuda.synchronize()
-    valid = [int(lv["num_ims"].sum().item()) for lv in trace]            # per level, this rank
-    flop = 0.0
-    ms = 0.0
-    for i, (name, e0, e1, meta) in enumerate(events):
-        lvl = i % cfg.num_levels
-        flop += 2.0 * valid[lvl] * meta["K"] * meta["Ncols"]
-        ms += e0.elapsed_time(e1)
-    n_launch = max(1, len(events))
+    nims = [lv["num_ims"].cpu().numpy().astype("float64") for lv in trace]
+    valid = [float(n.sum()) for n in nims]
+    d_t, L_t = cfg.model_config.trans_dim, cfg.model_config.trans_layers
+    # F_layer = 24 T d^2 + 4 T^2 d per slide (QKV 6Td^2, out 2Td^2, FFN 16Td^2, QK^T + PV 4T^2 d), T = valid patches + 1
+    f_agg = [float(sum(L_t * (24.0 * (n + 1) * d_t * d_t + 4.0 * (n + 1) ** 2 * d_t) for n in lv)) for lv in nims]
+
+    def gemm_o_roofline(samples):
+        flop = sum(2.0 * valid[i % cfg.num_levels] * m["K"] * m["Ncols"] for i, (_, m) in enumerate(samples))
+        ms = sum(t for t, _ in samples)
+        return flop, ms, max(1, len(samples))
+
+    # ---- serialised breakdown pass (one stream, every kernel group bracketed): what each kernel takes with the chip to itself
+    breakdown = None
+    if args.breakdown_steps > 0:
+        ops.KERNEL_TIMER, ops.TIMER_ALL = timer, True
+        saved_overlap, putils.OVERLAP_AGGREGATOR = putils.OVERLAP_AGGREGATOR, False
+        for _ in range(args.breakdown_steps):
+            step()
+        torch.cuda.synchronize()
+        putils.OVERLAP_AGGREGATOR = saved_overlap
+        ops.KERNEL_TIMER, ops.TIMER_ALL = None, False
+        ser = {}
+        for name, e0, e1, meta in events:
+            ser.setdefault(name, []).append((e0.elapsed_time(e1), meta))
+        events.clear()
+        breakdown = {"steps": args.breakdown_steps,
+                     "note": "single stream, events around every kernel group (includes the launch gaps either side); us per launch, "
+                             "launches per step",
+                     "us_per_launch": {k: round(sum(t for t, _ in v) * 1e3 / len(v), 2) for k, v in sorted(ser.items())},
+                     "launches_per_step": {k: len(v) // args.breakdown_steps for k, v in sorted(ser.items())}}
+        breakdown["us_per_step_sum"] = round(sum(breakdown["us_per_launch"][k] * breakdown["launches_per_step"][k]
+                                                 for k in ser if k != "aggregator"), 1)
+    else:
+        ser = {}
+
+    # ---- roofline of the dominant kernel: algorithmic FLOP = 2 * valid_rows * K * N per launch
+    samples_o = live.get("lstm_gate_o", [])
+    flop, ms, n_launch = gemm_o_roofline(samples_o)
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    x6 = bool(events and events[0][3].get("x6"))
-    planes = int(events[0][3].get("planes", 3)) if x6 else 0
+    meta0 = samples_o[0][1] if samples_o else {}
+    x6 = bool(meta0.get("x6"))
+    planes = int(meta0.get("planes", 3)) if x6 else 0
     traffic = None            # HBM-side bytes per launch from the committed PMC passes (separate --pmc runs, profiles/)
-    prof = {2: "r01m_pmc_traffic.json", 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
-    serialized_us = None      # the same kernel with nothing beside it (those passes serialise the streams)
+    prof = {2: PMC_PROFILE_H3, 3: "r01e_pmc_traffic.json"}.get(planes, "r01_pmc_traffic.json")
     try:
         with open(os.path.join(ROOT, "profiles", prof)) as fh:
             kstat = json.load(fh)["kernels"]["EpiLstmO"]
         traffic = kstat["traffic_bytes_per_launch"]
-        serialized_us = kstat.get("avg_us")
     except (OSError, KeyError, ValueError):
         pass
     if x6:
@@ -292,25 +343,50 @@ def main():
         what = ("2 fp16 planes (hi + lo), hi*hi + hi*lo + lo*hi = 3 x v_mfma_f32_32x32x16_f16" if planes == 2 else
                 "3 bf16 planes (hi + mid + lo), 6 x v_mfma_f32_32x32x16_bf16")
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": f"profiles/{prof} (separate --pmc passes)",
                     "kernel": f"gemm_x6_kernel<{planes},4,4,1,EpiLstmO> (LSTM output-gate GEMM, fp32 operands split into {what} "
                               "per product block, fp32 accumulate)",
                     "peak_basis": f"dense 16-bit MFMA peak 2500 TFLOP/s / {nprod} MFMAs per fp32 product block; achieved counts "
                                   "ALGORITHMIC flops 2MNK, so frac == 16-bit MFMA flops issued / 2500",
                     "mfma_issue_tflops": round(achieved * nprod, 1),
                     "vs_f32_matrix_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
-                    "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": len(events),
+                    "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": n_launch,
                     "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
-        if serialized_us:
-            # context only (not live): `achieved` above is the kernel sharing the chip with the aggregator stream's kernels
-            roofline["serialized_us_from_profile"] = serialized_us
-            roofline["serialized_frac_from_profile"] = round(flop / n_launch / (serialized_us * 1e-6) / 1e12 / peak, 4)
+        if ser.get("lstm_gate_o"):
+            f2, ms2, n2 = gemm_o_roofline(ser["lstm_gate_o"])
+            roofline["serialized_us"] = round(ms2 * 1e3 / n2, 2)          # measured in this run (breakdown pass), not from a file
+            roofline["serialized_frac"] = round(f2 / (ms2 * 1e-3) / 1e12 / peak, 4)
     else:
+        peak = PEAK_F32_MFMA_TFLOPS
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel": "gemm_f32_kernel<2,2,2,2,EpiLstmO> (LSTM output-gate GEMM, v_mfma_f32_32x32x2_f32)",
-                    "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": len(events),
+                    "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": n_launch,
                     "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
+
+    # ---- roofline of the attention + FFN kernels (north_star target: >= 0.50): the aggregator span of every level (in_proj,
+    # attention, token-layer chain, token-0 tail) event-timed on ITS stream inside the timed region; algorithmic FLOPs = L * F_layer
+    def agg_roofline(samples):
+        fl = sum(f_agg[i % cfg.num_levels] for i in range(len(samples)))
+        ms_ = sum(t for t, _ in samples)
+        return fl, ms_, max(1, len(samples))
+
+    roofline_attn = None
+    if live.get("aggregator"):
+        fl, ms_a, n_a = agg_roofline(live["aggregator"])
+        ach = fl / (ms_a * 1e-3) / 1e12 if ms_a > 0 else 0.0
+        roofline_attn = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "kernels": "tlayer (in_proj) + attention + tlayer (out_proj, LN x3, FFN, next in_proj) + token-0 tail, per level",
+                         "algorithmic_gflop_per_level_launch": round(fl / n_a / 1e9, 3), "avg_span_us": round(ms_a * 1e3 / n_a, 2),
+                         "spans": n_a,
+                         "flops_basis": "SURVEY 8(d): L * (24 T d^2 + 4 T^2 d) per slide, T = valid patches + 1, all L layers counted in "
+                                        "full; the build computes the LAST layer at token 0 only (its other rows are never read, "
+                                        "reference model/aggregator.py:75), so executed FLOPs are ~0.52 of the algorithmic count",
+                         "timing": "live: the span shares the chip with the selection chain of the next level (second stream)"}
+        if ser.get("aggregator"):
+            fl2, ms2, n2 = agg_roofline(ser["aggregator"])
+            roofline_attn["serialized_span_us"] = round(ms2 * 1e3 / n2, 2)
+            roofline_attn["serialized_frac"] = round(fl2 / (ms2 * 1e-3) / 1e12 / peak, 4)
 
     if rank == 0:
         total_slides = spg * world * args.steps
@@ -330,7 +406,13 @@ def main():
                                     ("x6: operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product block, fp32 "
                                      "accumulate (error <= an fp32 FMA chain's); everything else fp32") if x6 else "f32 MFMA"},
             "roofline": roofline,
+            "roofline_attn_ffn": roofline_attn,
+            "host": {"t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3)},
         }
+        if sustained is not None:
+            line["sustained"] = sustained
+        if breakdown is not None:
+            line["serialized_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], ids, otrace, ohz = cpu_baseline(cfg, sd, K, args.cpu_slides, args.cpu_reps)
             line["parity_checked"] = parity_check(cfg, model, K, ids, otrace, ohz, dev)

@@ -82,8 +82,11 @@ uint64_t* g_x6_dbg = nullptr;
 
 // PF = how many stages ahead of its LDS write a stage is loaded into registers (1 or 2 register sets).  Stages of the
 // 128-row tiles are only ~1,500 cycles long, shorter than a loaded-L2 round trip, so those run two stages ahead.
-template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+// OCC = waves per SIMD the register allocation is sized for: 1 (the whole 512-register file: the 256-row tiles) or more for the
+// small-tile instantiations of epilogue-bound products (K = 256 mem_to_out: several workgroups per CU hide each other's
+// epilogue loads / stores, which one wave per SIMD cannot).
+template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi, int OCC = 1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 gemm_x6_kernel(X6Operands g, Epi epi) {
   static_assert(NP == 2 || NP == 3, "two fp16 planes or three bf16 planes");
   constexpr int SUBT = subt<NP>();
@@ -427,7 +430,7 @@ __global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, uint16_
   }
 }
 
-template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi>
+template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi, int OCC = 1>
 int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
   constexpr int BM = WTM * 64, BN = WTN * 64;
   constexpr size_t lds = 2ull * (2 * WTM + 2 * WTN) * subt<NP>();
@@ -439,7 +442,7 @@ int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stre
   PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Wt % 16 == 0), "%s: operands must be 16-byte aligned", name);
   PATHS_REQUIRE(ROWS == (g.A0rows != nullptr) && (!ROWS || g.K1 == 0), "%s: row-pointer form is single-panel", name);
   PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? (g.lda0 > g.ldadd ? g.lda0 : g.ldadd) : (g.lda1 > g.ldadd ? g.lda1 : g.ldadd)) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
-  auto kern = gemm_x6_kernel<NP, WTM, WTN, PF, ADD, ROWS, Epi>;
+  auto kern = gemm_x6_kernel<NP, WTM, WTN, PF, ADD, ROWS, Epi, OCC>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -521,6 +524,12 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
   return paths_set_error(PATHS_EINVAL, "%s: planes must be 3 (bf16 x6) or 2 (fp16 x3), got %d", name, planes);
 }
 
+#ifndef PATHS_H_OCC
+#define PATHS_H_OCC 2
+#endif
+constexpr int H_OCC = PATHS_H_OCC;
+static const bool H_SMALL_TILES = getenv("PATHS_H_SMALL_TILES") == nullptr || atoi(getenv("PATHS_H_SMALL_TILES")) != 0;
+
 inline int64_t group_stride(int planes, int Kpacked) { return (int64_t)(Kpacked / 16) * planes * FRAG; }
 inline bool pow2(float x) { int e; return x > 0.f && frexpf(x, &e) == 0.5f; }
 
@@ -597,7 +606,9 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
       rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h)");
     } else {
       EpiLstmH<false, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, nullptr, 0, D, nullptr, sm};
-      rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, no y)");
+      // inference: 16 k16 stages of MFMA against 120 MB of epilogue traffic -> 128 x 128 tiles, several workgroups per CU
+      if (planes == 2 && H_SMALL_TILES) rc = launch_x6_np<2, 2, 2, 2, false, false, decltype(e), H_OCC>(gh, D, e, stream, "lstm_cell_x6(h, no y, 128x128)");
+      else rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, no y)");
     }
     if (rc) return rc;
   }

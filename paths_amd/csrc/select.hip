@@ -19,61 +19,87 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 // ------------------------------------------------------------------------------------------------
 // top-K: indices of the `keep` largest scores, ordered by (score descending, index ascending).
 // torch.topk (slide.py:298) leaves tie order unspecified; this rule equals it whenever scores are distinct.
+//
+// Selection by RANK COUNTING instead of a sort: with the 64-bit key (~monotone(score) << 32 | index) every element's output
+// position is simply the number of keys below its own, rank_i = #{j : key_j < key_i} (keys are unique), and it is kept iff
+// rank_i < count.  That is O(n^2) compares, but they are independent: 64 elements per workgroup x n/64 workgroups per slide put
+// the whole chip on a top-K that a one-workgroup-per-slide bitonic sort (66 dependent stages at n = 2048, 21 us) ran on 8 CUs.
+// Each workgroup builds all n keys of its slide in LDS (n <= 8192: 64 KiB); lane l of every wave owns element 64 blockIdx.x + l,
+// the four waves count over a quarter of the keys each (key pairs read by LDS broadcast), partial counts meet in LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int TOPK_MAX = 8192;
 
-__global__ void __launch_bounds__(1024)
-topk_kernel(const float* __restrict__ scores, int64_t ld, const int64_t* __restrict__ num_ims, int keep,
-            int* __restrict__ keep_idx, int64_t ldk, int* __restrict__ keep_count,
-            const float* __restrict__ row_base, int64_t row_ld, int64_t slide_rows,        // optional: kept_rows[b, i] = address of
-            int64_t* __restrict__ kept_rows, const float* __restrict__ zero_row) {          // row_base[b, keep_idx[b, i], :] (zero_row beyond count)
-  __shared__ unsigned long long keys[TOPK_MAX];
-  const int b = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ unsigned long long topk_key(float score, int idx) {
+  uint32_t u = __float_as_uint(score);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // monotone float -> uint
+  return ((unsigned long long)(~u) << 32) | (uint32_t)idx;
+}
+
+__global__ void __launch_bounds__(256)
+topk_rank_kernel(const float* __restrict__ scores, int64_t ld, const int64_t* __restrict__ num_ims, int keep,
+                 int* __restrict__ keep_idx, int64_t ldk, int* __restrict__ keep_count,
+                 const float* __restrict__ row_base, int64_t row_ld, int64_t slide_rows,        // optional: kept_rows[b, i] = address of
+                 int64_t* __restrict__ kept_rows, const float* __restrict__ zero_row) {          // row_base[b, keep_idx[b, i], :] (zero_row beyond count)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = (int)num_ims[b];
   const int count = keep < 0 ? n : min(n, keep);
-  if (tid == 0) keep_count[b] = count;
+  const int i = blockIdx.x * 64 + lane;                 // this lane's element
+  if (blockIdx.x == 0 && tid == 0) keep_count[b] = count;
   auto row_addr = [&](int idx) { return (int64_t)reinterpret_cast<uintptr_t>(row_base + ((int64_t)b * slide_rows + idx) * row_ld); };
-  if (keep < 0) {                                     // keep all, original order (slide.py:294 not taken)
-    for (int i = tid; i < n; i += 1024) keep_idx[(int64_t)b * ldk + i] = i;
-    if (kept_rows)
-      for (int i = tid; i < ldk; i += 1024) kept_rows[(int64_t)b * ldk + i] = i < n ? row_addr(i) : (int64_t)reinterpret_cast<uintptr_t>(zero_row);
+  // entries [count, ldk) of the row table point at the zero row (every workgroup covers its own 64 positions)
+  if (kept_rows && wave == 0 && i >= count && i < ldk) kept_rows[(int64_t)b * ldk + i] = (int64_t)reinterpret_cast<uintptr_t>(zero_row);
+  if (blockIdx.x * 64 >= n) return;                     // nothing valid here (workgroup-uniform)
+  if (keep < 0) {                                       // keep all, original order (slide.py:294 not taken)
+    if (wave == 0 && i < n) {
+      keep_idx[(int64_t)b * ldk + i] = i;
+      if (kept_rows) kept_rows[(int64_t)b * ldk + i] = row_addr(i);
+    }
     return;
   }
-  int np = 1;
-  while (np < n) np <<= 1;
+  const int np = (n + 7) & ~7;                          // keys beyond n: all ones (never below a real key)
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  int* part = reinterpret_cast<int*>(smem + (size_t)((np + 1) & ~1) * 8);      // [4][64] partial counts
   const float* s = scores + (int64_t)b * ld;
-  for (int i = tid; i < np; i += 1024) {
-    unsigned long long key = ~0ull;
-    if (i < n) {
-      uint32_t u = __float_as_uint(s[i]);
-      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone float -> uint
-      key = ((unsigned long long)(~u) << 32) | (uint32_t)i;
-    }
-    keys[i] = key;
-  }
+  for (int j = tid; j < np; j += 256) keys[j] = j < n ? topk_key(s[j], j) : ~0ull;
   __syncthreads();
-  for (int size = 2; size <= np; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (np >> 1); t += 1024) {
-        const int lo = 2 * t - (t & (stride - 1));
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const unsigned long long a = keys[lo], c = keys[hi];
-        if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
-      }
-      // thread t touches elements 2t - (t & (stride-1)) and + stride: for stride <= 64 the 64 threads of a wave stay inside their
-      // own 128 elements.  A stage whose own and whose successor's stride are both <= 64 only has to make its LDS writes visible
-      // to its wave (45 of the 66 stages at n = 2048 skip the 16-wave barrier).
-      const int next_stride = stride > 1 ? (stride >> 1) : size;
-      if (stride > 64 || next_stride > 64) __syncthreads();
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned long long mine = i < n ? keys[i] : 0ull;
+  // quarter of the key range per wave, in units of key PAIRS (16-byte broadcast reads)
+  const int pairs = np >> 1, q0 = (pairs * wave) >> 2, q1 = (pairs * (wave + 1)) >> 2;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
+  int cnt = 0;
+  int q = q0;
+  for (; q + 4 <= q1; q += 4) {
+    const u64x2 a = kp[q], c = kp[q + 1], d = kp[q + 2], e = kp[q + 3];
+    cnt += (a[0] < mine) + (a[1] < mine) + (c[0] < mine) + (c[1] < mine) + (d[0] < mine) + (d[1] < mine) + (e[0] < mine) + (e[1] < mine);
+  }
+  for (; q < q1; ++q) { const u64x2 a = kp[q]; cnt += (a[0] < mine) + (a[1] < mine); }
+  part[wave * 64 + lane] = cnt;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    const int rank = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    if (rank < count) {
+      keep_idx[(int64_t)b * ldk + rank] = i;
+      if (kept_rows) kept_rows[(int64_t)b * ldk + rank] = row_addr(i);
     }
   }
-  __syncthreads();
-  for (int i = tid; i < count; i += 1024) keep_idx[(int64_t)b * ldk + i] = (int)(uint32_t)keys[i];
-  if (kept_rows)
-    for (int i = tid; i < ldk; i += 1024)
-      kept_rows[(int64_t)b * ldk + i] = i < count ? row_addr((int)(uint32_t)keys[i]) : (int64_t)reinterpret_cast<uintptr_t>(zero_row);
+}
+
+static int launch_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, int n_max, int keep, int* keep_idx, int64_t ldk,
+                       int* keep_count, const float* row_base, int64_t row_ld, int64_t slide_rows, int64_t* kept_rows,
+                       const float* zero_row, hipStream_t stream) {
+  const size_t lds = (size_t)(((n_max + 7) & ~7) + 2) * 8 + 4 * 64 * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((TOPK_MAX + 2) * 8 + 1024));
+    attr_set = true;
+  }
+  // x covers every element AND every position of the kept-row table (ldk may exceed n_max only through padding; both <= TOPK_MAX)
+  const int cover = (int)(ldk > n_max ? ldk : n_max);
+  hipLaunchKernelGGL(topk_rank_kernel, dim3((cover + 63) / 64, B), dim3(256), lds, stream, scores, ld, num_ims, keep, keep_idx, ldk,
+                     keep_count, row_base, row_ld, slide_rows, kept_rows, zero_row);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,8 +429,8 @@ int paths_topk(const float* scores, int64_t ld, const int64_t* num_ims, int B, i
   PATHS_REQUIRE(B > 0 && n_max > 0 && n_max <= TOPK_MAX, "topk: n_max (%d) must be in [1, %d]", n_max, TOPK_MAX);
   PATHS_REQUIRE(keep == -1 || keep > 0, "topk: keep must be -1 (all) or > 0");
   PATHS_REQUIRE(ldk >= (keep < 0 ? n_max : (keep < n_max ? keep : n_max)), "topk: keep_idx row too short");
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, stream, scores, ld, num_ims, keep, keep_idx, ldk, keep_count,
-                     (const float*)nullptr, (int64_t)0, (int64_t)0, (int64_t*)nullptr, (const float*)nullptr);
+  PATHS_REQUIRE(ldk <= TOPK_MAX, "topk: keep_idx row longer than %d", TOPK_MAX);
+  launch_topk(scores, ld, num_ims, B, n_max, keep, keep_idx, ldk, keep_count, nullptr, 0, 0, nullptr, nullptr, stream);
   PATHS_LAUNCH_CHECK("topk");
   return PATHS_OK;
 }
@@ -418,8 +444,8 @@ int paths_topk_rows(const float* scores, int64_t ld, const int64_t* num_ims, int
   PATHS_REQUIRE(keep == -1 || keep > 0, "topk_rows: keep must be -1 (all) or > 0");
   PATHS_REQUIRE(ldk >= (keep < 0 ? n_max : (keep < n_max ? keep : n_max)), "topk_rows: keep_idx row too short");
   PATHS_REQUIRE(row_base && kept_rows && zero_row && row_ld > 0 && slide_rows >= n_max, "topk_rows: row table arguments");
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, stream, scores, ld, num_ims, keep, keep_idx, ldk, keep_count,
-                     row_base, row_ld, slide_rows, kept_rows, zero_row);
+  PATHS_REQUIRE(ldk <= TOPK_MAX, "topk_rows: keep_idx row longer than %d", TOPK_MAX);
+  launch_topk(scores, ld, num_ims, B, n_max, keep, keep_idx, ldk, keep_count, row_base, row_ld, slide_rows, kept_rows, zero_row, stream);
   PATHS_LAUNCH_CHECK("topk_rows");
   return PATHS_OK;
 }

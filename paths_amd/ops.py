@@ -26,6 +26,16 @@ LOG2E = 1.4426950408889634
 QKV_IMAGES = os.environ.get("PATHS_QKV_IMAGES", "1") != "0"
 SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
+TIMER_ALL = False     # with KERNEL_TIMER: False = bracket only the dominant kernel and the aggregator span (the timed region of
+                      # bench.py), True = every kernel group (bench.py's serialised breakdown pass)
+
+
+def timed(name: str, fn, meta=None, detail: bool = True):
+    """Run ``fn`` (a launch sequence on the current stream); bench.py may bracket it with events.  ``detail`` groups are only
+    bracketed in the breakdown pass."""
+    if KERNEL_TIMER is None or (detail and not TIMER_ALL):
+        return fn()
+    return KERNEL_TIMER(name, fn, meta or {})
 # Which matrix pipe the big products (selection-chain GEMMs, attention) use.  All are HIP kernels of libpaths_hip.so with fp32
 # inputs, outputs and accumulation:
 #   "h3"  : operands split into TWO fp16 planes, 3 MFMAs per product block (csrc/gemm_x6.hip, NP = 2)            - default
@@ -420,14 +430,14 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         if KERNEL_TIMER is None:
             lstm(7)
         else:                   # bench.py: bracket the dominant kernel (output-gate GEMM) with events on this stream
-            lstm(1)
-            KERNEL_TIMER("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D,
-                                                          "parent_partials": parent is not None, "x6": x6, "planes": split_planes() if x6 else 0})
-            lstm(4)
+            timed("lstm_gate_c", lambda: lstm(1))
+            timed("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D, "parent_partials": parent is not None,
+                                                   "x6": x6, "planes": split_planes() if x6 else 0}, detail=False)
+            timed("lstm_mem_to_out", lambda: lstm(4))
         if x6:
-            importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out)
+            timed("importance_proj", lambda: importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out))
         else:
-            importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance)
+            timed("importance_proj", lambda: importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance))
         del ws_o
     else:
         # lstm=false (reference model/paths.py:95-109): alpha from X; Z = alpha*X (+ hctx_mlp(previous Z) on valid rows);
@@ -469,7 +479,7 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
         # default split mode: the GEMM reads the kept parents' h rows where they are (addresses from paths_topk_rows)
         assert use_x6(D, Hc) and G % 256 == 0 and split_planes() == 2 and kept_rows.shape == (B, cap) and kept_rows.dtype == torch.int64
         wg, wg_s = _x6_of(lstm_pack, "w_gates")
-        _lib.call("paths_gemm_rows_nt_x6", p(kept_rows), p(wg), 2 * D, D, p(hp), G, B * cap, G, D, 2, wg_s, a_scale(), st)
+        timed("parent_gemm", lambda: _lib.call("paths_gemm_rows_nt_x6", p(kept_rows), p(wg), 2 * D, D, p(hp), G, B * cap, G, D, 2, wg_s, a_scale(), st))
         return hp
     hk = torch.empty((B * cap, D), **f32)
     _lib.call("paths_gather_kept_rows", p(state_out), N, Dp, p(keep_idx), cap, p(keep_count), D, B, p(hk), st)
@@ -486,6 +496,12 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
 def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
     """The transformer aggregator + classifier of a level (reference model/aggregator.py:58-76, model/paths.py:126-139).
     Nothing here feeds the next level's patch selection, so the device recursion runs it on a second HIP stream."""
+    return timed("aggregator", lambda: _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all),
+                 {"T": tokens.shape[1], "d": tokens.shape[2], "L": mc.trans_layers, "planes": split_planes() if GEMM_MODE != "f32" else 0},
+                 detail=False)
+
+
+def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
     _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
@@ -533,23 +549,24 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
     # default mode: the in_proj of a layer that feeds the full attention writes the attention kernel's operand images itself
     # (no fp32 q, k, v round trip, no re-write launch); the last layer's q, k, v stay fp32 for the token-0 tail
     direct = GEMM_MODE == "h3" and attn_ws is not None and QKV_IMAGES
-    token_layer(xa, None, None, layers[0], qkv_images=attn_ws if direct else None)
+    timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0], qkv_images=attn_ws if direct else None))
     for l in range(L - 1):
         if GEMM_MODE != "f32":
-            _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, p(attn_ws), split_planes(),
-                      1 if direct else 0, st)
+            timed("agg_attention", lambda: _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0,
+                                                     p(attn_ws), split_planes(), 1 if direct else 0, st))
         else:
-            _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st)
-        token_layer(xa, xb, layers[l], layers[l + 1], qkv_images=attn_ws if (direct and l + 1 < L - 1) else None)
+            timed("agg_attention", lambda: _lib.call("paths_attention_f32", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0, st))
+        timed("agg_token_chain", lambda: token_layer(xa, xb, layers[l], layers[l + 1], qkv_images=attn_ws if (direct and l + 1 < L - 1) else None))
         xa, xb = xb, xa
     # Last layer: only token 0 of its output is read (aggregator.py:75) -> one fused launch per level computes the
     # single-query attention, the row chain, decoder.norm, the slide-context residual and the classifier.
     w = layers[L - 1]
     ws_part = torch.empty((B * H * 16 * 36,), **f32)
-    _lib.call("paths_token0_tail", p(xa), p(q), p(k), p(v), p(num_ims), p(w["wo"]), p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
-              p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["w1"]), p(w["b1"]), p(w["w2"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]),
-              p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
-              res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
-              p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
-              p(ws_part), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
+    timed("agg_token0_tail", lambda: _lib.call(
+        "paths_token0_tail", p(xa), p(q), p(k), p(v), p(num_ims), p(w["wo"]), p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
+        p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["w1"]), p(w["b1"]), p(w["w2"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]),
+        p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
+        res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
+        p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
+        p(ws_part), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st))
     return {"logits": logits, "ctx_slide": ctx_out}

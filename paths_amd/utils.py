@@ -187,8 +187,8 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         if rows_in_place:
             # ... with the addresses of the kept parents' h rows (row b, i -> ctx_patch[b, keep_idx[b, i], :D]) for the parent GEMM
             kept_rows = torch.empty((B, cap_keep), **i64)
-            _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count),
-                      p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st)
+            ops.timed("topk", lambda: _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep,
+                                                p(keep_count), p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st))
         else:
             _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
         Nn = 4 * cap_keep
@@ -209,7 +209,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
                           p(bufs[3]), p(bufs[4]), p(status), None, p(bufs[5]) if share_parent else None, st2)
                 return bufs
 
-            num_next, locs_next, parent_next, src_row, src_cell, hp_row = expand(Nn)
+            num_next, locs_next, parent_next, src_row, src_cell, hp_row = ops.timed("expand", lambda: expand(Nn))
             if careful:
                 empty = (num_next == 0).cpu()                      # per-level sync: slow path only
                 if bool(empty.any()):
@@ -233,8 +233,9 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
                     # ... and their feature rows are not copied either: the GEMMs of the next level read them in the resident grids
                     fts_next = None
                     x_rows_next = torch.empty((B, Nn), **i64)
-                    _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
-                              p(src_row), Hc, p(num_next), B, Nn, None, p(state_next), 0, p(x_rows_next), p(zero_row), st2)
+                    ops.timed("gather", lambda: _lib.call(
+                        "paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
+                        p(src_row), Hc, p(num_next), B, Nn, None, p(state_next), 0, p(x_rows_next), p(zero_row), st2))
                 else:
                     fts_next = torch.empty((B, Nn, D), **f32)
                     _lib.call("paths_gather_rows", p(grid_ptrs[i + 1]), p(src_cell), D, out["ctx_patch"].data_ptr() + 4 * D, N, Dp,
