@@ -153,13 +153,28 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[2], const u32x4 (&b
   return c;
 }
 
+__device__ __forceinline__ float rows_max(float x) { x = fmaxf(x, __shfl_xor(x, 16)); return fmaxf(x, __shfl_xor(x, 32)); }
+__device__ __forceinline__ float rows_sum(float x) { x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32); }
+
 template <int NP>
 __global__ void __launch_bounds__(256)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
-               float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
+               float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H,
+               int npairs_arg, int nqb_arg) {
   constexpr int STEP_BYTES = step_bytes<NP>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];          // 2 x STEP_BYTES (+ occupancy padding, see the launcher)
-  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+  // XCD-aware placement (speed only): every workgroup of one (slide, head) pair streams that pair's whole K / V^T images (0.5 MB
+  // at T = 2049), and blocks are dealt round-robin over the 8 XCDs.  With the query block as the fastest grid index each XCD's
+  // 4 MiB L2 saw ALL pairs (8.4 MB at 8 slides): the images were re-fetched ~16 x from beyond L2 (133 MB per launch, measured)
+  // and a key step took 1.5 x as long at 8 slides as at 2.  Here pair p only ever runs on the XCD group p % 8: linear id ->
+  // (group x = id % 8, j = id / 8), the group's pairs are x, x + 8, ..., pair index fastest within the group.
+  const int npairs = npairs_arg, nqb = nqb_arg;         // grid.x = 8 * ceil(npairs / 8) * nqb
+  const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
+  const int cnt = (npairs - xg + 7) >> 3;               // pairs of this group
+  if (cnt <= 0) return;
+  const int pair = xg + 8 * (jx % cnt), qb = jx / cnt;
+  if (qb >= nqb) return;
+  const int b = pair / H, head = pair - b * H, q0 = qb * 128;
   const int len = min((int)num_ims[b] + 1, T);          // valid keys = special token + patches
   if (q0 >= len) return;                                // every query of this block is padding
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,12 +240,13 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   f32x4 sA[2][4], sB[2][4];                             // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
   qk(0, sA);
   // one step: s = S(kt) (ready), sn receives S(kt+1)
-  auto step = [&](int kt, f32x4 (&s)[2][4], f32x4 (&sn)[2][4]) __attribute__((always_inline)) {
+  auto step = [&](int kt, f32x4 (&s)[2][4], f32x4 (&sn)[2][4], auto lastc) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(lastc)::value;       // the masked step is peeled: 26 selects per step otherwise
     if (kt + 2 < nkt) gload_k(kt + 2);
     if (kt + 1 < nkt) gload_v(kt + 1);
     const char* sV = sVb + (kt & 1) * HALF + lane * 16;
     // ---- mask (last step only) + online softmax (lane: query ql of each tile; keys 16 t + 4 g4 + r)
-    if (kt == nkt - 1) {
+    if constexpr (LAST) {
       const int kbase = kt * KSTEP + 4 * g4;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
@@ -250,8 +266,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
         mx = fmaxf(fmaxf(mx, s[qt][t][0]), s[qt][t][1]);
         mx = fmaxf(fmaxf(mx, s[qt][t][2]), s[qt][t][3]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = rows_max(mx);
       const float m_new = fmaxf(m_run[qt], mx);         // finite: key 0 (special token) is always valid
       const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
       float psum = 0.f;
@@ -287,15 +302,20 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     if (kt + 1 < nkt) swrite_v(kt + 1);                 // over V(kt-1)
     __syncthreads();
   };
-  for (int kt = 0; kt < nkt; kt += 2) {
-    step(kt, sA, sB);
-    if (kt + 1 < nkt) step(kt + 1, sB, sA);
+  {
+    constexpr std::false_type MID{};
+    constexpr std::true_type END{};
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      step(kt, sA, sB, MID);
+      step(kt + 1, sB, sA, MID);
+    }
+    if (kt + 1 < nkt) { step(kt, sA, sB, MID); step(kt + 1, sB, sA, END); }
+    else step(kt, sA, sB, END);
   }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = rows_sum(l_run[qt]);
     const float inv = 1.0f / l;
     const int qi = qw + 16 * qt + ql;
     if (qi < T) {
@@ -334,7 +354,9 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_x6_kernel<NP>, dim3((nq + 127) / 128, H, B), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H);
+  const int nqb = (nq + 127) / 128, npairs = H * B;
+  // 1-D grid walked in XCD-aware order (see the kernel)
+  hipLaunchKernelGGL(attn_x6_kernel<NP>, dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb);
   PATHS_LAUNCH_CHECK("attention_x6");
   return PATHS_OK;
 }

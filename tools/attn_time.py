@@ -6,10 +6,10 @@ sys.path.insert(0, ROOT)
 import torch
 from paths_amd import _lib
 dev = torch.device("cuda:0")
-B, H, T, hd, planes = 8, 4, 2049, 32, 2
+B, H, T, hd, planes = int(os.environ.get('ATTN_B', '8')), 4, int(os.environ.get('ATTN_T', '2049')), 32, 2
 g = torch.Generator(device=dev); g.manual_seed(0)
 q, k, v = ((torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1) for _ in range(3))
-num_ims = torch.tensor([1844, 1850, 1839, 1861, 1822, 1847, 1855, 1830], device=dev)
+num_ims = torch.tensor(([1844, 1850, 1839, 1861, 1822, 1847, 1855, 1830] * 4)[:B], device=dev).clamp(max=T - 1)
 ws = torch.empty(int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, planes)), device=dev, dtype=torch.uint8)
 o = torch.empty(B, T, H * hd, device=dev)
 p, st = _lib.ptr, _lib.stream()

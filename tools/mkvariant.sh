@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: mkvariant.sh NAME file.hip [extra hipcc flags...]   -> tools/_bin/v/NAME.so (all other objects from the product build)
+set -e
+NAME=$1; SRC=$2; shift 2
+cd /root/repo/paths_amd/csrc
+base=$(basename $SRC .hip)
+extra=""
+if [ "$base" = "attn_x6" ] || [ "$base" = "tlayer_h3" ]; then extra="-mllvm -amdgpu-mfma-vgpr-form"; fi
+hipcc -O3 --offload-arch=gfx950 -fPIC -Wno-unused-value $extra "$@" -c -o /tmp/v_${NAME}.o $(basename $SRC)
+objs=""
+for o in build/*.o; do b=$(basename $o .o); if [ "$b" != "$base" ]; then objs="$objs $o"; fi; done
+hipcc --offload-arch=gfx950 -fPIC -shared -o /root/repo/tools/_bin/v/${NAME}.so $objs /tmp/v_${NAME}.o
+echo built $NAME
