@@ -673,3 +673,29 @@ def test_topk_rows_and_row_addressed_gemm(dev):
     assert torch.equal(out_rows, out_copy)
     ref = gathered.double() @ w.double().t()
     assert (out_rows.double() - ref).abs().max().item() < 2e-5
+
+
+def test_graphed_recursion_replays_bit_identically(dev):
+    """paths_amd.utils.GraphedRecursion: the three-stream recursion captured into a HIP graph; replays equal the eager pass bit for
+    bit, a changed weight triggers a re-capture, a batch that needs the zero-children fallback is handed to the eager path."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 3, None, top_k_patches=[24] * 4)
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(99, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)])
+    with torch.no_grad():
+        ref = putils.recurse(model, slides, cfg.top_k_patches, 5)
+    g = putils.GraphedRecursion(model, slides, cfg.top_k_patches, 5)
+    for _ in range(3):
+        out = g.run()
+        assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
+    with torch.no_grad():
+        model.procs[4].classification_layer.bias.add_(0.25)
+        ref2 = putils.recurse(model, slides, cfg.top_k_patches, 5)
+    out2 = g.run()
+    assert torch.equal(out2["logits"], ref2["logits"]) and not torch.equal(out2["logits"], ref["logits"])
+    cfg2, model2, _ = build_model(dev, 9, None, top_k_patches=[2] * 4)
+    fb = DeviceSlideBatch([DeviceSlide.synthetic(57, sid, (4, 4), p_bg=0.93, device=dev) for sid in range(4)])
+    with torch.no_grad():
+        ref3 = putils.recurse(model2, fb, cfg2.top_k_patches, 5)
+    out3 = putils.GraphedRecursion(model2, fb, cfg2.top_k_patches, 5).run()
+    assert torch.equal(out3["logits"], ref3["logits"])
