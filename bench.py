@@ -64,11 +64,12 @@ def host_cpu_share() -> int:
     return max(1, min(n, int(os.environ.get("PATHS_CPU_THREADS", "16"))))
 
 
-def build_model(K: int, dev):
+def build_model(K: int, dev, dropout=None):
     from paths_amd import synthetic as syn
     from paths_amd.config import Config
     cfg = Config.load(os.path.join(ROOT, "tests", "golden", "sample"), test_mode=True)
-    cfg.model_config.dropout = 0.0
+    if dropout is not None:               # (None: the shipped value, models/sample/config.json: 0.05; only train mode reads it)
+        cfg.model_config.dropout = float(dropout)
     cfg.top_k_patches = [K // 4] * (cfg.num_levels - 1)
     model = cfg.get_model()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -171,7 +172,7 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train step (reference train.py:59-68 semantics): 5-level recursion K={K}, forward + HIP backward + "
-                                   f"AdamW, {len(slides)} slides per GPU, dropout 0", "global_batch": gb,
+                                   f"AdamW, {len(slides)} slides per GPU, dropout {cfg.model_config.dropout}", "global_batch": gb,
                        "parallelism": f"dp{world}: one flat fp32 gradient all-reduce per step" if world > 1 else "single GPU"},
             "final_loss_share": float(loss), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
     if world > 1:
@@ -196,6 +197,7 @@ def main():
                     "overlap (3.92 ms per step against 2.43 ms eager), so eager launches stay the default")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra DVFS-steady loop (0 = skip)")
     ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
+    ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer (default, the BASELINE metric) or train: forward + HIP backward + AdamW + gradient all-reduce")
     args = ap.parse_args()
@@ -220,7 +222,7 @@ def main():
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     _lib.load()
     K, spg = args.k, args.slides_per_gpu
-    cfg, model, sd = build_model(K, dev)
+    cfg, model, sd = build_model(K, dev, args.dropout)
     slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)])
     torch.cuda.synchronize()
     log(f"model + {spg} slides resident ({torch.cuda.memory_allocated() / 2**30:.1f} GiB)")

@@ -314,6 +314,31 @@ int paths_tissue_mask_absmax(const float* grid, int64_t cells, int D, uint8_t* m
 int paths_synth_grid(float* grid, int X, int Y, int D, uint32_t slide_level_key, int level, uint64_t bg_threshold,
                      paths_stream_t stream);
 
+/* ---- dropout (training; reference nn.Transformer(..., dropout=p), model/aggregator.py:25-33: attention probabilities,
+ * dropout1, dropout2, the feed-forward's inner dropout, dropout3).  Masks are never stored: element idx of site `key` is kept iff
+ * hash(idx, key) >= p * 2^32 (csrc/dropout.h) and is regenerated by every kernel that needs it; kept values are scaled by
+ * 1 / (1 - p).  The host derives one 64-bit key per (step seed, level, layer, site). */
+
+/* out[r, c] = (resid ? resid[r, c] : 0) + (vec ? vec[c] : x[r, c]) * mask(r * N + c) / (1 - p); exactly one of x / vec is given;
+ * x, resid, out may alias.  Covers dropout1 / dropout3 (+ residual), the inner feed-forward dropout (in place), dropout2 on the
+ * broadcast cross-attention bias (vec) and the masking of gradients in the backward pass. */
+int paths_dropout_rows(const float* x, int64_t ldx, const float* vec, const float* resid, int64_t ldr, float* out, int64_t ldo,
+                       int64_t M, int N, uint64_t key, float p, paths_stream_t stream);
+/* mask[i] = 1 kept / 0 dropped, i in [0, n): tests only */
+int paths_dropout_mask(float* mask, int64_t n, uint64_t key, float p, paths_stream_t stream);
+/* paths_attention_x6 with dropout on the softmax probabilities: O = (softmax(S) * mask / (1 - p)) V, lse un-dropped; mask element
+ * ((b * H + h) * T + q) * T + k.  q, k, v fp32 (no pre-built images). */
+int paths_attention_x6_dropout(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B,
+                               int T, int H, int head_dim, int max_queries, void* workspace, int planes, uint64_t drop_key,
+                               float drop_p, paths_stream_t stream);
+/* backward twins (same key, same p as the forward) */
+int paths_attention_bwd_f32_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                                    const float* lse, const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H,
+                                    int head_dim, uint64_t drop_key, float drop_p, paths_stream_t stream);
+int paths_attention_token0_bwd_dropout(const float* q, const float* k, const float* v, const float* a0, const float* da0,
+                                       const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, uint64_t drop_key,
+                                       float drop_p, paths_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

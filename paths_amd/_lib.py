@@ -63,6 +63,11 @@ SIGNATURES = {
     "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_scale_add_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
+    "paths_dropout_rows": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _u64, _f32, _vp],
+    "paths_dropout_mask": [_vp, _i64, _u64, _f32, _vp],
+    "paths_attention_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _u64, _f32, _vp],
+    "paths_attention_bwd_f32_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
+    "paths_attention_token0_bwd_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
     "paths_tissue_mask_absmax": [_vp, _i64, _i32, _vp, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],

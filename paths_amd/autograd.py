@@ -7,7 +7,8 @@ launch sequences of paths_amd/backward.py:
     the tensors the backward needs, backward = transformer_backward + selection_backward;
   * :class:`GatherFn` — the child gather between levels (``PreprocessedSlide.iter``): backward = paths_gather_rows_bwd.
 
-Round-1 training limits (raised, never approximated): lstm=True, slide_ctx_mode in {residual, none}, dropout inactive.
+Training limits (raised, never approximated): lstm=True, slide_ctx_mode in {residual, none}.  Dropout > 0 in train mode runs the
+transformer's row chain on the generic kernels with regenerated masks (paths_amd/backward.py:Drop).
 """
 from __future__ import annotations
 
@@ -105,7 +106,7 @@ def check_dropout_supported(proc):
                                   "or call model.eval()")
 
 
-DROPOUT_IMPLEMENTED = False
+DROPOUT_IMPLEMENTED = True
 
 
 class LevelFn(torch.autograd.Function):
@@ -118,7 +119,11 @@ class LevelFn(torch.autograd.Function):
         lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
         sel = bw.selection_forward_train(mc, lp, vp, fts, locs.contiguous(), num_ims.contiguous(), state_prev)
         res = ctx_prev if mc.slide_ctx_mode == "residual" else None
-        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res)
+        drop = None
+        if proc.training and mc.dropout > 0:
+            # one seed per level forward from torch's global generator (torch.manual_seed controls the masks, as in the reference)
+            drop = bw.Drop(mc.dropout, int(torch.empty((), dtype=torch.int64).random_().item()), proc.depth)
+        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop)
         ctx.proc, ctx.lstm, ctx.sel, ctx.tr = proc, lstm, sel, tr
         ctx.has_state, ctx.has_ctx = state_prev is not None, res is not None
         ctx.set_materialize_grads(False)

@@ -226,6 +226,35 @@ def unpack_lstm_grads(lstm, g: Dict[str, torch.Tensor]) -> Dict[str, torch.Tenso
 LOG2E = 1.4426950408889634
 
 
+class Drop:
+    """Dropout of one level's transformer in one training step (reference nn.Transformer(..., dropout=p): five sites per decoder
+    layer).  ``seed`` is drawn once per level forward from torch's global generator (so ``torch.manual_seed`` controls it);
+    every (layer, site) gets its own 64-bit key; masks are regenerated from (key, element index) wherever they are needed
+    (csrc/dropout.h) - forward, the backward's recompute and the gradient masking all see the same mask."""
+    ATTN, SA_OUT, CA_OUT, FF_INNER, FF_OUT = range(5)
+
+    def __init__(self, p: float, seed: int, depth: int = 0):
+        self.p, self.seed, self.depth = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(depth)
+
+    def key(self, layer: int, site: int) -> int:
+        z = (self.seed + 0x9E3779B97F4A7C15 * (1 + site + 8 * layer + 1024 * self.depth)) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF          # splitmix64 finaliser
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+
+def dropout_rows(x, ldx, M, N, key, p, out=None, ldo=None, resid=None, ldr=0, vec=None):
+    """out = (resid) + (vec broadcast | x) * mask / (1 - p)   (paths_dropout_rows); x / resid / out may be raw pointers."""
+    ptr = lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr())
+    dev = next(t for t in (out, x, resid, vec) if t is not None and not isinstance(t, int)).device
+    if out is None:
+        out = torch.empty((M, N), **_f32(dev))
+        ldo = N
+    _lib.call("paths_dropout_rows", ptr(x) if vec is None else None, ldx, ptr(vec), ptr(resid), ldr, ptr(out), ldo if ldo is not None else N,
+              M, N, key, p, _lib.stream())
+    return out
+
+
 def _ln_fwd(x, add, g, b, rows, eps, want_y=True):
     f32 = _f32(x.device)
     y = torch.empty((rows, 128), **f32) if want_y else None
@@ -256,40 +285,86 @@ def _ln_bwd_sums(dy, xh, rs, g, rows):
     return dx, gb[:128], gb[128:256], gb[256:]
 
 
-def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dx_out: torch.Tensor, dev):
-    """Row chain of one decoder layer (out_proj .. norm3): recompute its intermediates with the generic kernels,
-    then differentiate.  x_in / attn are raw pointers with row strides (token-0 rows of the last layer are strided).
-    Returns (grads, dx_in [M,128], dattn [M,128])."""
+def chain_forward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dev, drop: Optional[Drop] = None, layer: int = 0,
+                  want_out: bool = True):
+    """Row chain of one decoder layer (out_proj .. norm3) with the generic kernels, keeping what its backward needs.
+    x_in / attn are raw pointers with row strides (token-0 rows of the last layer are strided).  With ``drop`` the four row-wise
+    dropout sites of the layer are applied (dropout1, dropout2 on the broadcast cross-attention bias, the feed-forward's inner
+    dropout, dropout3); without it this is the plain chain.  Mask element index = row * width + column of the [M, width] matrix."""
     f32 = _f32(dev)
     eps = w["eps"]
+    c: Dict[str, object] = {}
+    if drop is None:
+        u1 = torch.empty((M, 128), **f32)
+        gemm_nt(attn_ptr, lda, w["wo"], u1, 128, M, 128, 128, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
+        n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps)
+        n2, c["xh2"], c["rs2"] = _ln_fwd(n1, w["cab"], w["ln2g"], w["ln2b"], M, eps)
+        hid = torch.empty((M, 512), **f32)
+        gemm_nt(n2, 128, w["w1"], hid, 512, M, 512, 128, bias=w["b1"], act=1)
+        u3 = torch.empty((M, 128), **f32)
+        gemm_nt(hid, 512, w["w2"], u3, 128, M, 128, 512, bias=w["b2"], residual=n2, ldr=128)
+        c["hid"], c["hid_used"] = hid, hid
+    else:
+        p = drop.p
+        sa = torch.empty((M, 128), **f32)
+        gemm_nt(attn_ptr, lda, w["wo"], sa, 128, M, 128, 128, bias=w["bo"])
+        u1 = dropout_rows(sa, 128, M, 128, drop.key(layer, Drop.SA_OUT), p, out=sa, ldo=128, resid=x_in_ptr, ldr=ldx)       # x + dropout1(sa)
+        n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps)
+        u2 = dropout_rows(None, 0, M, 128, drop.key(layer, Drop.CA_OUT), p, resid=n1, ldr=128, vec=w["cab"])                 # n1 + dropout2(cab)
+        n2, c["xh2"], c["rs2"] = _ln_fwd(u2, None, w["ln2g"], w["ln2b"], M, eps)
+        hid = torch.empty((M, 512), **f32)
+        gemm_nt(n2, 128, w["w1"], hid, 512, M, 512, 128, bias=w["b1"], act=1)
+        hd = dropout_rows(hid, 512, M, 512, drop.key(layer, Drop.FF_INNER), p)                                             # dropout(relu(linear1))
+        ffo = torch.empty((M, 128), **f32)
+        gemm_nt(hd, 512, w["w2"], ffo, 128, M, 128, 512, bias=w["b2"])
+        u3 = dropout_rows(ffo, 128, M, 128, drop.key(layer, Drop.FF_OUT), p, out=ffo, ldo=128, resid=n2, ldr=128)           # n2 + dropout3(ffo)
+        c["hid"], c["hid_used"] = hid, hd
+    c["n2"] = n2
+    x3, c["xh3"], c["rs3"] = _ln_fwd(u3, None, w["ln3g"], w["ln3b"], M, eps, want_y=want_out)
+    c["x3"] = x3
+    return c
+
+
+def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dx_out: torch.Tensor, dev,
+                   drop: Optional[Drop] = None, layer: int = 0):
+    """Row chain of one decoder layer (out_proj .. norm3): recompute its intermediates with the generic kernels
+    (:func:`chain_forward`, same dropout masks as the forward), then differentiate.
+    Returns (grads, dx_in [M,128], dattn [M,128])."""
+    f32 = _f32(dev)
     g: Dict[str, torch.Tensor] = {}
-    # ---- recompute
-    u1 = torch.empty((M, 128), **f32)
-    gemm_nt(attn_ptr, lda, w["wo"], u1, 128, M, 128, 128, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
-    n1, xh1, rs1 = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps)
-    n2, xh2, rs2 = _ln_fwd(n1, w["cab"], w["ln2g"], w["ln2b"], M, eps)
-    hid = torch.empty((M, 512), **f32)
-    gemm_nt(n2, 128, w["w1"], hid, 512, M, 512, 128, bias=w["b1"], act=1)
-    u3 = torch.empty((M, 128), **f32)
-    gemm_nt(hid, 512, w["w2"], u3, 128, M, 128, 512, bias=w["b2"], residual=n2, ldr=128)
-    _, xh3, rs3 = _ln_fwd(u3, None, w["ln3g"], w["ln3b"], M, eps, want_y=False)
+    c = chain_forward(w, x_in_ptr, ldx, attn_ptr, lda, M, dev, drop, layer, want_out=False)
+    hid, hd, n2 = c["hid"], c["hid_used"], c["n2"]
+    p = drop.p if drop is not None else 0.0
     # ---- backward
-    du3, g["ln3g"], g["ln3b"], g["b2"] = _ln_bwd_sums(dx_out, xh3, rs3, w["ln3g"], M)
+    du3, g["ln3g"], g["ln3b"], cs3 = _ln_bwd_sums(dx_out, c["xh3"], c["rs3"], w["ln3g"], M)
+    if drop is None:
+        dffo, g["b2"] = du3, cs3
+    else:
+        dffo = dropout_rows(du3, 128, M, 128, drop.key(layer, Drop.FF_OUT), p)
+        g["b2"] = colsum(dffo, 128, M, 128)
     dhid = torch.empty((M, 512), **f32)
-    gemm_nt(du3, 128, transpose(w["w2"], 128, 512), dhid, 512, M, 512, 128, mask=hid, ldm=512)
+    gemm_nt(dffo, 128, transpose(w["w2"], 128, 512), dhid, 512, M, 512, 128, mask=hid, ldm=512)
+    if drop is not None:
+        dropout_rows(dhid, 512, M, 512, drop.key(layer, Drop.FF_INNER), p, out=dhid, ldo=512)
     g["w2"] = torch.empty((128, 512), **f32)
-    gemm_tn(du3, 128, hid, 512, g["w2"], M, 128, 512)
+    gemm_tn(dffo, 128, hd, 512, g["w2"], M, 128, 512)
     dn2 = torch.empty((M, 128), **f32)
     gemm_nt(dhid, 512, transpose(w["w1"], 512, 128), dn2, 128, M, 128, 512, residual=du3, ldr=128)
     g["w1"] = torch.empty((512, 128), **f32)
     gemm_tn(dhid, 512, n2, 128, g["w1"], M, 512, 128)
     g["b1"] = colsum(dhid, 512, M, 512)
-    du2, g["ln2g"], g["ln2b"], g["cab"] = _ln_bwd_sums(dn2, xh2, rs2, w["ln2g"], M)
-    du1, g["ln1g"], g["ln1b"], g["bo"] = _ln_bwd_sums(du2, xh1, rs1, w["ln1g"], M)
+    du2, g["ln2g"], g["ln2b"], cs2 = _ln_bwd_sums(dn2, c["xh2"], c["rs2"], w["ln2g"], M)
+    g["cab"] = cs2 if drop is None else colsum(dropout_rows(du2, 128, M, 128, drop.key(layer, Drop.CA_OUT), p), 128, M, 128)
+    du1, g["ln1g"], g["ln1b"], cs1 = _ln_bwd_sums(du2, c["xh1"], c["rs1"], w["ln1g"], M)
+    if drop is None:
+        dsa, g["bo"] = du1, cs1
+    else:
+        dsa = dropout_rows(du1, 128, M, 128, drop.key(layer, Drop.SA_OUT), p)
+        g["bo"] = colsum(dsa, 128, M, 128)
     dattn = torch.empty((M, 128), **f32)
-    gemm_nt(du1, 128, transpose(w["wo"], 128, 128), dattn, 128, M, 128, 128)
+    gemm_nt(dsa, 128, transpose(w["wo"], 128, 128), dattn, 128, M, 128, 128)
     g["wo"] = torch.empty((128, 128), **f32)
-    gemm_tn(du1, 128, attn_ptr, lda, g["wo"], M, 128, 128)
+    gemm_tn(dsa, 128, attn_ptr, lda, g["wo"], M, 128, 128)
     return g, du1, dattn
 
 
@@ -308,20 +383,28 @@ def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: floa
     return g
 
 
-def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries):
+def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries, drop_key: int = 0, drop_p: float = 0.0):
     """Masked self-attention forward (+ log2-domain lse for the backward kernels): split-bf16 MFMA kernel (exact fp32
-    products) unless PATHS_GEMM_MODE=f32."""
+    products) unless PATHS_GEMM_MODE=f32.  drop_p > 0: dropout on the attention probabilities (site key drop_key)."""
     st = _lib.stream()
     if ops.GEMM_MODE != "f32":
         TP = ops.TRAIN_FWD_PLANES
         ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, TP)),), device=q.device, dtype=torch.uint8)
-        _lib.call("paths_attention_x6", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP, 0, st)
+        if drop_p > 0:
+            _lib.call("paths_attention_x6_dropout", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP,
+                      drop_key, drop_p, st)
+        else:
+            _lib.call("paths_attention_x6", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, P(ws), TP, 0, st)
+    elif drop_p > 0:
+        raise NotImplementedError("dropout needs the split-operand attention kernel (PATHS_GEMM_MODE h3 or x6)")
     else:
         _lib.call("paths_attention_f32", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, st)
 
 
-def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev):
-    """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output)."""
+def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Optional[Drop] = None):
+    """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output).
+    ``drop`` (train mode with dropout > 0): the fused row-chain kernels have no dropout sites, so the chain of every layer runs
+    on the generic kernels of :func:`chain_forward` - the very sequence the backward recomputes - with the masks applied."""
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
     hd = d // H
@@ -343,13 +426,19 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev):
     x = tokens
     q, k, v = (torch.empty((B, H, T, hd), **f32) for _ in range(3))
     token_layer(x, None, None, layers[0], None, q, k, v)
+    sv["drop"] = drop
     for l in range(L - 1):
         attn = torch.zeros((B, T, d), **f32)
         lse = torch.zeros((B, H, T), **f32)
-        attention(q, k, v, attn, lse, num_ims, B, T, H, hd, 0)
-        x_out = torch.empty((B, T, d), **f32)
         q2, k2, v2 = (torch.empty((B, H, T, hd), **f32) for _ in range(3))
-        token_layer(x, x_out, layers[l], layers[l + 1], attn, q2, k2, v2)
+        if drop is None:
+            attention(q, k, v, attn, lse, num_ims, B, T, H, hd, 0)
+            x_out = torch.empty((B, T, d), **f32)
+            token_layer(x, x_out, layers[l], layers[l + 1], attn, q2, k2, v2)
+        else:
+            attention(q, k, v, attn, lse, num_ims, B, T, H, hd, 0, drop.key(l, Drop.ATTN), drop.p)
+            x_out = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, B * T, tokens.device, drop, l)["x3"].view(B, T, d)
+            token_layer(x_out, None, None, layers[l + 1], None, q2, k2, v2)
         sv["layers"].append({"x_in": x, "q": q, "k": k, "v": v, "attn": attn, "lse": lse})
         x, q, k, v = x_out, q2, k2, v2
     # last layer at token 0 (+ decoder.norm, residual, classifier): one fused launch
@@ -357,6 +446,18 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev):
     nlog = lvl_pack["wcls"].shape[0]
     ctx_out = torch.empty((B, d), **f32)
     logits = torch.empty((B, nlog), **f32)
+    if drop is not None:
+        # the fused token-0 tail has no dropout sites either: single-query attention (rows > 0 of the output are not needed), the
+        # row chain on the B token-0 rows, decoder.norm, slide-context residual and classifier with the generic kernels
+        attn0 = torch.zeros((B, T, d), **f32)
+        attention(q, k, v, attn0, None, num_ims, B, T, H, hd, 1, drop.key(L - 1, Drop.ATTN), drop.p)
+        x3 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, tokens.device, drop, L - 1)["x3"]
+        _lib.call("paths_final_head", P(x3), d, P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev),
+                  ctx_prev.stride(0) if ctx_prev is not None else 0, None, 0, P(lvl_pack["wcls"]), P(lvl_pack["bcls"]), nlog,
+                  lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), B, d, lvl_pack["lnf_eps"], st)
+        sv["last"] = {"x_in": x, "q": q, "k": k, "v": v}
+        sv["ctx_out"], sv["logits"] = ctx_out, logits
+        return sv
     ws = torch.empty((B * H * 16 * 36,), **f32)
     _lib.call("paths_token0_tail", P(x), P(q), P(k), P(v), P(num_ims), P(w["wo"]), P(w["bo"]), P(w["ln1g"]), P(w["ln1b"]),
               P(w["cab"]), P(w["ln2g"]), P(w["ln2b"]), P(w["w1"]), P(w["b1"]), P(w["w2"]), P(w["b2"]), P(w["ln3g"]), P(w["ln3b"]),
@@ -387,18 +488,12 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     wl = layers[L - 1]
     last = sv["last"]
     x_last = last["x_in"]
+    drop: Optional[Drop] = sv.get("drop")
+    dk = lambda l: (drop.key(l, Drop.ATTN), drop.p) if drop is not None else (0, 0.0)
     # recompute token 0 of the last layer up to x3 (its attention output first)
     attn0 = torch.zeros((B, T, d), **f32)
-    attention(last["q"], last["k"], last["v"], attn0, None, num_ims, B, T, H, hd, 1)
-    u1 = torch.empty((B, 128), **f32)
-    gemm_nt(attn0.data_ptr(), T * d, wl["wo"], u1, 128, B, 128, 128, bias=wl["bo"], residual=x_last.data_ptr(), ldr=T * d)
-    n1, _, _ = _ln_fwd(u1, None, wl["ln1g"], wl["ln1b"], B, wl["eps"])
-    n2, _, _ = _ln_fwd(n1, wl["cab"], wl["ln2g"], wl["ln2b"], B, wl["eps"])
-    hid = torch.empty((B, 512), **f32)
-    gemm_nt(n2, 128, wl["w1"], hid, 512, B, 512, 128, bias=wl["b1"], act=1)
-    u3 = torch.empty((B, 128), **f32)
-    gemm_nt(hid, 512, wl["w2"], u3, 128, B, 128, 512, bias=wl["b2"], residual=n2, ldr=128)
-    x3, _, _ = _ln_fwd(u3, None, wl["ln3g"], wl["ln3b"], B, wl["eps"])
+    attention(last["q"], last["k"], last["v"], attn0, None, num_ims, B, T, H, hd, 1, *dk(L - 1))
+    x3 = chain_forward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)["x3"]
     xf, xhf, rsf = _ln_fwd(x3, None, lvl_pack["lnfg"], lvl_pack["lnfb"], B, lvl_pack["lnf_eps"])
     feat = xf + ctx_prev if ctx_prev is not None else xf                     # [B,128] (8 rows: bookkeeping)
     dF = torch.zeros((B, 128), **f32)
@@ -422,11 +517,11 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     grads["lnfg"], grads["lnfb"] = colsum(dyxf, 128, B, 128), colsum(dF, 128, B, 128)
 
     # ---- last layer, token 0 only
-    g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dx3, dev)
+    g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dx3, dev, drop, L - 1)
     dqkv = torch.zeros((B, T, 3 * d), **f32)
     a0 = attn0[:, 0, :].contiguous()
-    _lib.call("paths_attention_token0_bwd", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(num_ims), P(dqkv),
-              B, T, H, hd, st)
+    _lib.call("paths_attention_token0_bwd_dropout", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(num_ims), P(dqkv),
+              B, T, H, hd, *dk(L - 1), st)
     dx = torch.zeros((B, T, d), **f32)                                       # gradient of the last layer's input
     dx[:, 0, :] = dx0
     g.update(qkv_backward(wl, x_last, dqkv, B * T, qscale, dx))
@@ -437,11 +532,11 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         lv = sv["layers"][l]
         w = layers[l]
         M = B * T
-        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev)
+        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev, drop, l)
         dqkv = torch.zeros((B, T, 3 * d), **f32)
         ws = torch.empty((B * H * T,), **f32)
-        _lib.call("paths_attention_bwd_f32", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
-                  P(num_ims), P(dqkv), P(ws), B, T, H, hd, st)
+        _lib.call("paths_attention_bwd_f32_dropout", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
+                  P(num_ims), P(dqkv), P(ws), B, T, H, hd, *dk(l), st)
         g.update(qkv_backward(w, lv["x_in"], dqkv, M, qscale, dx_in))
         grads["layers"][l] = g
         dx = dx_in.view(B, T, d)

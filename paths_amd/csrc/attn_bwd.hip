@@ -15,6 +15,9 @@
 //                          as the forward: per-lane query state)
 //   attn_token0_bwd_kernel last layer: a single query (token 0) per head, VALU only
 #include "common.h"
+#include "dropout.h"
+
+DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
 
 namespace {
 
@@ -51,7 +54,7 @@ attn_bwd_prep_kernel(const float* __restrict__ o, const float* __restrict__ d_o,
 __global__ void __launch_bounds__(256)
 attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                    const float* __restrict__ d_o /*[B,T,128]*/, const float* __restrict__ lse, const float* __restrict__ dsum,
-                   const int64_t* __restrict__ num_ims, float* __restrict__ dqkv, int T, int H) {
+                   const int64_t* __restrict__ num_ims, float* __restrict__ dqkv, int T, int H, DropSite drop) {
   __shared__ __attribute__((aligned(16))) float sQ40[16 * LD40], sQ36[16 * LD36], sG40[16 * LD40], sG36[16 * LD36];
   __shared__ float sLse[16], sD[16];
   const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 64;
@@ -120,13 +123,16 @@ attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
       }
     }
     // accumulator: column = this lane's key, rows q = q0 + 4 g + r
+    // with attention dropout (drop.thr != 0): O = (P * m) V, so dV takes P * m and dP = (dO V^T) * m; m = mask / (1 - p)
     f32x4 p, ds;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ql = 4 * g4 + r;
       const bool ok = key_ok && (q0 + ql < len);
-      p[r] = ok ? __builtin_amdgcn_exp2f(s[r] - sLse[ql]) : 0.f;
-      ds[r] = LN2 * p[r] * (dp[r] - sD[ql]);
+      const float pr = ok ? __builtin_amdgcn_exp2f(s[r] - sLse[ql]) : 0.f;
+      const float m = drop.thr ? drop_mult(drop, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)min(q0 + ql, T - 1)) * (uint64_t)T + (uint64_t)keyc) : 1.0f;
+      ds[r] = LN2 * pr * (dp[r] * m - sD[ql]);
+      p[r] = pr * m;
     }
     // dV^T[dv][key] += dO^T[dv][q] P[q][key] ; dK^T[d][key] += Q_s^T[d][q] ds[q][key]   (A: 4-byte column reads)
 #pragma unroll
@@ -154,7 +160,7 @@ attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
 __global__ void __launch_bounds__(256)
 attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                   const float* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ dsum,
-                  const int64_t* __restrict__ num_ims, float* __restrict__ dqkv, int T, int H) {
+                  const int64_t* __restrict__ num_ims, float* __restrict__ dqkv, int T, int H, DropSite drop) {
   __shared__ __attribute__((aligned(16))) float sK40[64 * LD40], sK36[64 * LD36], sV40[64 * LD40];
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
   const int len = (int)num_ims[b] + 1;
@@ -208,7 +214,8 @@ attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, cons
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 64 + 16 * t + 4 * g4 + r;
         const float p = key < len ? __builtin_amdgcn_exp2f(s[r] - my_lse) : 0.f;
-        ds[r] = LN2 * p * (dp[r] - my_d);
+        const float m = drop.thr ? drop_mult(drop, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)qc) * (uint64_t)T + (uint64_t)min(key, T - 1)) : 1.0f;
+        ds[r] = LN2 * p * (dp[r] * m - my_d);
       }
       const float* kp = &sK36[(16 * t + 4 * g4) * LD36 + ql];     // dQ_s^T[d][q] += K^T[d][key] ds^T[key][q]
 #pragma unroll
@@ -232,7 +239,7 @@ attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, cons
 __global__ void __launch_bounds__(256)
 attn_token0_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                        const float* __restrict__ a0, const float* __restrict__ da0, const int64_t* __restrict__ num_ims,
-                       float* __restrict__ dqkv, int T, int H) {
+                       float* __restrict__ dqkv, int T, int H, DropSite drop) {
   __shared__ float red[4][34];
   const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = (int)num_ims[b] + 1;
@@ -285,12 +292,13 @@ attn_token0_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
       dp += v[base + (int64_t)key * HD + i] * gv[i];
     }
     const float p = exp2f(sc - lse);
-    const float ds = LN2 * p * (dp - dsumv);
+    const float m = drop.thr ? drop_mult(drop, (((uint64_t)b * H + head) * (uint64_t)T) * (uint64_t)T + (uint64_t)key) : 1.0f;   // query 0
+    const float ds = LN2 * p * (dp * m - dsumv);
     float* dst = dqkv + ((int64_t)b * T + key) * (3 * H * HD) + head * HD;
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
       dst[H * HD + i] = ds * qv[i];
-      dst[2 * H * HD + i] = p * gv[i];
+      dst[2 * H * HD + i] = p * m * gv[i];
       dq[i] += ds * kk[i];
     }
   }
@@ -308,29 +316,55 @@ attn_token0_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
 extern "C" {
 
 // dqkv [B,T,384] must be zero-initialised by the caller (rows of padded tokens are never written).
+static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                              const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, DropSite site,
+                              hipStream_t stream);
+
 int paths_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                             const int64_t* num_ims, float* dqkv, float* ws_dsum /*[B*H*T]*/, int B, int T, int H, int head_dim,
                             hipStream_t stream) {
+  return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(0, 0.f), stream);
+}
+
+// the same with the forward's attention-probability dropout (paths_attention_x6_dropout: same drop_key, same p)
+int paths_attention_bwd_f32_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                                    const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim,
+                                    uint64_t drop_key, float drop_p, hipStream_t stream) {
+  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention_bwd_dropout: p must be in [0, 1)");
+  return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(drop_key, drop_p), stream);
+}
+
+static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                              const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, DropSite site,
+                              hipStream_t stream) {
   PATHS_REQUIRE(head_dim == HD && H == 4, "attention_bwd: head_dim must be 32 and H 4");
   PATHS_REQUIRE(B > 0 && T > 0 && q && k && v && o && d_o && lse && num_ims && dqkv && ws_dsum, "attention_bwd: bad arguments");
   const int64_t rows = (int64_t)B * T;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, o, d_o, ws_dsum, rows, T, H);
   PATHS_LAUNCH_CHECK("attention_bwd(prep)");
   dim3 grid((T + 63) / 64, H, B);
-  hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H);
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(kv)");
-  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H);
+  hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(q)");
+  return PATHS_OK;
+}
+
+int paths_attention_token0_bwd_dropout(const float* q, const float* k, const float* v, const float* a0, const float* da0,
+                                       const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, uint64_t drop_key,
+                                       float drop_p, hipStream_t stream) {
+  PATHS_REQUIRE(head_dim == HD && H == 4, "attention_token0_bwd: head_dim must be 32 and H 4");
+  PATHS_REQUIRE(B > 0 && T > 0 && q && k && v && a0 && da0 && num_ims && dqkv, "attention_token0_bwd: bad arguments");
+  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention_token0_bwd: p must be in [0, 1)");
+  hipLaunchKernelGGL(attn_token0_bwd_kernel, dim3(H, B), dim3(256), 0, stream, q, k, v, a0, da0, num_ims, dqkv, T, H,
+                     paths_make_drop_site(drop_key, drop_p));
+  PATHS_LAUNCH_CHECK("attention_token0_bwd");
   return PATHS_OK;
 }
 
 int paths_attention_token0_bwd(const float* q, const float* k, const float* v, const float* a0, const float* da0,
                                const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, hipStream_t stream) {
-  PATHS_REQUIRE(head_dim == HD && H == 4, "attention_token0_bwd: head_dim must be 32 and H 4");
-  PATHS_REQUIRE(B > 0 && T > 0 && q && k && v && a0 && da0 && num_ims && dqkv, "attention_token0_bwd: bad arguments");
-  hipLaunchKernelGGL(attn_token0_bwd_kernel, dim3(H, B), dim3(256), 0, stream, q, k, v, a0, da0, num_ims, dqkv, T, H);
-  PATHS_LAUNCH_CHECK("attention_token0_bwd");
-  return PATHS_OK;
+  return paths_attention_token0_bwd_dropout(q, k, v, a0, da0, num_ims, dqkv, B, T, H, head_dim, 0, 0.f, stream);
 }
 
 }  // extern "C"

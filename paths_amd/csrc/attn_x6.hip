@@ -19,6 +19,9 @@
 //     48 MFMAs of 16 cycles against 128 of 32 cycles (v_mfma_f32_16x16x4_f32) in the f32 kernel for the same 32 x 32 block.
 // The six kept partial products per operand pair are accumulated smallest first, exactly as in gemm_x6.hip.
 #include "common.h"
+#include "dropout.h"
+
+DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
 
 namespace {
 
@@ -156,11 +159,14 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[2], const u32x4 (&b
 __device__ __forceinline__ float rows_max(float x) { x = fmaxf(x, __shfl_xor(x, 16)); return fmaxf(x, __shfl_xor(x, 32)); }
 __device__ __forceinline__ float rows_sum(float x) { x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32); }
 
-template <int NP>
+// DROP (training with dropout > 0, reference nn.MultiheadAttention(dropout=p)): the softmax probabilities that enter the PV product
+// are multiplied by the regenerated mask / (1 - p) (element ((slide*H + head)*T + query)*T + key of the site, csrc/dropout.h); the
+// normaliser l and the saved log-sum-exp stay those of the un-dropped softmax, as in the reference.
+template <int NP, bool DROP>
 __global__ void __launch_bounds__(256)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H,
-               int npairs_arg, int nqb_arg) {
+               int npairs_arg, int nqb_arg, DropSite drop) {
   constexpr int STEP_BYTES = step_bytes<NP>();
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];          // 2 x STEP_BYTES (+ occupancy padding, see the launcher)
   // XCD-aware placement (speed only): every workgroup of one (slide, head) pair streams that pair's whole K / V^T images (0.5 MB
@@ -280,6 +286,11 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
           pv[j + 1] = __builtin_amdgcn_exp2f(d[1]);
           psum += pv[j] + pv[j + 1];
         }
+        if constexpr (DROP) {
+          const uint64_t row = ((uint64_t)pair * (uint64_t)T + (uint64_t)min(qw + 16 * qt + ql, T - 1)) * (uint64_t)T;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] *= drop_mult(drop, row + (uint64_t)(kt * KSTEP + 16 * (2 * kg + (j >> 2)) + 4 * g4 + (j & 3)));
+        }
         split_planes<NP>(pv, pf[qt][kg]);
       }
       l_run[qt] = l_run[qt] * alpha + psum;
@@ -329,7 +340,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 
 template <int NP>
 int attention_split(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B, int T,
-                           int H, int max_queries, void* workspace, int images_ready, hipStream_t stream) {
+                           int H, int max_queries, void* workspace, int images_ready, hipStream_t stream, uint64_t drop_key = 0, float drop_p = 0.f) {
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
   const int64_t img = (int64_t)B * H * Tp * HD * 2 * NP;
   char* q6 = reinterpret_cast<char*>(workspace);
@@ -351,12 +362,17 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
   const int nqb = (nq + 127) / 128, npairs = H * B;
+  const DropSite site = paths_make_drop_site(drop_key, drop_p);
   // 1-D grid walked in XCD-aware order (see the kernel)
-  hipLaunchKernelGGL(attn_x6_kernel<NP>, dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb);
+  if (drop_p > 0.f)
+    hipLaunchKernelGGL((attn_x6_kernel<NP, true>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site);
+  else
+    hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site);
   PATHS_LAUNCH_CHECK("attention_x6");
   return PATHS_OK;
 }
@@ -384,6 +400,18 @@ int paths_attention_x6(const float* q, const float* k, const float* v, float* o,
   PATHS_REQUIRE(planes == 2 || planes == 3, "attention_x6: planes must be 3 (bf16 x6) or 2 (fp16 x3)");
   return planes == 3 ? attention_split<3>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, 0, stream)
                      : attention_split<2>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, images_ready, stream);
+}
+
+// paths_attention_x6 in train mode with dropout p on the attention probabilities (reference nn.MultiheadAttention dropout):
+// O = (softmax(S) * mask / (1 - p)) V, lse = the un-dropped log-sum-exp; mask element ((b*H + h)*T + q)*T + k of site `drop_key`.
+int paths_attention_x6_dropout(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B, int T,
+                               int H, int head_dim, int max_queries, void* workspace, int planes, uint64_t drop_key, float drop_p,
+                               hipStream_t stream) {
+  PATHS_REQUIRE(head_dim == HD && q && k && v, "attention_x6_dropout: head_dim must be %d and q, k, v given", HD);
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && num_ims != nullptr && workspace != nullptr, "attention_x6_dropout: bad arguments");
+  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (planes == 2 || planes == 3), "attention_x6_dropout: p in [0, 1), planes 2 or 3");
+  return planes == 3 ? attention_split<3>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, 0, stream, drop_key, drop_p)
+                     : attention_split<2>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, 0, stream, drop_key, drop_p);
 }
 
 }  // extern "C"

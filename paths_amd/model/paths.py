@@ -52,8 +52,9 @@ class PATHSProcessor(nn.Module, Processor):
         mc = self.config
         ops.check_supported(mc)
         assert lstm is not None or not mc.lstm, "lstm=True needs the shared LSTMCell (RecursiveModel passes it)"
-        if self.training and mc.dropout > 0:
-            raise NotImplementedError("paths_amd round 1: dropout (train mode) is not implemented on the HIP path")
+        if self.training and mc.dropout > 0 and not torch.is_grad_enabled():
+            raise NotImplementedError("dropout > 0 in train mode is implemented on the differentiable path only: call model.eval() "
+                                      "for inference, or run under autograd (torch.enable_grad) for training")
         if mc.patch_embed_dim % 4 == 0 and (ops.GEMM_MODE == "h3" or ops.TRAIN_FWD_PLANES == 2):
             # drop-in batches come from the caller: reduce max|x| on entry (one host sync; the reference's own PatchBatch
             # constructor syncs on num_ims.max(), data_utils/patch_batch.py:50) and keep out-of-range data off the fp16 split

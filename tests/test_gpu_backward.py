@@ -335,3 +335,144 @@ def test_train_loop_harness(dev, tmp_path):
     model2 = cfg.get_model().to(dev)
     stats2 = train_loop(model2, ds[6:], None, None, cfg, str(tmp_path), log=logs.append)
     assert stats2["epoch"] == 3 and 3 in stats2["train_loss"]
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout (reference nn.Transformer(..., dropout=p), model/aggregator.py:25-33; shipped configs: p = 0.05)
+# ------------------------------------------------------------------------------------------------
+def _mask(dev, key, n, p):
+    from paths_amd import _lib
+    m = torch.empty(n, device=dev)
+    _lib.call("paths_dropout_mask", m.data_ptr(), n, key, p, _lib.stream())
+    return m
+
+
+def test_dropout_mask_statistics(dev):
+    """Counter-based masks: keep rate 1 - p, reproducible from (key, index), independent across sites / layers / levels / seeds and
+    along the index (no lattice structure at the strides the kernels use)."""
+    from paths_amd import backward as bw
+    n, p = 1 << 22, 0.05
+    d0 = bw.Drop(p, 12345, 1)
+    m = _mask(dev, d0.key(0, bw.Drop.SA_OUT), n, p)
+    assert torch.equal(m, _mask(dev, d0.key(0, bw.Drop.SA_OUT), n, p))                       # a function of (key, index) only
+    rate = 1.0 - float(m.mean())
+    assert abs(rate - p) < 4 * np.sqrt(p * (1 - p) / n), rate                              # 4 sigma
+    others = [d0.key(0, bw.Drop.CA_OUT), d0.key(1, bw.Drop.SA_OUT), bw.Drop(p, 12345, 2).key(0, bw.Drop.SA_OUT),
+              bw.Drop(p, 12346, 1).key(0, bw.Drop.SA_OUT)]
+    keep = m - m.mean()
+    for k in others:
+        o = _mask(dev, k, n, p)
+        corr = float((keep * (o - o.mean())).mean()) / (p * (1 - p))
+        assert abs(corr) < 5 / np.sqrt(n), corr                                            # uncorrelated masks
+    for lag in (1, 4, 128, 512, 2049, 128 * 2049):                                         # neighbours in a row / column / key row
+        corr = float((keep[:-lag] * keep[lag:]).mean()) / (p * (1 - p))
+        assert abs(corr) < 5 / np.sqrt(n), (lag, corr)
+    assert float(_mask(dev, d0.key(0, 0), 1000, 0.0).min()) == 1.0                         # p = 0: everything kept
+
+
+def test_dropout_forward_backward_vs_fp64_with_exported_masks(dev):
+    """All five dropout sites of both decoder layers (the last one at token 0 only): forward outputs and every gradient of the HIP
+    training path against float64 autograd through a reference that multiplies by the SAME masks (exported by paths_dropout_mask)."""
+    from paths_amd import backward as bw, ops
+    cfg, model, params = build_model(dev, 33)
+    mc = cfg.model_config
+    depth, B, N, H, pd = 1, 3, 150, 4, 0.1
+    num_ims = torch.tensor([150, 97, 31])
+    T = N + 1
+    g = torch.Generator().manual_seed(5)
+    tokvalid = torch.arange(T)[None, :] < (num_ims + 1)[:, None]
+    tokens = torch.randn(B, T, 128, generator=g) * tokvalid[..., None]
+    ctx_prev = torch.randn(B, 128, generator=g)
+    vp = ops.pack_level(model.procs[depth])
+    drop = bw.Drop(pd, 0xC0FFEE, depth)
+    sv = bw.transformer_forward_train(mc, vp, tokens.to(dev), num_ims.to(dev), ctx_prev.to(dev), drop)
+    G_log = torch.randn(B, 4, generator=g)
+    G_ctx = torch.randn(B, 128, generator=g)
+    grads, d_tok, d_ctx = bw.transformer_backward(mc, vp, sv, G_log.to(dev), G_ctx.to(dev))
+
+    sc = 1.0 / (1.0 - pd)
+    mk = lambda layer, site, shape: (_mask(dev, drop.key(layer, site), int(np.prod(shape)), pd).cpu().double() * sc).view(*shape)
+    p = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    tk = tokens.double().requires_grad_(True)
+    cp = ctx_prev.double().requires_grad_(True)
+    pre = f"procs.{depth}."
+    t = pre + "global_agg.transformer.decoder."
+
+    def layer(l, S, rows_q):
+        """S [B,T,128]; returns the layer output for query rows rows_q (slice(None) = all, or [0]); masks indexed like the kernels"""
+        q_ = t + f"layers.{l}."
+        qkv = F.linear(S, p[q_ + "self_attn.in_proj_weight"], p[q_ + "self_attn.in_proj_bias"])
+        qq, kk, vv = [x.view(B, T, H, 32).transpose(1, 2) for x in qkv.split(128, dim=-1)]
+        scores = (qq @ kk.transpose(-1, -2)) / np.sqrt(32.0)
+        scores = scores.masked_fill(~tokvalid[:, None, None, :], float("-inf"))
+        A = torch.softmax(scores, dim=-1) * mk(l, bw.Drop.ATTN, (B, H, T, T))
+        att = (A @ vv).transpose(1, 2).reshape(B, T, 128)[:, rows_q]
+        x = S[:, rows_q]
+        R = x.shape[1]
+        sa = F.linear(att, p[q_ + "self_attn.out_proj.weight"], p[q_ + "self_attn.out_proj.bias"])
+        x = F.layer_norm(x + sa * mk(l, bw.Drop.SA_OUT, (B, R, 128)), (128,), p[q_ + "norm1.weight"], p[q_ + "norm1.bias"])
+        x = F.layer_norm(x + p[q_ + "multihead_attn.out_proj.bias"] * mk(l, bw.Drop.CA_OUT, (B, R, 128)), (128,), p[q_ + "norm2.weight"], p[q_ + "norm2.bias"])
+        hid = torch.relu(F.linear(x, p[q_ + "linear1.weight"], p[q_ + "linear1.bias"])) * mk(l, bw.Drop.FF_INNER, (B, R, 512))
+        ff = F.linear(hid, p[q_ + "linear2.weight"], p[q_ + "linear2.bias"])
+        return F.layer_norm(x + ff * mk(l, bw.Drop.FF_OUT, (B, R, 128)), (128,), p[q_ + "norm3.weight"], p[q_ + "norm3.bias"])
+
+    S1 = layer(0, tk, slice(None))
+    x3 = layer(1, S1, slice(0, 1))[:, 0]                 # the last layer is only read at token 0 (reference model/aggregator.py:75)
+    F_ = F.layer_norm(x3, (128,), p[t + "norm.weight"], p[t + "norm.bias"]) + cp
+    logits = F.linear(F_, p[pre + "classification_layer.weight"], p[pre + "classification_layer.bias"])
+    assert rel_err(sv["logits"], logits.detach()) < 1e-5 and rel_err(sv["ctx_out"], F_.detach()) < 1e-5
+    plain = bw.transformer_forward_train(mc, vp, tokens.to(dev), num_ims.to(dev), ctx_prev.to(dev))
+    assert rel_err(sv["logits"], plain["logits"]) > 1e-3                                   # the masks do something
+    ((logits * G_log.double()).sum() + (F_ * G_ctx.double()).sum()).backward()
+    tol = 3e-4
+    assert rel_err(d_tok[tokvalid.to(dev)], tk.grad[tokvalid]) < tol
+    assert rel_err(d_ctx, cp.grad) < tol
+    assert rel_err(grads["wcls"], p[pre + "classification_layer.weight"].grad) < tol
+    assert rel_err(grads["lnfg"], p[t + "norm.weight"].grad) < tol and rel_err(grads["lnfb"], p[t + "norm.bias"].grad) < tol
+    names = {"wqkv": "self_attn.in_proj_weight", "bqkv": "self_attn.in_proj_bias", "wo": "self_attn.out_proj.weight",
+             "bo": "self_attn.out_proj.bias", "cab": "multihead_attn.out_proj.bias", "ln1g": "norm1.weight", "ln1b": "norm1.bias",
+             "ln2g": "norm2.weight", "ln2b": "norm2.bias", "ln3g": "norm3.weight", "ln3b": "norm3.bias",
+             "w1": "linear1.weight", "b1": "linear1.bias", "w2": "linear2.weight", "b2": "linear2.bias"}
+    for l in range(2):
+        for k, name in names.items():
+            ref = p[t + f"layers.{l}.{name}"].grad
+            assert rel_err(grads["layers"][l][k], ref) < tol, (l, k, rel_err(grads["layers"][l][k], ref))
+
+
+def test_training_with_shipped_dropout_config(dev):
+    """models/sample/config.json as shipped (dropout 0.05) trains: the masks follow torch.manual_seed (same seed -> bit-identical
+    loss and gradients, another seed -> different), eval mode is untouched by the dropout setting."""
+    from paths_amd import utils as putils
+    cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3)
+    for proc in model.procs:
+        proc.config.dropout = 0.05
+    model.eval()
+    with torch.no_grad():
+        ev = putils.recurse(model, batch["slide"], cfg.top_k_patches, 5)["logits"].clone()
+    model.train()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        model.zero_grad(set_to_none=True)
+        _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
+        return float(loss.detach()), {n: p_.grad.clone() for n, p_ in model.named_parameters() if p_.grad is not None}
+
+    l1, g1 = run(7)
+    l2, g2 = run(7)
+    l3, g3 = run(8)
+    assert l1 == l2 and all(torch.equal(g1[n], g2[n]) for n in g1)
+    assert l1 != l3 and np.isfinite(l3) and all(torch.isfinite(v).all() for v in g3.values())
+    for proc in model.procs:
+        proc.config.dropout = 0.0
+    l0, _ = run(7)
+    assert abs(l0 - l1) > 1e-6 and abs(l0 - l1) < 0.5 * abs(l0)                             # dropout perturbs, does not destroy
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(putils.recurse(model, batch["slide"], cfg.top_k_patches, 5)["logits"], ev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    for proc in model.procs:
+        proc.config.dropout = 0.05
+    model.train()
+    torch.manual_seed(0)
+    losses = [float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)) for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses)
