@@ -89,7 +89,9 @@ int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npa
                           paths_stream_t stream);
 /* w_gates_x6 = pack of the PACKED gate matrix [3Hc+D, 2D] of paths_lstm_cell (scale wg_scale); w_mem_x6 = pack of [D, Hc]
  * (scale wm_scale); D % 256 == 0; y may be NULL (Y = X + h1 not materialised).  x_rows (optional, planes = 2, needs hp / no
- * h0, y = NULL): [M] addresses of the feature rows - x is then read in place (paths_gather_rows row_ptrs), x / ldx unused */
+ * h0, y = NULL): [M] addresses of the feature rows - x is then read in place (paths_gather_rows row_ptrs), x / ldx unused.
+ * ws_o: scratch of ceil(M / 256) * 256 x D floats (with y = NULL and no training saves the output gate crosses from phase 2 to
+ * phase 4 as raw pre-activations in whole 32x32 accumulator tiles; otherwise as the [M, D] gate values) */
 int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const float* h0, int64_t ldh0, const float* c0, int64_t ldc0,
                        const void* w_gates_x6, const float* b_gates, const void* w_mem_x6, const float* b_mem,
                        float* state_out, int64_t ldso, float* y, int64_t ldy, float* ws_o, float* save_frm, float* save_tc,

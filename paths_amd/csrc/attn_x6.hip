@@ -358,7 +358,8 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   // Workgroups per CU: registers allow 2, LDS would allow more.  The dispatcher fills a CU to its limit before it moves on, so
   // small grids ask for more LDS than needed to spread out: depth ~ grid / 256.
   const int nblk = ((nq + 127) / 128) * H * B;
-  const int depth = nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
+  static const int depth_env = getenv("PATHS_ATTN_DEPTH") ? atoi(getenv("PATHS_ATTN_DEPTH")) : 0;   // experiment
+  const int depth = depth_env ? depth_env : nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
   const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
   static bool attr_set = false;
   if (!attr_set) {

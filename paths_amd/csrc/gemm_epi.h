@@ -144,8 +144,14 @@ struct EpiLstmC {
   }
 };
 
-// o = sigmoid(acc + b)
-struct EpiLstmO {
+// o = sigmoid(acc + b).
+// RAW (inference): the gate is only ever read back by the mem_to_out epilogue (EpiLstmH) on the same 32x32 tiles and lanes, so it
+// is stored (a) as the PRE-activation a = acc + b (the sigmoid moves into that HBM-bound epilogue, whose VALU has slack; with one
+// wave per SIMD here nothing hid its ~18 instructions per element) and (b) in the accumulator layout itself,
+// [tile row][tile col][4][64 lanes][4] (one 16-byte store per lane and quarter tile instead of sixteen 4-byte stores).  `o` is then
+// a scratch of ceil(M / 256) * 256 x N floats, `ldo` = N.
+template <bool RAW>
+struct EpiLstmO_ {
   const float* bias; float* o; int64_t ldo; int N;   // N % 32 == 0
   const float* hp; int64_t ldhp; const int* hp_row; int hp_col0;   // optional parent partials (columns hp_col0 + col)
   float acc_scale = 1.0f;          // see EpiLstmC
@@ -204,13 +210,35 @@ struct EpiLstmO {
   }
   template <int WTM, int WTN, int WGM, int WGN>
   __device__ __forceinline__ void run(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int, int, int M, float*) const {
-    if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
-    else run_impl<false>(acc, row0, col0, lane, M);
+    if constexpr (RAW) {
+      const int ntn = N >> 5;
+#pragma unroll
+      for (int j = 0; j < WTN; ++j) {
+        const int tcol = col0 + 32 * j;
+        if (tcol < N) {
+          const float b = bias[tcol + (lane & 31)];
+#pragma unroll
+          for (int i = 0; i < WTM; ++i) {
+            f32x4* t = reinterpret_cast<f32x4*>(o + ((int64_t)((row0 >> 5) + i) * ntn + (tcol >> 5)) * 1024) + lane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              t[64 * q] = f32x4{fmaf(acc[i][j][4 * q], acc_scale, b), fmaf(acc[i][j][4 * q + 1], acc_scale, b),
+                                fmaf(acc[i][j][4 * q + 2], acc_scale, b), fmaf(acc[i][j][4 * q + 3], acc_scale, b)};
+          }
+        }
+      }
+    } else {
+      if (row0 + 32 * WTM <= M) run_impl<true>(acc, row0, col0, lane, M);
+      else run_impl<false>(acc, row0, col0, lane, M);
+    }
   }
 };
+typedef EpiLstmO_<false> EpiLstmO;
+typedef EpiLstmO_<true> EpiLstmORaw;
 
 // h1 = o * tanh(acc + bc) ; Y = X + h1 (WITH_Y; otherwise Y is never materialised: see paths_importance_proj_x6's y_add)
-template <bool WITH_Y, bool WITH_TC = false>
+// RAW_O: `o` holds the gate's PRE-activations in the accumulator layout (EpiLstmORaw): four 16-byte loads per tile, sigmoid here.
+template <bool WITH_Y, bool WITH_TC = false, bool RAW_O = false>
 struct EpiLstmH {
   template <int WTM, int WTN>
   __device__ __forceinline__ void init(f32x16 (&acc)[WTM][WTN], int, int, int, int) const {
@@ -238,13 +266,21 @@ struct EpiLstmH {
       constexpr int t = decltype(tc)::value, i = t % WTM, j = t / WTM, s = t % NB;
       const int trow = row0 + 32 * i, tcol = min(col0 + 32 * j, N - 32);
       char* to = ovw.tile(trow, tcol); char* tx = xvw.tile(trow, tcol);
+      if constexpr (RAW_O) {
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(o + ((int64_t)(trow >> 5) * (N >> 5) + (tcol >> 5)) * 1024) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = t4[64 * q];
+          ov[s][4 * q] = v[0]; ov[s][4 * q + 1] = v[1]; ov[s][4 * q + 2] = v[2]; ov[s][4 * q + 3] = v[3];
+        }
+      }
       static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         if constexpr (FULL) {
-          ov[s][r] = *ovw.elem(to, r);
+          if constexpr (!RAW_O) ov[s][r] = *ovw.elem(to, r);
           if constexpr (WITH_Y) xv[s][r] = *xvw.elem(tx, r);
         } else {
-          ov[s][r] = *ovw.at_clamped(trow, tcol, r, lane, M);
+          if constexpr (!RAW_O) ov[s][r] = *ovw.at_clamped(trow, tcol, r, lane, M);
           if constexpr (WITH_Y) xv[s][r] = *xvw.at_clamped(trow, tcol, r, lane, M);
         }
       });
@@ -260,7 +296,7 @@ struct EpiLstmH {
         static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
           constexpr int r = decltype(rc)::value;
           const float tcv = tanh_acc(fmaf(acc[i][j][r], acc_scale, b));
-          const float h = ov[s][r] * tcv;
+          const float h = (RAW_O ? sigmoid_acc(ov[s][r]) : ov[s][r]) * tcv;
           if constexpr (FULL) {
             if constexpr (WITH_TC) *tv.elem(tt, r) = tcv;
             *hv.elem(th, r) = h;

@@ -528,6 +528,7 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
 #define PATHS_H_OCC 2
 #endif
 constexpr int H_OCC = PATHS_H_OCC;
+static const bool O_RAW = getenv("PATHS_O_RAW") == nullptr || atoi(getenv("PATHS_O_RAW")) != 0;
 static const bool H_SMALL_TILES = getenv("PATHS_H_SMALL_TILES") == nullptr || atoi(getenv("PATHS_H_SMALL_TILES")) != 0;
 
 inline int64_t group_stride(int planes, int Kpacked) { return (int64_t)(Kpacked / 16) * planes * FRAG; }
@@ -587,11 +588,19 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
     int rc = launch_x6<4, 3, 1, false>(planes, g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
     if (rc) return rc;
   }
+  // inference (no Y, no training saves): the gate travels to phase 4 as raw pre-activations in the accumulator layout (EpiLstmORaw)
+  const bool o_raw = y == nullptr && save_tc == nullptr && save_frm == nullptr && O_RAW;
   if (phases & 2) {   // o gate: N = D, block 256 x 256
     X6Operands go = g;
     go.Wt = wg + (int64_t)(3 * Hc / 32) * gs;
-    EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc, sg};
-    int rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o)");
+    int rc;
+    if (o_raw) {
+      EpiLstmORaw e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc, sg};
+      rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o, raw)");
+    } else {
+      EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc, sg};
+      rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o)");
+    }
     if (rc) return rc;
   }
   if (phases & 4) {   // h1 = o * tanh(Wc c1 + bc), Y = X + h1
@@ -604,9 +613,13 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
     } else if (y != nullptr) {
       EpiLstmH<true, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, nullptr, sm};
       rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h)");
+    } else if (o_raw) {
+      EpiLstmH<false, false, true> e{b_mem, ws_o, D, x, ldx, state_out, ldso, nullptr, 0, D, nullptr, sm};
+      // inference: 16 k16 stages of MFMA against 120 MB of epilogue traffic -> 128 x 128 tiles, several workgroups per CU
+      if (planes == 2 && H_SMALL_TILES) rc = launch_x6_np<2, 2, 2, 2, false, false, decltype(e), H_OCC>(gh, D, e, stream, "lstm_cell_x6(h, raw o, 128x128)");
+      else rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, raw o)");
     } else {
       EpiLstmH<false, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, nullptr, 0, D, nullptr, sm};
-      // inference: 16 k16 stages of MFMA against 120 MB of epilogue traffic -> 128 x 128 tiles, several workgroups per CU
       if (planes == 2 && H_SMALL_TILES) rc = launch_x6_np<2, 2, 2, 2, false, false, decltype(e), H_OCC>(gh, D, e, stream, "lstm_cell_x6(h, no y, 128x128)");
       else rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, no y)");
     }

@@ -391,7 +391,8 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
   }
   const int nt = max_tokens > 0 && max_tokens < T ? max_tokens : T;
   const int nblk = ((nt + 63) / 64) * B;
-  const size_t lds = nblk <= 2 * 256 ? lds_solo : lds_min;      // spread small grids one workgroup per CU (see tlayer_f32.hip)
+  static const int pack_mode = getenv("PATHS_TLAYER_PACK") ? atoi(getenv("PATHS_TLAYER_PACK")) : 0;   // experiment: 1 = always two per CU
+  const size_t lds = (nblk <= 2 * 256 && pack_mode == 0) ? lds_solo : lds_min;      // spread small grids one workgroup per CU (see tlayer_f32.hip)
   hipLaunchKernelGGL(tlayer_h3_kernel, dim3((nt + 63) / 64, B), dim3(256), lds, stream, p);
   PATHS_LAUNCH_CHECK("token_layer_h3");
   return PATHS_OK;

@@ -400,7 +400,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         Dp = D + Hc
         state_out = torch.empty((B, N, Dp), **f32)
         y = None if x6 else torch.empty((B, N, D), **f32)   # x6: Y = X + h1 is summed inside the importance/proj GEMM's staging
-        ws_o = torch.empty((B, N, D), **f32)
+        ws_o = torch.empty(((M + 255) // 256 * 256, D), **f32)       # gate scratch: whole 256-row tiles (raw accumulator layout)
         hp, hp_row = None, None
         if parent is not None:
             assert state_prev is None

@@ -34,7 +34,7 @@ wip6, wips = ops.x6_pack(wip)
 hk = rnd(MP, D)
 hp = torch.empty(MP, G, device=dev)
 hp_row = (torch.arange(M, device=dev, dtype=torch.int32) // 4) % MP
-so, y, ws = torch.empty(M, D + Hc, device=dev), torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+so, y, ws = torch.empty(M, D + Hc, device=dev), torch.empty(M, D, device=dev), torch.empty((M + 255) // 256 * 256, D, device=dev)
 B = 8; N = (M + B - 1) // B
 Mi = B * N
 yi = rnd(Mi, D)
