@@ -316,6 +316,12 @@ int paths_tissue_mask_absmax(const float* grid, int64_t cells, int D, uint8_t* m
 int paths_synth_grid(float* grid, int X, int Y, int D, uint32_t slide_level_key, int level, uint64_t bg_threshold,
                      paths_stream_t stream);
 
+/* lstm = false training (reference model/paths.py:95-109, Z = alpha X + hctx): gradient of the importance MLP through the row
+ * scaling: dalpha = dZ . X per row, dz = valid dalpha alpha (1 - alpha); dh [M,128] = (hid > 0) dz w2, dah = dz hid, da = dz. */
+int paths_importance_rows_bwd(const float* dz_rows, const float* x, int D, const float* hid, const float* alpha, const float* w2,
+                              const int64_t* num_ims, int rows_per_slide, int64_t M, float* dh, float* da, float* dah,
+                              paths_stream_t stream);
+
 /* ---- dropout (training; reference nn.Transformer(..., dropout=p), model/aggregator.py:25-33: attention probabilities,
  * dropout1, dropout2, the feed-forward's inner dropout, dropout3).  Masks are never stored: element idx of site `key` is kept iff
  * hash(idx, key) >= p * 2^32 (csrc/dropout.h) and is regenerated by every kernel that needs it; kept values are scaled by

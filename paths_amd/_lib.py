@@ -63,6 +63,7 @@ SIGNATURES = {
     "paths_gather_rows": [_vp, _vp, _i32, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_level0_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp],
     "paths_scale_add_rows": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp],
+    "paths_importance_rows_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     "paths_dropout_rows": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _u64, _f32, _vp],
     "paths_dropout_mask": [_vp, _i64, _u64, _f32, _vp],
     "paths_attention_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _u64, _f32, _vp],

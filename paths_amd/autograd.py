@@ -7,7 +7,7 @@ launch sequences of paths_amd/backward.py:
     the tensors the backward needs, backward = transformer_backward + selection_backward;
   * :class:`GatherFn` — the child gather between levels (``PreprocessedSlide.iter``): backward = paths_gather_rows_bwd.
 
-Training limits (raised, never approximated): lstm=True, slide_ctx_mode in {residual, none}.  Dropout > 0 in train mode runs the
+Training covers lstm = true / false and slide_ctx_mode residual / concat / none.  Dropout > 0 in train mode runs the
 transformer's row chain on the generic kernels with regenerated masks (paths_amd/backward.py:Drop).
 """
 from __future__ import annotations
@@ -66,7 +66,18 @@ def live_grad_params(model, num_levels: Optional[int] = None) -> List[torch.nn.P
     L = len(model.procs) if num_levels is None else min(int(num_levels), len(model.procs))
     out = list(lstm_params(model.lstm)) if model.use_lstm else []
     for i in range(L):
-        lp = level_params(model.procs[i])
+        if model.use_lstm:
+            lp = level_params(model.procs[i])
+        else:
+            # lstm = false: hctx_mlp of level 0 never runs (no previous state); the importance MLP only with importance_mode "mul"
+            lp = level_params_nolstm(model.procs[i])
+            mc = model.procs[i].config
+            drop = set()
+            if i == 0 or not mc.hierarchical_ctx:
+                drop |= {4, 5, 6, 7}
+            if mc.importance_mode != "mul":
+                drop |= {0, 1, 2, 3}
+            lp = [p for j, p in enumerate(lp) if j not in drop]
         out += lp if i == L - 1 else lp[:-2]
     return out
 
@@ -112,20 +123,23 @@ DROPOUT_IMPLEMENTED = True
 class LevelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, proc, lstm, fts, locs, num_ims, state_prev, ctx_prev, *params):
+        """ctx_prev: [B,d] (slide_ctx_mode "residual": the previous level's slide context) or [B,depth,d] (mode "concat": all
+        previous levels' slide contexts, reference model/paths.py:134-137) or None."""
         mc = proc.config
-        if mc.slide_ctx_mode == "concat":
-            raise NotImplementedError("training with slide_ctx_mode='concat' is not implemented on the HIP path")
         check_dropout_supported(proc)
         lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
         sel = bw.selection_forward_train(mc, lp, vp, fts, locs.contiguous(), num_ims.contiguous(), state_prev)
-        res = ctx_prev if mc.slide_ctx_mode == "residual" else None
+        res = ctx_prev if (mc.slide_ctx_mode == "residual" and ctx_prev is not None) else None
+        cat = ctx_prev.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_prev is not None and ctx_prev.shape[1] > 0) else None
+        assert res is None or res.dim() == 2
+        assert cat is None or cat.dim() == 3
         drop = None
         if proc.training and mc.dropout > 0:
             # one seed per level forward from torch's global generator (torch.manual_seed controls the masks, as in the reference)
             drop = bw.Drop(mc.dropout, int(torch.empty((), dtype=torch.int64).random_().item()), proc.depth)
-        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop)
+        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop, cat)
         ctx.proc, ctx.lstm, ctx.sel, ctx.tr = proc, lstm, sel, tr
-        ctx.has_state, ctx.has_ctx = state_prev is not None, res is not None
+        ctx.has_state, ctx.has_ctx = state_prev is not None, (res is not None or cat is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(sel["importance"])
         return tr["logits"], tr["ctx_out"], sel["state_out"], sel["importance"]
@@ -150,8 +164,58 @@ class LevelFn(torch.autograd.Function):
                 d_ctx_prev if ctx.has_ctx else None, *grads)
 
 
+def level_params_nolstm(proc) -> List[torch.nn.Parameter]:
+    """lstm = false: the level's live parameters incl. its hctx_mlp, in the order LevelFnNoLstm returns their gradients."""
+    return [proc.importance_mlp[0].weight, proc.importance_mlp[0].bias, proc.importance_mlp[2].weight, proc.importance_mlp[2].bias,
+            proc.hctx_mlp[0].weight, proc.hctx_mlp[0].bias, proc.hctx_mlp[2].weight, proc.hctx_mlp[2].bias] + level_params(proc)[4:]
+
+
+class LevelFnNoLstm(torch.autograd.Function):
+    """One level of the lstm = false variant (reference model/paths.py:95-109): same transformer as LevelFn, the selection chain
+    is alpha * X + hctx_mlp(previous Z) (paths_amd/backward.py:selection_forward_train_nolstm)."""
+
+    @staticmethod
+    def forward(ctx, proc, fts, locs, num_ims, state_prev, ctx_prev, *params):
+        mc = proc.config
+        check_dropout_supported(proc)
+        vp = ops.pack_level(proc)
+        if state_prev is not None:
+            state_prev = state_prev.contiguous()
+        sel = bw.selection_forward_train_nolstm(mc, vp, fts, locs.contiguous(), num_ims.contiguous(), state_prev)
+        res = ctx_prev if (mc.slide_ctx_mode == "residual" and ctx_prev is not None) else None
+        cat = ctx_prev.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_prev is not None and ctx_prev.shape[1] > 0) else None
+        drop = None
+        if proc.training and mc.dropout > 0:
+            drop = bw.Drop(mc.dropout, int(torch.empty((), dtype=torch.int64).random_().item()), proc.depth)
+        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop, cat)
+        ctx.proc, ctx.sel, ctx.tr = proc, sel, tr
+        ctx.has_state, ctx.has_ctx = state_prev is not None, (res is not None or cat is not None)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(sel["importance"])
+        return tr["logits"], tr["ctx_out"], sel["state_out"], sel["importance"]
+
+    @staticmethod
+    def backward(ctx, d_logits, d_ctx_out, d_state_out, _d_imp):
+        proc, sel, tr = ctx.proc, ctx.sel, ctx.tr
+        mc = proc.config
+        vp = ops.pack_level(proc)
+        cont = lambda t: t.contiguous() if t is not None else None
+        tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+        sg, d_state_prev = bw.selection_backward_nolstm(mc, vp, sel, d_tok, cont(d_state_out))
+        v = lambda t, shape: t.view(shape) if t is not None else None
+        grads = [sg["w1"], sg["b1"], v(sg["w2"], (1, -1)), sg["b2"], sg["wh1"], sg["bh1"], sg["wh2"], sg["bh2"], sg["wp"], sg["bp"], sg["special"]]
+        for l, g in enumerate(tg["layers"]):
+            grads += [g[key] for _, key in LAYER_ORDER]
+        grads += [tg["lnfg"], tg["lnfb"]]
+        grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]
+        return (None, None, None, None, d_state_prev if (ctx.has_state and d_state_prev is not None) else None,
+                d_ctx_prev if ctx.has_ctx else None, *grads)
+
+
 def level_apply(proc, lstm, fts, locs, num_ims, state_prev, ctx_prev):
     """Differentiable ``process``: returns (logits, ctx_slide, ctx_patch, importance)."""
+    if not proc.config.lstm:
+        return LevelFnNoLstm.apply(proc, fts, locs, num_ims, state_prev, ctx_prev, *level_params_nolstm(proc))
     return LevelFn.apply(proc, lstm, fts, locs, num_ims, state_prev, ctx_prev, *lstm_params(lstm), *level_params(proc))
 
 

@@ -206,6 +206,96 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     return grads, d_state_prev
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# selection chain of the lstm = false variant (reference model/paths.py:95-109: RNN hierarchical context instead of the LSTM)
+#   alpha = valid * sigmoid(importance_mlp(X)) ; Z = alpha * X (+ hctx_mlp(previous Z) on valid rows) ; patch ctx = Z ;
+#   tokens = proj_in(Z) + PE.   Re-uses the generic f32-MFMA kernels; not a tuned path.
+# ---------------------------------------------------------------------------------------------------------------
+def selection_forward_train_nolstm(mc, lvl_pack, fts, locs, num_ims, state_prev) -> Dict[str, torch.Tensor]:
+    B, N, D = fts.shape
+    d, Hi = mc.trans_dim, mc.importance_mlp_hidden_dim
+    M, T = B * N, N + 1
+    f32 = _f32(fts.device)
+    st = _lib.stream()
+    sv = {"fts": fts, "state_prev": state_prev, "num_ims": num_ims, "locs": locs}
+    sv["importance"] = torch.empty((B, N), **f32)
+    sv["tokens"] = torch.empty((B, T, d), **f32)
+    sv["hid"] = torch.empty((B, N, Hi), **f32)
+    scratch_p = torch.empty((B, N, d), **f32)
+    pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+
+    def imp_proj(src, imp_out, hid_out, pproj_out):
+        _lib.call("paths_importance_proj", P(src), D, P(lvl_pack["w_ip_fwd"]), P(lvl_pack["b1"]), P(lvl_pack["w2"]), P(lvl_pack["b2"]),
+                  P(lvl_pack["bp"]), P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), None, 0, P(locs),
+                  P(num_ims), N, mc.patch_size, pe_mode, 0, P(imp_out), P(sv["tokens"]), P(hid_out), P(pproj_out), M, D, Hi, d, 0, st)
+
+    imp_proj(fts, sv["importance"], sv["hid"], scratch_p)                    # pass 1: alpha and the importance MLP's hidden layer
+    hctx = None
+    if state_prev is not None and mc.hierarchical_ctx:
+        assert state_prev.shape == (B, N, D) and state_prev.is_contiguous()
+        Hh = lvl_pack["wh1"].shape[0]
+        assert Hh % 128 == 0, "hierarchical_ctx_mlp_hidden_dim must be a multiple of 128 for lstm=false"
+        sv["hid_h"] = torch.empty((B, N, Hh), **f32)
+        hctx = torch.empty((B, N, D), **f32)
+        _lib.call("paths_linear_f32", P(state_prev), D, P(lvl_pack["wh1"]), P(lvl_pack["bh1"]), P(sv["hid_h"]), Hh, M, Hh, Hh, D, 1, st)
+        _lib.call("paths_linear_f32", P(sv["hid_h"]), Hh, P(lvl_pack["wh2"]), P(lvl_pack["bh2"]), P(hctx), D, M, D, D, Hh, 0, st)
+    sv["has_hctx"] = hctx is not None
+    sv["state_out"] = torch.empty((B, N, D), **f32)
+    _lib.call("paths_scale_add_rows", P(fts), P(sv["importance"]), P(hctx), P(num_ims), N, D, M,
+              1 if mc.importance_mode == "mul" else 0, P(sv["state_out"]), st)
+    scratch_i, scratch_h = torch.empty((B, N), **f32), torch.empty((B, N, Hi), **f32)
+    imp_proj(sv["state_out"], scratch_i, scratch_h, scratch_p)               # pass 2: tokens = proj_in(Z) + PE
+    return sv
+
+
+def selection_backward_nolstm(mc, lvl_pack, sv, d_tokens: torch.Tensor, d_state_out: Optional[torch.Tensor]):
+    """Returns (grads {"w1","b1","w2","b2","wp","bp","special","wh1","bh1","wh2","bh2"} (None where unused), d_state_prev [B,N,D] or None)."""
+    fts, state_prev, num_ims = sv["fts"], sv["state_prev"], sv["num_ims"]
+    B, N, D = fts.shape
+    M, T = B * N, N + 1
+    dev = fts.device
+    f32 = _f32(dev)
+    st = _lib.stream()
+    g: Dict[str, Optional[torch.Tensor]] = {k: None for k in ("w1", "b1", "w2", "b2", "wh1", "bh1", "wh2", "bh2")}
+    Z = sv["state_out"]
+    # tokens[:, 1:] = Z Wp^T + bp + PE on valid rows (padded token rows carry exact zero gradients: masked keys, unused queries)
+    dpp = d_tokens[:, 1:, :].contiguous().view(M, 128)
+    g["special"] = colsum(d_tokens, T * 128, B, 128)
+    g["bp"] = colsum(dpp, 128, M, 128)
+    wp = lvl_pack["w_ip"][128:]                                          # [128, D] proj_in.weight
+    g["wp"] = torch.empty((128, D), **f32)
+    gemm_tn(dpp, 128, Z, D, g["wp"], M, 128, D)
+    dZ = torch.empty((M, D), **f32)
+    gemm_nt(dpp, 128, transpose(wp, 128, D), dZ, D, M, D, 128, residual=d_state_out, ldr=D)
+    d_state_prev = None
+    if sv["has_hctx"]:
+        # hctx = Wh2 relu(Wh1 s + bh1) + bh2 added on valid rows; dZ is exactly zero on padded rows (no token, never kept)
+        Hh = lvl_pack["wh1"].shape[0]
+        hid_h = sv["hid_h"]
+        g["bh2"] = colsum(dZ, D, M, D)
+        g["wh2"] = torch.empty((D, Hh), **f32)
+        gemm_tn(dZ, D, hid_h, Hh, g["wh2"], M, D, Hh)
+        dhh = torch.empty((M, Hh), **f32)
+        gemm_nt(dZ, D, transpose(lvl_pack["wh2"], D, Hh), dhh, Hh, M, Hh, D, mask=hid_h, ldm=Hh)
+        g["bh1"] = colsum(dhh, Hh, M, Hh)
+        g["wh1"] = torch.empty((Hh, D), **f32)
+        gemm_tn(dhh, Hh, state_prev, D, g["wh1"], M, Hh, D)
+        d_state_prev = torch.empty((B, N, D), **f32)
+        gemm_nt(dhh, Hh, transpose(lvl_pack["wh1"], Hh, D), d_state_prev, D, M, D, Hh)
+    if mc.importance_mode == "mul":
+        dh = torch.empty((M, 128), **f32)
+        da = torch.empty((M,), **f32)
+        dah = torch.empty((M, 128), **f32)
+        _lib.call("paths_importance_rows_bwd", P(dZ), P(fts), D, P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]), P(num_ims), N, M,
+                  P(dh), P(da), P(dah), st)
+        g["w2"] = colsum(dah, 128, M, 128)
+        g["b2"] = colsum(da, 1, M, 1)
+        g["b1"] = colsum(dh, 128, M, 128)
+        g["w1"] = torch.empty((128, D), **f32)
+        gemm_tn(dh, 128, fts, D, g["w1"], M, 128, D)
+    return g, d_state_prev
+
+
 def unpack_lstm_grads(lstm, g: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Packed gate layout -> the reference's parameter names (inverse of ops.pack_lstm)."""
     Hc = lstm.cdim
@@ -401,7 +491,8 @@ def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries, drop_key: in
         _lib.call("paths_attention_f32", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, st)
 
 
-def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Optional[Drop] = None):
+def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Optional[Drop] = None,
+                              ctx_all: Optional[torch.Tensor] = None):
     """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output).
     ``drop`` (train mode with dropout > 0): the fused row-chain kernels have no dropout sites, so the chain of every layer runs
     on the generic kernels of :func:`chain_forward` - the very sequence the backward recomputes - with the masks applied."""
@@ -412,7 +503,12 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
     st = _lib.stream()
     qscale = LOG2E / math.sqrt(hd)
     layers = lvl_pack["layers"]
-    sv = {"layers": [], "num_ims": num_ims, "tokens": tokens, "ctx_prev": ctx_prev}
+    # ctx_prev [B,128]: slide_ctx_mode "residual" (added to the slide feature); ctx_all [B,depth,128] contiguous: "concat" (the
+    # classifier reads cat(flatten(ctx_all), slide feature), reference model/paths.py:134-137); at most one of the two is given
+    assert ctx_prev is None or ctx_all is None
+    cdepth = ctx_all.shape[1] if ctx_all is not None else 0
+    cat_ptr = P(ctx_all) if cdepth > 0 else None
+    sv = {"layers": [], "num_ims": num_ims, "tokens": tokens, "ctx_prev": ctx_prev, "ctx_all": ctx_all if cdepth > 0 else None}
 
     def token_layer(x_in, x_out, post, nxt, attn, q, k, v):
         w = post or nxt
@@ -453,7 +549,7 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
         attention(q, k, v, attn0, None, num_ims, B, T, H, hd, 1, drop.key(L - 1, Drop.ATTN), drop.p)
         x3 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, tokens.device, drop, L - 1)["x3"]
         _lib.call("paths_final_head", P(x3), d, P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev),
-                  ctx_prev.stride(0) if ctx_prev is not None else 0, None, 0, P(lvl_pack["wcls"]), P(lvl_pack["bcls"]), nlog,
+                  ctx_prev.stride(0) if ctx_prev is not None else 0, cat_ptr, cdepth, P(lvl_pack["wcls"]), P(lvl_pack["bcls"]), nlog,
                   lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), B, d, lvl_pack["lnf_eps"], st)
         sv["last"] = {"x_in": x, "q": q, "k": k, "v": v}
         sv["ctx_out"], sv["logits"] = ctx_out, logits
@@ -461,7 +557,7 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
     ws = torch.empty((B * H * 16 * 36,), **f32)
     _lib.call("paths_token0_tail", P(x), P(q), P(k), P(v), P(num_ims), P(w["wo"]), P(w["bo"]), P(w["ln1g"]), P(w["ln1b"]),
               P(w["cab"]), P(w["ln2g"]), P(w["ln2b"]), P(w["w1"]), P(w["b1"]), P(w["w2"]), P(w["b2"]), P(w["ln3g"]), P(w["ln3b"]),
-              P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev), ctx_prev.stride(0) if ctx_prev is not None else 0, None, 0,
+              P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev), ctx_prev.stride(0) if ctx_prev is not None else 0, cat_ptr, cdepth,
               P(lvl_pack["wcls"]), P(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), P(ws),
               B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
     sv["last"] = {"x_in": x, "q": q, "k": k, "v": v}
@@ -470,8 +566,9 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
 
 
 def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_ctx_out: Optional[torch.Tensor]):
-    """Returns (grads, d_tokens [B,T,128], d_ctx_prev [B,128] or None).  grads: {"layers": [per-layer dict], "lnfg", "lnfb",
-    "wcls", "bcls"}.  d_logits / d_ctx_out may be None (zero)."""
+    """Returns (grads, d_tokens [B,T,128], d_ctx): d_ctx = gradient of ctx_prev [B,128] (residual mode), of ctx_all [B,depth,128]
+    (concat mode) or None.  grads: {"layers": [per-layer dict], "lnfg", "lnfb", "wcls", "bcls"}.  d_logits / d_ctx_out may be
+    None (zero)."""
     tokens, num_ims, ctx_prev = sv["tokens"], sv["num_ims"], sv["ctx_prev"]
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
@@ -496,23 +593,34 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     x3 = chain_forward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)["x3"]
     xf, xhf, rsf = _ln_fwd(x3, None, lvl_pack["lnfg"], lvl_pack["lnfb"], B, lvl_pack["lnf_eps"])
     feat = xf + ctx_prev if ctx_prev is not None else xf                     # [B,128] (8 rows: bookkeeping)
+    ctx_all = sv.get("ctx_all")
+    cdepth = ctx_all.shape[1] if ctx_all is not None else 0
     dF = torch.zeros((B, 128), **f32)
+    d_ctx_all = torch.zeros((B, cdepth, 128), **f32) if cdepth > 0 else None
     if d_ctx_out is not None:
         dF += d_ctx_out
     if d_logits is not None:
         dl = torch.zeros((B, 128), **f32)
         dl[:, :nlog] = d_logits
-        wc = torch.zeros((128, 128), **f32)
-        wc[:, :nlog] = lvl_pack["wcls"].t()                                  # [in=128, out padded]
-        gemm_nt(dl, 128, wc, dF, 128, B, 128, 128, accumulate=True)          # dF += dlogits Wcls
-        gw = torch.empty((128, 128), **f32)
-        gemm_tn(dl, 128, feat, 128, gw, B, 128, 128)                         # (dlogits^T F), rows >= nlog are zero
+        wcls = lvl_pack["wcls"]                                              # [nlog, (cdepth + 1) * 128]: blocks = [ctx levels | F]
+        for kb in range(cdepth + 1):
+            wc = torch.zeros((128, 128), **f32)
+            wc[:, :nlog] = wcls[:, kb * 128:(kb + 1) * 128].t()              # [in=128, out padded]
+            if kb == cdepth:
+                gemm_nt(dl, 128, wc, dF, 128, B, 128, 128, accumulate=True)  # dF += dlogits Wcls[:, F block]
+            else:
+                blk = torch.empty((B, 128), **f32)
+                gemm_nt(dl, 128, wc, blk, 128, B, 128, 128)                  # gradient of the concatenated context of level kb
+                d_ctx_all[:, kb] = blk
+        cat_in = torch.cat((ctx_all.reshape(B, cdepth * 128), feat), dim=1).contiguous() if cdepth > 0 else feat
+        gw = torch.empty((128, (cdepth + 1) * 128), **f32)
+        gemm_tn(dl, 128, cat_in, (cdepth + 1) * 128, gw, B, 128, (cdepth + 1) * 128)     # (dlogits^T [ctx | F]), rows >= nlog are zero
         grads["wcls"] = gw[:nlog].contiguous()
         grads["bcls"] = colsum(dl, 128, B, 128)[:nlog].contiguous()
     else:
         grads["wcls"] = torch.zeros_like(lvl_pack["wcls"])
         grads["bcls"] = torch.zeros_like(lvl_pack["bcls"])
-    d_ctx_prev = dF.clone() if ctx_prev is not None else None
+    d_ctx_prev = dF.clone() if ctx_prev is not None else d_ctx_all
     dx3, dyxf = _ln_bwd(dF, xhf, rsf, lvl_pack["lnfg"], B)
     grads["lnfg"], grads["lnfb"] = colsum(dyxf, 128, B, 128), colsum(dF, 128, B, 128)
 

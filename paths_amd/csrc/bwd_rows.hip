@@ -105,6 +105,32 @@ imp_bwd_kernel(const float* __restrict__ dtok /*[B,T,128]*/, const float* __rest
   if (lane == 0) da[row] = dz;
 }
 
+// lstm = false variant (reference model/paths.py:95-109): Z = alpha * X (+ hctx), alpha = valid * sigmoid(w2 . relu(X W1^T + b1) + b2).
+//   dalpha[row] = dZ[row] . X[row] (D columns), dz = valid * dalpha * alpha (1 - alpha);  dh [M,128] = (hid > 0) dz w2 feeds
+//   dW1 = dh^T X and db1; dah = dz * hid feeds dw2; da = dz feeds db2.  One wave per row.
+__global__ void __launch_bounds__(256)
+imp_rows_bwd_kernel(const float* __restrict__ dz_rows /*[M,D]*/, const float* __restrict__ x /*[M,D]*/, int D, const float* __restrict__ hid,
+                    const float* __restrict__ alpha, const float* __restrict__ w2, const int64_t* __restrict__ num_ims, int rows_per_slide,
+                    int64_t M, float* __restrict__ dh /*[M,128]*/, float* __restrict__ da, float* __restrict__ dah) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int b = (int)(row / rows_per_slide), idx = (int)(row % rows_per_slide);
+  const bool valid = idx < (int)num_ims[b];
+  float acc = 0.f;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(dz_rows + row * D);
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x + row * D);
+  for (int i = lane; i < D / 4; i += 64) { const f32x4 g = g4[i], v = x4[i]; acc += (g[0] * v[0] + g[1] * v[1]) + (g[2] * v[2] + g[3] * v[3]); }
+  const float dalpha = wave_sum(acc);
+  const float a = alpha[row];
+  const float dz = valid ? dalpha * a * (1.0f - a) : 0.f;
+  const float2 hv = *reinterpret_cast<const float2*>(hid + row * 128 + 2 * lane);
+  const float2 wv = *reinterpret_cast<const float2*>(w2 + 2 * lane);
+  *reinterpret_cast<float2*>(dh + row * 128 + 2 * lane) = float2{hv.x > 0.f ? dz * wv.x : 0.f, hv.y > 0.f ? dz * wv.y : 0.f};
+  *reinterpret_cast<float2*>(dah + row * 128 + 2 * lane) = float2{dz * hv.x, dz * hv.y};
+  if (lane == 0) da[row] = dz;
+}
+
 // ---- LayerNorm forward with saved statistics (recompute pass of the backward) and backward; width 128, one wave/row
 __global__ void __launch_bounds__(256)
 ln_fwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ add /*[128] or null: x + add first*/,
@@ -207,6 +233,14 @@ int paths_importance_bwd(const float* dtok, const float* pproj, const float* hid
   PATHS_REQUIRE(M > 0 && dtok && pproj && hid && alpha && w2 && num_ims && du && da && dah, "importance_bwd: bad arguments");
   hipLaunchKernelGGL(imp_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, dtok, pproj, hid, alpha, w2, num_ims, rows_per_slide, M, imp_mul, du, da, dah);
   PATHS_LAUNCH_CHECK("importance_bwd");
+  return PATHS_OK;
+}
+
+int paths_importance_rows_bwd(const float* dz_rows, const float* x, int D, const float* hid, const float* alpha, const float* w2,
+                              const int64_t* num_ims, int rows_per_slide, int64_t M, float* dh, float* da, float* dah, hipStream_t stream) {
+  PATHS_REQUIRE(M > 0 && D % 4 == 0 && dz_rows && x && hid && alpha && w2 && num_ims && dh && da && dah, "importance_rows_bwd: bad arguments");
+  hipLaunchKernelGGL(imp_rows_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, dz_rows, x, D, hid, alpha, w2, num_ims, rows_per_slide, M, dh, da, dah);
+  PATHS_LAUNCH_CHECK("importance_rows_bwd");
   return PATHS_OK;
 }
 

@@ -68,8 +68,6 @@ class PATHSProcessor(nn.Module, Processor):
         mc = self.config
         if torch.is_grad_enabled():
             # differentiable path (training): same kernels + saved activations, backward in HIP (paths_amd/autograd.py)
-            if not mc.lstm:
-                raise NotImplementedError("training with lstm=false is not implemented on the HIP path")
             from .. import autograd as pag
             fts = data.fts.float().contiguous()
             state_prev = data.ctx_patch[:, :, -1] if self.depth > 0 else None
@@ -79,6 +77,8 @@ class PATHSProcessor(nn.Module, Processor):
             ctx_prev = data.ctx_slide[:, -1] if (mc.slide_ctx_mode == "residual" and data.ctx_depth > 0) else None
             if ctx_prev is not None and ctx_prev.stride(1) != 1:
                 ctx_prev = ctx_prev.contiguous()
+            if mc.slide_ctx_mode == "concat" and data.ctx_depth > 0:
+                ctx_prev = data.ctx_slide.float().contiguous()        # [B, depth, d]: all previous slide contexts
             logits, ctx_slide, ctx_patch, importance = pag.level_apply(self, lstm, fts, data.locs, data.num_ims, state_prev, ctx_prev)
             return {"logits": logits, "ctx_slide": ctx_slide, "ctx_patch": ctx_patch, "importance": importance}
         fts = data.fts

@@ -344,7 +344,6 @@ def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
     from . import autograd as pag
     mc = model.procs[0].config
     ops.check_supported(mc)
-    assert model.use_lstm, "training on the HIP path needs lstm=true"
     B, dev, D = len(batch), batch.device, batch.dim
     st = _lib.stream()
     p = _lib.ptr
@@ -359,11 +358,15 @@ def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
     num_ims = torch.empty((B,), **i64)
     _lib.call("paths_level0_batch", p(batch.grid_ptrs[0]), p(batch.gx[0]), p(batch.gy[0]), B, D, mc.patch_size, N,
               p(fts), p(locs), p(parent), p(num_ims), 1, None, None, st)
-    state_prev, ctx_prev = None, None
+    state_prev, ctx_prev, ctx_hist = None, None, []
     logits = None
     for i in range(num_levels):
-        logits, ctx_slide, state_out, importance = pag.level_apply(model.procs[i], model.lstm, fts, locs, num_ims, state_prev, ctx_prev)
+        if mc.slide_ctx_mode == "concat":          # the classifier reads every previous level's slide context (model/paths.py:134-137)
+            ctx_prev = torch.stack(ctx_hist, dim=1) if ctx_hist else None
+        logits, ctx_slide, state_out, importance = pag.level_apply(model.procs[i], model.lstm if model.use_lstm else None, fts, locs,
+                                                                   num_ims, state_prev, ctx_prev)
         ctx_prev = ctx_slide
+        ctx_hist.append(ctx_slide)
         if i == num_levels - 1:
             break
         keep = int(keep_patches[i])

@@ -165,10 +165,10 @@ def test_transformer_backward(dev):
             assert rel_err(grads["layers"][l][k], ref) < tol, (l, k, rel_err(grads["layers"][l][k], ref))
 
 
-def _train_setup(dev, wseed=3, dseed=14, top_k=64, base=(16, 16), n_slides=4):
+def _train_setup(dev, wseed=3, dseed=14, top_k=64, base=(16, 16), n_slides=4, cfg_over=None):
     from paths_amd import synthetic as syn
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
-    cfg, model, params = build_model(dev, wseed, None, top_k_patches=[top_k] * 4)
+    cfg, model, params = build_model(dev, wseed, cfg_over, top_k_patches=[top_k] * 4)
     slides = [DeviceSlide.synthetic(dseed, sid, base, p_bg=0.1, device=dev) for sid in range(n_slides)]
     labels = np.asarray([s.synthetic_spec.label(4) for s in slides], np.int64)
     batch = {"slide": DeviceSlideBatch(slides), "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
@@ -204,6 +204,41 @@ def test_recursion_gradients_vs_oracle_autograd(dev):
         assert rel_err(g, ref.grad) < 2e-3, (k, rel_err(g, ref.grad))
         live += 1
     assert live > 100
+
+
+@pytest.mark.parametrize("over", [{"lstm": False}, {"slide_ctx_mode": "concat"}, {"lstm": False, "slide_ctx_mode": "concat"},
+                                  {"slide_ctx_mode": "none"}], ids=["nolstm", "concat", "nolstm_concat", "ctx_none"])
+def test_variant_training_gradients_vs_oracle_autograd(dev, over):
+    """the non-default model variants train on the HIP path too (reference model/paths.py:49-54,101-109: RNN
+    hierarchical context instead of the LSTM; :34-37,134-137: slide contexts concatenated into the classifier): 5-level training
+    forward / backward on the device vs torch autograd through the oracle, every live parameter."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    cfg_over = {"model_config": dict(over)}
+    cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3, cfg_over=cfg_over)
+    model.train()
+    _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(cfg_over, top_k_patches=[16] * 4)
+    labels = {"survival_bin": batch["survival_bin"], "censored": batch["censored"]}
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], labels)
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5
+    sd = dict(model.named_parameters())
+    live = 0
+    for k, ref in p.items():
+        g = sd[k].grad
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            # unused by the oracle's graph: either really unused (grad None) or one of the reference's dead nn.Transformer
+            # parameters, which forward_backward fills with the reference's zero gradients
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        assert g is not None, k
+        assert rel_err(g, ref.grad) < 2e-3, (k, rel_err(g, ref.grad))
+        live += 1
+    assert live > (40 if over.get("slide_ctx_mode") == "none" else 90)      # ("none": the earlier levels' aggregators do not reach the loss)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    assert np.isfinite(float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)))
 
 
 def test_training_on_zero_children_slides_takes_the_fallback(dev):
