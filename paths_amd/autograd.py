@@ -109,6 +109,20 @@ def fill_dead_grads(model):
         p.grad = zero[:p.numel()].view_as(p)
 
 
+def next_dropout_seed(device) -> int:
+    """A fresh 64-bit seed for one level's dropout masks, taken from the DEVICE's default generator - the stream the reference's
+    dropout consumes when it trains on a GPU - by reading (seed, philox offset) on the host and advancing the offset: no device
+    sync, ``torch.manual_seed`` restarts the sequence, and the CPU generator is untouched, so the DataLoader-compatible shuffle
+    order (paths_amd/train.py:epoch_permutation) does not depend on whether dropout is on."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    seed, off = int(gen.initial_seed()), int(gen.get_offset())
+    gen.set_offset(off + 4)
+    z = (seed * 0x9E3779B97F4A7C15 + (off + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 29)
+
+
 def check_dropout_supported(proc):
     """Every entry to the differentiable path passes here (LevelFn.forward): a config with dropout > 0 in train mode is
     never silently run with its five dropout sites per layer as identity (reference model/aggregator.py:25-33)."""
@@ -135,8 +149,7 @@ class LevelFn(torch.autograd.Function):
         assert cat is None or cat.dim() == 3
         drop = None
         if proc.training and mc.dropout > 0:
-            # one seed per level forward from torch's global generator (torch.manual_seed controls the masks, as in the reference)
-            drop = bw.Drop(mc.dropout, int(torch.empty((), dtype=torch.int64).random_().item()), proc.depth)
+            drop = bw.Drop(mc.dropout, next_dropout_seed(fts.device), proc.depth)       # (torch.manual_seed controls the masks)
         tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop, cat)
         ctx.proc, ctx.lstm, ctx.sel, ctx.tr = proc, lstm, sel, tr
         ctx.has_state, ctx.has_ctx = state_prev is not None, (res is not None or cat is not None)
@@ -186,7 +199,7 @@ class LevelFnNoLstm(torch.autograd.Function):
         cat = ctx_prev.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_prev is not None and ctx_prev.shape[1] > 0) else None
         drop = None
         if proc.training and mc.dropout > 0:
-            drop = bw.Drop(mc.dropout, int(torch.empty((), dtype=torch.int64).random_().item()), proc.depth)
+            drop = bw.Drop(mc.dropout, next_dropout_seed(fts.device), proc.depth)
         tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop, cat)
         ctx.proc, ctx.sel, ctx.tr = proc, sel, tr
         ctx.has_state, ctx.has_ctx = state_prev is not None, (res is not None or cat is not None)

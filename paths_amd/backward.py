@@ -318,7 +318,8 @@ LOG2E = 1.4426950408889634
 
 class Drop:
     """Dropout of one level's transformer in one training step (reference nn.Transformer(..., dropout=p): five sites per decoder
-    layer).  ``seed`` is drawn once per level forward from torch's global generator (so ``torch.manual_seed`` controls it);
+    layer).  ``seed`` is drawn once per level forward from the device's default generator (paths_amd/autograd.py:next_dropout_seed:
+    ``torch.manual_seed`` controls it, the CPU generator that orders the epochs is untouched);
     every (layer, site) gets its own 64-bit key; masks are regenerated from (key, element index) wherever they are needed
     (csrc/dropout.h) - forward, the backward's recompute and the gradient masking all see the same mask."""
     ATTN, SA_OUT, CA_OUT, FF_INNER, FF_OUT = range(5)

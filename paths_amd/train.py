@@ -46,11 +46,14 @@ def load_state(root_path: str, model, map_location=None) -> Dict:
 
 
 def epoch_permutation(n: int, shuffle: bool) -> List[int]:
-    """Order of one epoch, drawn exactly like ``DataLoader(shuffle=True)``'s RandomSampler: a seed from the global
-    RNG, then ``torch.randperm`` with a private generator — so ``torch.manual_seed(s)`` gives the reference's order."""
+    """Order of one pass over a dataset, consuming the global CPU generator exactly like iterating the reference's
+    ``DataLoader`` does (train.py:19-28): EVERY iterator first draws its worker base seed (the validation / test loaders too -
+    one draw per evaluation pass, which shifts the next epoch's shuffle; fixture G10 pins this), a shuffling one then draws the
+    RandomSampler's seed and runs ``torch.randperm`` with a private generator.  So ``torch.manual_seed(s)`` gives the reference's
+    sample order across a whole training run."""
+    torch.empty((), dtype=torch.int64).random_()      # the DataLoader iterator draws its worker base seed first
     if not shuffle:
         return list(range(n))
-    torch.empty((), dtype=torch.int64).random_()      # the DataLoader iterator draws its worker base seed first
     seed = int(torch.empty((), dtype=torch.int64).random_().item())
     g = torch.Generator()
     g.manual_seed(seed)

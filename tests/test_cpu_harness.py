@@ -90,6 +90,14 @@ def test_epoch_permutation_equals_dataloader_shuffle():
     torch.manual_seed(123)
     assert epoch_permutation(23, True) == ref and epoch_permutation(23, True) == ref2
     assert epoch_permutation(5, False) == [0, 1, 2, 3, 4]
+    # a non-shuffling loader consumes one draw of the global generator per pass too (its iterator's base seed): the order of the
+    # NEXT shuffled epoch depends on it
+    torch.manual_seed(5)
+    a = [int(x) for x in torch.utils.data.DataLoader(data, batch_size=1, shuffle=True)]
+    _ = [x for x in torch.utils.data.DataLoader(data, batch_size=4, shuffle=False)]
+    b = [int(x) for x in torch.utils.data.DataLoader(data, batch_size=1, shuffle=True)]
+    torch.manual_seed(5)
+    assert epoch_permutation(23, True) == a and epoch_permutation(23, False) == data and epoch_permutation(23, True) == b
 
 
 def test_importance_map_weighting():

@@ -511,3 +511,58 @@ def test_training_with_shipped_dropout_config(dev):
     torch.manual_seed(0)
     losses = [float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)) for _ in range(3)]
     assert all(np.isfinite(l) for l in losses)
+
+
+def test_epoch_loop_matches_reference_g10(dev, tmp_path):
+    """paths_amd.train.train_loop against the reference's own epoch loop (train.py:31-116, fixture G10 captured by
+    tools/make_goldens.py: DataLoader shuffle order, AdamW + ExponentialLR, per-epoch train / validation losses, early-stopping
+    save + reload, final test evaluation) on the same synthetic slides, weights and seeds."""
+    import os, pickle
+    from paths_amd import synthetic as syn
+    from paths_amd.config import Config
+    from paths_amd import train as ptrain
+    from tests.conftest import load_golden
+    g, info = load_golden("g10_epoch_loop_6x6_top8")
+    cfg = Config.load(os.path.join(os.path.dirname(__file__), "golden", "sample"), test_mode=True)
+    cfg.model_config.dropout = 0.0
+    cfg.num_levels, cfg.top_k_patches, cfg.batch_size = 3, [info["top_k"]] * 2, [info["batch_size"]] * 3
+    cfg.num_epochs, cfg.lr, cfg.early_stopping, cfg.eval_epochs, cfg.min_epochs = info["num_epochs"], info["lr"], True, 1, 0
+    cfg.lr_decay_per_epoch = info["lr_decay_per_epoch"]
+    model = cfg.get_model()
+    sd = syn.make_state_dict(info["wseed"], {k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev)
+    ds = ptrain.synthetic_dataset(info["n_slides"], tuple(info["base_shape"]), 3, dev, seed=info["dseed"])
+    order = []
+    orig = ptrain.epoch_permutation
+
+    def spy(n, shuffle):
+        perm = orig(n, shuffle)
+        if shuffle:
+            order.extend(info["train_ids"][i] for i in perm)
+        return perm
+
+    ptrain.epoch_permutation = spy
+    try:
+        torch.manual_seed(info["seed"])
+        logs = []
+        stats = ptrain.train_loop(model, [ds[i] for i in info["train_ids"]], [ds[i] for i in info["val_ids"]],
+                                  [ds[i] for i in info["test_ids"]], cfg, str(tmp_path), log=logs.append)
+    finally:
+        ptrain.epoch_permutation = orig
+    assert order == g["order"].tolist()                                                    # DataLoader(shuffle=True) order, 3 epochs
+    np.testing.assert_allclose([stats["train_loss"][e] for e in (1, 2, 3)], g["train_loss"], atol=3e-5, rtol=0)
+    np.testing.assert_allclose([stats["val_loss"][e] for e in (1, 2, 3)], g["val_loss"], atol=3e-5, rtol=0)
+    np.testing.assert_allclose([stats["val_c-index"][e] for e in (1, 2, 3)], g["val_cindex"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose([stats["train_c-index"][e] for e in (1, 2, 3)], g["train_cindex"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(stats["test"]["test_loss"], float(g["test_loss"]), atol=3e-5, rtol=0)
+    saved = pickle.load(open(tmp_path / "train_stats.pkl", "rb"))
+    assert saved["epoch"] == info["epoch_saved"] and sorted(saved.keys()) >= sorted(info["stats_keys"])
+    # final weights = the early-stopping checkpoint re-loaded after the last epoch (reference train.py:96-98)
+    for k, v in model.state_dict().items():
+        ref = g["digest." + k]
+        got = np.asarray([float(v.double().sum()), float(v.double().abs().sum())])
+        # (Adam's first steps move every element by ~lr whatever its gradient's size, so elements whose gradient is pure rounding
+        # noise - e.g. the key bias of in_proj, whose exact gradient is 0 - step in implementation-dependent directions: a few
+        # times lr = 2e-4 per tensor.  The bar still separates the epoch-1 checkpoint from the epoch-3 weights by orders of magnitude)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * ref[1] + 2e-3, err_msg=k)

@@ -144,3 +144,23 @@ def test_compare_recursion_checker_detects_differences():
     assert not compare_recursion(bad, tr, hz, hz, raise_on_mismatch=False)["parent_pairs_identical"]
     with pytest.raises(AssertionError):
         compare_recursion(as_gpu(tr), tr, hz + 1e-3, hz)
+
+
+def test_importance_map_equals_reference_overlay_g11():
+    """paths_amd.heatmap.importance_map against the array the REFERENCE's own overlay code (heatmap_visualise.py:147-171, run inside
+    heatmap_camelyon17 by tools/make_goldens.py on the per-level locations / importances of fixture G3) handed to imshow."""
+    from paths_amd.heatmap import importance_map
+    g11, info = load_golden("g11_heatmap_g3_slide0")
+    g3, info3 = load_golden(info["source"])
+    j, L = info["slide"], info["levels"]
+    levels = []
+    for l in range(L):
+        n = int(g3[f"L{l}_num_ims"][j])
+        levels.append({"locs": g3[f"L{l}_locs"][j, :n], "importance": g3[f"L{l}_importance"][j, :n]})
+    m = importance_map(levels, tuple(info["base_shape"]), patch_size=info["patch_size"])
+    assert m.shape == g11["map"].shape == (96, 112)
+    seen = m > 0
+    assert np.array_equal(seen, g11["alpha"] > 0)                         # the same cells are covered (alpha = 0.5 where drawn)
+    np.testing.assert_allclose(m[seen], g11["map"][seen], rtol=0, atol=1e-12)
+    # the reference paints never-visited pixels with the smallest drawn value before plotting (heatmap_visualise.py:174)
+    assert np.all(g11["map"][~seen] == g11["map"][seen].min()) if (~seen).any() else True

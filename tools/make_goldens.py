@@ -313,6 +313,147 @@ def init_digest(ref, name, seed=0):
     save(name, arrays, {"kind": "init_digest", "seed": seed, "keys": list(sd.keys())})
 
 
+def epoch_loop(ref, name, base_shape=(6, 6), top_k=8, n_slides=14, wseed=6, dseed=77, seed=123):
+    """G10: the reference's own epoch loop (train.py:31-116: DataLoader(shuffle=True) order, AdamW + ExponentialLR, per-epoch train /
+    validation evaluators, early-stopping save / reload, final test evaluation) on a tiny synthetic dataset, dropout 0.
+    scikit-survival / torcheval are not installed here: the c-index inside this run comes from the pair-counting restatement below
+    (definition of sksurv's concordance_index_censored), so the fixture pins losses, sample order, bookkeeping and final weights -
+    the c-index values it records are informative only."""
+    rcfg, rutils, patch_batch, rslide, rdataset, rloader = ref
+
+    def cindex(event, time, risk, tied_tol=1e-8):
+        event, time, risk = np.asarray(event, bool), np.asarray(time, np.float64), np.asarray(risk, np.float64)
+        num = conc = tied = 0
+        for i in range(len(time)):
+            if not event[i]:
+                continue
+            for j in range(len(time)):
+                if i != j and (time[i] < time[j] or (time[i] == time[j] and not event[j])):
+                    num += 1
+                    if abs(risk[i] - risk[j]) <= tied_tol:
+                        tied += 1
+                    elif risk[i] > risk[j]:
+                        conc += 1
+        return ((conc + 0.5 * tied) / num, conc, 0, tied, 0)
+
+    _stub("sksurv"); _stub("sksurv.metrics", concordance_index_censored=cindex)
+    _stub("torcheval"); _stub("torcheval.metrics", BinaryAUROC=object)
+    logged = []
+    sys.modules["wandb"].log = lambda d, *a, **k: logged.append(dict(d))
+    import train as rtrain          # noqa  (reference train.py; its argparse / wandb.init only run under __main__)
+    import tempfile
+    c = make_config(rcfg)
+    c.num_levels, c.top_k_patches, c.batch_size = 3, [top_k, top_k], [4, 4, 4]
+    c.num_epochs, c.lr, c.early_stopping, c.eval_epochs, c.min_epochs, c.lr_decay_per_epoch = 3, 2e-4, True, 1, 0, 0.9
+    model, _ = build_model(c, wseed)
+    order = []
+
+    class DS:
+        """list-like dataset of synthetic slides; a fresh reference slide object per access (iteration mutates them)"""
+        def __init__(self, ids, tag):
+            self.ids, self.tag = list(ids), tag
+
+        def __len__(self):
+            return len(self.ids)
+
+        def __getitem__(self, i):
+            sid = self.ids[i]
+            if self.tag == "train":
+                order.append(sid)
+            slides, synth = make_slides(ref, c, model, dseed, list(range(n_slides)), base_shape, 0.1)
+            s, sy = slides[sid], synth[sid]
+            sb, cen = sy.label(c.nbins)
+            return s.todict() | {"survival_bin": sb, "survival": float(sb) + 0.5, "censored": cen, "slide": s}
+
+    rtrain.config = c                  # get_dataloaders reads the module-level config (train.py:19)
+    torch.manual_seed(seed)
+    with tempfile.TemporaryDirectory() as tmp:
+        rtrain.train_loop(model.train(), DS(range(6, n_slides), "train"), DS(range(0, 3), "val"), DS(range(3, 6), "test"), c, tmp)
+        import pickle
+        stats = pickle.load(open(os.path.join(tmp, "train_stats.pkl"), "rb"))
+    digest = {k: np.asarray([float(v.double().sum()), float(v.double().abs().sum())]) for k, v in model.state_dict().items()}
+    arrays = {"train_loss": np.asarray([stats["train_loss"][e] for e in (1, 2, 3)], np.float64),
+              "val_loss": np.asarray([stats["val_loss"][e] for e in (1, 2, 3)], np.float64),
+              "train_cindex": np.asarray([stats["train_c-index"][e] for e in (1, 2, 3)], np.float64),
+              "val_cindex": np.asarray([stats["val_c-index"][e] for e in (1, 2, 3)], np.float64),
+              "order": np.asarray(order, np.int64),
+              "test_loss": np.float64(logged[-1]["test_loss"]), "test_cindex": np.float64(logged[-1]["test_c-index"])}
+    arrays.update({"digest." + k: v for k, v in digest.items()})
+    save(name, arrays, {"kind": "epoch_loop", "base_shape": list(base_shape), "top_k": top_k, "n_slides": n_slides, "wseed": wseed,
+                        "dseed": dseed, "seed": seed, "epoch_saved": int(stats["epoch"]), "num_epochs": 3, "lr": 2e-4,
+                        "lr_decay_per_epoch": 0.9, "batch_size": 4, "stats_keys": sorted(k for k in stats.keys()),
+                        "train_ids": list(range(6, n_slides)), "val_ids": [0, 1, 2], "test_ids": [3, 4, 5],
+                        "cindex_source": "pair-counting restatement in tools/make_goldens.py (sksurv not installed)"})
+
+
+def heatmap(ref, name, src="g3_recursion_6x7_top5", slide=0):
+    """G11: the reference's overlay arithmetic (heatmap_visualise.py:147-171, inside heatmap_camelyon17) run on the per-level patch
+    locations and importances the reference itself produced for fixture G3: the function is driven with stand-in slide / model
+    objects that replay those values, and the array it hands to imshow is captured (down-sampled to one value per finest patch)."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.axes
+    z = np.load(os.path.join(OUT, src + ".npz"))
+    info = json.loads(bytes(z["__info__"]).decode())
+    rcfg = ref[0]
+    c = make_config(rcfg)
+    c.top_k_patches = [info["top_k"]] * (c.num_levels - 1)
+    L, P = c.num_levels, c.model_config.patch_size
+    X0, Y0 = info["base_shape"]
+    levels = []
+    for l in range(L):
+        n = int(z[f"L{l}_num_ims"][slide])
+        levels.append((z[f"L{l}_locs"][slide, :n], z[f"L{l}_importance"][slide, :n]))
+    _stub("model.image_encoder", from_name=lambda *_: None)
+    import heatmap_visualise as hv    # noqa (reference)
+
+    class FakeSlide:
+        def __init__(self, depth):
+            self.depth, self.locs = depth, torch.from_numpy(levels[depth][0].copy())
+
+        def load_patches(self):
+            pass
+
+        def recurse(self, *a):
+            return FakeSlide(self.depth + 1)
+
+        def view_at_power(self, power):
+            return np.zeros((X0 * P, Y0 * P, 3), np.uint8)
+
+    class FakeModel:
+        procs = [types.SimpleNamespace(ctx_dim=lambda: (128, 1280))]
+
+        def __call__(self, depth, data):
+            imp = torch.from_numpy(levels[depth][1].copy())[None]
+            return {"ctx_slide": torch.zeros(1, 128), "ctx_patch": torch.zeros(1, imp.shape[1], 1280), "importance": imp}
+
+    hv.load_raw_slide = lambda *a, **k: FakeSlide(0)
+    hv.from_raw_slide = lambda slide_, enc, tr: slide_
+    captured = []
+    orig = matplotlib.axes.Axes.imshow
+
+    def spy(self, X, *a, **k):
+        if np.asarray(X).ndim == 2:
+            captured.append((np.array(X, dtype=np.float64), np.array(k.get("alpha"), dtype=np.float64)))
+        return orig(self, X, *a, **k)
+
+    matplotlib.axes.Axes.imshow = spy
+    try:
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".svs") as fh:
+            hv.heatmap_camelyon17(c, FakeModel(), None, None, fh.name, None, None)
+    finally:
+        matplotlib.axes.Axes.imshow = orig
+    assert len(captured) == 1
+    full, alpha = captured[0]
+    cell = P // 2 ** (L - 1)
+    small, asmall = full[::cell, ::cell], alpha[::cell, ::cell]
+    assert np.array_equal(np.kron(small, np.ones((cell, cell))), full), "map is not constant on finest-level patches"
+    save(name, {"map": small, "alpha": asmall}, {"kind": "heatmap", "source": src, "slide": slide, "base_shape": [X0, Y0], "patch_size": P,
+                                                  "levels": L, "cell_px": cell})
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present: nothing to do")
@@ -350,6 +491,10 @@ def main():
         single_level(ref, "g8_level0_b1_k2048", 0, 1, 2048, [2048], wseed=1, dseed=18, probe_only=True)
     if want("g9"):
         single_level(ref, "g9_level1_b2_k2048", 1, 2, 2048, [2048, 1900], wseed=1, dseed=19, probe_only=True)
+    if want("g10"):
+        epoch_loop(ref, "g10_epoch_loop_6x6_top8")
+    if want("g11"):
+        heatmap(ref, "g11_heatmap_g3_slide0")
 
 
 if __name__ == "__main__":
