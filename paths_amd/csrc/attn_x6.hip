@@ -22,6 +22,9 @@
 #include "dropout.h"
 
 DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
+#ifdef PATHS_ATTN_DEBUG
+unsigned long long* g_attn_dbg = nullptr;
+#endif
 
 namespace {
 
@@ -162,12 +165,33 @@ __device__ __forceinline__ float rows_sum(float x) { x += __shfl_xor(x, 16); ret
 // DROP (training with dropout > 0, reference nn.MultiheadAttention(dropout=p)): the softmax probabilities that enter the PV product
 // are multiplied by the regenerated mask / (1 - p) (element ((slide*H + head)*T + query)*T + key of the site, csrc/dropout.h); the
 // normaliser l and the saved log-sum-exp stay those of the un-dropped softmax, as in the reference.
+#ifndef PATHS_ATTN_OCC
+#define PATHS_ATTN_OCC 2
+#endif
+// PATHS_ATTN_OCC = waves per SIMD the kernel is built for.  2: the software-pipelined loop (S of the next step computed before the
+// softmax of this one; two score buffers).  3: one score buffer (32 registers less: fits 168), three workgroups per CU - the same
+// work on two thirds of the CUs, which leaves more of the chip to the selection chain's GEMMs running beside it.
+constexpr int ATTN_OCC = PATHS_ATTN_OCC;
+#ifndef PATHS_ATTN_QT
+#define PATHS_ATTN_QT 2
+#endif
+// QT = 16-query tiles per wave (a workgroup = 4 waves = 64 QT queries).  2: every K / V^T fragment read from LDS feeds two query
+// tiles.  1 (with ATTN_OCC >= 3): twice the workgroups at half the registers - four or more waves per SIMD hide each other's
+// LDS / softmax latencies (the loop is latency-bound at two), at twice the LDS fragment traffic per MFMA.
+constexpr int QT = PATHS_ATTN_QT;
 template <int NP, bool DROP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, ATTN_OCC)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H,
-               int npairs_arg, int nqb_arg, DropSite drop) {
+               int npairs_arg, int nqb_arg, DropSite drop
+#ifdef PATHS_ATTN_DEBUG
+               , unsigned long long* dbg
+#endif
+               ) {
   constexpr int STEP_BYTES = step_bytes<NP>();
+#ifdef PATHS_ATTN_DEBUG
+  const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];          // 2 x STEP_BYTES (+ occupancy padding, see the launcher)
   // XCD-aware placement (speed only): every workgroup of one (slide, head) pair streams that pair's whole K / V^T images (0.5 MB
   // at T = 2049), and blocks are dealt round-robin over the 8 XCDs.  With the query block as the fastest grid index each XCD's
@@ -180,28 +204,30 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   if (cnt <= 0) return;
   const int pair = xg + 8 * (jx % cnt), qb = jx / cnt;
   if (qb >= nqb) return;
-  const int b = pair / H, head = pair - b * H, q0 = qb * 128;
+  const int b = pair / H, head = pair - b * H, q0 = qb * 64 * QT;
   const int len = min((int)num_ims[b] + 1, T);          // valid keys = special token + patches
   if (q0 >= len) return;                                // every query of this block is padding
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 15, g4 = lane >> 4;
   const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * NP;
-  const int qw = q0 + wave * 32;                        // this wave's first query
+  const int qw = q0 + wave * 16 * QT;                   // this wave's first query
 
   // Q fragments (B operand of S^T): two 16-query tiles x 3 planes, kept in registers
-  u32x4 qf[2][NP];
+  u32x4 qf[QT][NP];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int p = 0; p < NP; ++p)
       qf[qt][p] = *reinterpret_cast<const u32x4*>(q6 + ibase + ((int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * NP + p) * FRAG + lane * 16);
 
-  f32x4 oacc[2][2];                                     // [dv tile][query tile]: rows = dims 4 g4 .. +3, col = query ql
+  f32x4 oacc[2][QT];                                    // [dv tile][query tile]: rows = dims 4 g4 .. +3, col = query ql
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
 
   // staging: one 64-key step = 4 NP KiB of K fragments + 4 NP KiB of V^T fragments, both contiguous in their images.
   // Software pipeline: S(k+1) = K(k+1) Q^T is issued BEFORE the softmax of S(k), so one wave's MFMAs run under its own VALU work
@@ -228,7 +254,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #pragma unroll
     for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sVb + (kt & 1) * HALF + (tid + 256 * i) * 16) = st[NP + i];
   };
-  auto qk = [&](int kt, f32x4 (&s)[2][4]) __attribute__((always_inline)) {      // S^T = K Q^T for the 4 key tiles of step kt
+  auto qk = [&](int kt, f32x4 (&s)[QT][4]) __attribute__((always_inline)) {      // S^T = K Q^T for the 4 key tiles of step kt
     const char* sK = sKb + (kt & 1) * HALF + lane * 16;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -236,36 +262,48 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #pragma unroll
       for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const u32x4*>(sK + (t * NP + p) * FRAG);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) s[qt][t] = mfma_split(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma_split(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
     }
   };
   gload_k(0); gload_v(0);
   swrite_k(0); swrite_v(0);
   if (nkt > 1) { gload_k(1); swrite_k(1); }
   __syncthreads();
-  f32x4 sA[2][4], sB[2][4];                             // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
-  qk(0, sA);
+  f32x4 sA[QT][4], sB[QT][4];                             // [query tile][key tile]: rows = keys 4 g4 .. +3, col = query ql
+  if constexpr (ATTN_OCC < 3) qk(0, sA);
   // one step: s = S(kt) (ready), sn receives S(kt+1)
-  auto step = [&](int kt, f32x4 (&s)[2][4], f32x4 (&sn)[2][4], auto lastc) __attribute__((always_inline)) {
+  // Fair share for the SECOND workgroup of a CU.  Issue arbitration on a SIMD is oldest-first: measured per workgroup
+  // (tools/attn_wg_times.py), the 256 first-dispatched workgroups ran 46 us and their 224 younger CU mates 58 us - the last
+  // 12 us with a single workgroup per CU.  Alternating the priority between the two every few key steps lets both finish together.
+#ifndef PATHS_ATTN_PRIO_SHIFT
+#define PATHS_ATTN_PRIO_SHIFT 2
+#endif
+  const int prio_parity = (qb * npairs + pair) >= 256 ? 1 : 0;
+  auto step = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], auto lastc) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(lastc)::value;       // the masked step is peeled: 26 selects per step otherwise
+    if constexpr (PATHS_ATTN_PRIO_SHIFT >= 0) {
+      if ((((kt >> PATHS_ATTN_PRIO_SHIFT) ^ prio_parity) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     if (kt + 2 < nkt) gload_k(kt + 2);
     if (kt + 1 < nkt) gload_v(kt + 1);
+    if constexpr (ATTN_OCC >= 3) qk(kt, s);
     const char* sV = sVb + (kt & 1) * HALF + lane * 16;
     // ---- mask (last step only) + online softmax (lane: query ql of each tile; keys 16 t + 4 g4 + r)
     if constexpr (LAST) {
       const int kbase = kt * KSTEP + 4 * g4;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
     }
-    qk(kt + 1, sn);                                     // (past the end: stale K fragments, finite garbage nobody reads)
-    u32x4 pf[2][2][NP];                                 // [query tile][32-key group][plane]
+    if constexpr (ATTN_OCC < 3) qk(kt + 1, sn);         // (past the end: stale K fragments, finite garbage nobody reads)
+    u32x4 pf[QT][2][NP];                                // [query tile][32-key group][plane]
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float mx = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {                     // two v_max3_f32 per key tile
@@ -307,7 +345,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #pragma unroll
         for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + ((kg * 2 + dvt) * NP + p) * FRAG);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
+        for (int qt = 0; qt < QT; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
       }
     if (kt + 2 < nkt) swrite_k(kt + 2);                 // over K(kt): read one step ago
     if (kt + 1 < nkt) swrite_v(kt + 1);                 // over V(kt-1)
@@ -317,15 +355,20 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     constexpr std::false_type MID{};
     constexpr std::true_type END{};
     int kt = 0;
-    for (; kt + 2 < nkt; kt += 2) {
-      step(kt, sA, sB, MID);
-      step(kt + 1, sB, sA, MID);
+    if constexpr (ATTN_OCC >= 3) {
+      for (; kt + 1 < nkt; ++kt) step(kt, sA, sA, MID);
+      step(kt, sA, sA, END);
+    } else {
+      for (; kt + 2 < nkt; kt += 2) {
+        step(kt, sA, sB, MID);
+        step(kt + 1, sB, sA, MID);
+      }
+      if (kt + 1 < nkt) { step(kt, sA, sB, MID); step(kt + 1, sB, sA, END); }
+      else step(kt, sA, sB, END);
     }
-    if (kt + 1 < nkt) { step(kt, sA, sB, MID); step(kt + 1, sB, sA, END); }
-    else step(kt, sA, sB, END);
   }
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const float l = rows_sum(l_run[qt]);
     const float inv = 1.0f / l;
     const int qi = qw + 16 * qt + ql;
@@ -336,6 +379,15 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
       if (lse && g4 == 0) lse[((int64_t)b * H + head) * T + qi] = m_run[qt] + log2f(l);
     }
   }
+#ifdef PATHS_ATTN_DEBUG
+  if (dbg && threadIdx.x == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[3 * blockIdx.x] = dbg_t0; dbg[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); dbg[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 template <int NP>
@@ -357,9 +409,9 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   }
   // Workgroups per CU: registers allow 2, LDS would allow more.  The dispatcher fills a CU to its limit before it moves on, so
   // small grids ask for more LDS than needed to spread out: depth ~ grid / 256.
-  const int nblk = ((nq + 127) / 128) * H * B;
+  const int nblk = ((nq + 64 * QT - 1) / (64 * QT)) * H * B;
   static const int depth_env = getenv("PATHS_ATTN_DEPTH") ? atoi(getenv("PATHS_ATTN_DEPTH")) : 0;   // experiment
-  const int depth = depth_env ? depth_env : nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
+  const int depth = depth_env ? depth_env : ATTN_OCC >= 3 ? (nblk <= 256 ? 1 : nblk <= 512 ? 2 : 3) : nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
   const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
   static bool attr_set = false;
   if (!attr_set) {
@@ -367,19 +419,27 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  const int nqb = (nq + 127) / 128, npairs = H * B;
+  const int nqb = (nq + 64 * QT - 1) / (64 * QT), npairs = H * B;
   const DropSite site = paths_make_drop_site(drop_key, drop_p);
   // 1-D grid walked in XCD-aware order (see the kernel)
+#ifdef PATHS_ATTN_DEBUG
+  hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, g_attn_dbg);
+#else
   if (drop_p > 0.f)
     hipLaunchKernelGGL((attn_x6_kernel<NP, true>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site);
   else
     hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site);
+#endif
   PATHS_LAUNCH_CHECK("attention_x6");
   return PATHS_OK;
 }
 
 
 }  // namespace
+
+#ifdef PATHS_ATTN_DEBUG
+extern "C" void paths_attn_debug_buffer(unsigned long long* p) { g_attn_dbg = p; }     // development hook (tools/attn_wg_times.py)
+#endif
 
 extern "C" {
 

@@ -32,6 +32,14 @@ constexpr int FRAG = 1024;         // bytes of one 16-row x 32-k fragment of one
 constexpr int CHUNK = 32 * FRAG;   // one staged chunk: [64 out rows][128 k] or [128 out rows][64 k], 2 planes
 constexpr int N_POST = 18;         // chunks of the post-attention part: 0-1 Wo | 2+2h W1 rows 64h | 3+2h W2[:, 64h:64h+64]
 constexpr int N_QKV = 6;           // chunks of in_proj: rows 64 c
+#ifndef PATHS_TLAYER_WAVES
+#define PATHS_TLAYER_WAVES 8
+#endif
+// Waves per workgroup (16 tokens each).  8 = two waves per SIMD sharing every staged weight chunk: the chain is latency-bound (one
+// wave per SIMD re-reads a 32-KiB chunk from LDS per 48 MFMAs, MFMA pipe 11 % busy), a second wave on the SIMD runs under the
+// first one's LDS / barrier waits, the global -> LDS chunk traffic per token halves, and the launch needs half the CUs.
+constexpr int NWAVES = PATHS_TLAYER_WAVES;
+constexpr int NTHREADS = 64 * NWAVES, TOK_WG = 16 * NWAVES, NSTAGE = 2048 / NTHREADS;   // 16-byte pieces per thread and chunk
 
 __device__ __forceinline__ uint32_t pk_f16(float a, float b) {
   f32x2 v = {a, b};
@@ -126,7 +134,7 @@ __device__ __forceinline__ void mm_chunk(const char* sW, f32x4 (&acc)[NOT], cons
   }
 }
 
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(NTHREADS, NWAVES == 8 ? 1 : 2)
 tlayer_h3_kernel(TLayerH3Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][CHUNK] + biases / LayerNorm vectors [512 + 384 + 9 x 128] floats
   float* s_b1 = reinterpret_cast<float*>(smem + 2 * CHUNK);
@@ -134,7 +142,7 @@ tlayer_h3_kernel(TLayerH3Params p) {
   // the nine 128-float vectors of the post part (bo, ln1 g/b, cab, ln2 g/b, b2, ln3 g/b): read from HBM/L2 at their point of use
   // each was a ~1 us round trip with nothing to hide it (one wave per SIMD); staged here they ride under the first chunk load
   float* s_vec = s_bqkv + 3 * DM;
-  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  const int b = blockIdx.y, t0 = blockIdx.x * TOK_WG;
   if (p.skip_padding && t0 >= (int)p.num_ims[b] + 1) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
   const int tok = t0 + wave * 16 + ql;
@@ -143,26 +151,26 @@ tlayer_h3_kernel(TLayerH3Params p) {
 
   // ---- weight chunk stream: ids 0-17 from w_post, 18-23 from w_qkv; a chunk is 32 KiB of fragments, copied linearly
   const int c_first = p.do_post ? 0 : N_POST, c_last = p.do_qkv ? N_POST + N_QKV : N_POST;
-  u32x4 rs[8];
+  u32x4 rs[NSTAGE];
   auto stage_load = [&](int c) {
     const char* src = c < N_POST ? p.w_post + (int64_t)c * CHUNK : p.w_qkv + (int64_t)(c - N_POST) * CHUNK;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rs[i] = *reinterpret_cast<const u32x4*>(src + (tid + i * 256) * 16);
+    for (int i = 0; i < NSTAGE; ++i) rs[i] = *reinterpret_cast<const u32x4*>(src + (tid + i * NTHREADS) * 16);
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(smem + buf * CHUNK + (tid + i * 256) * 16) = rs[i];
+    for (int i = 0; i < NSTAGE; ++i) *reinterpret_cast<u32x4*>(smem + buf * CHUNK + (tid + i * NTHREADS) * 16) = rs[i];
   };
   act_t x;      // activations first (oldest loads), then biases, then the first weight chunk
 #pragma unroll
   for (int t = 0; t < 8; ++t) x[t] = *reinterpret_cast<const f32x4*>(p.x_in + rowoff + 16 * t + 4 * g4);
   if (p.do_post) {
-    for (int i = threadIdx.x; i < DFF; i += 256) s_b1[i] = p.b1[i];
+    for (int i = threadIdx.x; i < DFF; i += NTHREADS) s_b1[i] = p.b1[i];
     const float* const vecs[9] = {p.bo, p.ln1g, p.ln1b, p.cab, p.ln2g, p.ln2b, p.b2, p.ln3g, p.ln3b};
 #pragma unroll
     for (int j = 0; j < 9; ++j) if (threadIdx.x < DM) s_vec[j * DM + threadIdx.x] = vecs[j][threadIdx.x];
   }
-  if (p.do_qkv) for (int i = threadIdx.x; i < 3 * DM; i += 256) s_bqkv[i] = p.bqkv[i];
+  if (p.do_qkv) for (int i = threadIdx.x; i < 3 * DM; i += NTHREADS) s_bqkv[i] = p.bqkv[i];
   int buf = 0, c = c_first;
   stage_load(c);
   stage_store(0);
@@ -254,6 +262,7 @@ tlayer_h3_kernel(TLayerH3Params p) {
       float* dst = qc < 2 ? p.q : qc < 4 ? p.k : p.v;
       const float sc = qc < 2 ? p.qscale : 1.0f;
       if (p.qkv_img != nullptr) {
+        if (t0 + wave * 16 < p.Tp) {                   // (a 128-token workgroup can reach past the images' 64-token padding: wave-uniform)
         // Straight into the attention kernel's operand images (what attn_x6_prep_kernel<2> would build from q, k, v): this
         // lane owns 4 consecutive dims of one token, and both image layouts keep the token (Q, K) or the dim (V^T, after a
         // 4x4 exchange inside the lane quad) on lane & 15, so every piece is one 8-byte store per plane.
@@ -296,6 +305,7 @@ tlayer_h3_kernel(TLayerH3Params p) {
           const uint32_t l0 = pk_f16(r0, r1), l1 = pk_f16(r2, r3);
           *reinterpret_cast<u32x2*>(base + off) = u32x2{h0, h1};
           *reinterpret_cast<u32x2*>(base + off + FRAG) = u32x2{l0, l1};
+        }
         }
       } else if (tok < p.T) {
 #pragma unroll
@@ -390,10 +400,9 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
     attr_set = true;
   }
   const int nt = max_tokens > 0 && max_tokens < T ? max_tokens : T;
-  const int nblk = ((nt + 63) / 64) * B;
-  static const int pack_mode = getenv("PATHS_TLAYER_PACK") ? atoi(getenv("PATHS_TLAYER_PACK")) : 0;   // experiment: 1 = always two per CU
-  const size_t lds = (nblk <= 2 * 256 && pack_mode == 0) ? lds_solo : lds_min;      // spread small grids one workgroup per CU (see tlayer_f32.hip)
-  hipLaunchKernelGGL(tlayer_h3_kernel, dim3((nt + 63) / 64, B), dim3(256), lds, stream, p);
+  const int nblk = ((nt + TOK_WG - 1) / TOK_WG) * B;
+  const size_t lds = nblk <= (NWAVES == 8 ? 256 : 2 * 256) ? lds_solo : lds_min;      // spread small grids one workgroup per CU (see tlayer_f32.hip)
+  hipLaunchKernelGGL(tlayer_h3_kernel, dim3((nt + TOK_WG - 1) / TOK_WG, B), dim3(NTHREADS), lds, stream, p);
   PATHS_LAUNCH_CHECK("token_layer_h3");
   return PATHS_OK;
 }
