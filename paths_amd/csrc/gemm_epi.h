@@ -83,22 +83,28 @@ struct EpiLstmC {
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) pr[i][r] = hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)];
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) {     // batched like EpiLstmO::init
-      float t[3][16];
+    float t[2][3][16];                  // two batches in flight, like EpiLstmO::init
+    auto issue = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float* ph = hp + (int64_t)max(pr[i][r], 0) * ldhp + col0 + jj;
-        t[0][r] = ph[0]; t[1][r] = ph[32]; t[2][r] = ph[64];
+        t[i & 1][0][r] = ph[0]; t[i & 1][1][r] = ph[32]; t[i & 1][2][r] = ph[64];
       }
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, WTM>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i + 1 < WTM) issue(std::integral_constant<int, i + 1>{});
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool has = pr[i][r] >= 0;
-        acc[i][0][r] = has ? t[0][r] * seed : 0.f; acc[i][1][r] = has ? t[1][r] * seed : 0.f; acc[i][2][r] = has ? t[2][r] * seed : 0.f;
+        acc[i][0][r] = has ? t[i & 1][0][r] * seed : 0.f; acc[i][1][r] = has ? t[i & 1][1][r] * seed : 0.f; acc[i][2][r] = has ? t[i & 1][2][r] * seed : 0.f;
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    });
+    __builtin_amdgcn_sched_barrier(0);
   }
   template <bool FULL, bool WITH_FRM, int WTM, int WTN>
   __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
@@ -172,24 +178,31 @@ struct EpiLstmO_ {
     for (int i = 0; i < WTM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) pr[i][r] = hp_row[min(row0 + 32 * i + c32_row(r, lane), M - 1)];
-    // one row-tile (16 x WTN gathers per lane) per batch: all of a batch's loads are issued before the first is consumed
-    // (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) -> v_accvgpr_write per element: 256 serial L2 round trips)
-#pragma unroll
-    for (int i = 0; i < WTM; ++i) {
-      float t[WTN][16];
+    // one row-tile (16 x WTN gathers per lane) per batch, two batches in flight: batch i+1 is issued BEFORE batch i is consumed,
+    // so the L2 round trips of consecutive batches overlap (left to itself hipcc emitted load -> s_waitcnt vmcnt(0) ->
+    // v_accvgpr_write per element: 256 serial L2 round trips; one batch at a time still paid four full round trips)
+    float t[2][WTN][16];
+    auto issue = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float* ph = hp + (int64_t)max(pr[i][r], 0) * ldhp + hp_col0 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) t[j][r] = ph[min(col0 + 32 * j, N - 32)];
+        for (int j = 0; j < WTN; ++j) t[i & 1][j][r] = ph[min(col0 + 32 * j, N - 32)];
       }
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, WTM>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (i + 1 < WTM) issue(std::integral_constant<int, i + 1>{});
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r)
 #pragma unroll
-        for (int j = 0; j < WTN; ++j) acc[i][j][r] = pr[i][r] >= 0 ? t[j][r] * seed : 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int j = 0; j < WTN; ++j) acc[i][j][r] = pr[i][r] >= 0 ? t[i & 1][j][r] * seed : 0.f;
+    });
+    __builtin_amdgcn_sched_barrier(0);
   }
   template <bool FULL, int WTM, int WTN>
   __device__ __forceinline__ void run_impl(f32x16 (&acc)[WTM][WTN], int row0, int col0, int lane, int M) const {
