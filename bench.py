@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--cpu-slides", type=int, default=2)
     ap.add_argument("--cpu-reps", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="timed region issues every launch through the Python launch path instead of "
+                    "replaying the recorded launch tape (paths_amd.utils.TapedRecursion)")
     ap.add_argument("--graph", action="store_true", help="timed region replays the captured HIP graph of the recursion "
                     "(paths_amd.utils.GraphedRecursion) instead of issuing every launch from Python.  Measured on ROCm 7.2: the host "
                     "share drops from 0.65 to 0.13 of the step but the replay executes the three captured streams with far less "
@@ -243,10 +245,17 @@ def main():
 
     # --graph: the whole recursion (5 levels, 3 streams, ~70 launches) captured once into a HIP graph and replayed per step
     # (paths_amd.utils.GraphedRecursion); default: the eager launch sequence (faster on this stack, see --graph's help)
-    graphed = None
+    # default: the recursion recorded once as a flat launch tape and replayed (same three streams and joins as the eager pass,
+    # Python's per-launch work gone: paths_amd.utils.TapedRecursion); --eager: every launch through the Python launch path
+    graphed, launch_mode = None, "eager"
     if args.graph:
         graphed = putils.GraphedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).capture()
+        launch_mode = "hip_graph_replay"
         log("recursion captured into a HIP graph")
+    elif not args.eager:
+        graphed = putils.TapedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).record()
+        launch_mode = "launch_tape_replay"
+        log(f"recursion recorded as a launch tape ({len(graphed.tape)} C calls per step)")
 
     def timed_step():
         return graphed.replay() if graphed is not None else step()
@@ -442,10 +451,10 @@ def main():
                                      "accumulate (error <= an fp32 FMA chain's); everything else fp32") if x6 else "f32 MFMA"},
             "roofline": roofline,
             "roofline_attn_ffn": roofline_attn,
-            "host": {"launch_mode": "hip_graph_replay" if graphed is not None else "eager",
+            "host": {"launch_mode": launch_mode,
                      "t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3), "eager_instrumented_pass": eager,
                      "note": "roofline / roofline_attn_ffn event timings come from the eager instrumented pass of the same K steps "
-                             "(events cannot be timed inside a captured graph)" if graphed is not None else None},
+                             "(the replayed launch sequence carries no events)" if graphed is not None else None},
         }
         if sustained is not None:
             line["sustained"] = sustained

@@ -38,6 +38,13 @@ const char* paths_last_error(void);
 const char* paths_build_info(void);
 int paths_abi_version(void);
 
+/* Stream plumbing of the launch tape (paths_amd/utils.py:TapedRecursion replays a recorded recursion as a flat list of C calls;
+ * no reference equivalent).  paths_event_create: a timing-less event handle (host object) for paths_stream_wait, which makes `dst`
+ * wait for everything enqueued on `src` so far; paths_memset_zero: hipMemsetAsync(0).  None of them synchronises the host. */
+void* paths_event_create(void);
+int paths_stream_wait(paths_stream_t dst, paths_stream_t src, void* event);
+int paths_memset_zero(void* p, size_t bytes, paths_stream_t stream);
+
 /* LSTMCell.forward over depth + residual (reference model/interface.py:31-58, model/paths.py:78-91).
  *   x [M,D] (ldx), h0/c0 = previous state views (both NULL at depth 0), M = B * rows_per_slide.
  *   w_gates [3Hc+D, 2D] PACKED: rows [0,3Hc) in groups of 96 = forget|remember|map rows of one block of

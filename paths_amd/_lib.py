@@ -69,11 +69,13 @@ SIGNATURES = {
     "paths_attention_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _u64, _f32, _vp],
     "paths_attention_bwd_f32_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_attention_token0_bwd_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
+    "paths_stream_wait": [_vp, _vp, _vp],
+    "paths_memset_zero": [_vp, C.c_size_t, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
     "paths_tissue_mask_absmax": [_vp, _i64, _i32, _vp, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],
 }
-_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, [])}
+_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, []), "paths_event_create": (_vp, [])}
 
 _lib: Optional[C.CDLL] = None
 
@@ -110,11 +112,36 @@ def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+TAPE = None        # a list while paths_amd.utils.TapedRecursion records: every launch is executed AND appended as (fn, args, name)
+
+
 def call(name: str, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = getattr(lib, name)
+    rc = fn(*args)
     if rc != 0:
         raise PathsHipError(f"{name} failed ({rc}): {lib.paths_last_error().decode()}")
+    if TAPE is not None:
+        TAPE.append((fn, args, name))
+
+
+def stream_wait(dst: "torch.cuda.Stream", src: "torch.cuda.Stream"):
+    """``dst.wait_stream(src)``; recorded on the launch tape (as a paths_stream_wait with its own event) when one is being built."""
+    dst.wait_stream(src)
+    if TAPE is not None:
+        lib = load()
+        ev = lib.paths_event_create()
+        if not ev:
+            raise PathsHipError("paths_event_create failed")
+        TAPE.append((lib.paths_stream_wait, (dst.cuda_stream, src.cuda_stream, ev), "paths_stream_wait"))
+
+
+def zeros(shape, **kw) -> torch.Tensor:
+    """``torch.zeros`` whose fill is repeated on every replay of a launch tape (status words, importance of padding rows)."""
+    t = torch.zeros(shape, **kw)
+    if TAPE is not None:
+        TAPE.append((load().paths_memset_zero, (t.data_ptr(), t.numel() * t.element_size(), stream()), "paths_memset_zero"))
+    return t
 
 
 def require_cuda(*tensors: torch.Tensor):

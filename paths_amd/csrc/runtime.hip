@@ -14,6 +14,27 @@ int paths_set_error(int code, const char* fmt, ...) {
 
 extern "C" {
 const char* paths_last_error(void) { return g_err; }
-const char* paths_build_info(void) { return "paths_hip gfx950 fp32-mfma r1"; }
+const char* paths_build_info(void) { return "paths_hip gfx950 split-operand MFMA r2"; }
 int paths_abi_version(void) { return 1; }
+
+// ---- stream plumbing for the launch tape (paths_amd/utils.py:TapedRecursion): the recorded launch sequence of a recursion is
+// replayed as a flat list of C calls, so its cross-stream joins and zero fills are C calls too.
+// An event handle for paths_stream_wait (host object, created once per join of a tape; never destroyed before process exit).
+void* paths_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { paths_set_error(PATHS_ELAUNCH, "event_create failed"); return nullptr; }
+  return ev;
+}
+// dst waits for everything enqueued on src so far (hipEventRecord + hipStreamWaitEvent: no host synchronisation)
+int paths_stream_wait(hipStream_t dst, hipStream_t src, void* event) {
+  PATHS_REQUIRE(event != nullptr, "stream_wait: null event");
+  if (hipEventRecord(static_cast<hipEvent_t>(event), src) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "stream_wait: hipEventRecord failed");
+  if (hipStreamWaitEvent(dst, static_cast<hipEvent_t>(event), 0) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "stream_wait: hipStreamWaitEvent failed");
+  return PATHS_OK;
+}
+int paths_memset_zero(void* p, size_t bytes, hipStream_t stream) {
+  PATHS_REQUIRE(p != nullptr && bytes > 0, "memset_zero: bad arguments");
+  if (hipMemsetAsync(p, 0, bytes, stream) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "memset_zero: hipMemsetAsync failed");
+  return PATHS_OK;
+}
 }

@@ -699,3 +699,31 @@ def test_graphed_recursion_replays_bit_identically(dev):
         ref3 = putils.recurse(model2, fb, cfg2.top_k_patches, 5)
     out3 = putils.GraphedRecursion(model2, fb, cfg2.top_k_patches, 5).run()
     assert torch.equal(out3["logits"], ref3["logits"])
+
+
+def test_taped_recursion_replays_bit_identically(dev):
+    """paths_amd.utils.TapedRecursion: the recorded launch tape (C calls + stream joins + zero fills on three streams) replays to
+    the eager pass's results bit for bit, is re-recorded when a weight changes, and hands fallback batches to the eager path."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 3, None, top_k_patches=[24] * 4)
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(99, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)])
+    with torch.no_grad():
+        ref = putils.recurse(model, slides, cfg.top_k_patches, 5)
+    t = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5)
+    for _ in range(4):
+        out = t.run()
+        assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
+        assert torch.equal(out["ctx_patch"], ref["ctx_patch"])
+    n_calls = len(t.tape)
+    assert 60 <= n_calls <= 140 and sum(1 for _, _, name in t.tape if name == "paths_stream_wait") >= 10
+    with torch.no_grad():
+        model.procs[4].classification_layer.bias.add_(0.25)
+        ref2 = putils.recurse(model, slides, cfg.top_k_patches, 5)
+    out2 = t.run()
+    assert torch.equal(out2["logits"], ref2["logits"]) and not torch.equal(out2["logits"], ref["logits"])
+    cfg2, model2, _ = build_model(dev, 9, None, top_k_patches=[2] * 4)
+    fb = DeviceSlideBatch([DeviceSlide.synthetic(57, sid, (4, 4), p_bg=0.93, device=dev) for sid in range(4)])
+    with torch.no_grad():
+        ref3 = putils.recurse(model2, fb, cfg2.top_k_patches, 5)
+    assert torch.equal(putils.TapedRecursion(model2, fb, cfg2.top_k_patches, 5).run()["logits"], ref3["logits"])
