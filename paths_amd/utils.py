@@ -124,8 +124,8 @@ class TapedRecursion:
     status word and hands such a batch to ``recurse()``.  ``slide_ctx_mode="concat"`` stacks contexts with a torch op per level
     and is not taped (eager path)."""
 
-    def __init__(self, model, slides, keep_patches: Sequence[int], num_levels: int):
-        self.model, self.keep, self.levels = model, list(keep_patches), int(num_levels)
+    def __init__(self, model, slides, keep_patches: Sequence[int], num_levels: int, lane: int = 0):
+        self.model, self.keep, self.levels, self.lane = model, list(keep_patches), int(num_levels), int(lane)
         self.batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
         self.tape, self.out, self.versions, self.stream_handle = None, None, None, None
         if model.procs[0].config.slide_ctx_mode == "concat":
@@ -135,29 +135,44 @@ class TapedRecursion:
         return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
 
     def record(self):
-        with torch.no_grad():
-            _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)      # warm-up: builds cached images / tables
-            torch.cuda.synchronize(self.batch.device)
-            assert _lib.TAPE is None, "a launch tape is already being recorded"
-            _lib.TAPE = tape = []
-            try:
-                out = _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)
-            finally:
-                _lib.TAPE = None
+        global STREAM_LANE
+        saved_lane, STREAM_LANE = STREAM_LANE, self.lane
+        try:
+            with torch.no_grad():
+                _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)      # warm-up: builds cached images / tables
+                torch.cuda.synchronize(self.batch.device)
+                assert _lib.TAPE is None, "a launch tape is already being recorded"
+                _lib.TAPE = tape = []
+                try:
+                    out = _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)
+                finally:
+                    _lib.TAPE = None
+        finally:
+            STREAM_LANE = saved_lane
         # arguments pre-converted to their ctypes types once: a replayed call then skips ctypes' per-argument conversion
         tape = [(fn, tuple(a if a is None else t(a) for t, a in zip(fn.argtypes, args)), name) for fn, args, name in tape]
         self.tape, self.out, self.versions = tape, out, self._param_versions()
         self.stream_handle = torch.cuda.current_stream(self.batch.device).cuda_stream
         return self
 
-    def replay(self) -> Dict[str, torch.Tensor]:
+    def _play(self, ops_):
+        for fn, args, name in ops_:
+            if fn(*args) != 0:
+                raise _lib.PathsHipError(f"{name} failed during tape replay: {_lib.load().paths_last_error().decode()}")
+
+    def replay(self, join: bool = True) -> Dict[str, torch.Tensor]:
+        """join=False leaves out the tape's last entry (the caller stream waiting for this lane's streams): several lanes
+        (sub-batches recorded on different stream triples) are then enqueued back to back and run CONCURRENTLY; call
+        :meth:`join` on each afterwards."""
         if self.tape is None or self.versions != self._param_versions():
             self.record()
         assert torch.cuda.current_stream(self.batch.device).cuda_stream == self.stream_handle, "replay on the stream the tape was recorded on"
-        for fn, args, name in self.tape:
-            if fn(*args) != 0:
-                raise _lib.PathsHipError(f"{name} failed during tape replay: {_lib.load().paths_last_error().decode()}")
+        assert self.tape[-1][2] == "paths_stream_wait"
+        self._play(self.tape if join else self.tape[:-1])
         return self.out
+
+    def join(self):
+        self._play(self.tape[-1:])
 
     def run(self) -> Dict[str, torch.Tensor]:
         """replay + the status check of :func:`recurse` (one host sync after the last level)."""
@@ -176,14 +191,19 @@ ROWS_IN_PLACE = os.environ.get("PATHS_ROWS_IN_PLACE", "1") != "0"
 _STREAMS: Dict[int, tuple] = {}
 
 
-def _streams(dev):
+STREAM_LANE = 0      # which stream triple _recurse uses (TapedRecursion(lane=k) records each lane on its own streams)
+
+
+def _streams(dev, lane: Optional[int] = None):
     """(selection-chain stream, aggregator stream, parent-partials stream) of a device.  The selection chain is the critical path of the recursion,
     so it gets the high-priority queue: its workgroups are dispatched first and the aggregator fills what is left."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _STREAMS:
-        _STREAMS[idx] = (torch.cuda.Stream(device=idx, priority=-1), torch.cuda.Stream(device=idx, priority=0),
-                         torch.cuda.Stream(device=idx, priority=-1))
-    return _STREAMS[idx]
+    key = (idx, STREAM_LANE if lane is None else lane)
+    if key not in _STREAMS:
+        hi = -1 if os.environ.get("PATHS_STREAM_PRIORITIES", "1") != "0" else 0
+        _STREAMS[key] = (torch.cuda.Stream(device=idx, priority=hi), torch.cuda.Stream(device=idx, priority=0),
+                         torch.cuda.Stream(device=idx, priority=hi))
+    return _STREAMS[key]
 
 
 def _recurse(model, slides, keep_patches: Sequence[int], num_levels: int,

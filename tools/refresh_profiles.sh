@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX (through gpurun) from the repo root: regenerates the raw profile data under gpurun_out/<tag>_*.
 # usage: tools/refresh_profiles.sh TAG        then copy / summarise into profiles/ (tools/pmc_profile_summary.py)
 set -e
-TAG=${1:-r01e}
+TAG=${1:-r02a}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT
