@@ -528,6 +528,7 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
 #define PATHS_H_OCC 2
 #endif
 constexpr int H_OCC = PATHS_H_OCC;
+static const bool IP_TILE128 = getenv("PATHS_IP_TILE128") != nullptr && atoi(getenv("PATHS_IP_TILE128")) != 0;   // measured: 69 us vs 58 (split-K)
 static const bool O_RAW = getenv("PATHS_O_RAW") == nullptr || atoi(getenv("PATHS_O_RAW")) != 0;
 static const bool H_SMALL_TILES = getenv("PATHS_H_SMALL_TILES") == nullptr || atoi(getenv("PATHS_H_SMALL_TILES")) != 0;
 
@@ -655,26 +656,39 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
     decltype(epi) e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
                     save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0, sc};
     if constexpr (!std::is_same<decltype(epi), EpiImpProj<true, true>>::value && !std::is_same<decltype(epi), EpiImpProj<false, true>>::value) {
-      // two-launch split-K (inference, default split, Y = X + h1 form): k halves on 2 x the blocks, epilogue on 64-row blocks
+      // two launches (inference, default split, Y = X + h1 form): the GEMM stores RAW accumulators, the epilogue runs on 64-row
+      // blocks.  Default: split-K, two k halves of 128 x 256 tiles.  PATHS_IP_TILE128=1 (experiment, slower): 128 x 128 tiles over
+      // the full k at two waves per SIMD - the x + h1 operand is then staged twice as often.
       if (splitk_ws != nullptr && planes == 2 && y_add != nullptr && D % 64 == 0 && D >= 256) {
         const int mt = (M + 127) / 128 * 4;                         // 32-row tiles, padded to the GEMM's 128-row blocks
         const int64_t zstride = (int64_t)mt * 8 * 1024;
-        X6Operands gs = g; gs.ksplit = 2;
-        EpiRaw raw{splitk_ws, zstride, 8};
-        int rc = y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(gs, 256, raw, stream, "importance_proj_x6(split-k)")
-                        : launch_x6_np<2, 2, 4, 2, true, false>(gs, 256, raw, stream, "importance_proj_x6(split-k)");
+        int rc;
+        if (IP_TILE128) {
+          EpiRaw raw{splitk_ws, zstride, 8};
+          rc = y_rows ? launch_x6_np<2, 2, 2, 2, true, true, EpiRaw, 2>(g, 256, raw, stream, "importance_proj_x6(raw, 128x128)")
+                      : launch_x6_np<2, 2, 2, 2, true, false, EpiRaw, 2>(g, 256, raw, stream, "importance_proj_x6(raw, 128x128)");
+        } else {
+          X6Operands gs = g; gs.ksplit = 2;
+          EpiRaw raw{splitk_ws, zstride, 8};
+          rc = y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(gs, 256, raw, stream, "importance_proj_x6(split-k)")
+                      : launch_x6_np<2, 2, 4, 2, true, false>(gs, 256, raw, stream, "importance_proj_x6(split-k)");
+        }
         if (rc != PATHS_OK) return rc;
         // the dispatcher packs a CU to its limit before it moves on: ask for LDS that spreads the blocks over all CUs
         const int fblk = (M + 63) / 64, fdepth = (fblk + 255) / 256;
         const int flds = fdepth == 1 ? 84 * 1024 : fdepth == 2 ? 54 * 1024 : fdepth == 3 ? 41 * 1024 : 1024;
-        auto fk = x6_finish_kernel<2, decltype(epi)>;
         static bool fattr = false;
         if (!fattr) {
-          hipFuncSetAttribute(reinterpret_cast<const void*>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(x6_finish_kernel<2, decltype(epi)>), hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
+          hipFuncSetAttribute(reinterpret_cast<const void*>(x6_finish_kernel<1, decltype(epi)>), hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
           fattr = true;
         }
-        hipLaunchKernelGGL(fk, dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
-                           skip_padding ? num_ims : nullptr, rows_per_slide, e);
+        if (IP_TILE128)
+          hipLaunchKernelGGL((x6_finish_kernel<1, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
+                             skip_padding ? num_ims : nullptr, rows_per_slide, e);
+        else
+          hipLaunchKernelGGL((x6_finish_kernel<2, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
+                             skip_padding ? num_ims : nullptr, rows_per_slide, e);
         PATHS_LAUNCH_CHECK("importance_proj_x6(finish)");
         return PATHS_OK;
       }
