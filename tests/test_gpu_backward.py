@@ -285,7 +285,7 @@ def test_three_adamw_steps_match_reference_g6(dev):
     losses = []
     for _ in range(len(g["losses"])):
         losses.append(float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)))
-    np.testing.assert_allclose(losses, g["losses"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(losses, g["losses"], atol=1e-5, rtol=0)      # SURVEY 8(a) row T bar; measured: <= 4e-7
     none = sorted(n for n, p_ in model.named_parameters() if p_.grad is None)
     assert none == sorted(info["grad_none"])
 
