@@ -113,6 +113,8 @@ def stream() -> int:
 
 
 TAPE = None        # a list while paths_amd.utils.TapedRecursion records: every launch is executed AND appended as (fn, args, name)
+TAPE_EVENTS = None # the recorder's event pool: [events, next index]; events are created once per tape position and re-used when a
+                   # tape is recorded again (a weight changed), so re-recording does not leak HIP events
 
 
 def call(name: str, *args):
@@ -130,9 +132,14 @@ def stream_wait(dst: "torch.cuda.Stream", src: "torch.cuda.Stream"):
     dst.wait_stream(src)
     if TAPE is not None:
         lib = load()
-        ev = lib.paths_event_create()
-        if not ev:
-            raise PathsHipError("paths_event_create failed")
+        pool = TAPE_EVENTS if TAPE_EVENTS is not None else [[], 0]
+        if pool[1] == len(pool[0]):
+            ev = lib.paths_event_create()
+            if not ev:
+                raise PathsHipError("paths_event_create failed")
+            pool[0].append(ev)
+        ev = pool[0][pool[1]]
+        pool[1] += 1
         TAPE.append((lib.paths_stream_wait, (dst.cuda_stream, src.cuda_stream, ev), "paths_stream_wait"))
 
 

@@ -118,7 +118,9 @@ def next_dropout_seed(device) -> int:
     gen = torch.cuda.default_generators[idx]
     seed, off = int(gen.initial_seed()), int(gen.get_offset())
     gen.set_offset(off + 4)
-    z = (seed * 0x9E3779B97F4A7C15 + (off + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    import os
+    rank = int(os.environ.get("RANK", "0"))      # ranks share torch.manual_seed(config.seed): fold the rank in, or every rank would
+    z = (seed * 0x9E3779B97F4A7C15 + (off + 1) * 0xD1B54A32D192ED03 + rank * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF   # draw the same masks
     z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
     return z ^ (z >> 29)
 

@@ -128,6 +128,7 @@ class TapedRecursion:
         self.model, self.keep, self.levels, self.lane = model, list(keep_patches), int(num_levels), int(lane)
         self.batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
         self.tape, self.out, self.versions, self.stream_handle = None, None, None, None
+        self._events = [[], 0]               # HIP events of the tape's stream joins, re-used when the tape is recorded again
         if model.procs[0].config.slide_ctx_mode == "concat":
             raise NotImplementedError("TapedRecursion: slide_ctx_mode='concat' is not taped; use recurse()")
 
@@ -143,10 +144,12 @@ class TapedRecursion:
                 torch.cuda.synchronize(self.batch.device)
                 assert _lib.TAPE is None, "a launch tape is already being recorded"
                 _lib.TAPE = tape = []
+                self._events[1] = 0
+                _lib.TAPE_EVENTS = self._events
                 try:
                     out = _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)
                 finally:
-                    _lib.TAPE = None
+                    _lib.TAPE, _lib.TAPE_EVENTS = None, None
         finally:
             STREAM_LANE = saved_lane
         # arguments pre-converted to their ctypes types once: a replayed call then skips ctypes' per-argument conversion

@@ -727,3 +727,30 @@ def test_taped_recursion_replays_bit_identically(dev):
     with torch.no_grad():
         ref3 = putils.recurse(model2, fb, cfg2.top_k_patches, 5)
     assert torch.equal(putils.TapedRecursion(model2, fb, cfg2.top_k_patches, 5).run()["logits"], ref3["logits"])
+
+
+def test_keep_all_and_single_level(dev):
+    """Edge cases of the driver (reference data_utils/slide.py:294: keep == -1 keeps every patch in its original order; a
+    one-level model): against the oracle."""
+    from oracle import paths_oracle as orc
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    cfg, model, params = build_model(dev, 21, None, top_k_patches=[-1, 6, 6, 6])
+    ocfg = H.oracle_config(top_k_patches=[-1, 6, 6, 6])
+    slides = [DeviceSlide.synthetic(5, sid, (3, 4), p_bg=0.2, device=dev) for sid in range(2)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["index_sets_identical"] and res["parent_pairs_identical"]
+    for j in range(2):        # keep == -1: indices 0 .. n-1 in order, every tissue child of every level-0 patch at level 1
+        n = int(trace[0]["num_ims"][j])
+        assert trace[0]["keep_idx"][j, :n].cpu().tolist() == list(range(n)) and int(trace[0]["keep_count"][j]) == n
+    # one level only: the first processor's logits are the model output
+    with torch.no_grad():
+        one = putils.recurse(model, slides, [], 1)
+    ocfg1 = H.oracle_config(top_k_patches=[], num_levels=1)
+    hz1, _ = orc.inference_end2end(params, ocfg1, [orc.LazyGrids(s.synthetic_spec) for s in slides])
+    np.testing.assert_allclose(torch.sigmoid(one["logits"]).cpu().numpy(), hz1.numpy(), atol=LOGIT_TOL, rtol=0)
