@@ -137,6 +137,12 @@ int64_t paths_gemm_tn_workspace(int N1, int N2, int splits);
 int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
                       float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
                       paths_stream_t stream);
+/* The same product on the bf16 matrix cores, three exact bf16 planes per operand split in registers (6 MFMAs per block, as
+ * accurate as the f32 MFMA: see csrc/gemm_tn_x6.hip).  `splits` is an upper bound (>= 32 rows per split are kept); operands
+ * must be smaller than 4 GiB each (32-bit buffer offsets). */
+int paths_gemm_tn_x6(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
+                     float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
+                     paths_stream_t stream);
 int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int splits, int accumulate, float* workspace,
                      paths_stream_t stream);
 int paths_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, paths_stream_t stream);

@@ -21,6 +21,8 @@ from . import _lib, ops
 
 P = _lib.ptr
 TN_SPLIT2 = int(os.environ.get("PATHS_TN_SPLIT2", "2"))
+# weight-gradient GEMMs: "x6" = split-bf16 MFMA kernel (csrc/gemm_tn_x6.hip), "f32" = the f32-MFMA kernel (csrc/gemm_bwd.hip)
+TN_MODE = os.environ.get("PATHS_TN_MODE", "x6")
 
 
 def _f32(dev):
@@ -64,9 +66,26 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
               mp, ldm, 1 if accumulate else 0, _lib.stream())
 
 
+def _splits_x6(M: int, N1: int, N2: int, nb0: int) -> int:
+    """Row splits of the split-bf16 weight-gradient kernel: 256 x 256 tiles run one workgroup per CU, 128 x 128 tiles two; aim at
+    two full rounds of the 256 CUs with at least 128 rows (8 stages) per split."""
+    big = N1 % 256 == 0 and N2 % 256 == 0 and nb0 % 256 == 0
+    tiles = (N1 // 256) * (N2 // 256) if big else (N1 // 128) * (N2 // 128)
+    return max(1, min(64, (512 if big else 1024) // tiles, M // 128))
+
+
 def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, accumulate=False):
     """out[N1,N2] (+)= a[M,N1]^T [b0 | b1][M,N2]."""
     dev = out.device
+    if TN_MODE == "x6" and M >= 512 and M * 4 * max(lda, ldb0, ldb1) < (1 << 31):
+        splits = _splits_x6(M, N1, N2, nb0 if b1 is not None else 0)
+        ws = torch.empty((splits * N1 * N2,), **_f32(dev))
+        ap = a if isinstance(a, int) else a.data_ptr()
+        b0p = b0 if isinstance(b0, int) else b0.data_ptr()
+        b1p = None if b1 is None else (b1 if isinstance(b1, int) else b1.data_ptr())
+        _lib.call("paths_gemm_tn_x6", ap, lda, b0p, ldb0, nb0, b1p, ldb1, P(out), ldo if ldo is not None else N2, M, N1, N2,
+                  splits, 1 if accumulate else 0, P(ws), _lib.stream())
+        return
     splits = _splits(M, (N1 // 128) * (N2 // 128))
     ws = torch.empty((splits * N1 * N2,), **_f32(dev))
     ap = a if isinstance(a, int) else a.data_ptr()

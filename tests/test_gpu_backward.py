@@ -52,6 +52,46 @@ def test_gemm_tn_colsum_transpose(dev):
     assert rel_err(o, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N1,N2,nb0,pad", [(4096, 256, 512, 256, 0), (1000, 256, 384, 256, 0), (2500, 512, 512, 0, 0),
+                                             (777, 128, 128, 0, 0), (5003, 256, 768, 512, 64), (16384, 1792, 2048, 1024, 256)])
+def test_gemm_tn_x6_matches_fp64(dev, M, N1, N2, nb0, pad):
+    """Split-bf16 weight-gradient kernel vs float64: both tile sizes, ragged M (zero rows past the end come from the buffer range
+    check), two-panel B with a row stride wider than the panel, gradients spanning 12 binades, accumulate, bit-reproducible."""
+    from paths_amd import backward as bw
+    g = torch.Generator().manual_seed(M + N1)
+    a = torch.randn(M, N1, generator=g) * torch.exp2(torch.randint(-30, -18, (M, 1), generator=g).float())
+    b = torch.randn(M, N2, generator=g)
+    ad = a.to(dev)
+    if nb0:
+        b0s = torch.zeros(M, nb0 + pad)
+        b0s[:, :nb0] = b[:, :nb0]
+        b1s = torch.zeros(M, N2 - nb0 + pad)
+        b1s[:, :N2 - nb0] = b[:, nb0:]
+        b0d, b1d = b0s.to(dev), b1s.to(dev)
+        kw = dict(b1=b1d, ldb1=b1s.shape[1], nb0=nb0)
+        ldb0 = b0s.shape[1]
+    else:
+        b0d, kw, ldb0 = b.to(dev), {}, N2
+    ref = a.double().t() @ b.double()
+    assert bw.TN_MODE == "x6"
+    out = torch.full((N1, N2), 3.0, device=dev)
+    bw.gemm_tn(ad, N1, b0d, ldb0, out, M, N1, N2, **kw)
+    f32 = torch.empty((N1, N2), device=dev)
+    bw.TN_MODE = "f32"
+    try:
+        bw.gemm_tn(ad, N1, b0d, ldb0, f32, M, N1, N2, **kw)
+    finally:
+        bw.TN_MODE = "x6"
+    e6, e32 = rel_err(out, ref), rel_err(f32, ref)
+    assert e6 < 2e-6 and e6 < 1.5 * e32 + 1e-8, (e6, e32)          # fp32 accumulation over M rows: no worse than the f32 MFMA
+    out2 = out.clone()
+    bw.gemm_tn(ad, N1, b0d, ldb0, out2, M, N1, N2, accumulate=True, **kw)
+    assert rel_err(out2, 2 * ref) < 2e-6
+    out3 = torch.empty_like(out)
+    bw.gemm_tn(ad, N1, b0d, ldb0, out3, M, N1, N2, **kw)
+    assert torch.equal(out3, out)
+
+
 @pytest.mark.parametrize("depth", [0, 2])
 def test_selection_chain_backward(dev, depth):
     """LSTM cell + importance MLP + proj_in: gradients of all parameters and of the previous (h|c) state."""
