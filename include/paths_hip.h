@@ -118,7 +118,8 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
  * [M/128 x 1]-block GEMM covers half the chip, so its k loop runs as two halves on twice the blocks (raw accumulators to the
  * workspace) and a second launch sums them and applies the epilogue on 64-row blocks.  null = one launch. */
 int64_t paths_importance_proj_x6_workspace(int M);
-/* out (+)= maskop(act(a W[:, k0:k0+K]^T + b)) + residual, W = pack of an [Npad, Kpacked] weight; Npad % 256 == 0 */
+/* out (+)= maskop(act(a W[:, k0:k0+K]^T + b)) + residual, W = pack of an [Npad, Kpacked] weight; Npad % 128 == 0
+ * (256-column tiles when Npad % 256 == 0, else 128-column tiles) */
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                      int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, paths_stream_t stream);

@@ -23,6 +23,8 @@ P = _lib.ptr
 TN_SPLIT2 = int(os.environ.get("PATHS_TN_SPLIT2", "2"))
 # weight-gradient GEMMs: "x6" = split-bf16 MFMA kernel (csrc/gemm_tn_x6.hip), "f32" = the f32-MFMA kernel (csrc/gemm_bwd.hip)
 TN_MODE = os.environ.get("PATHS_TN_MODE", "x6")
+# dX / recompute GEMMs go to the split-operand kernel when the output width is a multiple of this (128: the d = 128 products too)
+NT_X6_MIN_N = int(os.environ.get("PATHS_NT_X6_MIN_N", "128"))
 
 
 def _f32(dev):
@@ -55,7 +57,7 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
     rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
     mp = None if mask is None else (mask if isinstance(mask, int) else mask.data_ptr())
     ldw = ldw if ldw is not None else K
-    if ops.GEMM_MODE != "f32" and N % 256 == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
+    if ops.GEMM_MODE != "f32" and N % NT_X6_MIN_N == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
             and wt.shape[0] >= N and wt.stride(0) == ldw and wt.stride(1) == 1:
         # split-bf16 GEMM: the (transposed) weight is re-imaged per call - 6 N K bytes, microseconds next to an M >= 1024 product
         wx, wx_s = ops.x6_pack(wt[:N, :K], planes=ops.TRAIN_PLANES)

@@ -710,6 +710,10 @@ int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked,
   if (planes == 3) w_scale = a_scale = 1.0f;
   X6Operands g{a, lda, K, nullptr, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * planes * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
   EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate, 1.0f / (w_scale * a_scale)};
+  if (Npad % 256 != 0) {           // 128 / 384 output columns (the transformer layers' d = 128 products): 128 x 128 tiles, 2 workgroups per CU
+    if (planes == 3) return launch_x6_np<3, 2, 2, 2, false, false, EpiBias, 2>(g, Npad, e, stream, "gemm_nt_x6(n128)");
+    return launch_x6_np<2, 2, 2, 2, false, false, EpiBias, 2>(g, Npad, e, stream, "gemm_nt_x6(n128)");
+  }
   return launch_x6<2, 4, 2, false>(planes, g, Npad, e, stream, "gemm_nt_x6");
 }
 

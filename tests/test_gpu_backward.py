@@ -553,6 +553,34 @@ def test_training_with_shipped_dropout_config(dev):
     assert all(np.isfinite(l) for l in losses)
 
 
+@pytest.mark.parametrize("over", [{}, {"lstm": False}])
+def test_training_steps_do_not_leak_device_memory(dev, over):
+    """The activations saved for a step's backward die with the step: device memory after step 6 equals device memory after step 3
+    (a ctx -> saved dict -> returned tensor -> grad_fn -> ctx cycle once kept every level's activations alive forever), and a
+    forward whose backward never runs is freed once its outputs go out of scope."""
+    import gc
+    from paths_amd import utils as putils
+    cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3, cfg_over={"model_config": dict(over)} if over else None)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+
+    def steps(n):
+        for _ in range(n):
+            putils.train_step(model, opt, batch, 5, cfg.top_k_patches)
+        torch.cuda.synchronize()
+        gc.collect()
+        return torch.cuda.memory_allocated()
+
+    m3 = steps(3)
+    m6 = steps(3)
+    assert m6 == m3, (m3, m6)
+    out = putils.recurse_train(model, batch["slide"], cfg.top_k_patches, 5)
+    held = torch.cuda.memory_allocated()
+    del out
+    gc.collect()
+    assert held > m6 and torch.cuda.memory_allocated() == m6
+
+
 def test_epoch_loop_matches_reference_g10(dev, tmp_path):
     """paths_amd.train.train_loop against the reference's own epoch loop (train.py:31-116, fixture G10 captured by
     tools/make_goldens.py: DataLoader shuffle order, AdamW + ExponentialLR, per-epoch train / validation losses, early-stopping
