@@ -140,6 +140,57 @@ def parity_check(cfg, model, K, ids, otrace, ohz, dev):
     return res
 
 
+def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
+    """Extra line (BASELINE.json configs[4] geometry): ONE level over K = 8192 patches of d = 1536 features per slide = full
+    quadratic attention over 8193 tokens, on the split-operand fp32-accurate kernels (the fp8 MFMA variant that config names
+    is not built; tests/test_gpu_parity.py::test_stress_shape_k8192_d1536_single_level_vs_oracle checks this shape)."""
+    from paths_amd import synthetic as syn
+    from paths_amd.config import Config
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg = Config.load(os.path.join(ROOT, "tests", "golden", "sample"), test_mode=True)
+    cfg.model_config.patch_embed_dim, cfg.num_levels, cfg.top_k_patches = 1536, 1, []
+    model = cfg.get_model()
+    sd = syn.make_state_dict(0, {k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model = model.to(dev).eval()
+    spg = args.slides_per_gpu
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, (64, 128), dim=1536, num_levels=1, device=dev)
+                               for i in range(spg)])
+
+    def step():
+        with torch.no_grad():
+            return putils.recurse(model, slides, [], 1, check_status=False)
+
+    def barrier():
+        torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
+    assert int(out["status"].item()) == 0
+    if rank == 0:
+        T, d, L = 8193, 128, 2
+        flops = spg * world * (L * (24 * T * d * d + 4 * T * T * d))          # attention + FFN, per step
+        print(json.dumps({
+            "metric": "stress_slides_per_sec_1level_K8192_D1536", "value": round(spg * world * args.steps / elapsed, 2),
+            "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (two fp16 planes per operand, fp32 accumulate); the fp8 variant of BASELINE configs[4] is not built",
+            "data": "synthetic",
+            "config": {"workload": f"single level, 8192 patches x 1536 features per slide, {spg} slides per GPU, full quadratic "
+                                   "attention over 8193 tokens (BASELINE.json configs[4] geometry)", "global_batch": spg * world},
+            "attn_ffn_flops_per_step": flops}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unused):
     """Secondary metric (BASELINE.json configs[3]): training slides/s = recursion forward + hand-written HIP backward +
     AdamW, one flat 39.5 MB gradient all-reduce per step over RCCL when world > 1."""
@@ -200,8 +251,9 @@ def main():
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra DVFS-steady loop (0 = skip)")
     ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
-                    help="infer (default, the BASELINE metric) or train: forward + HIP backward + AdamW + gradient all-reduce")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "stress"],
+                    help="infer (default, the BASELINE metric); train: forward + HIP backward + AdamW + gradient all-reduce; "
+                         "stress: one level over 8192 patches x 1536 features (BASELINE configs[4] geometry, fp32-accurate path)")
     args = ap.parse_args()
 
     from paths_amd import distributed as pdist
@@ -223,6 +275,9 @@ def main():
     from paths_amd import utils as putils
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     _lib.load()
+    if args.mode == "stress":
+        stress_bench(args, rank, world, dev, dev_reduce, pdist, putils)
+        return
     K, spg = args.k, args.slides_per_gpu
     cfg, model, sd = build_model(K, dev, args.dropout)
     slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)])

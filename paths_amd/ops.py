@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
@@ -196,15 +196,34 @@ def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None, lagg
 
 def pe_table(lvl_pack: Dict[str, object], pe_mode: int, d: int, rows: int) -> torch.Tensor:
     """[cap >= rows, d/2 or d] table of the positional-encoding sin/cos values (paths_pe_table), cached beside the weights."""
-    key = f"pe_table_{pe_mode}"
-    tab = lvl_pack.get(key)
+    div = lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]
+    key = (pe_mode, d, div.device)
+    tab = _PE_TABLES.get(key)
     if tab is None or tab.shape[0] < rows:
         cap = 1 << max(6, (rows - 1).bit_length())
-        div = lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]
         tab = torch.empty((cap, d // 2 if pe_mode == 2 else d), device=div.device, dtype=torch.float32)
         _lib.call("paths_pe_table", _lib.ptr(div), pe_mode, d, cap, _lib.ptr(tab), _lib.stream())
-        lvl_pack[key] = tab
+        if key in _PE_TABLES:
+            _PE_RETIRED.append(_PE_TABLES[key])      # a recorded launch tape may still hold the smaller table's address
+        _PE_TABLES[key] = tab
     return tab
+
+
+# The positional-encoding constants depend on (d, device) only, not on the weights: kept across re-packs (training re-packs every
+# step; two pageable host-to-device copies per level per step were 2.7 ms of a 25 ms step).
+_PE_TABLES: Dict[tuple, torch.Tensor] = {}
+_PE_RETIRED: List[torch.Tensor] = []
+_PE_DIVS: Dict[tuple, tuple] = {}
+
+
+def _pe_divs(d: int, dev) -> tuple:
+    """(div_1d, div_2d): same expressions as reference utils.py:18 / :56, evaluated on the CPU like the CPU reference."""
+    key = (d, dev)
+    if key not in _PE_DIVS:
+        k = 10000.0
+        _PE_DIVS[key] = (torch.exp(torch.arange(0, d, 2) * (-math.log(k) / d)).float().to(dev),
+                         torch.exp(torch.arange(0, d // 2, 2) * (-math.log(k) / d)).float().to(dev))
+    return _PE_DIVS[key]
 
 
 def use_x6(D: int, Hc: int = 64) -> bool:
@@ -275,7 +294,7 @@ def pack_level(proc) -> Dict[str, object]:
                 "eps": float(lyr.norm1.eps),
             })
         dev = agg.proj_in.weight.device
-        k = 10000.0
+        div_1d, div_2d = _pe_divs(d, dev)
         packed = {
             "w_ip": torch.cat([proc.importance_mlp[0].weight, agg.proj_in.weight], dim=0).float().contiguous(),
             # forward kernels: rows interleaved in blocks of 64 so that each column half of a workgroup owns 64 hidden units
@@ -285,9 +304,7 @@ def pack_level(proc) -> Dict[str, object]:
             "b1": c(proc.importance_mlp[0].bias), "w2": c(proc.importance_mlp[2].weight.view(-1)),
             "b2": c(proc.importance_mlp[2].bias.view(-1)),        # read on the device (a .item() here was a host sync per re-pack)
             "bp": c(agg.proj_in.bias), "special": c(agg.special_token),
-            # same expressions as reference utils.py:18 / :56, evaluated on the CPU like the CPU reference
-            "div_1d": torch.exp(torch.arange(0, d, 2) * (-math.log(k) / d)).float().to(dev),
-            "div_2d": torch.exp(torch.arange(0, d // 2, 2) * (-math.log(k) / d)).float().to(dev),
+            "div_1d": div_1d, "div_2d": div_2d,
             "layers": layers,
             "lnfg": c(agg.transformer.decoder.norm.weight), "lnfb": c(agg.transformer.decoder.norm.bias),
             "lnf_eps": float(agg.transformer.decoder.norm.eps),

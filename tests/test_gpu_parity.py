@@ -393,6 +393,29 @@ def test_headline_recursion_vs_oracle(dev, K, base, ids):
     np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
 
 
+def test_stress_shape_k8192_d1536_single_level_vs_oracle(dev):
+    """BASELINE configs[4] geometry (K = 8192 patches on ONE level = full quadratic attention over 8193 tokens, d = 1536 features)
+    on the split-operand fp32-accurate path, against the oracle.  (The fp8 MFMA variant that config names is not built: DESIGN.md §6.)"""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    over = {"model_config": {"patch_embed_dim": 1536}, "num_levels": 1}
+    cfg, model, params = build_model(dev, 5, over, top_k_patches=[])
+    ocfg = H.oracle_config(over, top_k_patches=[])
+    slides = [DeviceSlide.synthetic(77, sid, (64, 128), dim=1536, num_levels=1, device=dev) for sid in (0, 1)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, [], 1, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    n = trace[0]["num_ims"].cpu().numpy()
+    assert np.array_equal(n, otrace[0]["num_ims"].numpy()) and n.tolist() == [8192, 8192]      # level 0 keeps every cell
+    for j in range(2):
+        gi, oi = trace[0]["importance"][j, : n[j]].cpu().numpy(), otrace[0]["importance"][j, : n[j]].numpy()
+        np.testing.assert_allclose(gi, oi, atol=STATE_TOL, rtol=0)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(torch.sigmoid(out["logits"]).cpu().numpy(), hz.numpy(), atol=LOGIT_TOL, rtol=0)
+
+
 def test_topk_at_n8192(dev):
     """paths_topk at its documented size limit (N = 8192 scores per slide, BASELINE configs[4] shape), ragged, with ties."""
     from paths_amd import _lib
