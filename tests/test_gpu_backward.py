@@ -448,6 +448,9 @@ def test_dropout_mask_statistics(dev):
 def test_dropout_forward_backward_vs_fp64_with_exported_masks(dev):
     """All five dropout sites of both decoder layers (the last one at token 0 only): forward outputs and every gradient of the HIP
     training path against float64 autograd through a reference that multiplies by the SAME masks (exported by paths_dropout_mask)."""
+    from paths_amd import ops as _ops
+    if _ops.GEMM_MODE == "f32":
+        pytest.skip("dropout needs the split-operand attention kernel: PATHS_GEMM_MODE=f32 rejects it loudly (backward.py)")
     from paths_amd import backward as bw, ops
     cfg, model, params = build_model(dev, 33)
     mc = cfg.model_config
@@ -517,6 +520,9 @@ def test_dropout_forward_backward_vs_fp64_with_exported_masks(dev):
 def test_training_with_shipped_dropout_config(dev):
     """models/sample/config.json as shipped (dropout 0.05) trains: the masks follow torch.manual_seed (same seed -> bit-identical
     loss and gradients, another seed -> different), eval mode is untouched by the dropout setting."""
+    from paths_amd import ops as _ops
+    if _ops.GEMM_MODE == "f32":
+        pytest.skip("dropout needs the split-operand attention kernel: PATHS_GEMM_MODE=f32 rejects it loudly (backward.py)")
     from paths_amd import utils as putils
     cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3)
     for proc in model.procs:
@@ -555,9 +561,9 @@ def test_training_with_shipped_dropout_config(dev):
 
 @pytest.mark.parametrize("over", [{}, {"lstm": False}])
 def test_training_steps_do_not_leak_device_memory(dev, over):
-    """The activations saved for a step's backward die with the step: device memory after step 6 equals device memory after step 3
-    (a ctx -> saved dict -> returned tensor -> grad_fn -> ctx cycle once kept every level's activations alive forever), and a
-    forward whose backward never runs is freed once its outputs go out of scope."""
+    """The activations saved for a step's backward die with the step: device memory after step 9 is what it was after step 3 (a
+    ctx -> saved dict -> returned tensor -> grad_fn -> ctx cycle once kept every level's activations alive forever: one step's worth
+    per step), and a forward whose backward never runs is freed once its outputs go out of scope."""
     import gc
     from paths_amd import utils as putils
     cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3, cfg_over={"model_config": dict(over)} if over else None)
@@ -571,14 +577,17 @@ def test_training_steps_do_not_leak_device_memory(dev, over):
         gc.collect()
         return torch.cuda.memory_allocated()
 
+    gc.collect()
     m3 = steps(3)
-    m6 = steps(3)
-    assert m6 == m3, (m3, m6)
+    m9 = steps(6)
     out = putils.recurse_train(model, batch["slide"], cfg.top_k_patches, 5)
     held = torch.cuda.memory_allocated()
     del out
     gc.collect()
-    assert held > m6 and torch.cuda.memory_allocated() == m6
+    one_step = held - m9                 # what one step's saved activations occupy
+    assert one_step > (8 << 20)
+    assert m9 - m3 < one_step // 8, (m3, m9, one_step)          # six more steps: nothing like a step's activations was kept
+    assert torch.cuda.memory_allocated() - m9 < one_step // 8
 
 
 def test_epoch_loop_matches_reference_g10(dev, tmp_path):
