@@ -129,6 +129,11 @@ class TapedRecursion:
         self.batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
         self.tape, self.out, self.versions, self.stream_handle = None, None, None, None
         self._events = [[], 0]               # HIP events of the tape's stream joins, re-used when the tape is recorded again
+        # The tape holds raw device addresses of every intermediate of the recorded pass.  Those tensors are freed when the pass
+        # returns; from the default caching allocator their blocks would be handed to whoever allocates next, and a replay would
+        # then write into memory somebody else owns.  So the recorded pass allocates from a pool of its own: freed blocks stay in
+        # it (re-used only by this tape's next recording) for as long as the tape lives.
+        self._pool = torch.cuda.MemPool()
         if model.procs[0].config.slide_ctx_mode == "concat":
             raise NotImplementedError("TapedRecursion: slide_ctx_mode='concat' is not taped; use recurse()")
 
@@ -143,13 +148,16 @@ class TapedRecursion:
                 _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)      # warm-up: builds cached images / tables
                 torch.cuda.synchronize(self.batch.device)
                 assert _lib.TAPE is None, "a launch tape is already being recorded"
+                self.out = None                                   # (a re-recording re-uses the pool's blocks: drop the old outputs first)
                 _lib.TAPE = tape = []
                 self._events[1] = 0
                 _lib.TAPE_EVENTS = self._events
                 try:
-                    out = _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)
+                    with torch.cuda.use_mem_pool(self._pool, device=self.batch.device):
+                        out = _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)
                 finally:
                     _lib.TAPE, _lib.TAPE_EVENTS = None, None
+                torch.cuda.synchronize(self.batch.device)
         finally:
             STREAM_LANE = saved_lane
         # arguments pre-converted to their ctypes types once: a replayed call then skips ctypes' per-argument conversion

@@ -758,6 +758,35 @@ def test_taped_recursion_replays_bit_identically(dev):
     assert torch.equal(putils.TapedRecursion(model2, fb, cfg2.top_k_patches, 5).run()["logits"], ref3["logits"])
 
 
+def test_tape_owns_its_buffers(dev):
+    """The tape replays raw device addresses: the recorded pass's intermediates must stay the tape's after that pass has returned.
+    An eager recursion of ANOTHER batch made afterwards allocates on the same three streams - from the default caching allocator
+    it would be handed exactly the blocks the recorded pass freed - and its held results (every traced tensor) must survive later
+    replays untouched, while the replays stay exact."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 3, None, top_k_patches=[24] * 4)
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(98, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)])
+    other = DeviceSlideBatch([DeviceSlide.synthetic(97, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)])
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in putils.recurse(model, slides, cfg.top_k_patches, 5).items()}
+    t = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5).record()
+    torch.cuda.synchronize()
+    trace = []
+    with torch.no_grad():
+        held = putils.recurse(model, other, cfg.top_k_patches, 5, trace=trace)
+    torch.cuda.synchronize()
+    tensors = [v for rec in trace for v in rec.values() if torch.is_tensor(v)] + [v for v in held.values() if torch.is_tensor(v)]
+    copies = [v.clone() for v in tensors]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        out = t.replay()
+    torch.cuda.synchronize()
+    assert len(tensors) >= 40 and all(torch.equal(a, b) for a, b in zip(tensors, copies))
+    assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
+    assert not torch.equal(held["logits"], ref["logits"])
+
+
 def test_keep_all_and_single_level(dev):
     """Edge cases of the driver (reference data_utils/slide.py:294: keep == -1 keeps every patch in its original order; a
     one-level model): against the oracle."""
