@@ -157,6 +157,8 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
     slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, (64, 128), dim=1536, num_levels=1, device=dev)
                                for i in range(spg)])
 
+    from paths_amd import ops
+
     def step():
         with torch.no_grad():
             return putils.recurse(model, slides, [], 1, check_status=False)
@@ -164,15 +166,49 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
     def barrier():
         torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
-    assert int(out["status"].item()) == 0
+    def timed_run():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ev = []
+
+        def timer(name, launch, meta):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = launch()
+            e1.record()
+            ev.append((name, e0, e1))
+            return r
+
+        ops.KERNEL_TIMER, ops.TIMER_ALL = timer, True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_ = step()
+        barrier()
+        el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
+        ops.KERNEL_TIMER, ops.TIMER_ALL = None, False
+        assert int(out_["status"].item()) == 0
+        att = [e0.elapsed_time(e1) * 1e3 for n, e0, e1 in ev if n == "agg_attention"]
+        return el, out_["logits"].clone(), (sum(att) / len(att) if att else None)
+
+    elapsed, logits, attn_us = timed_run()
+    fp8 = None
+    if args.fp8:
+        # the e4m3 attention variant (csrc/attn_fp8.hip) on the same batch: its speed AND its distance from the fp32-accurate logits
+        ops.ATTN_FP8 = True
+        el8, logits8, attn8_us = timed_run()
+        ops.ATTN_FP8 = False
+        T_, d_ = 8193, 128
+        afl = spg * 4 * T_ * T_ * d_                                           # the full attention of layer 0, per launch
+        fp8 = {"slides_per_s": round(spg * world * args.steps / el8, 2), "ms_per_step": round(el8 / args.steps * 1e3, 3),
+               "attention_us": round(attn8_us, 1), "attention_us_split_path": round(attn_us, 1),
+               "max_logit_diff_vs_split_path": float((logits8 - logits).abs().max()),
+               "meets_1e-4_logit_bar": bool(float((logits8 - logits).abs().max()) <= 1e-4),
+               "roofline": {"bound": "mfma", "achieved": round(afl / (attn8_us * 1e-6) / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                            "frac": round(afl / (attn8_us * 1e-6) / 1e12 / 5000.0, 4),
+                            "note": "algorithmic 4 T^2 d FLOPs of the one full attention launch / its event-timed duration, against the "
+                                    "dense fp8 MFMA peak; head_dim 32 gives one 16x16x32 k-step per score tile, the loop is exp2 / "
+                                    "conversion (VALU) bound"}}
     if rank == 0:
         T, d, L = 8193, 128, 2
         flops = spg * world * (L * (24 * T * d * d + 4 * T * T * d))          # attention + FFN, per step
@@ -180,11 +216,12 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
             "metric": "stress_slides_per_sec_1level_K8192_D1536", "value": round(spg * world * args.steps / elapsed, 2),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (two fp16 planes per operand, fp32 accumulate); the fp8 variant of BASELINE configs[4] is not built",
+            "dtype": "f32 (two fp16 planes per operand, fp32 accumulate) - the parity path; 'fp8_attention' (--fp8) is the opt-in "
+                     "e4m3 attention variant of BASELINE configs[4], outside the 1e-4 logit bar",
             "data": "synthetic",
             "config": {"workload": f"single level, 8192 patches x 1536 features per slide, {spg} slides per GPU, full quadratic "
                                    "attention over 8193 tokens (BASELINE.json configs[4] geometry)", "global_batch": spg * world},
-            "attn_ffn_flops_per_step": flops}), flush=True)
+            "attn_ffn_flops_per_step": flops, "attention_us": round(attn_us, 1) if attn_us else None, "fp8_attention": fp8}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -251,6 +288,8 @@ def main():
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra DVFS-steady loop (0 = skip)")
     ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
+    ap.add_argument("--fp8", action="store_true", help="stress mode: also run the opt-in e4m3 attention variant and report its speed and "
+                    "its logit distance from the fp32-accurate path")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "stress"],
                     help="infer (default, the BASELINE metric); train: forward + HIP backward + AdamW + gradient all-reduce; "
                          "stress: one level over 8192 patches x 1536 features (BASELINE configs[4] geometry, fp32-accurate path)")

@@ -348,6 +348,12 @@ int paths_dropout_rows(const float* x, int64_t ldx, const float* vec, const floa
                        int64_t M, int N, uint64_t key, float p, paths_stream_t stream);
 /* mask[i] = 1 kept / 0 dropped, i in [0, n): tests only */
 int paths_dropout_mask(float* mask, int64_t n, uint64_t key, float p, paths_stream_t stream);
+/* Opt-in low-precision variant for the stress geometry (BASELINE.json configs[4]): the same attention with OCP e4m3 operands, one
+ * v_mfma_f32_16x16x32_fp8_fp8 per product block (csrc/attn_fp8.hip).  4 significant bits per operand: NOT within the 1e-4 logit bar;
+ * never used unless PATHS_ATTN_FP8=1.  workspace: paths_attention_fp8_workspace(B, T, H, head_dim) bytes. */
+int64_t paths_attention_fp8_workspace(int B, int T, int H, int head_dim);
+int paths_attention_fp8(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims, int B, int T, int H,
+                        int head_dim, void* workspace, paths_stream_t stream);
 /* paths_attention_x6 with dropout on the softmax probabilities: O = (softmax(S) * mask / (1 - p)) V, lse un-dropped; mask element
  * ((b * H + h) * T + q) * T + k.  q, k, v fp32 (no pre-built images). */
 int paths_attention_x6_dropout(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B,

@@ -1,0 +1,250 @@
+// Masked self-attention with fp8 (OCP e4m3) operands on the CDNA4 matrix cores: the low-precision variant BASELINE.json configs[4]
+// names for the stress geometry (one level, 8192 patches -> 8193 tokens of full quadratic attention).  NOT the product path: an
+// e4m3 operand has 4 significant bits, the result misses the 1e-4 logit bar of the north star by two orders of magnitude (the
+// measured error is printed by `bench.py --mode stress --fp8` and asserted loosely in tests/test_gpu_parity.py); it exists so that
+// the cost / accuracy trade of that config is measured rather than guessed.  Opt-in: PATHS_ATTN_FP8=1 or ops.ATTN_FP8 = True.
+//
+// Same contract and the same structure as attn_x6.hip (reference model/aggregator.py:70-72 + utils.py:97-103; q pre-scaled by
+// log2(e)/sqrt(hd); keys >= num_ims[b]+1 masked; one wave = 32 queries, a 4-wave workgroup shares 64-key K / V^T fragment sets
+// through LDS, S(k+1) issued before the softmax of S(k), P never leaves the registers), with ONE v_mfma_f32_16x16x32_fp8_fp8 where
+// the split kernels issue 3 (fp16 hi|lo) or 6 (bf16 hi|mid|lo), 8-byte fragments per lane instead of 16 x planes, and no operand
+// split of P in the loop.  Scaling: q_s, k, v are O(1) and go to e4m3 as they are (saturated at +-448); P in [0, 1] is multiplied
+// by 256 before the conversion (e4m3's normal range starts at 2^-6) and the 1/256 is folded into the final normalisation; the row
+// sum l is accumulated in fp32 from the unquantised probabilities.
+#include "common.h"
+
+namespace {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int HD = 32;
+constexpr int F8 = 512;                    // bytes of one 16-row x 32-k fp8 fragment (64 lanes x 8 bytes)
+constexpr int KSTEP = 64;                  // keys per LDS buffer
+constexpr int QT = 2;                      // 16-query tiles per wave
+constexpr float P_SCALE = 256.0f;
+
+__device__ __forceinline__ u32x2 fp8x8(const float (&x)[8], float scale) {
+  float y[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) y[i] = fminf(fmaxf(x[i] * scale, -448.f), 448.f);
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[4], y[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(y[6], y[7], hi, true);
+  return u32x2{(uint32_t)lo, (uint32_t)hi};
+}
+__device__ __forceinline__ long as_long(u32x2 v) { return __builtin_bit_cast(long, v); }
+__device__ __forceinline__ f32x4 mfma8(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float rows_max(float x) { x = fmaxf(x, __shfl_xor(x, 16)); return fmaxf(x, __shfl_xor(x, 32)); }
+__device__ __forceinline__ float rows_sum(float x) { x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32); }
+
+// Fragment images per (slide, head), Tp = T rounded up to 64 (the lane maps of attn_x6.hip, 8 bytes per lane):
+//   Q8 / K8 : [Tp/16 tiles][64 lanes][8 fp8]         lane (r = l&15, g = l>>4): token 16 tile + r, dims 8g .. 8g+7
+//   V8      : [Tp/32 groups][2 dv tiles][64 lanes][8] lane (dv = l&15, g): dim 16 dvt + dv, keys 32 grp + 4g + (j&3) + 16 (j>>2)
+__global__ void __launch_bounds__(256)
+attn_fp8_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                     char* __restrict__ q8, char* __restrict__ k8, char* __restrict__ v8,
+                     const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
+  __shared__ float sv[KSTEP][HD + 1];
+  const int b = blockIdx.z, head = blockIdx.y, t0 = blockIdx.x * KSTEP;
+  const int len = min((int)num_ims[b] + 1, T);
+  const int tid = threadIdx.x;
+  const int64_t base = ((int64_t)b * H + head) * T * HD;
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD;
+  {
+    const int tl = tid >> 2, g = tid & 3, tok = t0 + tl;
+    float xq[8], xk[8];
+    const bool kvalid = tok < len, qvalid = tok < T;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xk[i] = kvalid ? k[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
+      xq[i] = qvalid ? q[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
+    }
+    const int64_t off = ibase + (int64_t)(tok >> 4) * F8 + ((tok & 15) + 16 * g) * 8;
+    *reinterpret_cast<u32x2*>(k8 + off) = fp8x8(xk, 1.0f);
+    *reinterpret_cast<u32x2*>(q8 + off) = fp8x8(xq, 1.0f);
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int idx = tid + 256 * p, tl = idx >> 5, dcol = idx & 31, tok = t0 + tl;
+    sv[tl][dcol] = tok < len ? v[base + (int64_t)tok * HD + dcol] : 0.f;
+  }
+  __syncthreads();
+  {
+    const int kg = tid >> 7, dvt = (tid >> 6) & 1, l = tid & 63, dv = l & 15, g = l >> 4;
+    float xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[j] = sv[32 * kg + 4 * g + (j & 3) + 16 * (j >> 2)][16 * dvt + dv];
+    const int64_t off = ibase + (int64_t)(((t0 >> 5) + kg) * 2 + dvt) * F8 + l * 8;
+    *reinterpret_cast<u32x2*>(v8 + off) = fp8x8(xv, 1.0f);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2)
+attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const char* __restrict__ v8,
+                float* __restrict__ o, const int64_t* __restrict__ num_ims, int T, int Tp, int H, int npairs, int nqb) {
+  __shared__ __attribute__((aligned(16))) char sKb[2][4 * F8], sVb[2][4 * F8];
+  // XCD-aware placement as in attn_x6.hip: pair p only ever runs on the XCD group p % 8
+  const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
+  const int cnt = (npairs - xg + 7) >> 3;
+  if (cnt <= 0) return;
+  const int pair = xg + 8 * (jx % cnt), qb = jx / cnt;
+  if (qb >= nqb) return;
+  const int b = pair / H, head = pair - b * H, q0 = qb * 64 * QT;
+  const int len = min((int)num_ims[b] + 1, T);
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 15, g4 = lane >> 4;
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD;
+  const int qw = q0 + wave * 16 * QT;
+
+  long qf[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
+    qf[qt] = *reinterpret_cast<const long*>(q8 + ibase + (int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * F8 + lane * 8);
+  f32x4 oacc[2][QT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
+
+  // staging: a 64-key step is 2 KiB of K fragments + 2 KiB of V^T fragments: threads 0-127 carry K (one step ahead), 128-255 V
+  const int nkt = (len + KSTEP - 1) / KSTEP;
+  const bool carriesK = tid < 128;
+  const int chunk = (tid & 127) * 16;
+  u32x4 st;
+  auto gload = [&](int ktk, int ktv) {        // K of step ktk / V of step ktv (the caller checks the ranges)
+    const char* src = carriesK ? k8 + ibase + (int64_t)ktk * (4 * F8) : v8 + ibase + (int64_t)ktv * (4 * F8);
+    st = *reinterpret_cast<const u32x4*>(src + chunk);
+  };
+  auto swrite = [&](int ktk, int ktv, bool dok, bool dov) {
+    if (carriesK) { if (dok) *reinterpret_cast<u32x4*>(&sKb[ktk & 1][chunk]) = st; }
+    else if (dov) *reinterpret_cast<u32x4*>(&sVb[ktv & 1][chunk]) = st;
+  };
+  auto qk = [&](int kt, f32x4 (&s)[QT][4]) __attribute__((always_inline)) {
+    const char* sK = &sKb[kt & 1][lane * 8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long kf = *reinterpret_cast<const long*>(sK + t * F8);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma8(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  };
+  gload(0, 0);
+  swrite(0, 0, true, true);
+  if (nkt > 1) { if (carriesK) gload(1, 0); swrite(1, 0, true, false); }
+  __syncthreads();
+  f32x4 sA[QT][4], sB[QT][4];
+  qk(0, sA);
+  auto step = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], bool last) __attribute__((always_inline)) {
+    const bool morek = kt + 2 < nkt, morev = kt + 1 < nkt;
+    if (carriesK ? morek : morev) gload(kt + 2, kt + 1);
+    const char* sV = &sVb[kt & 1][lane * 8];
+    if (last) {
+      const int kbase = kt * KSTEP + 4 * g4;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
+    }
+    qk(kt + 1, sn);                                     // (past the end: stale K fragments, finite garbage nobody reads)
+    long pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        mx = fmaxf(fmaxf(mx, s[qt][t][0]), s[qt][t][1]);
+        mx = fmaxf(fmaxf(mx, s[qt][t][2]), s[qt][t][3]);
+      }
+      mx = rows_max(mx);
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) of the PV product = key 4 g4 + (j&3) + 16 (j>>2) of the group
+          pv[j] = __builtin_amdgcn_exp2f(s[qt][2 * kg + (j >> 2)][j & 3] - m_new);
+          psum += pv[j];
+        }
+        pf[qt][kg] = as_long(fp8x8(pv, P_SCALE));
+      }
+      l_run[qt] = l_run[qt] * alpha + psum;
+      m_run[qt] = m_new;
+      oacc[0][qt] *= alpha;
+      oacc[1][qt] *= alpha;
+    }
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int dvt = 0; dvt < 2; ++dvt) {
+        const long vf = *reinterpret_cast<const long*>(sV + (kg * 2 + dvt) * F8);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) oacc[dvt][qt] = mfma8(vf, pf[qt][kg], oacc[dvt][qt]);
+      }
+    swrite(kt + 2, kt + 1, morek, morev);               // K over K(kt) (read one step ago), V over V(kt-1)
+    __syncthreads();
+  };
+  {
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      step(kt, sA, sB, false);
+      step(kt + 1, sB, sA, false);
+    }
+    if (kt + 1 < nkt) { step(kt, sA, sB, false); step(kt + 1, sB, sA, true); }
+    else step(kt, sA, sB, true);
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float l = rows_sum(l_run[qt]);
+    const float inv = 1.0f / (l * P_SCALE);
+    const int qi = qw + 16 * qt + ql;
+    if (qi < T) {
+      float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * g4;
+      *reinterpret_cast<f32x4*>(op) = oacc[0][qt] * inv;
+      *reinterpret_cast<f32x4*>(op + 16) = oacc[1][qt] * inv;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the workspace paths_attention_fp8 needs (three e4m3 fragment images)
+int64_t paths_attention_fp8_workspace(int B, int T, int H, int head_dim) {
+  const int64_t Tp = ((int64_t)T + KSTEP - 1) / KSTEP * KSTEP;
+  return 3 * (int64_t)B * H * Tp * head_dim;
+}
+
+// o[B, T, H*32] = softmax(q_s k^T) v with e4m3 operands (see the file header: opt-in, outside the 1e-4 logit bar).
+// q, k, v head-major [B][H][T][32] fp32, q pre-scaled by log2(e)/sqrt(head_dim); keys >= num_ims[b] + 1 are masked.
+int paths_attention_fp8(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims, int B, int T, int H,
+                        int head_dim, void* workspace, hipStream_t stream) {
+  PATHS_REQUIRE(head_dim == HD, "attention_fp8: head_dim must be %d (got %d)", HD, head_dim);
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && q && k && v && o && num_ims && workspace, "attention_fp8: bad arguments B=%d T=%d H=%d", B, T, H);
+  PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_fp8: buffers must be 16-byte aligned");
+  const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
+  const int64_t img = (int64_t)B * H * Tp * HD;
+  char* q8 = reinterpret_cast<char*>(workspace);
+  char* k8 = q8 + img;
+  char* v8 = k8 + img;
+  hipLaunchKernelGGL(attn_fp8_prep_kernel, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q8, k8, v8, num_ims, T, Tp, H);
+  PATHS_LAUNCH_CHECK("attention_fp8(prep)");
+  const int nqb = (T + 64 * QT - 1) / (64 * QT), npairs = H * B;
+  hipLaunchKernelGGL(attn_fp8_kernel, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 0, stream, q8, k8, v8, o, num_ims, T, Tp, H, npairs, nqb);
+  PATHS_LAUNCH_CHECK("attention_fp8");
+  return PATHS_OK;
+}
+
+}  // extern "C"

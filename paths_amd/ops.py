@@ -44,6 +44,7 @@ def timed(name: str, fn, meta=None, detail: bool = True):
 #   "f32" : f32-input MFMA (csrc/gemm_f32.hip, csrc/attn_f32.hip)
 GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "h3")
 A_SCALE = float(os.environ.get("PATHS_H3_A_SCALE", "16"))      # a power of two
+ATTN_FP8 = os.environ.get("PATHS_ATTN_FP8", "0") != "0"     # inference attention with e4m3 operands (opt-in, see csrc/attn_fp8.hip)
 TRAIN_PLANES = 3        # training re-images weights every step: the bf16 split needs no scale, i.e. no host sync on max|w|
 # forward GEMMs / attention of the TRAINING step: 2 = the inference split (fp16 planes) with lagged weight scales, 3 = exact bf16
 TRAIN_FWD_PLANES = int(os.environ.get("PATHS_TRAIN_FWD_PLANES", "2"))
@@ -560,15 +561,20 @@ def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dic
     depth = cat.shape[1] if cat is not None else 0
 
     attn_ws = None
-    if GEMM_MODE != "f32" and L > 1:
+    fp8 = ATTN_FP8 and L > 1          # opt-in e4m3 attention (csrc/attn_fp8.hip: outside the 1e-4 logit bar, stress-config measurement only)
+    if fp8:
+        attn_ws = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=tokens.device, dtype=torch.uint8)
+    elif GEMM_MODE != "f32" and L > 1:
         attn_ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, split_planes())),),
                               device=tokens.device, dtype=torch.uint8)
     # default mode: the in_proj of a layer that feeds the full attention writes the attention kernel's operand images itself
     # (no fp32 q, k, v round trip, no re-write launch); the last layer's q, k, v stay fp32 for the token-0 tail
-    direct = GEMM_MODE == "h3" and attn_ws is not None and QKV_IMAGES
+    direct = GEMM_MODE == "h3" and attn_ws is not None and QKV_IMAGES and not fp8
     timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0], qkv_images=attn_ws if direct else None))
     for l in range(L - 1):
-        if GEMM_MODE != "f32":
+        if fp8:
+            timed("agg_attention", lambda: _lib.call("paths_attention_fp8", p(q), p(k), p(v), p(attn), p(num_ims), B, T, H, hd, p(attn_ws), st))
+        elif GEMM_MODE != "f32":
             timed("agg_attention", lambda: _lib.call("paths_attention_x6", p(q), p(k), p(v), p(attn), None, p(num_ims), B, T, H, hd, 0,
                                                      p(attn_ws), split_planes(), 1 if direct else 0, st))
         else:

@@ -5,6 +5,8 @@ Bars (BASELINE.json north_star): selected-patch index SETS bit-identical (sequen
 permutations among scores closer than 1e-6, SURVEY.md §7 hard part 1); fp32 logits within 1e-4 — the tests
 use tighter working tolerances (logits 2e-5, importance / LSTM state 5e-6) so regressions show early.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -785,6 +787,41 @@ def test_tape_owns_its_buffers(dev):
     assert len(tensors) >= 40 and all(torch.equal(a, b) for a, b in zip(tensors, copies))
     assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
     assert not torch.equal(held["logits"], ref["logits"])
+
+
+def test_fp8_attention_variant_error_is_measured(dev, monkeypatch):
+    """csrc/attn_fp8.hip (opt-in, BASELINE configs[4]'s "fp8 MFMA path"): e4m3 operands carry 4 significant bits, so this is NOT a
+    parity test - it pins the variant's error band (attention output within a few percent of float64, ragged batch and masked keys
+    handled, nothing non-finite) and records that a level's logits move by far more than the 1e-4 bar when it is switched on."""
+    from paths_amd import _lib, ops
+    B, T, H, hd = 3, 777, 4, 32
+    g = torch.Generator().manual_seed(4)
+    q, k, v = (torch.randn(B, H, T, hd, generator=g) for _ in range(3))
+    qs = q * (math.log2(math.e) / math.sqrt(hd))
+    num_ims = torch.tensor([776, 400, 63])
+    qd, kd, vd, nd = qs.to(dev), k.to(dev), v.to(dev), num_ims.to(dev)
+    o = torch.full((B, T, H * hd), float("nan"), device=dev)
+    ws = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8)
+    _lib.call("paths_attention_fp8", qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), nd.data_ptr(), B, T, H, hd, ws.data_ptr(),
+              _lib.stream())
+    torch.cuda.synchronize()
+    s = torch.einsum("bhqd,bhkd->bhqk", q.double(), k.double()) / math.sqrt(hd)
+    mask = torch.arange(T)[None, :] > num_ims[:, None]                        # keys 0 .. num_ims[b] are valid
+    s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(s, -1), v.double()).reshape(B, T, H * hd)
+    out = o.cpu().double()
+    valid = (torch.arange(T)[None, :] <= num_ims[:, None])                    # (query blocks that are all padding are not written)
+    out, ref = out[valid], ref[valid]
+    assert torch.isfinite(out).all()
+    rel = float((out - ref).norm() / ref.norm())
+    assert 1e-3 < rel < 0.08, rel                                              # e4m3: percent-level, and visibly not the split path
+    # end to end on a golden level: finite, close in the coarse sense, far outside the parity bar
+    gold, info, out_def = run_single(dev, "g9_level1_b2_k2048")
+    monkeypatch.setattr(ops, "ATTN_FP8", True)
+    _, _, out_fp8 = run_single(dev, "g9_level1_b2_k2048")
+    err = float((out_fp8["logits"] - out_def["logits"]).abs().max())
+    assert torch.isfinite(out_fp8["logits"]).all() and 1e-4 < err < 0.2, err
+    assert torch.equal(out_fp8["importance"], out_def["importance"])           # the selection chain does not depend on the aggregator
 
 
 def test_keep_all_and_single_level(dev):
