@@ -363,6 +363,12 @@ int paths_attention_x6_dropout(const float* q, const float* k, const float* v, f
 int paths_attention_bwd_f32_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o,
                                     const float* lse, const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H,
                                     int head_dim, uint64_t drop_key, float drop_p, paths_stream_t stream);
+/* The same with the dQ part on the split-bf16 matrix-core kernel (csrc/attn_bwd_x6.hip: three exact bf16 planes per operand, as
+ * accurate as the f32 MFMA); images: paths_attention_bwd_x6_workspace(B, T, H, head_dim) bytes of scratch. */
+int64_t paths_attention_bwd_x6_workspace(int B, int T, int H, int head_dim);
+int paths_attention_bwd_x6_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                                   const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
+                                   uint64_t drop_key, float drop_p, paths_stream_t stream);
 int paths_attention_token0_bwd_dropout(const float* q, const float* k, const float* v, const float* a0, const float* da0,
                                        const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, uint64_t drop_key,
                                        float drop_p, paths_stream_t stream);

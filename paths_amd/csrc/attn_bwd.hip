@@ -14,10 +14,15 @@
 //   attn_bwd_q_kernel      one wave = 16 queries, loops over all keys:   dQ_s^T += K^T ds^T                 (transposed form,
 //                          as the forward: per-lane query state)
 //   attn_token0_bwd_kernel last layer: a single query (token 0) per head, VALU only
+#include <cstdlib>
+
 #include "common.h"
 #include "dropout.h"
 
 DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
+int paths_attention_bwd_x6_launch(const float* q, const float* k, const float* v, const float* d_o, const float* lse, const float* dsum,
+                                  const int64_t* num_ims, float* dqkv, void* images, int B, int T, int H, DropSite site, int kv_too,
+                                  hipStream_t stream);       // attn_bwd_x6.hip
 
 namespace {
 
@@ -327,7 +332,7 @@ extern "C" {
 // dqkv [B,T,384] must be zero-initialised by the caller (rows of padded tokens are never written).
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                               const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, DropSite site,
-                              hipStream_t stream);
+                              hipStream_t stream, void* images = nullptr);
 
 int paths_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                             const int64_t* num_ims, float* dqkv, float* ws_dsum /*[B*H*T]*/, int B, int T, int H, int head_dim,
@@ -343,17 +348,28 @@ int paths_attention_bwd_f32_dropout(const float* q, const float* k, const float*
   return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(drop_key, drop_p), stream);
 }
 
+// the dQ part on the split-bf16 kernel (paths_attention_bwd_x6_workspace bytes of images), dK / dV on the f32 MFMA
+int paths_attention_bwd_x6_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                                   const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
+                                   uint64_t drop_key, float drop_p, hipStream_t stream) {
+  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && images != nullptr && (uintptr_t)images % 16 == 0, "attention_bwd_x6: p in [0, 1), 16-byte aligned images");
+  return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(drop_key, drop_p), stream, images);
+}
+
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                               const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, DropSite site,
-                              hipStream_t stream) {
+                              hipStream_t stream, void* images) {
   PATHS_REQUIRE(head_dim == HD && H == 4, "attention_bwd: head_dim must be 32 and H 4");
   PATHS_REQUIRE(B > 0 && T > 0 && q && k && v && o && d_o && lse && num_ims && dqkv && ws_dsum, "attention_bwd: bad arguments");
   const int64_t rows = (int64_t)B * T;
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, o, d_o, ws_dsum, rows, T, H);
   PATHS_LAUNCH_CHECK("attention_bwd(prep)");
   dim3 grid((T + 63) / 64, H, B);
+  static const int x6_kv = getenv("PATHS_ATTN_BWD_KV_X6") == nullptr || atoi(getenv("PATHS_ATTN_BWD_KV_X6")) != 0;   // A/B switch
+  if (images != nullptr && x6_kv) return paths_attention_bwd_x6_launch(q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, images, B, T, H, site, 1, stream);
   hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(kv)");
+  if (images != nullptr) return paths_attention_bwd_x6_launch(q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, images, B, T, H, site, 0, stream);
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(q)");
   return PATHS_OK;

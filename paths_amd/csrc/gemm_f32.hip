@@ -196,6 +196,48 @@ __global__ void pe_table_kernel(const float* __restrict__ div_term, int W, int r
   out[i] = (c & 1) ? cosf(ang) : sinf(ang);
 }
 
+// out[M, N] (+)= maskop(act(a[M, K] w[N, K]^T + bias)) + residual for M <= SMALL_M rows (EpiBias semantics).  The 128 x 128 tile
+// kernel spent 23 us on an 8-row product (61 launches per training step: the last layer's token-0 row chain, forward, recompute and
+// backward); here one wave owns one output column: 16-byte coalesced reads of its weight row, the few rows of `a` re-read through
+// L1, one wave reduction per (row, column).
+constexpr int SMALL_M = 16;
+__global__ void __launch_bounds__(256)
+gemm_nt_small_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ w, int64_t ldw, const float* __restrict__ bias,
+                     float* __restrict__ out, int64_t ldo, int M, int N, int K, int act, const float* __restrict__ residual, int64_t ldr,
+                     const float* __restrict__ mask, int64_t ldm, int accumulate) {
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[SMALL_M];
+#pragma unroll
+  for (int m = 0; m < SMALL_M; ++m) acc[m] = 0.f;
+  for (int k0 = 4 * lane; k0 < K; k0 += 256) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)n * ldw + k0);
+#pragma unroll
+    for (int m = 0; m < SMALL_M; ++m) {
+      if (m < M) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a + (int64_t)m * lda + k0);
+        acc[m] = fmaf(av[0], wv[0], fmaf(av[1], wv[1], fmaf(av[2], wv[2], fmaf(av[3], wv[3], acc[m]))));
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < SMALL_M; ++m) {
+    if (m < M) {
+      float v = acc[m];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if (lane == 0) {
+        v += bias ? bias[n] : 0.f;
+        if (act == 1) v = fmaxf(v, 0.f);
+        if (mask && !(mask[(int64_t)m * ldm + n] > 0.f)) v = 0.f;
+        if (residual) v += residual[(int64_t)m * ldr + n];
+        float* o = out + (int64_t)m * ldo + n;
+        *o = accumulate ? *o + v : v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -297,6 +339,13 @@ int paths_gemm_nt_f32(const float* a, int64_t lda, const float* w, int64_t ldw, 
                       int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                       int64_t ldm, int accumulate, hipStream_t stream) {
   PATHS_REQUIRE(ldw >= K, "gemm_nt: ldw < K");
+  if (M <= SMALL_M && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)a | (uintptr_t)w) % 16 == 0) {
+    // a handful of rows (the last decoder layer's token-0 chain: M = slides per batch): one wave per output column
+    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, a, lda, w, ldw, b, out, ldo, M, N, K, act, residual, ldr,
+                       mask, ldm, accumulate);
+    PATHS_LAUNCH_CHECK("gemm_nt_f32(small M)");
+    return PATHS_OK;
+  }
   GemmOperands g{a, lda, K, nullptr, 0, 0, w, ldw, M, nullptr, 0};
   EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate};
   return launch_gemm<2, 2, 2, 2>(g, Npad, e, stream, "gemm_nt_f32");

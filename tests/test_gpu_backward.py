@@ -50,6 +50,19 @@ def test_gemm_tn_colsum_transpose(dev):
     bw.gemm_nt(ad, N1, wd, o, 128, M, 128, N1, residual=resd, ldr=128, mask=maskd, ldm=128, accumulate=True)
     ref = (a.double() @ w.double().t()) * mask.double() + res.double() + 1.0
     assert rel_err(o, ref) < 2e-6
+    # a handful of rows (the token-0 chain, M = slides per batch): the one-wave-per-column kernel, strided rows, relu, bias
+    for Ms, Ks, Ns in ((8, 512, 128), (3, 128, 512), (16, 384, 128)):
+        a_s = torch.randn(Ms, 2, Ks)[:, 0, :]                       # row stride 2 K
+        w_s, b_s = torch.randn(Ns, Ks), torch.randn(Ns)
+        res_s, mask_s = torch.randn(Ms, Ns), (torch.randn(Ms, Ns) > 0).float()
+        full = torch.randn(Ms, 2, Ks)
+        full[:, 0, :] = a_s
+        fd = full.to(dev)
+        o_s = torch.full((Ms, Ns), 2.0, device=dev)
+        bw.gemm_nt(fd.data_ptr(), 2 * Ks, w_s.to(dev), o_s, Ns, Ms, Ns, Ks, bias=b_s.to(dev), act=1, residual=res_s.to(dev), ldr=Ns,
+                   mask=mask_s.to(dev), ldm=Ns, accumulate=True)
+        ref_s = torch.relu(a_s.double() @ w_s.double().t() + b_s.double()) * mask_s.double() + res_s.double() + 2.0
+        assert rel_err(o_s, ref_s) < 2e-6, (Ms, Ks, Ns)
 
 
 @pytest.mark.parametrize("M,N1,N2,nb0,pad", [(4096, 256, 512, 256, 0), (1000, 256, 384, 256, 0), (2500, 512, 512, 0, 0),
