@@ -49,12 +49,16 @@ def dead_params(model) -> List[torch.nn.Parameter]:
     """Parameters that exist for checkpoint compatibility but never influence an output: the whole nn.Transformer
     encoder and the cross-attention matrices.  The reference gives them ZERO gradients (so AdamW still
     applies weight decay to them); :func:`fill_dead_grads` reproduces that."""
+    cached = getattr(model, "_paths_dead_params", None)      # (the module walk below is ~1 ms of host time per training step)
+    if cached is not None:
+        return cached
     out = []
     for proc in model.procs:
         tr = proc.global_agg.transformer
         out += list(tr.encoder.parameters())
         for lyr in tr.decoder.layers:
             out += [lyr.multihead_attn.in_proj_weight, lyr.multihead_attn.in_proj_bias, lyr.multihead_attn.out_proj.weight]
+    object.__setattr__(model, "_paths_dead_params", out)     # Parameter objects are stable (load_state_dict / .to() work in place)
     return out
 
 
