@@ -739,13 +739,15 @@ def test_taped_recursion_replays_bit_identically(dev):
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     cfg, model, _ = build_model(dev, 3, None, top_k_patches=[24] * 4)
     slides = DeviceSlideBatch([DeviceSlide.synthetic(99, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)])
+    tr = []
     with torch.no_grad():
-        ref = putils.recurse(model, slides, cfg.top_k_patches, 5)
+        ref = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=tr)
+    n_last = tr[-1]["num_ims"].cpu().tolist()          # (rows past num_ims of the state tensor are never written in the x6 / f32 modes)
     t = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5)
     for _ in range(4):
         out = t.run()
         assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
-        assert torch.equal(out["ctx_patch"], ref["ctx_patch"])
+        assert all(torch.equal(out["ctx_patch"][b, :n], ref["ctx_patch"][b, :n]) for b, n in enumerate(n_last))
     n_calls = len(t.tape)
     assert 60 <= n_calls <= 140 and sum(1 for _, _, name in t.tape if name == "paths_stream_wait") >= 10
     with torch.no_grad():
