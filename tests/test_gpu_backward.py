@@ -259,6 +259,41 @@ def test_recursion_gradients_vs_oracle_autograd(dev):
     assert live > 100
 
 
+def test_recursion_gradients_at_headline_size_vs_oracle_autograd(dev):
+    """BASELINE configs[3] shape: the K = 2048 x 5-level training step (top_k 512, the bench's weights and two of its oracle-screened
+    slides) - loss and every live parameter gradient of the HIP forward + backward against torch autograd through the oracle (fp32
+    CPU), dropout off so that both sides compute the same function."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    K = 2048
+    cfg, model, params = build_model(dev, 0, None, top_k_patches=[K // 4] * 4)
+    slides = [DeviceSlide.synthetic(1234, sid, (32, 64), device=dev) for sid in (10003, 10004)]
+    labels = np.asarray([s.synthetic_spec.label(4) for s in slides], np.int64)
+    batch = {"slide": DeviceSlideBatch(slides), "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
+    model.train()
+    _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(top_k_patches=[K // 4] * 4)
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides],
+                                      {"survival_bin": batch["survival_bin"], "censored": batch["censored"]})
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5
+    sd = dict(model.named_parameters())
+    live, worst = 0, 0.0
+    for k, ref in p.items():
+        g = sd[k].grad
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            continue
+        assert g is not None, k
+        e = rel_err(g, ref.grad)
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+        live += 1
+    assert live > 100, (live, worst)
+
+
 @pytest.mark.parametrize("over", [{"lstm": False}, {"slide_ctx_mode": "concat"}, {"lstm": False, "slide_ctx_mode": "concat"},
                                   {"slide_ctx_mode": "none"}], ids=["nolstm", "concat", "nolstm_concat", "ctx_none"])
 def test_variant_training_gradients_vs_oracle_autograd(dev, over):
