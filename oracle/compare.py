@@ -8,7 +8,7 @@ Compares one recursion of the HIP path (the ``trace`` list filled by ``paths_amd
 * the patch LOCATION set of the level                     bit-exact  (row order inside a level may legally differ where two
                                                           importance scores nearly tie: SURVEY.md §7 hard part 1)
 * the kept (top-K) patches, as a location set             bit-exact
-* ``parent_inds`` as (child location -> parent location)  bit-exact
+* ``parent_inds`` as (child location -> parent location)  bit-exact  (fallback levels: as (cell location -> cell index))
 * importance per location                                 <= ``imp_tol``
 * final hazards                                           <= ``hazard_tol`` (north_star bar 1e-4)
 
@@ -72,6 +72,12 @@ def compare_recursion(gpu_trace: Sequence[dict], oracle_trace: Sequence[dict], g
             if l == 0:
                 if not np.array_equal(gp[j, :n], np.arange(n)) or not np.array_equal(op_[j, :n], np.arange(n)):
                     problems.append(f"L0 slide {j}: parent_inds != arange")
+            elif o.get("fallback", [False] * B)[j]:
+                # the reference's all-cells fallback (slide.py:336-352): parent_inds are the cell indices of this level's grid
+                pairs_g = {tuple(c) + (int(p_),) for c, p_ in zip(gl[j, :n].tolist(), gp[j, :n].tolist())}
+                pairs_o = {tuple(c) + (int(p_),) for c, p_ in zip(ol[j, :n].tolist(), op_[j, :n].tolist())}
+                if pairs_g != pairs_o:
+                    problems.append(f"L{l} slide {j}: (cell -> parent_inds) pairs of the fallback differ")
             else:
                 pg, po = gpu_trace[l - 1], oracle_trace[l - 1]
                 kg = _np(pg["keep_idx"])[j, : int(_np(pg["keep_count"])[j])].astype(np.int64)

@@ -265,7 +265,8 @@ def iter_slide(grids, level: int, npatches: int, locs_px: Tensor, ctx_slide: Ten
     rows = grids.rows(level + 1, safe[:, 0], safe[:, 1])
     flt = in_bound & (rows.sum(dim=1) != 0)                                   # slide.py:324-325
     new_locs, parent_inds, ctx_patch, new_fts = new_locs[flt], parent_inds[flt], ctx_patch[flt], rows[flt]
-    if new_locs.shape[0] == 0:                                                # slide.py:336-352 (rare fallback)
+    fallback = new_locs.shape[0] == 0
+    if fallback:                                                              # slide.py:336-352 (rare fallback)
         gx, gy = torch.meshgrid(torch.arange(X), torch.arange(Y), indexing="ij")
         new_locs = torch.stack((gx.reshape(-1), gy.reshape(-1)), dim=1)
         rows = grids.rows(level + 1, new_locs[:, 0], new_locs[:, 1])
@@ -276,7 +277,8 @@ def iter_slide(grids, level: int, npatches: int, locs_px: Tensor, ctx_slide: Ten
         parent_inds = torch.arange(X * Y)[flt]
         new_locs, new_fts = new_locs[flt], rows[flt]
     item = {"fts": new_fts, "ctx_patch": ctx_patch, "ctx_slide": ctx_slide,
-            "locs": new_locs * patch_size, "parent_inds": parent_inds}
+            "locs": new_locs * patch_size, "parent_inds": parent_inds,
+            "fallback": fallback}         # (trace only: parent_inds are then CELL indices of the new level, not indices into the kept list)
     return item, keep_inds
 
 
@@ -297,6 +299,7 @@ def collate(items: List[Dict[str, Tensor]]) -> Dict[str, Tensor]:
         "ctx_patch": torch.stack([padrows(it["ctx_patch"]) for it in items]),
         "ctx_slide": torch.stack([it["ctx_slide"] for it in items]),
         "num_ims": torch.tensor(num, dtype=torch.int64),
+        "fallback": [bool(it.get("fallback", False)) for it in items],
     }
 
 
@@ -338,7 +341,8 @@ def inference_end2end(p: Dict[str, Tensor], cfg: OracleConfig, slides_grids: Seq
                             batch["ctx_slide"], batch["ctx_patch"])
         rec = {"num_ims": batch["num_ims"].clone(), "locs": batch["locs"].clone(),
                "parent_inds": batch["parent_inds"].clone(), "importance": out["importance"].clone(),
-               "logits": out["logits"].clone(), "ctx_slide": out["ctx_slide"].clone(), "keep_inds": []}
+               "logits": out["logits"].clone(), "ctx_slide": out["ctx_slide"].clone(), "keep_inds": [],
+               "fallback": list(batch.get("fallback", [False] * len(slides_grids)))}
         if i != cfg.num_levels - 1:
             items = []
             for j, g in enumerate(slides_grids):

@@ -210,6 +210,11 @@ def test_zero_children_fallback_vs_oracle(dev):
             n = int(otrace[l]["num_ims"][j])
             assert {tuple(r) for r in trace[l]["locs"][j, :n].cpu().numpy()} == {tuple(r) for r in otrace[l]["locs"][j, :n].numpy()}
     np.testing.assert_allclose(torch.sigmoid(out["logits"]).cpu().numpy(), hz.numpy(), atol=LOGIT_TOL, rtol=0)
+    # the shared checker knows the fallback's parent_inds (cell indices of the new level) and pins them too
+    from oracle.compare import compare_recursion
+    assert any(any(t["fallback"]) for t in otrace)
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["problems"] == [] and res["parent_pairs_identical"]
 
 
 def test_recursion_nolstm_variant_vs_oracle(dev):
@@ -824,6 +829,34 @@ def test_fp8_attention_variant_error_is_measured(dev, monkeypatch):
     err = float((out_fp8["logits"] - out_def["logits"]).abs().max())
     assert torch.isfinite(out_fp8["logits"]).all() and 1e-4 < err < 0.2, err
     assert torch.equal(out_fp8["importance"], out_def["importance"])           # the selection chain does not depend on the aggregator
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_small_recursions_vs_oracle(dev, case):
+    """A seeded sweep over the driver's shape space - grid shape, background rate (down to slides whose kept patches have no tissue
+    children: the all-cells fallback), batch size, number of levels, top-K (1 .. more than a level holds, -1 = keep all) - each run
+    against the oracle through the shared checker: num_ims, location sets, kept sets and (child -> parent) pairs exact."""
+    from oracle import paths_oracle as orc
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    rng = np.random.RandomState(1000 + case)
+    levels = int(rng.choice([2, 3, 5]))
+    base = (int(rng.randint(1, 9)), int(rng.randint(1, 9)))
+    B = int(rng.choice([1, 2, 5]))
+    p_bg = float(rng.choice([0.0, 0.3, 0.6, 0.85]))
+    keeps = [int(rng.choice([-1, 1, 2, 3, 7, 16, 40])) for _ in range(levels - 1)]
+    over = {"num_levels": levels}
+    cfg, model, params = build_model(dev, 40 + case, over, top_k_patches=keeps)
+    ocfg = H.oracle_config(over, top_k_patches=keeps)
+    slides = [DeviceSlide.synthetic(300 + case, sid, base, num_levels=levels, p_bg=p_bg, device=dev) for sid in range(B)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, keeps, levels, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["problems"] == [], (levels, base, B, p_bg, keeps, res["problems"])
+    assert len(res["near_tie_slides"]) < B or B == 1, (levels, base, B, p_bg, keeps, res)      # (a screened slide is not a failure)
 
 
 def test_keep_all_and_single_level(dev):
