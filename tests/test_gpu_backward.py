@@ -259,6 +259,46 @@ def test_recursion_gradients_vs_oracle_autograd(dev):
     assert live > 100
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_random_small_training_steps_vs_oracle_autograd(dev, case):
+    """A seeded sweep over shapes for the differentiable path (grid shape, background rate incl. fallback slides, batch size, level
+    count, top-K incl. keep-all): loss and every live parameter gradient against torch autograd through the oracle."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    rng = np.random.RandomState(2000 + case)
+    levels = int(rng.choice([2, 3, 5]))
+    base = (int(rng.randint(2, 8)), int(rng.randint(2, 8)))
+    B = int(rng.choice([1, 2, 4]))
+    p_bg = float(rng.choice([0.0, 0.3, 0.6, 0.85]))
+    keeps = [int(rng.choice([-1, 1, 3, 7, 16])) for _ in range(levels - 1)]
+    over = {"num_levels": levels}
+    cfg, model, params = build_model(dev, 60 + case, over, top_k_patches=keeps)
+    slides = [DeviceSlide.synthetic(400 + case, sid, base, num_levels=levels, p_bg=p_bg, device=dev) for sid in range(B)]
+    labels = np.asarray([s.synthetic_spec.label(4) for s in slides], np.int64)
+    batch = {"slide": DeviceSlideBatch(slides), "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
+    model.train()
+    _, loss = putils.forward_backward(model, batch, levels, keeps, "survival")
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(over, top_k_patches=keeps)
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides],
+                                      {"survival_bin": batch["survival_bin"], "censored": batch["censored"]})
+    oloss.backward()
+    tag = (levels, base, B, p_bg, keeps)
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5, tag
+    sd = dict(model.named_parameters())
+    live = 0
+    for k, ref in p.items():
+        g = sd[k].grad
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, (k, tag)
+            continue
+        assert g is not None, (k, tag)
+        assert rel_err(g, ref.grad) < 2e-3, (k, rel_err(g, ref.grad), tag)
+        live += 1
+    assert live > 20, (live, tag)
+
+
 def test_recursion_gradients_at_headline_size_vs_oracle_autograd(dev):
     """BASELINE configs[3] shape: the K = 2048 x 5-level training step (top_k 512, the bench's weights and two of its oracle-screened
     slides) - loss and every live parameter gradient of the HIP forward + backward against torch autograd through the oracle (fp32
