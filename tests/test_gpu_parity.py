@@ -859,6 +859,37 @@ def test_random_small_recursions_vs_oracle(dev, case):
     assert len(res["near_tie_slides"]) < B or B == 1, (levels, base, B, p_bg, keeps, res)      # (a screened slide is not a failure)
 
 
+VARIANT_OVERS = [{"lstm": False}, {"slide_ctx_mode": "concat"}, {"pos_encoding_mode": "1d"}, {"importance_mode": "none"},
+                 {"slide_ctx_mode": "none"}, {"lstm": False, "slide_ctx_mode": "concat"}, {"lstm": False, "pos_encoding_mode": "1d"},
+                 {"slide_ctx_mode": "concat", "importance_mode": "none"}]
+
+
+@pytest.mark.parametrize("case", range(len(VARIANT_OVERS)))
+def test_random_small_recursions_of_model_variants_vs_oracle(dev, case):
+    """The same sweep over the config surface of reference config.py:25-44 (lstm on / off, slide_ctx_mode residual / concat / none,
+    1-D / 2-D positional encoding, importance_mode mul / none), one random shape per variant, through the shared checker."""
+    from oracle import paths_oracle as orc
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    rng = np.random.RandomState(3000 + case)
+    levels = int(rng.choice([3, 5]))
+    base = (int(rng.randint(2, 8)), int(rng.randint(2, 8)))
+    B = int(rng.choice([1, 2, 3]))
+    p_bg = float(rng.choice([0.0, 0.3, 0.6]))
+    keeps = [int(rng.choice([2, 5, 12, 30])) for _ in range(levels - 1)]
+    over = {"num_levels": levels, "model_config": dict(VARIANT_OVERS[case])}
+    cfg, model, params = build_model(dev, 80 + case, over, top_k_patches=keeps)
+    ocfg = H.oracle_config(over, top_k_patches=keeps)
+    slides = [DeviceSlide.synthetic(500 + case, sid, base, num_levels=levels, p_bg=p_bg, device=dev) for sid in range(B)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, keeps, levels, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["problems"] == [], (VARIANT_OVERS[case], levels, base, B, p_bg, keeps, res["problems"])
+
+
 def test_keep_all_and_single_level(dev):
     """Edge cases of the driver (reference data_utils/slide.py:294: keep == -1 keeps every patch in its original order; a
     one-level model): against the oracle."""
