@@ -236,6 +236,27 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
 /* qkv_images (optional, max_tokens = 0): a paths_attention_x6_workspace(B, T, H, 32, 2) buffer; the in_proj outputs are written
  * as the two-plane operand images of paths_attention_x6 (masked keys zeroed) instead of fp32 q, k, v (which may then be null). */
 
+/* paths_token_layer_h3 in WEIGHT-STATIONARY form (csrc/tlayer_ws.hip; reference model/aggregator.py:25-33, 70-72 = torch's post-LN
+ * TransformerDecoderLayer after the self-attention, and the next layer's in_proj).  A workgroup = 4 waves = 64 tokens; wave w owns a
+ * quarter of every product's output features for all 64 tokens, its weight fragments stream L2 -> registers (never through LDS),
+ * activations cross LDS as the fp16 hi | lo B-operand fragments of the next product, LayerNorm statistics as (mean, M2) pairs.
+ * w_post / w_qkv: paths_tlayer_pack_ws images (part 0 = out_proj, linear1, linear2 of THIS layer; part 1 = in_proj of the NEXT layer)
+ * with their power-of-two scales.  attn: fp32 [B,T,d], or attn_img: the fragment image written by paths_attention_h3_img.
+ * qkv_images: a paths_attention_x6_workspace(B, T, 4, 32, 2) buffer that receives the attention operand images (masked keys zeroed).
+ * zero_words (optional, do_post): n_zero <= 256 int32 words set to 0 by the launch (arrival counters of paths_token0_tail_ws). */
+int64_t paths_tlayer_ws_image_bytes(int part, int d);
+int paths_tlayer_pack_ws(int part, const float* wa, const float* wb, const float* wc, float s_a, float s_b, float s_c, void* out, int d,
+                         paths_stream_t stream);
+int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_img, float* x_out, const void* w_post, const void* w_qkv,
+                         const float* bo, const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                         const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
+                         float s_wo, float s_w1, float s_w2, float s_wqkv, void* qkv_images, const int64_t* num_ims,
+                         int B, int T, int d, int H, int do_post, int do_qkv, int skip_padding, float qscale, float eps,
+                         int* zero_words, int n_zero, paths_stream_t stream);
+/* paths_attention_x6 (planes = 2, operand images already in `workspace`) with the output written as the out_proj operand image of
+ * paths_token_layer_ws: B * ceil(T/64) * 64 * H * 32 * 4 bytes, [slide][64-token group][head][16-token tile][plane][64 lanes][16 B]. */
+int paths_attention_h3_img(void* o_img, const int64_t* num_ims, int B, int T, int H, int head_dim, void* workspace, paths_stream_t stream);
+
 /* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
  * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only
  * out[:, 0] of the final layer is read: it needs K/V of every token (q,k,v as written by paths_token_layer_f32 for

@@ -183,7 +183,7 @@ template <int NP, bool DROP>
 __global__ void __launch_bounds__(256, ATTN_OCC)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
                float* __restrict__ o, float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H,
-               int npairs_arg, int nqb_arg, DropSite drop
+               int npairs_arg, int nqb_arg, DropSite drop, char* __restrict__ o_img
 #ifdef PATHS_ATTN_DEBUG
                , unsigned long long* dbg
 #endif
@@ -372,6 +372,23 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     const float l = rows_sum(l_run[qt]);
     const float inv = 1.0f / l;
     const int qi = qw + 16 * qt + ql;
+    if constexpr (NP == 2) {
+      // O as the B-operand fragments of the out_proj product of tlayer_ws.hip: this lane's 8 values (dims 4 g4 + r of both dv tiles
+      // of query ql) are k-slot (g4, j) of k32 block `head`; image [slide][64-token group][head][16-token tile][plane][lane][16 B]
+      if (o_img != nullptr) {
+        const int tq = qw + 16 * qt;
+        if (tq < Tp) {
+          const float v[8] = {oacc[0][qt][0] * inv, oacc[0][qt][1] * inv, oacc[0][qt][2] * inv, oacc[0][qt][3] * inv,
+                              oacc[1][qt][0] * inv, oacc[1][qt][1] * inv, oacc[1][qt][2] * inv, oacc[1][qt][3] * inv};
+          u32x4 hi, lo;
+          split8h(v, hi, lo);
+          char* dst = o_img + ((((int64_t)b * (Tp >> 6) + (tq >> 6)) * H + head) * 4 + ((tq >> 4) & 3)) * (2 * FRAG) + lane * 16;
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+        }
+        continue;
+      }
+    }
     if (qi < T) {
       float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * g4;
       *reinterpret_cast<f32x4*>(op) = oacc[0][qt] * inv;
@@ -392,7 +409,8 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 
 template <int NP>
 int attention_split(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B, int T,
-                           int H, int max_queries, void* workspace, int images_ready, hipStream_t stream, uint64_t drop_key = 0, float drop_p = 0.f) {
+                           int H, int max_queries, void* workspace, int images_ready, hipStream_t stream, uint64_t drop_key = 0, float drop_p = 0.f,
+                           char* o_img = nullptr) {
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
   const int64_t img = (int64_t)B * H * Tp * HD * 2 * NP;
   char* q6 = reinterpret_cast<char*>(workspace);
@@ -423,12 +441,12 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   const DropSite site = paths_make_drop_site(drop_key, drop_p);
   // 1-D grid walked in XCD-aware order (see the kernel)
 #ifdef PATHS_ATTN_DEBUG
-  hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, g_attn_dbg);
+  hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, o_img, g_attn_dbg);
 #else
   if (drop_p > 0.f)
-    hipLaunchKernelGGL((attn_x6_kernel<NP, true>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site);
+    hipLaunchKernelGGL((attn_x6_kernel<NP, true>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, o_img);
   else
-    hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site);
+    hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, o_img);
 #endif
   PATHS_LAUNCH_CHECK("attention_x6");
   return PATHS_OK;
@@ -461,6 +479,16 @@ int paths_attention_x6(const float* q, const float* k, const float* v, float* o,
   PATHS_REQUIRE(planes == 2 || planes == 3, "attention_x6: planes must be 3 (bf16 x6) or 2 (fp16 x3)");
   return planes == 3 ? attention_split<3>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, 0, stream)
                      : attention_split<2>(q, k, v, o, lse, num_ims, B, T, H, max_queries, workspace, images_ready, stream);
+}
+
+// paths_attention_x6 with planes = 2 and images_ready (the workspace holds the operand images written by paths_token_layer_ws /
+// _h3), with the output written as the fp16 hi | lo fragment image paths_token_layer_ws reads as its out_proj operand
+// (B * ceil(T/64) * 64 * H * 32 * 4 bytes: [slide][64-token group][head][16-token tile][plane][64 lanes][16 B]) instead of fp32 o.
+int paths_attention_h3_img(void* o_img, const int64_t* num_ims, int B, int T, int H, int head_dim, void* workspace, hipStream_t stream) {
+  PATHS_REQUIRE(head_dim == HD && H == 4, "attention_h3_img: head_dim must be %d and H 4 (got %d, %d)", HD, head_dim, H);
+  PATHS_REQUIRE(B > 0 && T > 0 && num_ims != nullptr && workspace != nullptr && o_img != nullptr, "attention_h3_img: bad arguments B=%d T=%d", B, T);
+  PATHS_REQUIRE(((uintptr_t)o_img | (uintptr_t)workspace) % 16 == 0, "attention_h3_img: buffers must be 16-byte aligned");
+  return attention_split<2>(nullptr, nullptr, nullptr, nullptr, nullptr, num_ims, B, T, H, 0, workspace, 1, stream, 0, 0.f, reinterpret_cast<char*>(o_img));
 }
 
 // paths_attention_x6 in train mode with dropout p on the attention probabilities (reference nn.MultiheadAttention dropout):

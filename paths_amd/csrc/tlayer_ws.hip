@@ -1,0 +1,600 @@
+// Weight-stationary token-row chain of one post-LN nn.TransformerDecoderLayer (+ the next layer's QKV projection) on the fp16
+// matrix cores with fp32 accuracy (two-plane operand split, see gemm_x6.hip / tlayer_h3.hip).
+//
+// Same math and call site as paths_token_layer_h3 (reference model/aggregator.py:25-33, 70-72):
+//   x = norm1(x + out_proj(attn)) ; x = norm2(x + multihead_attn.out_proj.bias) ; x = norm3(x + linear2(relu(linear1(x))))
+//   q, k, v = in_proj(x) of the NEXT layer, q pre-scaled for the exp2 softmax
+//
+// What is different from tlayer_h3.hip (where every wave kept 16 tokens in registers and streamed ALL weights through LDS: each
+// wave re-read every 32-KiB weight chunk from LDS for 48 MFMAs, 24 dependent chunk steps, MFMA pipe 11 % busy):
+//   * a workgroup = 4 waves = 64 tokens; wave w owns the output features [w N/4, (w+1) N/4) of every product for ALL 64 tokens
+//     (products are still computed transposed, Y^T[out][token] = W[out][:] X^T[:][token]);
+//   * the weights of a wave's slice are read by that wave only, so they never touch LDS: they stream global (L2) -> registers
+//     through a prefetch ring, as ready-made MFMA fragments (1 KiB per load instruction, fully coalesced);
+//   * the ACTIVATIONS are what the waves share: each product's result is split into fp16 hi | lo planes in registers and written
+//     to LDS as the B-operand fragments of the next product (the accumulators of two 16-feature tiles in k-slot order (g, j) <->
+//     feature 4g + (j&3) + 16 (j>>2) ARE one k32 block of that operand), one barrier per product;
+//   * LayerNorm statistics cross the four waves through LDS as (mean, M2) pairs merged with Chan's formula (one barrier each);
+//   * 96-192 MFMAs per wave between barriers instead of 48, 10 barriers per 64 tokens instead of 24 per 128.
+// q / k images use the k-slot dim order (a permutation of the contraction index of q.k, harmless as long as q and k agree);
+// v is computed with the operands swapped (tokens as MFMA rows), which yields the V^T fragments of attn_x6.hip without shuffles.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FRAG = 1024;         // bytes of one 16-row x 32-k fragment of one plane
+constexpr int NW = 4;              // waves per workgroup
+constexpr int TT = 4;              // 16-token tiles per workgroup
+constexpr int TOK = 16 * TT;
+constexpr int NFF = 4;             // feed-forward hidden chunks of DM features (dim_feedforward = 4 DM, reference aggregator.py:29)
+#ifndef PATHS_WS_NPF
+#define PATHS_WS_NPF 4
+#endif
+constexpr int NPF = PATHS_WS_NPF;  // weight prefetch ring: k32 steps in flight per wave
+
+template <int DM> struct Geo {
+  static_assert(DM % 64 == 0, "trans_dim must be a multiple of 64");
+  static constexpr int KB = DM / 32;                      // k32 blocks of a DM-wide activation
+  static constexpr int OT = DM / 64;                      // 16-feature output tiles per wave of an N = DM product
+  static constexpr int STEP = OT * 2 * FRAG;              // weight bytes one wave consumes per k32 step
+  static constexpr int WAVE_UNIT = KB * STEP;             // one wave's slice of a unit (N = DM outputs x K = DM inputs)
+  static constexpr int UNIT = NW * WAVE_UNIT;             // = DM * DM * 4 bytes
+  static constexpr int ACT = KB * TT * 2 * FRAG;          // activation image of 64 tokens: [kb][tt][plane][64 lanes][16 B]
+  static constexpr int N_POST = 1 + 2 * NFF, N_QKV = 3;   // units: Wo | (W1 rows c DM.., W2[:, c DM..]) x 4   and   Wq | Wk | Wv
+};
+
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+// 8 fp32 -> hi | lo planes of 8 fp16 (22 significant bits)
+__device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const uint32_t h = pk_f16(a, b);
+    float ra, rb;
+    f16_pair_residuals(h, a, b, ra, rb);
+    hi[i] = h; lo[i] = pk_f16(ra, rb);
+  }
+}
+__device__ __forceinline__ void split4h(const float (&x)[4], u32x2& hi, u32x2& lo) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const uint32_t h = pk_f16(a, b);
+    float ra, rb;
+    f16_pair_residuals(h, a, b, ra, rb);
+    hi[i] = h; lo[i] = pk_f16(ra, rb);
+  }
+}
+__device__ __forceinline__ f32x4 mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 ldg_u32x4(const char* p) {
+  typedef const u32x4 __attribute__((address_space(1))) * gptr;
+  return *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p));
+}
+
+// x + (x of lane ^ 16) and x + (x of lane ^ 32) by v_permlane16/32_swap (VALU latency instead of the LDS round trip of
+// ds_bpermute).  v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second: given the same value in both, the two results
+// add up to the pair sum in every lane.  Inline asm: through __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) added result 0 to
+// itself here (v_add v, r0, r0: wrong sums).  s_nop 1 = the two wait states between a VALU write of an operand and the swap.
+__device__ __forceinline__ float sum_xor16(float x) {
+#ifdef PATHS_WS_LN_SHFL
+  return x + __shfl_xor(x, 16);
+#endif
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+#ifdef PATHS_WS_LN_SHFL
+  return x + __shfl_xor(x, 32);
+#endif
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+#ifdef PATHS_WS_STAMPS
+#define WS_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (p.stamps && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WS_STAMP(i) do { } while (0)
+#endif
+
+struct WsParams {
+  const float* x_in;            // [B][T][DM] residual stream (POST) / in_proj input (QKV only)
+  const float* attn;            // POST: attention output, fp32 token-major [B][T][DM] (when attn_img is null)
+  const char* attn_img;         // POST: or its fragment image [B][Tp/64][kb = head][tt][plane][64 lanes][16 B] (attn_x6.hip)
+  float* x_out;                 // POST: [B][T][DM]
+  const char* w_post;           // 9 units (paths_tlayer_pack_ws part 0 of THIS layer)
+  const char* w_qkv;            // 3 units (part 1 of the NEXT layer)
+  const float *bo, *ln1g, *ln1b, *cab, *ln2g, *ln2b, *b1, *b2, *ln3g, *ln3b, *bqkv;
+  float inv_wo, inv_w1, inv_w2, inv_wqkv;      // 1 / (power-of-two scale of the packed tensor)
+  char* qkv_img;                // QKV: the two-plane operand images of attn_x6_kernel<2>, Q | K | V
+  const int64_t* num_ims;
+  int T, Tp, B, skip_padding;
+  float qscale, eps;
+  int* zero_words; int n_zero;  // optional: words zeroed by block (0, 0) (the arrival counters of the token-0 tail that follows)
+#ifdef PATHS_WS_STAMPS
+  unsigned long long* stamps;   // diagnostic build only: 16 s_memtime stamps per workgroup
+#endif
+};
+
+// One workgroup = 64 tokens of one slide.  Lane (ql = lane & 15, g = lane >> 4) of wave w holds, for token tile tt and output
+// tile ot, the features 16 (OT w + ot) + 4 g + r (r = 0..3) of token 16 tt + ql  -  the C layout of v_mfma_f32_16x16x32_f16 with the
+// weights as A (rows = output features) and the activations as B (columns = tokens).
+template <int DM, bool POST, bool QKV>
+__global__ void __launch_bounds__(64 * NW, 1)
+tlayer_ws_kernel(WsParams p) {
+  using G = Geo<DM>;
+  constexpr int KB = G::KB, OT = G::OT;
+  constexpr int POST_STEPS = POST ? G::N_POST * KB : 0, NSTEPS = POST_STEPS + (QKV ? G::N_QKV * KB : 0);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sAct = smem;                                                        // [ACT]
+  char* const sHid = smem + G::ACT;                                               // POST: [2][ACT]
+  float* const sStat = reinterpret_cast<float*>(smem + G::ACT + (POST ? 2 * G::ACT : 0));   // [2][NW][TOK][2]
+  float* const sVec = sStat + 2 * NW * TOK * 2;                                   // POST: 9 DM + 4 DM floats, then QKV: 3 DM
+  float* const sB1 = sVec + 9 * DM;
+  float* const sBqkv = sVec + (POST ? 13 * DM : 0);
+
+  const int b = blockIdx.y, t0 = blockIdx.x * TOK;
+  const int tid = threadIdx.x, lane = tid & 63, ql = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (POST && p.zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid < p.n_zero) p.zero_words[tid] = 0;
+  const int len = p.num_ims ? min((int)p.num_ims[b] + 1, p.T) : p.T;               // valid tokens: special token + patches
+  if (p.skip_padding && t0 >= len) return;
+  const int fbase = 16 * OT * wave + 4 * g;                                       // this lane's first feature (tile 0)
+  WS_STAMP(0);
+
+  // ---- weight stream of this wave: [unit][wave][kb][ot][plane][64 lanes][16 B]; a k32 step = OT x 2 loads of 1 KiB
+  u32x4 wr[NPF][OT][2];
+  auto wload = [&](auto S_) __attribute__((always_inline)) {
+    constexpr int S = decltype(S_)::value;
+    if constexpr (S < NSTEPS) {
+      constexpr bool in_post = S < POST_STEPS;
+      constexpr int s = in_post ? S : S - POST_STEPS;
+      const char* src = (in_post ? p.w_post : p.w_qkv) + (int64_t)(s / KB) * G::UNIT + wave * G::WAVE_UNIT + (s % KB) * G::STEP + lane * 16;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wr[S % NPF][ot][pl] = ldg_u32x4(src + (ot * 2 + pl) * FRAG);
+    }
+  };
+
+  // ---- prologue: residual rows, the small vectors, the first activation image, the head of the weight stream
+  int tokc[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) tokc[tt] = min(t0 + 16 * tt + ql, p.T - 1);
+  f32x4 xr[OT][TT];                 // POST: the residual stream of this lane's (feature, token) set
+  if constexpr (POST) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) xr[ot][tt] = ldg_f32x4(p.x_in + ((int64_t)b * p.T + tokc[tt]) * DM + fbase + 16 * ot);
+  }
+  static_for<0, NPF - 1>([&](auto s) { wload(s); });
+  if constexpr (POST) {
+    const float* const vecs[9] = {p.bo, p.ln1g, p.ln1b, p.cab, p.ln2g, p.ln2b, p.b2, p.ln3g, p.ln3b};
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      for (int i = tid; i < DM; i += 64 * NW) sVec[j * DM + i] = vecs[j][i];
+    for (int i = tid; i < 4 * DM; i += 64 * NW) sB1[i] = p.b1[i];
+  }
+  if constexpr (QKV) for (int i = tid; i < 3 * DM; i += 64 * NW) sBqkv[i] = p.bqkv[i];
+
+  // first B-operand image: the attention output (POST) or the input rows themselves (QKV only)
+  if (POST && p.attn_img != nullptr) {
+    const char* src = p.attn_img + ((int64_t)b * (p.Tp / TOK) + (t0 / TOK)) * G::ACT;
+#pragma unroll
+    for (int i = 0; i < G::ACT / (16 * 64 * NW); ++i)
+      *reinterpret_cast<u32x4*>(sAct + (tid + i * 64 * NW) * 16) = ldg_u32x4(src + (tid + i * 64 * NW) * 16);
+  } else {
+    const float* src = POST ? p.attn : p.x_in;
+    for (int kb = wave; kb < KB; kb += NW) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const float* row = src + ((int64_t)b * p.T + tokc[tt]) * DM + 32 * kb + 4 * g;
+        const f32x4 a = ldg_f32x4(row), c = ldg_f32x4(row + 16);
+        const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        u32x4 hi, lo;
+        split8h(v, hi, lo);
+        *reinterpret_cast<u32x4*>(sAct + ((kb * TT + tt) * 2) * FRAG + lane * 16) = hi;
+        *reinterpret_cast<u32x4*>(sAct + ((kb * TT + tt) * 2 + 1) * FRAG + lane * 16) = lo;
+      }
+    }
+  }
+  __syncthreads();
+  WS_STAMP(1);
+
+  // acc[ot][tt] += W_unit[this wave's rows 16 ot ..][all DM k] . X[k][token tile tt]   (SWAP: the operands exchanged, rows = tokens)
+  // The B fragments of k32 step kb + 1 are read from LDS while the MFMAs of step kb run (two register sets; a step's reads were
+  // otherwise exposed: ~300 of ~700 cycles per step).  PRE: block 0 is already in bf[0] (the previous unit fetched it, NEXT).
+  u32x4 bf[2][TT][2];
+  auto ldsb = [&](auto slot_, const char* sB, int kb) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_)::value;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bf[slot][tt][pl] = *reinterpret_cast<const u32x4*>(sB + ((kb * TT + tt) * 2 + pl) * FRAG + lane * 16);
+  };
+  auto unit = [&](auto S0_, auto swap_, auto pre_, f32x4 (&acc)[OT][TT], const char* sB, const char* sNext) __attribute__((always_inline)) {
+    constexpr int S0 = decltype(S0_)::value;
+    constexpr bool SWAP = decltype(swap_)::value, PRE = decltype(pre_)::value;
+    static_assert(KB % 2 == 0, "fragment double buffer: even number of k32 steps per unit");
+    if constexpr (!PRE) ldsb(std::integral_constant<int, 0>{}, sB, 0);
+    static_for<0, KB>([&](auto kb_) {
+      constexpr int kb = decltype(kb_)::value, S = S0 + kb, slot = S % NPF, cur = kb & 1;
+      wload(std::integral_constant<int, S + NPF - 1>{});
+      if constexpr (kb + 1 < KB) ldsb(std::integral_constant<int, cur ^ 1>{}, sB, kb + 1);
+      else if (sNext != nullptr) ldsb(std::integral_constant<int, 0>{}, sNext, 0);
+      __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise sinks the fragment reads down to their first use: next step's head)
+      // hi*hi + hi*lo + lo*hi, smallest first
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+          acc[ot][tt] = SWAP ? mfma_f16(bf[cur][tt][0], wr[slot][ot][1], acc[ot][tt]) : mfma_f16(wr[slot][ot][1], bf[cur][tt][0], acc[ot][tt]);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+          acc[ot][tt] = SWAP ? mfma_f16(bf[cur][tt][1], wr[slot][ot][0], acc[ot][tt]) : mfma_f16(wr[slot][ot][0], bf[cur][tt][1], acc[ot][tt]);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+          acc[ot][tt] = SWAP ? mfma_f16(bf[cur][tt][0], wr[slot][ot][0], acc[ot][tt]) : mfma_f16(wr[slot][ot][0], bf[cur][tt][0], acc[ot][tt]);
+    });
+  };
+  constexpr std::false_type NO{};
+  constexpr std::true_type YES{};
+  auto zero = [&](f32x4 (&a)[OT][TT]) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) a[ot][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  // this wave's features of all 64 tokens -> fp16 hi | lo fragments of the k32 blocks they belong to (tile pair = one block)
+  auto put_act = [&](const f32x4 (&x)[OT][TT], char* img) __attribute__((always_inline)) {
+    if constexpr (OT % 2 == 0) {
+#pragma unroll
+      for (int op = 0; op < OT / 2; ++op) {
+        const int blk = (OT / 2) * wave + op;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const float v[8] = {x[2 * op][tt][0], x[2 * op][tt][1], x[2 * op][tt][2], x[2 * op][tt][3],
+                              x[2 * op + 1][tt][0], x[2 * op + 1][tt][1], x[2 * op + 1][tt][2], x[2 * op + 1][tt][3]};
+          u32x4 hi, lo;
+          split8h(v, hi, lo);
+          *reinterpret_cast<u32x4*>(img + ((blk * TT + tt) * 2) * FRAG + lane * 16) = hi;
+          *reinterpret_cast<u32x4*>(img + ((blk * TT + tt) * 2 + 1) * FRAG + lane * 16) = lo;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int gt = OT * wave + ot, blk = gt >> 1, half = gt & 1;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          const float v[4] = {x[ot][tt][0], x[ot][tt][1], x[ot][tt][2], x[ot][tt][3]};
+          u32x2 hi, lo;
+          split4h(v, hi, lo);
+          *reinterpret_cast<u32x2*>(img + ((blk * TT + tt) * 2) * FRAG + lane * 16 + 8 * half) = hi;
+          *reinterpret_cast<u32x2*>(img + ((blk * TT + tt) * 2 + 1) * FRAG + lane * 16 + 8 * half) = lo;
+        }
+      }
+    }
+  };
+  // LayerNorm over the DM features of every token: the wave's DM/4 features give (mean, M2) per token, the four waves' pairs
+  // cross through LDS and are merged with Chan's formula (two-pass accuracy, one barrier)
+  auto layernorm = [&](f32x4 (&x)[OT][TT], const float* gamma, const float* beta, int sbuf) __attribute__((always_inline)) {
+    float* st = sStat + sbuf * NW * TOK * 2;
+    constexpr float inv_w = 1.0f / (DM / NW);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      float s = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) s += (x[ot][tt][0] + x[ot][tt][1]) + (x[ot][tt][2] + x[ot][tt][3]);
+      s = sum_xor32(sum_xor16(s));
+      const float mw = s * inv_w;
+      float v = 0.f;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float c = x[ot][tt][r] - mw; v += c * c; }
+      v = sum_xor32(sum_xor16(v));
+      if (g == 0) *reinterpret_cast<f32x2*>(st + (wave * TOK + 16 * tt + ql) * 2) = f32x2{mw, v};
+    }
+    __syncthreads();
+    f32x4 gm[OT], bt[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      gm[ot] = *reinterpret_cast<const f32x4*>(gamma + fbase + 16 * ot);
+      bt[ot] = *reinterpret_cast<const f32x4*>(beta + fbase + 16 * ot);
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      f32x2 ms[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) ms[w] = *reinterpret_cast<const f32x2*>(st + (w * TOK + 16 * tt + ql) * 2);
+      const float mean = ((ms[0][0] + ms[1][0]) + (ms[2][0] + ms[3][0])) * (1.0f / NW);
+      float m2 = (ms[0][1] + ms[1][1]) + (ms[2][1] + ms[3][1]);
+      float dev = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const float dlt = ms[w][0] - mean; dev += dlt * dlt; }
+      m2 += dev * (float)(DM / NW);
+      const float rstd = 1.0f / sqrtf(m2 * (1.0f / DM) + p.eps);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[ot][tt][r] = (x[ot][tt][r] - mean) * rstd * gm[ot][r] + bt[ot][r];
+    }
+  };
+
+  if constexpr (POST) {
+    // ---- out_proj(attn) + residual -> norm1 -> + cross-attention bias -> norm2
+    {
+      f32x4 acc[OT][TT];
+      zero(acc);
+      unit(std::integral_constant<int, 0>{}, NO, NO, acc, sAct, nullptr);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const f32x4 bo = *reinterpret_cast<const f32x4*>(sVec + fbase + 16 * ot);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) xr[ot][tt] = xr[ot][tt] + (acc[ot][tt] * p.inv_wo + bo);
+      }
+    }
+    WS_STAMP(2);
+    layernorm(xr, sVec + DM, sVec + 2 * DM, 0);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x4 cab = *reinterpret_cast<const f32x4*>(sVec + 3 * DM + fbase + 16 * ot);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) xr[ot][tt] = xr[ot][tt] + cab;
+    }
+    layernorm(xr, sVec + 4 * DM, sVec + 5 * DM, 1);
+    WS_STAMP(3);
+    put_act(xr, sAct);                      // (every wave has finished reading the attention image: two barriers ago)
+    __syncthreads();
+    WS_STAMP(4);
+
+    // ---- feed-forward in 4 hidden chunks of DM: hid = relu(W1_c x + b1_c) -> LDS -> y += W2[:, c] hid.  linear2 of chunk c and
+    // linear1 of chunk c + 1 run back to back (no barrier between them): one 8-step pipelined sequence per chunk
+    f32x4 y[OT][TT], hid[OT][TT];
+    zero(y);
+    auto put_hidden = [&](auto c_) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_)::value;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB1 + c * DM + fbase + 16 * ot);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hid[ot][tt][r] = fmaxf(fmaf(hid[ot][tt][r], p.inv_w1, b1[r]), 0.f);
+      }
+      put_act(hid, sHid + (c & 1) * G::ACT);      // (chunk c-2's readers all passed the barrier of chunk c-1)
+      __syncthreads();
+    };
+    zero(hid);
+    unit(std::integral_constant<int, KB>{}, NO, NO, hid, sAct, nullptr);
+    put_hidden(std::integral_constant<int, 0>{});
+    static_for<0, NFF>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      unit(std::integral_constant<int, (2 + 2 * c) * KB>{}, NO, NO, y, sHid + (c & 1) * G::ACT, c + 1 < NFF ? sAct : nullptr);
+      if constexpr (c + 1 < NFF) {
+        zero(hid);
+        unit(std::integral_constant<int, (3 + 2 * c) * KB>{}, NO, YES, hid, sAct, nullptr);
+        put_hidden(std::integral_constant<int, c + 1>{});
+      }
+      WS_STAMP(5 + c);
+    });
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(sVec + 6 * DM + fbase + 16 * ot);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) xr[ot][tt] = xr[ot][tt] + (y[ot][tt] * p.inv_w2 + b2);
+    }
+    layernorm(xr, sVec + 7 * DM, sVec + 8 * DM, 0);
+    WS_STAMP(9);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      if (t0 + 16 * tt + ql < p.T) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+          *reinterpret_cast<f32x4*>(p.x_out + ((int64_t)b * p.T + t0 + 16 * tt + ql) * DM + fbase + 16 * ot) = xr[ot][tt];
+      }
+    if constexpr (QKV) {
+      put_act(xr, sAct);                    // (the last reader of the x1 image, linear1 of chunk 3, is two barriers back)
+      __syncthreads();
+    }
+    WS_STAMP(10);
+  }
+
+  if constexpr (QKV) {
+    static_assert(OT == 2, "in_proj images: head_dim 32 (one k32 block per head)");
+    // ---- in_proj: wave w = head w.  q, k: features on the accumulator rows; v: operands swapped, tokens on the rows
+    const int64_t img = (int64_t)p.B * NW * p.Tp * 128;          // bytes of one of the three images (32 dims x 2 planes x 2 B)
+    char* const hbase = p.qkv_img + ((int64_t)b * NW + wave) * p.Tp * 128;
+    static_for<0, 2>([&](auto which_) {
+      constexpr int which = decltype(which_)::value;
+      f32x4 acc[OT][TT];
+      zero(acc);
+      if constexpr (which == 0) unit(std::integral_constant<int, POST_STEPS>{}, NO, NO, acc, sAct, sAct);
+      else unit(std::integral_constant<int, POST_STEPS + KB>{}, NO, YES, acc, sAct, sAct);
+      WS_STAMP(11 + 2 * which);
+      const float sc = which == 0 ? p.qscale : 1.0f;
+      f32x4 bb[OT];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) bb[ot] = *reinterpret_cast<const f32x4*>(sBqkv + which * DM + fbase + 16 * ot);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int tok = t0 + 16 * tt + ql;
+        const bool live = which == 0 ? tok < p.T : tok < len;    // masked keys: K = 0 (V = 0 below: 0 * garbage would poison O)
+        float v[8];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * ot + r] = live ? (acc[ot][tt][r] * p.inv_wqkv + bb[ot][r]) * sc : 0.f;
+        u32x4 hi, lo;
+        split8h(v, hi, lo);
+        char* dst = hbase + which * img + (int64_t)((t0 >> 4) + tt) * 2 * FRAG + lane * 16;   // Q6 / K6: [16-token tile][plane][lane]
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+      }
+      WS_STAMP(12 + 2 * which);
+    });
+    {
+      f32x4 acc[OT][TT];                    // [dv tile][token tile]: column = dim 16 ot + ql, rows = tokens 16 tt + 4 g + r
+      zero(acc);
+      unit(std::integral_constant<int, POST_STEPS + 2 * KB>{}, YES, YES, acc, sAct, nullptr);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const float bv = sBqkv[2 * DM + 16 * OT * wave + 16 * ot + ql];
+#pragma unroll
+        for (int u = 0; u < TT / 2; ++u) {  // 32-key group: k-slot (g, j) <-> key 4 g + (j & 3) + 16 (j >> 2)
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int tok = t0 + 32 * u + 16 * (j >> 2) + 4 * g + (j & 3);
+            v[j] = tok < len ? acc[ot][2 * u + (j >> 2)][j & 3] * p.inv_wqkv + bv : 0.f;
+          }
+          u32x4 hi, lo;
+          split8h(v, hi, lo);
+          char* dst = hbase + 2 * img + (int64_t)(((t0 >> 5) + u) * 2 + ot) * 2 * FRAG + lane * 16;   // V6: [32 keys][dv tile][plane][lane]
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+        }
+      }
+    }
+  }
+  WS_STAMP(15);
+}
+
+// One fragment-pair chunk per workgroup: unit `blockIdx.x`, all of its [wave][kb][ot][plane] fragments.
+struct WsPackJob { const float* w; int ldw; int row0; int k0; float scale; };
+struct WsPackJobs { WsPackJob j[12]; };
+
+template <int DM>
+__global__ void __launch_bounds__(256)
+tlayer_pack_ws_kernel(WsPackJobs jobs, char* __restrict__ out) {
+  using G = Geo<DM>;
+  const WsPackJob jb = jobs.j[blockIdx.x];
+  char* dst = out + (int64_t)blockIdx.x * G::UNIT;
+  for (int piece = threadIdx.x; piece < G::UNIT / 16; piece += 256) {
+    const int lane = piece & 63, f = piece >> 6;                // fragment f = ((wave * KB + kb) * OT + ot) * 2 + plane
+    const int plane = f & 1, ot = (f >> 1) % G::OT, kb = ((f >> 1) / G::OT) % G::KB, wave = (f >> 1) / (G::OT * G::KB);
+    const int ql = lane & 15, g = lane >> 4;
+    const float* src = jb.w + (int64_t)(jb.row0 + 16 * (G::OT * wave + ot) + ql) * jb.ldw + jb.k0 + 32 * kb;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[4 * g + (j & 3) + 16 * (j >> 2)] * jb.scale;
+    u32x4 hi, lo;
+    split8h(v, hi, lo);
+    *reinterpret_cast<u32x4*>(dst + (int64_t)f * FRAG + lane * 16) = plane == 0 ? hi : lo;
+  }
+}
+
+template <int DM>
+size_t ws_lds_bytes(bool post, bool qkv) {
+  return Geo<DM>::ACT + (post ? 2 * Geo<DM>::ACT : 0) + 2 * NW * TOK * 2 * sizeof(float) + ((post ? 13 * DM : 0) + (qkv ? 3 * DM : 0)) * sizeof(float);
+}
+
+template <int DM, bool POST, bool QKV>
+int launch_ws(const WsParams& p, hipStream_t stream) {
+  const size_t lds = ws_lds_bytes<DM>(POST, QKV);
+  // per-device opt-in for > 64 KiB of dynamic LDS (checked: a failure here would otherwise surface as a launch error)
+  static int attr_dev[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "token_layer_ws: hipGetDevice failed");
+  if (dev < 0 || dev >= 64 || !attr_dev[dev]) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_ws_kernel<DM, POST, QKV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    if (e != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "token_layer_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (dev >= 0 && dev < 64) attr_dev[dev] = 1;
+  }
+  // (> 80 KiB per workgroup: one workgroup per CU, so a grid of ~one workgroup per CU spreads over the whole chip)
+  const size_t ask = lds > 84 * 1024 ? lds : 84 * 1024;
+  hipLaunchKernelGGL((tlayer_ws_kernel<DM, POST, QKV>), dim3((p.T + TOK - 1) / TOK, p.B), dim3(64 * NW), ask, stream, p);
+  PATHS_LAUNCH_CHECK("token_layer_ws");
+  return PATHS_OK;
+}
+
+}  // namespace
+
+#ifdef PATHS_WS_STAMPS
+static unsigned long long* g_ws_stamps = nullptr;
+extern "C" void paths_ws_stamp_buffer(unsigned long long* p) { g_ws_stamps = p; }     // development hook (tools/ws_time.py)
+#endif
+
+extern "C" {
+
+// bytes of the weight images of paths_token_layer_ws: part 0 = (Wo, W1, W2) of one layer (9 units), part 1 = in_proj (3 units)
+int64_t paths_tlayer_ws_image_bytes(int part, int d) {
+  return (int64_t)(part == 0 ? 9 : 3) * d * d * 4;
+}
+
+// Pack one part: part 0 = (wo [d,d], w1 [4d,d], w2 [d,4d]) scaled by the powers of two s_a, s_b, s_c; part 1 = wqkv [3d,d] by s_a.
+int paths_tlayer_pack_ws(int part, const float* wa, const float* wb, const float* wc, float s_a, float s_b, float s_c, void* out, int d,
+                         hipStream_t stream) {
+  PATHS_REQUIRE(d == 128, "tlayer_pack_ws: trans_dim must be 128 (got %d)", d);
+  PATHS_REQUIRE((part == 0 && wa && wb && wc) || (part == 1 && wa), "tlayer_pack_ws: bad arguments");
+  PATHS_REQUIRE(out != nullptr && (uintptr_t)out % 16 == 0, "tlayer_pack_ws: out must be 16-byte aligned");
+  WsPackJobs jobs;
+  int n = 0;
+  if (part == 0) {
+    jobs.j[n++] = WsPackJob{wa, d, 0, 0, s_a};
+    for (int c = 0; c < NFF; ++c) {
+      jobs.j[n++] = WsPackJob{wb, d, d * c, 0, s_b};
+      jobs.j[n++] = WsPackJob{wc, 4 * d, 0, d * c, s_c};
+    }
+  } else {
+    for (int c = 0; c < 3; ++c) jobs.j[n++] = WsPackJob{wa, d, d * c, 0, s_a};
+  }
+  hipLaunchKernelGGL(tlayer_pack_ws_kernel<128>, dim3(n), dim3(256), 0, stream, jobs, reinterpret_cast<char*>(out));
+  PATHS_LAUNCH_CHECK("tlayer_pack_ws");
+  return PATHS_OK;
+}
+
+// The decoder layer's token-row chain (reference model/aggregator.py:25-33, 70-72 = torch's post-LN TransformerDecoderLayer after
+// the self-attention) and / or the next layer's in_proj, weight-stationary form.  w_post / w_qkv: paths_tlayer_pack_ws images with
+// scales s_*.  attn: fp32 [B,T,d], or attn_img: the fragment image paths_attention_h3_img wrote.  qkv_images: a
+// paths_attention_x6_workspace(B, T, 4, 32, 2) buffer (the operand images of paths_attention_x6 / _h3_img).  zero_words
+// (optional): n_zero <= 256 int32 words set to 0 (the arrival counters of paths_token0_tail_ws, which follows on the same stream).
+int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_img, float* x_out, const void* w_post, const void* w_qkv,
+                         const float* bo, const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                         const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
+                         float s_wo, float s_w1, float s_w2, float s_wqkv, void* qkv_images, const int64_t* num_ims,
+                         int B, int T, int d, int H, int do_post, int do_qkv, int skip_padding, float qscale, float eps,
+                         int* zero_words, int n_zero, hipStream_t stream) {
+  PATHS_REQUIRE(d == 128 && H == 4, "token_layer_ws: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
+  PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer_ws: nothing to do");
+  PATHS_REQUIRE(!skip_padding || num_ims, "token_layer_ws: skip_padding needs num_ims");
+  PATHS_REQUIRE(x_in && (!do_post || ((attn || attn_img) && x_out && w_post && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b)),
+                "token_layer_ws: null operand (post)");
+  PATHS_REQUIRE(!do_qkv || (w_qkv && bqkv && qkv_images), "token_layer_ws: null operand (in_proj)");
+  PATHS_REQUIRE(n_zero >= 0 && n_zero <= 256 && (n_zero == 0 || (zero_words && do_post)), "token_layer_ws: zero_words needs do_post, n_zero <= 256");
+  PATHS_REQUIRE(((uintptr_t)x_in | (uintptr_t)attn | (uintptr_t)attn_img | (uintptr_t)x_out | (uintptr_t)w_post | (uintptr_t)w_qkv | (uintptr_t)qkv_images) % 16 == 0,
+                "token_layer_ws: buffers must be 16-byte aligned");
+  WsParams p{x_in, attn, reinterpret_cast<const char*>(attn_img), x_out, reinterpret_cast<const char*>(w_post), reinterpret_cast<const char*>(w_qkv),
+             bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, bqkv,
+             do_post ? 1.0f / s_wo : 1.0f, do_post ? 1.0f / s_w1 : 1.0f, do_post ? 1.0f / s_w2 : 1.0f, do_qkv ? 1.0f / s_wqkv : 1.0f,
+             reinterpret_cast<char*>(qkv_images), num_ims, T, (T + 63) / 64 * 64, B, skip_padding, qscale, eps, zero_words, n_zero
+#ifdef PATHS_WS_STAMPS
+             , g_ws_stamps
+#endif
+  };
+  if (do_post && do_qkv) return launch_ws<128, true, true>(p, stream);
+  if (do_post) return launch_ws<128, true, false>(p, stream);
+  return launch_ws<128, false, true>(p, stream);
+}
+
+}  // extern "C"

@@ -24,6 +24,7 @@ from . import _lib
 
 LOG2E = 1.4426950408889634
 QKV_IMAGES = os.environ.get("PATHS_QKV_IMAGES", "1") != "0"
+TLAYER_WS = os.environ.get("PATHS_TLAYER_WS", "1") != "0"      # weight-stationary token-layer kernel (csrc/tlayer_ws.hip)
 SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 TIMER_ALL = False     # with KERNEL_TIMER: False = bracket only the dominant kernel and the aggregator span (the timed region of
@@ -180,6 +181,22 @@ def tlayer_h3_images(layer: Dict[str, object], part: int):
         pw = [_lib.ptr(w) for w in ws] + [None] * (3 - len(ws))
         sc = list(scales) + [1.0] * (3 - len(scales))
         _lib.call("paths_tlayer_pack_h3", part, pw[0], pw[1], pw[2], sc[0], sc[1], sc[2], _lib.ptr(img), _lib.stream())
+        layer[key] = (img, scales)
+    return layer[key]
+
+
+def tlayer_ws_images(layer: Dict[str, object], part: int):
+    """(image, scales) of a decoder layer's weights for paths_token_layer_ws: part 0 = (wo, w1, w2), part 1 = wqkv; cached in the
+    layer's pack dict like :func:`tlayer_h3_images`."""
+    key = f"ws_image_{part}"
+    if key not in layer:
+        ws = [layer["wo"], layer["w1"], layer["w2"]] if part == 0 else [layer["wqkv"]]
+        scales = tuple(_pow2_scale(w) for w in ws)
+        d = layer["wo"].shape[0]
+        img = torch.empty((int(_lib.load().paths_tlayer_ws_image_bytes(part, d)),), device=ws[0].device, dtype=torch.uint8)
+        pw = [_lib.ptr(w) for w in ws] + [None] * (3 - len(ws))
+        sc = list(scales) + [1.0] * (3 - len(scales))
+        _lib.call("paths_tlayer_pack_ws", part, pw[0], pw[1], pw[2], sc[0], sc[1], sc[2], _lib.ptr(img), d, _lib.stream())
         layer[key] = (img, scales)
     return layer[key]
 
@@ -525,6 +542,55 @@ def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict
                  detail=False)
 
 
+def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_img, q, k, v, xb, ctx_out, logits, token_layer_old):
+    """Default-mode aggregator on the weight-stationary token-layer kernel (csrc/tlayer_ws.hip): in_proj writes the attention
+    operand images, attention writes its output as the out_proj operand image, the chain kernel keeps weights in registers and
+    shares only activations through LDS."""
+    B, T, d = tokens.shape
+    H, L = mc.trans_heads, mc.trans_layers
+    hd = d // H
+    st = _lib.stream()
+    p = _lib.ptr
+    layers = lvl_pack["layers"]
+    qscale = LOG2E / math.sqrt(hd)
+    Tp = (T + 63) // 64 * 64
+    o_img = torch.empty((B * Tp * d * 4,), device=tokens.device, dtype=torch.uint8)
+    g = lambda dct, key: p(dct[key]) if dct is not None else None
+
+    def token_layer(x_in, x_out, post, nxt, use_img=True):
+        w = post or nxt
+        ip, sp = tlayer_ws_images(post, 0) if post is not None else (None, (1.0, 1.0, 1.0))
+        iq, sq = tlayer_ws_images(nxt, 1) if nxt is not None else (None, (1.0,))
+        _lib.call("paths_token_layer_ws", p(x_in), None, p(o_img) if post is not None else None, p(x_out) if post is not None else None,
+                  p(ip), p(iq), g(post, "bo"), g(post, "ln1g"), g(post, "ln1b"), g(post, "cab"), g(post, "ln2g"), g(post, "ln2b"),
+                  g(post, "b1"), g(post, "b2"), g(post, "ln3g"), g(post, "ln3b"), g(nxt, "bqkv"),
+                  sp[0], sp[1], sp[2], sq[0], p(qkv_img) if nxt is not None else None, p(num_ims), B, T, d, H,
+                  1 if post is not None else 0, 1 if nxt is not None else 0, 1, qscale, w["eps"], None, 0, st)
+
+    xa = tokens
+    timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0]))
+    for l in range(L - 1):
+        timed("agg_attention", lambda: _lib.call("paths_attention_h3_img", p(o_img), p(num_ims), B, T, H, hd, p(qkv_img), st))
+        last = l + 1 == L - 1
+        timed("agg_token_chain", lambda: token_layer(xa, xb, layers[l], None if last else layers[l + 1]))
+        xa, xb = xb, xa
+    w = layers[L - 1]
+
+    def tail():
+        token_layer_old(xa, None, None, w)          # fp32 q, k, v of the last layer for the token-0 tail
+        ws_part = torch.empty((B * H * 16 * 36,), device=tokens.device, dtype=torch.float32)
+        _lib.call(
+            "paths_token0_tail", p(xa), p(q), p(k), p(v), p(num_ims), p(w["wo"]), p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
+            p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["w1"]), p(w["b1"]), p(w["w2"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]),
+            p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
+            res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
+            p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), logits.shape[1], lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
+            p(ws_part), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
+
+    timed("agg_token0_tail", tail)
+    return {"logits": logits, "ctx_slide": ctx_out}
+
+
 def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
     _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
     B, T, d = tokens.shape
@@ -576,6 +642,8 @@ def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dic
     # default mode: the in_proj of a layer that feeds the full attention writes the attention kernel's operand images itself
     # (no fp32 q, k, v round trip, no re-write launch); the last layer's q, k, v stay fp32 for the token-0 tail
     direct = GEMM_MODE == "h3" and attn_ws is not None and QKV_IMAGES and not fp8
+    if direct and TLAYER_WS:
+        return _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, attn_ws, q, k, v, xb, ctx_out, logits, token_layer)
     timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0], qkv_images=attn_ws if direct else None))
     for l in range(L - 1):
         if fp8:

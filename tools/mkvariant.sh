@@ -5,7 +5,7 @@ NAME=$1; SRC=$2; shift 2
 cd /root/repo/paths_amd/csrc
 base=$(basename $SRC .hip)
 extra=""
-if [ "$base" = "attn_x6" ] || [ "$base" = "tlayer_h3" ]; then extra="-mllvm -amdgpu-mfma-vgpr-form"; fi
+if [ "$base" = "attn_x6" ] || [ "$base" = "tlayer_h3" ] || [ "$base" = "tlayer_ws" ]; then extra="-mllvm -amdgpu-mfma-vgpr-form"; fi
 hipcc -O3 --offload-arch=gfx950 -fPIC -Wno-unused-value $extra "$@" -c -o /tmp/v_${NAME}.o $(basename $SRC)
 objs=""
 for o in build/*.o; do b=$(basename $o .o); if [ "$b" != "$base" ]; then objs="$objs $o"; fi; done
