@@ -257,6 +257,26 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
  * paths_token_layer_ws: B * ceil(T/64) * 64 * H * 32 * 4 bytes, [slide][64-token group][head][16-token tile][plane][64 lanes][16 B]. */
 int paths_attention_h3_img(void* o_img, const int64_t* num_ims, int B, int T, int H, int head_dim, void* workspace, paths_stream_t stream);
 
+/* paths_token0_tail WITHOUT the last layer's K / V projections, in ONE launch (csrc/token0_ws.hip; reference model/aggregator.py:70-75
+ * for the final layer, model/paths.py:130-139).  With one query per head the projections fold into the query and the output:
+ * score_h,t = (Wk_h^T q_h) . x_t + const, o_h = Wv_h (sum_t p_h,t x_t) + bv_h, so the launch only reads the layer's INPUT rows
+ * x1 [B,T,128].  img: image built once per weight version by paths_token0_pack_ws (A_h = c Wk_h^T Wq_h, a0_h = c Wk_h^T bq_h and
+ * 16-byte-transposed Wv, Wo, W1, W2; qscale c = log2(e)/sqrt(head_dim)); bv = in_proj_bias + 2 d.  Workgroups = (token split, head)
+ * pairs per slide; each publishes a (max, sum, z[128]) partial, the LAST arriver of a slide (agent-scope release / acquire around an
+ * arrival ticket) runs the row chain.  partials: paths_token0_ws_partials(B, T) floats of scratch; counters: B int32 words, zero
+ * on entry, left zero (paths_token_layer_ws can zero them on the same stream).  Exact fp32 FMA chains. */
+int64_t paths_token0_ws_image_bytes(void);
+int64_t paths_token0_ws_partials(int B, int T);
+int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* w1, const float* w2, float qscale, void* out,
+                         paths_stream_t stream);
+int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* img, const float* bv, const float* bo,
+                         const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                         const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,
+                         const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
+                         const float* wcls, const float* bcls, int num_logits, int cls_in,
+                         float* ctx_out, float* logits, float* partials, int* counters, int B, int T, int d, int H,
+                         float eps, float eps_final, paths_stream_t stream);
+
 /* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
  * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only
  * out[:, 0] of the final layer is read: it needs K/V of every token (q,k,v as written by paths_token_layer_f32 for

@@ -179,6 +179,14 @@ constexpr int ATTN_OCC = PATHS_ATTN_OCC;
 // tiles.  1 (with ATTN_OCC >= 3): twice the workgroups at half the registers - four or more waves per SIMD hide each other's
 // LDS / softmax latencies (the loop is latency-bound at two), at twice the LDS fragment traffic per MFMA.
 constexpr int QT = PATHS_ATTN_QT;
+#ifndef PATHS_ATTN_P1
+#define PATHS_ATTN_P1 0
+#endif
+constexpr bool ATTN_P1 = PATHS_ATTN_P1 != 0;      // P as one fp16 plane (see the kernel)
+#ifndef PATHS_ATTN_DEFER
+#define PATHS_ATTN_DEFER 8
+#endif
+constexpr float ATTN_DEFER = (float)(PATHS_ATTN_DEFER);   // deferred-rescale threshold in log2 units (0 = rescale every step)
 template <int NP, bool DROP>
 __global__ void __launch_bounds__(256, ATTN_OCC)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
@@ -301,7 +309,14 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
             if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
     }
     if constexpr (ATTN_OCC < 3) qk(kt + 1, sn);         // (past the end: stale K fragments, finite garbage nobody reads)
-    u32x4 pf[QT][2][NP];                                // [query tile][32-key group][plane]
+    // P1 (two-plane mode, no dropout): P enters the PV product as ONE fp16 plane (P^ = fp16(P), 11 bits) against V hi | lo: two
+    // MFMAs per block instead of three and no residual plane to build (1.5 of ~4.5 VALU per score element).  The normaliser sums
+    // the SAME rounded values (v_fma_mix reads them out of the packed register), so the result is an exact softmax-weighted mean
+    // with weights p^_k / sum p^: rounding perturbs each weight by <= 2^-12 relative and the perturbations largely cancel between
+    // numerator and denominator (error ~ 2^-12 |v - o| / sqrt(effective keys)).
+    constexpr bool P1 = ATTN_P1 && NP == 2 && !DROP;
+    constexpr int NPP = P1 ? 1 : NP;
+    u32x4 pf[QT][2][NPP];                               // [query tile][32-key group][plane]
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float mx = -INFINITY;
@@ -310,9 +325,20 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
         mx = fmaxf(fmaxf(mx, s[qt][t][0]), s[qt][t][1]);
         mx = fmaxf(fmaxf(mx, s[qt][t][2]), s[qt][t][3]);
       }
-      mx = rows_max(mx);
-      const float m_new = fmaxf(m_run[qt], mx);         // finite: key 0 (special token) is always valid
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+      // deferred rescale: while no lane's new maximum exceeds the running one by more than ATTN_DEFER (in log2 units) the running
+      // maximum is kept - no cross-lane max, no exp2 of the correction, no pass over the output accumulators.  P then reaches
+      // 2^ATTN_DEFER at most, far inside fp16 / fp32 range; the first step (m_run = -inf) always takes the full path.
+      float m_new = m_run[qt];
+      const bool keep = ATTN_DEFER > 0.f && __all(mx - m_run[qt] <= ATTN_DEFER);
+      if (!keep) {
+        mx = rows_max(mx);
+        m_new = fmaxf(m_run[qt], mx);                   // finite: key 0 (special token) is always valid
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        l_run[qt] *= alpha;
+        oacc[0][qt] *= alpha;
+        oacc[1][qt] *= alpha;
+        m_run[qt] = m_new;
+      }
       float psum = 0.f;
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
@@ -322,19 +348,26 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
           const f32x2 d = f32x2{s[qt][2 * kg + (j >> 2)][j & 3], s[qt][2 * kg + (j >> 2)][(j & 3) + 1]} - f32x2{m_new, m_new};   // v_pk_add_f32
           pv[j] = __builtin_amdgcn_exp2f(d[0]);
           pv[j + 1] = __builtin_amdgcn_exp2f(d[1]);
-          psum += pv[j] + pv[j + 1];
+          if constexpr (!P1) psum += pv[j] + pv[j + 1];
         }
         if constexpr (DROP) {
           const uint64_t row = ((uint64_t)pair * (uint64_t)T + (uint64_t)min(qw + 16 * qt + ql, T - 1)) * (uint64_t)T;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pv[j] *= drop_mult(drop, row + (uint64_t)(kt * KSTEP + 16 * (2 * kg + (j >> 2)) + 4 * g4 + (j & 3)));
         }
-        split_planes<NP>(pv, pf[qt][kg]);
+        if constexpr (P1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t h = pk_f16(pv[2 * i], pv[2 * i + 1]);
+            pf[qt][kg][0][i] = h;
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(psum) : "v"(h));                    // psum += (float)h.lo
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(psum) : "v"(h));      // psum += (float)h.hi
+          }
+        } else {
+          split_planes<NP>(pv, pf[qt][kg]);
+        }
       }
-      l_run[qt] = l_run[qt] * alpha + psum;
-      m_run[qt] = m_new;
-      oacc[0][qt] *= alpha;
-      oacc[1][qt] *= alpha;
+      l_run[qt] += psum;
     }
     // ---- O^T += V^T P^T
 #pragma unroll
@@ -345,7 +378,14 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #pragma unroll
         for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + ((kg * 2 + dvt) * NP + p) * FRAG);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
+        for (int qt = 0; qt < QT; ++qt) {
+          if constexpr (P1) {
+            oacc[dvt][qt] = mfma_f16(vf[1], pf[qt][kg][0], oacc[dvt][qt]);      // V lo * P^
+            oacc[dvt][qt] = mfma_f16(vf[0], pf[qt][kg][0], oacc[dvt][qt]);      // V hi * P^
+          } else {
+            oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
+          }
+        }
       }
     if (kt + 2 < nkt) swrite_k(kt + 2);                 // over K(kt): read one step ago
     if (kt + 1 < nkt) swrite_v(kt + 1);                 // over V(kt-1)

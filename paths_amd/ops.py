@@ -24,6 +24,7 @@ from . import _lib
 
 LOG2E = 1.4426950408889634
 QKV_IMAGES = os.environ.get("PATHS_QKV_IMAGES", "1") != "0"
+TAIL_WS = os.environ.get("PATHS_TAIL_WS", "1") != "0"          # token-0 tail without K / V projections, one launch (csrc/token0_ws.hip)
 TLAYER_WS = os.environ.get("PATHS_TLAYER_WS", "1") != "0"      # weight-stationary token-layer kernel (csrc/tlayer_ws.hip)
 SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
@@ -199,6 +200,29 @@ def tlayer_ws_images(layer: Dict[str, object], part: int):
         _lib.call("paths_tlayer_pack_ws", part, pw[0], pw[1], pw[2], sc[0], sc[1], sc[2], _lib.ptr(img), d, _lib.stream())
         layer[key] = (img, scales)
     return layer[key]
+
+
+def token0_ws_image(layer: Dict[str, object], qscale: float) -> torch.Tensor:
+    """Weight image of paths_token0_tail_ws for the LAST decoder layer (cached in the layer's pack dict)."""
+    if "t0_image" not in layer:
+        img = torch.empty((int(_lib.load().paths_token0_ws_image_bytes()),), device=layer["wo"].device, dtype=torch.uint8)
+        _lib.call("paths_token0_pack_ws", _lib.ptr(layer["wqkv"]), _lib.ptr(layer["bqkv"]), _lib.ptr(layer["wo"]), _lib.ptr(layer["w1"]),
+                  _lib.ptr(layer["w2"]), qscale, _lib.ptr(img), _lib.stream())
+        layer["t0_image"] = img
+    return layer["t0_image"]
+
+
+_T0_COUNTERS: Dict[tuple, torch.Tensor] = {}
+
+
+def token0_counters(dev, B: int) -> torch.Tensor:
+    """Arrival tickets of paths_token0_tail_ws: int32 words that are zero between launches (the last arriver of a slide resets its
+    word).  One buffer per (device, stream): tails of different streams may be in flight together."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.stream())
+    t = _T0_COUNTERS.get(key)
+    if t is None or t.numel() < B:
+        t = _T0_COUNTERS[key] = torch.zeros((max(256, B),), device=dev, dtype=torch.int32)
+    return t
 
 
 def _x6_of(pack: Dict[str, object], key: str, planes: Optional[int] = None, lagged: bool = False):
@@ -575,6 +599,22 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
         timed("agg_token_chain", lambda: token_layer(xa, xb, layers[l], None if last else layers[l + 1]))
         xa, xb = xb, xa
     w = layers[L - 1]
+
+    def tail_ws():
+        img = token0_ws_image(w, qscale)
+        part = torch.empty((int(_lib.load().paths_token0_ws_partials(B, T)),), device=tokens.device, dtype=torch.float32)
+        cnt = token0_counters(tokens.device, B)
+        _lib.call(
+            "paths_token0_tail_ws", p(xa), p(num_ims), p(img), w["bqkv"].data_ptr() + 4 * 2 * d, p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
+            p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["b1"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]),
+            p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
+            res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
+            p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), logits.shape[1], lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
+            p(part), p(cnt), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
+
+    if TAIL_WS:
+        timed("agg_token0_tail", tail_ws)
+        return {"logits": logits, "ctx_slide": ctx_out}
 
     def tail():
         token_layer_old(xa, None, None, w)          # fp32 q, k, v of the last layer for the token-0 tail

@@ -630,29 +630,114 @@ def test_attention_x6_matches_fp64(dev, T, lens, planes):
         assert (lse6[b, :, :n].double() - lse_ref).abs().max().item() < 1e-4
 
 
-def test_token_layer_h3_matches_f32_kernel(dev):
-    """The fp16-split token-layer chain against the f32-MFMA one on the same random layer (both paths of one level)."""
-    from paths_amd import ops
-    if ops.GEMM_MODE != "h3":
-        pytest.skip("the fp16-split token layer is the default mode's kernel")
-    g, info, out_h3 = run_single(dev, "g2_level2_b2_k256")
+def _spy_calls(dev, name, **flags):
+    """Run one golden level and return (golden, outputs, names of the C entry points it went through)."""
     import paths_amd.ops as O
     calls = []
     orig = O._lib.call
 
-    def spy(name, *a):
-        calls.append(name)
-        return orig(name, *a)
+    def spy(cname, *a):
+        calls.append(cname)
+        return orig(cname, *a)
 
+    saved = {k: getattr(O, k) for k in flags}
+    for k, v in flags.items():
+        setattr(O, k, v)
     O._lib.call = spy
     try:
-        _, _, out_again = run_single(dev, "g2_level2_b2_k256")
+        g, _, out = run_single(dev, name)
     finally:
         O._lib.call = orig
-    assert "paths_token_layer_h3" in calls and "paths_token_layer_f32" not in calls
+        for k, v in saved.items():
+            setattr(O, k, v)
+    return g, out, calls
+
+
+def test_token_layer_h3_matches_f32_kernel(dev):
+    """The fp16-split token-layer chain (csrc/tlayer_h3.hip, now the non-default form) against the reference golden: both paths
+    of one level, deterministic."""
+    from paths_amd import ops
+    if ops.GEMM_MODE != "h3":
+        pytest.skip("the fp16-split token layer is the default mode's kernel")
+    g, out_h3, calls = _spy_calls(dev, "g2_level2_b2_k256", TLAYER_WS=False)
+    _, out_again, _ = _spy_calls(dev, "g2_level2_b2_k256", TLAYER_WS=False)
+    assert "paths_token_layer_h3" in calls and "paths_token_layer_f32" not in calls and "paths_token_layer_ws" not in calls
     np.testing.assert_allclose(out_again["logits"].numpy(), out_h3["logits"].numpy(), atol=0, rtol=0)      # deterministic
     np.testing.assert_allclose(out_h3["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out_h3["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["g2_level2_b2_k256", "g9_level1_b2_k2048"])
+def test_weight_stationary_aggregator_path(dev, name):
+    """Default mode: in_proj / chain on paths_token_layer_ws (weights in registers, activations through LDS), attention output as
+    the out_proj operand image, last layer on paths_token0_tail_ws (no K / V projection, one launch).  Against the reference golden,
+    against the previous kernels on the same inputs, and bit-reproducible (the tail's arrival order must not matter)."""
+    from paths_amd import ops
+    if ops.GEMM_MODE != "h3":
+        pytest.skip("the weight-stationary kernels are the default mode's")
+    g, out_ws, calls = _spy_calls(dev, name)
+    assert {"paths_token_layer_ws", "paths_attention_h3_img", "paths_token0_tail_ws"} <= set(calls)
+    assert "paths_token_layer_h3" not in calls and "paths_token0_tail" not in calls
+    np.testing.assert_allclose(out_ws["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out_ws["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
+    _, out_old, calls_old = _spy_calls(dev, name, TLAYER_WS=False)
+    assert "paths_token0_tail" in calls_old
+    assert float((out_ws["logits"] - out_old["logits"]).abs().max()) < 5e-6
+    assert float((out_ws["ctx_slide"] - out_old["ctx_slide"]).abs().max()) < 5e-6
+    # the chain kernel alone with the previous tail (fp32 q, k, v of the last layer + paths_token0_tail)
+    _, out_mix, calls_mix = _spy_calls(dev, name, TAIL_WS=False)
+    assert "paths_token_layer_ws" in calls_mix and "paths_token0_tail" in calls_mix
+    assert float((out_mix["logits"] - out_old["logits"]).abs().max()) < 5e-6
+    for _ in range(3):
+        _, again, _ = _spy_calls(dev, name)
+        assert torch.equal(again["logits"], out_ws["logits"]) and torch.equal(again["ctx_slide"], out_ws["ctx_slide"])
+
+
+@pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37, 129]), (65, [64, 65]), (8193, [8193, 5000])])
+def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens):
+    """paths_token_layer_ws (in_proj -> attention image -> post chain) and paths_token0_tail_ws on random weights and ragged slides
+    against a float64 torch evaluation of the same decoder layers (reference model/aggregator.py:70-75)."""
+    from paths_amd import _lib, ops
+    if ops.GEMM_MODE != "h3":
+        pytest.skip("default-mode kernels")
+    B, d, Hh, hd = len(lens), 128, 4, 32
+    gen = torch.Generator(device=dev); gen.manual_seed(T)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=gen) * 2 - 1
+    layers = []
+    for _ in range(2):
+        lay = {"wqkv": rnd(3 * d, d) * 0.15, "bqkv": rnd(3 * d) * 0.1, "wo": rnd(d, d) * 0.1, "bo": rnd(d) * 0.1, "cab": rnd(d) * 0.1,
+               "w1": rnd(4 * d, d) * 0.1, "b1": rnd(4 * d) * 0.1, "w2": rnd(d, 4 * d) * 0.05, "b2": rnd(d) * 0.1, "eps": 1e-5}
+        for n in ("ln1", "ln2", "ln3"):
+            lay[n + "g"], lay[n + "b"] = 1 + rnd(d) * 0.1, rnd(d) * 0.1
+        layers.append(lay)
+    lvl = {"layers": layers, "lnfg": 1 + rnd(d) * 0.1, "lnfb": rnd(d) * 0.1, "lnf_eps": 1e-5, "wcls": rnd(4, d) * 0.1, "bcls": rnd(4) * 0.1}
+
+    class MC:
+        trans_dim, trans_heads, trans_layers, slide_ctx_mode = d, Hh, 2, "residual"
+    tokens = rnd(B, T, d)
+    num_ims = torch.tensor([n - 1 for n in lens], device=dev, dtype=torch.int64)
+    ctx_prev = rnd(B, d)
+    out = ops._aggregator_forward(MC, lvl, tokens, num_ims, ctx_prev, None)
+    torch.cuda.synchronize()
+    ln = lambda x, g_, b_: torch.nn.functional.layer_norm(x, (d,), g_.double(), b_.double(), 1e-5)
+    D = lambda t: t.double()
+    for b, n in enumerate(lens):
+        x = D(tokens[b, :n])
+        for li, lay in enumerate(layers):
+            qkv = x @ D(lay["wqkv"]).T + D(lay["bqkv"])
+            q, k, v = (t.view(n, Hh, hd).transpose(0, 1) for t in qkv.split(d, dim=1))
+            if li == 1:
+                q = q[:, :1]
+            a = (torch.softmax(q @ k.transpose(1, 2) / math.sqrt(hd), dim=-1) @ v).transpose(0, 1).reshape(-1, d)
+            xin = x if li == 0 else x[:1]
+            y = ln(xin + a @ D(lay["wo"]).T + D(lay["bo"]), lay["ln1g"], lay["ln1b"])
+            y = ln(y + D(lay["cab"]), lay["ln2g"], lay["ln2b"])
+            y = ln(y + torch.relu(y @ D(lay["w1"]).T + D(lay["b1"])) @ D(lay["w2"]).T + D(lay["b2"]), lay["ln3g"], lay["ln3b"])
+            x = y
+        ctx = ln(x[0], lvl["lnfg"], lvl["lnfb"]) + D(ctx_prev[b])
+        logits = ctx @ D(lvl["wcls"]).T + D(lvl["bcls"])
+        assert float((D(out["ctx_slide"][b]) - ctx).abs().max()) < 1e-5, (b, n)
+        assert float((D(out["logits"][b]) - logits).abs().max()) < 1e-5, (b, n)
 
 
 @pytest.mark.parametrize("name", ["g2_level2_b2_k256", "g9_level1_b2_k2048"])
