@@ -222,8 +222,8 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
             "config": {"workload": f"single level, 8192 patches x 1536 features per slide, {spg} slides per GPU, full quadratic "
                                    "attention over 8193 tokens (BASELINE.json configs[4] geometry)", "global_batch": spg * world},
             "attn_ffn_flops_per_step": flops, "attention_us": round(attn_us, 1) if attn_us else None, "fp8_attention": fp8}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -242,6 +242,10 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
     def sync():
         torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
 
+    import torch.distributed as tdist
+    if ar is None and tdist.is_initialized():          # PATHS_FORCE_DIST=1: a one-rank group, so that the RCCL path runs and is timed
+        ar = pdist.allreduce_gradients
+    pdist.TIME_ALLREDUCE = ar is not None
     loss = None
     for i in range(args.warmup):
         loss = putils.train_step(model, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
@@ -249,8 +253,11 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
         log(f"train warm-up step {i}: local loss share {float(loss):.4f}")
     sync()
     t0 = time.perf_counter()
+    ar_ev = []
     for _ in range(args.steps):
         loss = putils.train_step(model, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
+        if ar is not None and pdist.LAST_ALLREDUCE_EVENTS is not None:
+            ar_ev.append(pdist.LAST_ALLREDUCE_EVENTS)
     sync()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
@@ -262,11 +269,89 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
             "config": {"workload": f"train step (reference train.py:59-68 semantics): 5-level recursion K={K}, forward + HIP backward + "
                                    f"AdamW, {len(slides)} slides per GPU, dropout {cfg.model_config.dropout}", "global_batch": gb,
                        "parallelism": f"dp{world}: one flat fp32 gradient all-reduce per step" if world > 1 else "single GPU"},
-            "final_loss_share": float(loss), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+            "final_loss_share": float(loss), "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+            "allreduce_ms": round(sum(a.elapsed_time(b) for a, b in ar_ev) / len(ar_ev), 3) if ar_ev else None}), flush=True)
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher (no RANK / WORLD_SIZE in the environment): the parent - BEFORE any
+    torch.cuda call, it never touches the GPU - starts N fresh child processes of this script, one per device, with the
+    torch.distributed.run environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), lets rank 0
+    write the ONE JSON line to the inherited stdout and returns non-zero if any child does.  Nothing is re-exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < n and "PATHS_DIST_BACKEND" not in env:      # (device_count() does not initialise the GPU)
+        # fewer devices than ranks: a rehearsal (ranks share devices), RCCL refuses two ranks of one communicator on one device
+        env["PATHS_DIST_BACKEND"] = "gloo"
+        log(f"self-launch: {torch.cuda.device_count()} device(s) for {n} ranks - rehearsal over gloo")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(n)]
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code if code > 0 else 1
+                        log(f"self-launch: rank {r} exited with {code}; stopping the other ranks")
+                        for q in pending:
+                            procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+            pr.wait()
+    return rc
+
+
+def train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, steps: int, warmup: int):
+    """Short training measurement for the DEFAULT bench line (BASELINE.json configs[3] shape on this rank's resident slides):
+    forward + hand-written HIP backward + AdamW (+ the flat gradient all-reduce when a process group exists) on a COPY of the
+    model; returns ms_per_step (max over ranks), slides/s of the whole job, peak memory and the all-reduce time per step."""
+    import copy
+    import numpy as np
+    m = copy.deepcopy(model).train()
+    labels = np.asarray([s.synthetic_spec.label(4) for s in slides.slides], np.int64)
+    batch = {"slide": slides, "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
+    opt = torch.optim.AdamW(m.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    gb = len(slides) * world
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    ar = pdist.allreduce_gradients if grouped else None
+    pdist.TIME_ALLREDUCE = grouped
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(warmup):
+        putils.train_step(m, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
+    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ar_ms = []
+    for _ in range(steps):
+        putils.train_step(m, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
+        if grouped and pdist.LAST_ALLREDUCE_EVENTS is not None:
+            ar_ms.append(pdist.LAST_ALLREDUCE_EVENTS)
+    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+    el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
+    pdist.TIME_ALLREDUCE = False
+    out = {"steps": steps, "warmup": warmup, "ms_per_step": round(el / steps * 1e3, 3), "slides_per_s": round(gb * steps / el, 2),
+           "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2), "dropout": cfg.model_config.dropout,
+           "allreduce_ms": round(sum(a.elapsed_time(b) for a, b in ar_ms) / len(ar_ms), 3) if ar_ms else None,
+           "allreduce": (f"one flat fp32 bucket per step over {torch.distributed.get_backend()} (world {world})" if grouped else
+                         "none (single rank without a process group)"),
+           "workload": "train step (reference train.py:59-68): 5-level recursion forward + HIP backward + AdamW on the same resident slides"}
+    del m, opt
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -290,14 +375,20 @@ def main():
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
     ap.add_argument("--fp8", action="store_true", help="stress mode: also run the opt-in e4m3 attention variant and report its speed and "
                     "its logit distance from the fp32-accurate path")
+    ap.add_argument("--train-steps", type=int, default=5, help="infer mode: timed steps of the short training measurement added to the "
+                    "line as 'train' (0 = skip); 3 warm-up steps")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "stress"],
                     help="infer (default, the BASELINE metric); train: forward + HIP backward + AdamW + gradient all-reduce; "
                          "stress: one level over 8192 patches x 1536 features (BASELINE configs[4] geometry, fp32-accurate path)")
     args = ap.parse_args()
 
     from paths_amd import distributed as pdist
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))           # parent of a self-launched job: never touches the GPU
     rank, world, local_rank = pdist.env_rank_world()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N ranks with torch.distributed.run (or run "
+                 f"'python bench.py --gpus N' without RANK / WORLD_SIZE in the environment and it starts them itself)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     ndev = torch.cuda.device_count()
     local_dev = local_rank % max(1, ndev)        # (rehearsals on a 1-GPU box put every rank on device 0)
@@ -539,13 +630,20 @@ def main():
             roofline_attn["serialized_span_us"] = round(ms2 * 1e3 / n2, 2)
             roofline_attn["serialized_frac"] = round(fl2 / (ms2 * 1e-3) / 1e12 / peak, 4)
 
+    train = None
+    if args.train_steps > 0:
+        train = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 3)
+        log(f"train probe: {train['ms_per_step']} ms per step, all-reduce {train['allreduce_ms']} ms")
     if rank == 0:
         total_slides = spg * world * args.steps
         line = {
             "metric": "slides_per_sec_5level_K%d_D1024" % K, "value": round(total_slides / elapsed, 2), "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32 (products as 2 fp16 planes per operand = 22 bits, 3 fp16 MFMAs per block, fp32 accumulate)" if planes == 2 else
+                      "f32 (products as 3 exact bf16 planes per operand, 6 bf16 MFMAs per block, fp32 accumulate)" if x6 else "f32"),
+            "data": "synthetic",
             "config": {"workload": f"5-level PATHS recursion (forward, eval): K={K} patches/level (level-0 grid "
                                    f"{BASE_SHAPES[K][0]}x{BASE_SHAPES[K][1]}, top_k {K // 4}, 10% background), D=1024 "
                                    f"features, trans_dim 128 x 4 heads x 2 layers, LSTM ctx 256; {spg} HBM-resident slides per GPU",
@@ -563,6 +661,8 @@ def main():
                      "note": "roofline / roofline_attn_ffn event timings come from the eager instrumented pass of the same K steps "
                              "(the replayed launch sequence carries no events)" if graphed is not None else None},
         }
+        if train is not None:
+            line["train"] = train
         if sustained is not None:
             line["sustained"] = sustained
         if breakdown is not None:
@@ -571,8 +671,8 @@ def main():
             line["cpu_baseline"], ids, otrace, ohz = cpu_baseline(cfg, sd, K, args.cpu_slides, args.cpu_reps)
             line["parity_checked"] = parity_check(cfg, model, K, ids, otrace, ohz, dev)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

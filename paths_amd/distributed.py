@@ -20,11 +20,15 @@ def env_rank_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init(backend: str, device: Optional[torch.device] = None) -> Tuple[int, int]:
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+def init(backend: str, device: Optional[torch.device] = None, force: bool = False) -> Tuple[int, int]:
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).  A single rank needs no
+    group; ``force`` (or PATHS_FORCE_DIST=1) creates one anyway, so that the collective code paths (RCCL with backend "nccl")
+    can be exercised and timed on a one-GPU box."""
     rank, world, _ = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    force = force or os.environ.get("PATHS_FORCE_DIST", "0") != "0"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
@@ -63,6 +67,10 @@ def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([bufs[r][: len(shard_range(n_total, r, world))] for r in range(world)], dim=0)
 
 
+LAST_ALLREDUCE_EVENTS = None     # (start, end) CUDA events around the most recent gradient all-reduce (bench.py --mode train)
+TIME_ALLREDUCE = False
+
+
 def allreduce_gradients(model, average: bool = False, num_levels: Optional[int] = None):
     """ONE flat-bucket all-reduce(sum) of the live gradients (RCCL over xGMI with backend "nccl").
     The loss of each rank is already scaled by local_batch / global_batch (paths_amd.utils.loss_from_logits), so the sum
@@ -80,12 +88,20 @@ def allreduce_gradients(model, average: bool = False, num_levels: Optional[int] 
             p.grad = torch.zeros_like(p)
     grads = [p.grad for p in params]
     flat = torch.cat([g.reshape(-1) for g in grads])          # one message per step
+    global LAST_ALLREDUCE_EVENTS
+    ev = None
+    if TIME_ALLREDUCE and flat.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if dist.get_backend() == "gloo" and flat.is_cuda:         # CPU-collective rehearsal path (tests / 1-GPU boxes)
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         flat.copy_(host)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if ev is not None:
+        ev[1].record()
+        LAST_ALLREDUCE_EVENTS = ev
     if average:
         flat /= dist.get_world_size()
     off = 0

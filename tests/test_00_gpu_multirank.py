@@ -18,15 +18,41 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run_children(cmds_envs, timeout=900):
+    """Start the child processes with stdout / stderr in temporary files (a full pipe cannot stall a rank that another rank is
+    waiting for inside a collective), wait for all of them, and ALWAYS reap them: on a timeout or a failure the survivors are
+    killed, so no orphan keeps the GPU."""
+    import tempfile
+    import time
+    files = [(tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")) for _ in cmds_envs]
+    procs = []
+    try:
+        for (cmd, env), (fo, fe) in zip(cmds_envs, files):
+            procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=fo, stderr=fe, text=True))
+        deadline = time.time() + timeout
+        while any(p.poll() is None for p in procs):
+            if time.time() > deadline or any(p.poll() not in (None, 0) for p in procs):
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    outs = []
+    for fo, fe in files:
+        fo.seek(0); fe.seek(0)
+        outs.append((fo.read(), fe.read()))
+        fo.close(); fe.close()
+    assert all(p.returncode == 0 for p in procs), "\n".join(f"rank {i} rc={p.returncode}\n" + o[1][-3000:] for i, (p, o) in enumerate(zip(procs, outs)))
+    return outs
+
+
 def _spawn(argv, port, extra_env=None, timeout=900):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PATHS_DIST_BACKEND="gloo",
                PATHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(extra_env or {})
-    procs = [subprocess.Popen([sys.executable] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT,
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=timeout) for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-3000:] for o in outs)
-    return outs
+    return _run_children([([sys.executable] + argv, dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)], timeout)
 
 
 @pytest.mark.parametrize("mode", ["infer", "train"])
@@ -109,3 +135,70 @@ def test_two_rank_training_equals_one_rank_and_survives_idle_ranks(tmp_path):
     outs = _spawn([str(script)], 29745, {"PATHS_MODEL_DIR": str(mdir)})
     recs = [json.loads([l for l in o[0].splitlines() if l.startswith("{")][-1]) for o in outs]
     assert recs[0]["digest"] == recs[1]["digest"] and max(r["worst_grad_rel_err"] for r in recs) < 2e-5
+
+
+def test_bench_self_launch_without_a_launcher():
+    """``python bench.py --gpus 2`` with no RANK / WORLD_SIZE in the environment: the parent (which never touches the GPU) starts
+    the two ranks itself, relays rank 0's single JSON line and exits 0; with one device the ranks rehearse over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PATHS_DIST_BACKEND")}
+    env.update(PATHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = _run_children([([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--slides-per-gpu", "2", "--k", "256",
+                           "--no-cpu-baseline", "--train-steps", "1", "--sustain", "0", "--breakdown-steps", "0"], env)])[0]
+    lines = [l for l in out[0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    assert rec["train"]["allreduce_ms"] is not None and rec["train"]["ms_per_step"] > 0       # the gradient all-reduce ran and was timed
+    # a WORLD_SIZE that contradicts --gpus is an error message, not a bare assert
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT, capture_output=True, text=True)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+RCCL_WORKER = r'''
+import os, sys, json, time
+sys.path.insert(0, os.environ["PATHS_ROOT"])
+import torch
+import torch.distributed as dist
+from paths_amd import distributed as pd, autograd as pag
+from paths_amd.config import Config
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+rank, world = pd.init("nccl", dev, force=True)            # RCCL communicator of ONE rank on the one GPU
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+cfg = Config.load(os.path.join(os.environ["PATHS_ROOT"], "tests", "golden", "sample"), test_mode=True)
+model = cfg.get_model().to(dev)
+params = pag.live_grad_params(model, cfg.num_levels)
+torch.manual_seed(1)
+for p in params[::2]:                                        # every other gradient missing: must count as zeros
+    p.grad = torch.randn_like(p)
+want = {id(p): (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for p in params}
+n = sum(p.numel() for p in params)
+pd.TIME_ALLREDUCE = True
+times = []
+for i in range(5):
+    pd.allreduce_gradients(model, num_levels=cfg.num_levels)
+    torch.cuda.synchronize()
+    a, b = pd.LAST_ALLREDUCE_EVENTS
+    times.append(a.elapsed_time(b))
+assert all(torch.equal(p.grad, want[id(p)]) for p in params)             # SUM over one rank = identity, zeros filled in
+rows = pd.gather_rows(torch.arange(12, device=dev, dtype=torch.float32).view(3, 4), 3)
+assert torch.equal(rows.cpu(), torch.arange(12, dtype=torch.float32).view(3, 4))
+assert pd.max_over_ranks(1.25, dev) == 1.25
+pd.barrier()
+print(json.dumps({"bucket_mb": n * 4 / 2**20, "allreduce_ms": sorted(times)[len(times) // 2], "first_ms": times[0]}))
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_collectives_on_one_gpu(tmp_path):
+    """The backend == "nccl" (RCCL) branches of paths_amd.distributed on a real device: a forced one-rank communicator runs the flat
+    29 MB gradient all-reduce (missing gradients = zeros), the row all-gather, the MAX-reduce and the barrier; prints the all-reduce
+    time.  (Two ranks of one communicator cannot share a device, so N > 1 over RCCL needs the multi-GPU node the driver has.)"""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(PATHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29751")
+    out = _run_children([([sys.executable, str(script)], env)])[0]
+    rec = json.loads([l for l in out[0].splitlines() if l.startswith("{")][-1])
+    print("RCCL one-rank all-reduce:", rec)
+    assert 25 < rec["bucket_mb"] < 32 and rec["allreduce_ms"] < 50
