@@ -39,9 +39,10 @@ const char* paths_build_info(void);
 int paths_abi_version(void);
 
 /* Stream plumbing of the launch tape (paths_amd/utils.py:TapedRecursion replays a recorded recursion as a flat list of C calls;
- * no reference equivalent).  paths_event_create: a timing-less event handle (host object) for paths_stream_wait, which makes `dst`
+ * no reference equivalent).  paths_event_create / paths_event_destroy: a timing-less event handle (host object) for paths_stream_wait, which makes `dst`
  * wait for everything enqueued on `src` so far; paths_memset_zero: hipMemsetAsync(0).  None of them synchronises the host. */
 void* paths_event_create(void);
+int paths_event_destroy(void* event);
 int paths_stream_wait(paths_stream_t dst, paths_stream_t src, void* event);
 int paths_memset_zero(void* p, size_t bytes, paths_stream_t stream);
 

@@ -8,6 +8,10 @@ Compares one recursion of the HIP path (the ``trace`` list filled by ``paths_amd
 * the patch LOCATION set of the level                     bit-exact  (row order inside a level may legally differ where two
                                                           importance scores nearly tie: SURVEY.md §7 hard part 1)
 * the kept (top-K) patches, as a location set             bit-exact
+* the kept patches as a SEQUENCE (torch.topk order)       identical up to permutations among scores closer than ``seq_tol``
+                                                          (the order decides row / token positions downstream: 1-D positional
+                                                          encoding, fp summation order); reported: positions that differ and
+                                                          the largest score gap among them
 * ``parent_inds`` as (child location -> parent location)  bit-exact  (fallback levels: as (cell location -> cell index))
 * importance per location                                 <= ``imp_tol``
 * final hazards                                           <= ``hazard_tol`` (north_star bar 1e-4)
@@ -33,7 +37,7 @@ def _locset(a) -> set:
 
 def compare_recursion(gpu_trace: Sequence[dict], oracle_trace: Sequence[dict], gpu_hazards, oracle_hazards,
                       imp_tol: float = 5e-6, hazard_tol: float = 1e-4, gap_screen: float = 2e-6,
-                      raise_on_mismatch: bool = True) -> Dict[str, object]:
+                      raise_on_mismatch: bool = True, seq_tol: float = 1e-6) -> Dict[str, object]:
     L = len(oracle_trace)
     assert len(gpu_trace) == L, (len(gpu_trace), L)
     B = int(_np(oracle_trace[0]["num_ims"]).shape[0])
@@ -42,6 +46,7 @@ def compare_recursion(gpu_trace: Sequence[dict], oracle_trace: Sequence[dict], g
     min_gap = float("inf")
     max_imp = 0.0
     n_idx = 0
+    seq_moved, seq_gap = 0, 0.0         # kept-sequence positions that differ from the oracle's, largest oracle-score gap among them
     for l in range(L):
         g, o = gpu_trace[l], oracle_trace[l]
         gn, on = _np(g["num_ims"]).astype(np.int64), _np(o["num_ims"]).astype(np.int64)
@@ -105,6 +110,18 @@ def compare_recursion(gpu_trace: Sequence[dict], oracle_trace: Sequence[dict], g
                 else:
                     problems.append(f"L{l} slide {j}: kept sets differ (boundary gap {gap:.3g})")
                     screened.add(j)
+                continue
+            # same set: the ORDER must agree too, except among (near-)tied scores
+            seq_g = [tuple(int(v) for v in r) for r in gl[j][kg]]
+            seq_o = [tuple(int(v) for v in r) for r in ol[j][ko]]
+            if seq_g != seq_o:
+                score = {tuple(int(v) for v in r): float(x) for r, x in zip(ol[j, :n], oi[j, :n])}
+                moved = [i for i in range(k) if seq_g[i] != seq_o[i]]
+                gmax = max(abs(score[seq_g[i]] - score[seq_o[i]]) for i in moved)
+                seq_moved += len(moved)
+                seq_gap = max(seq_gap, gmax)
+                if gmax >= seq_tol:
+                    problems.append(f"L{l} slide {j}: kept sequence differs at {len(moved)} positions, score gap {gmax:.3g}")
     gh, oh = _np(gpu_hazards), _np(oracle_hazards)
     ok_rows = [j for j in range(B) if j not in screened]
     hz = float(np.abs(gh[ok_rows] - oh[ok_rows]).max()) if ok_rows else 0.0
@@ -114,6 +131,7 @@ def compare_recursion(gpu_trace: Sequence[dict], oracle_trace: Sequence[dict], g
            "parent_pairs_identical": not any("pairs" in s or "parent_inds" in s for s in problems),
            "kept_indices_compared": n_idx, "max_importance_diff": max_imp, "max_hazard_diff": hz,
            "min_boundary_gap": None if min_gap == float("inf") else min_gap,
+           "sequence_identical": seq_moved == 0, "sequence_positions_moved": seq_moved, "sequence_max_gap": seq_gap,
            "near_tie_slides": sorted(j for j in screened if not any(f"slide {j}:" in s for s in problems)),
            "problems": problems}
     if raise_on_mismatch and problems:

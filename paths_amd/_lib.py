@@ -78,6 +78,7 @@ SIGNATURES = {
     "paths_attention_bwd_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_attention_token0_bwd_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_stream_wait": [_vp, _vp, _vp],
+    "paths_event_destroy": [_vp],
     "paths_memset_zero": [_vp, C.c_size_t, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
     "paths_tissue_mask_absmax": [_vp, _i64, _i32, _vp, _vp, _vp],

@@ -70,8 +70,14 @@ def live_grad_params(model, num_levels: Optional[int] = None) -> List[torch.nn.P
     L = len(model.procs) if num_levels is None else min(int(num_levels), len(model.procs))
     out = list(lstm_params(model.lstm)) if model.use_lstm else []
     for i in range(L):
+        mc = model.procs[i].config
+        no_agg = i < L - 1 and mc.slide_ctx_mode == "none"          # nothing of this level's aggregator reaches the loss
         if model.use_lstm:
             lp = level_params(model.procs[i])
+            if no_agg:
+                lp = []
+            elif mc.importance_mode != "mul":
+                lp = lp[4:]
         else:
             # lstm = false: hctx_mlp of level 0 never runs (no previous state); the importance MLP only with importance_mode "mul"
             lp = level_params_nolstm(model.procs[i])
@@ -81,8 +87,10 @@ def live_grad_params(model, num_levels: Optional[int] = None) -> List[torch.nn.P
                 drop |= {4, 5, 6, 7}
             if mc.importance_mode != "mul":
                 drop |= {0, 1, 2, 3}
+            if no_agg:
+                drop |= set(range(8, len(lp)))
             lp = [p for j, p in enumerate(lp) if j not in drop]
-        out += lp if i == L - 1 else lp[:-2]
+        out += lp if (i == L - 1 or no_agg) else lp[:-2]
     return out
 
 
@@ -184,16 +192,30 @@ class LevelFn(torch.autograd.Function):
         mc = proc.config
         lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
         cont = lambda t: t.contiguous() if t is not None else None
-        tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+        # Parameters without a path to the loss get NO gradient (None, as in the reference: AdamW then leaves them alone, weight
+        # decay included).  no_agg: neither this level's logits nor its slide context are used downstream (non-final levels
+        # under slide_ctx_mode "none"): the whole aggregator, proj_in and - its only consumer being the tokens - the
+        # importance MLP are cut off; importance_mode != "mul": the importance only drives the (non-differentiable) top-K.
+        no_agg = d_logits is None and d_ctx_out is None
+        if no_agg:
+            tg, d_ctx_prev = None, None
+            d_tok = torch.zeros_like(tr["tokens"])
+        else:
+            tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
         sg, d_state_prev = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
         lg = bw.unpack_lstm_grads(lstm, sg)
         grads = [lg[k] for k in LSTM_ORDER]
         Hi = mc.importance_mlp_hidden_dim
-        grads += [sg["w_ip"][:Hi], sg["b1"], sg["w2"].view(1, -1), sg["b2"], sg["w_ip"][Hi:], sg["bp"], sg["special"]]
-        for l, g in enumerate(tg["layers"]):
-            grads += [g[key] for _, key in LAYER_ORDER]
-        grads += [tg["lnfg"], tg["lnfb"]]
-        grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]     # unused logits: grad stays None
+        imp_live = mc.importance_mode == "mul" and not no_agg
+        grads += [sg["w_ip"][:Hi], sg["b1"], sg["w2"].view(1, -1), sg["b2"]] if imp_live else [None] * 4
+        if no_agg:
+            grads += [None] * (3 + len(LAYER_ORDER) * mc.trans_layers + 4)
+        else:
+            grads += [sg["w_ip"][Hi:], sg["bp"], sg["special"]]
+            for l, g in enumerate(tg["layers"]):
+                grads += [g[key] for _, key in LAYER_ORDER]
+            grads += [tg["lnfg"], tg["lnfb"]]
+            grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]     # unused logits: grad stays None
         return (None, None, None, None, None, d_state_prev if ctx.has_state else None,
                 d_ctx_prev if ctx.has_ctx else None, *grads)
 
@@ -236,14 +258,23 @@ class LevelFnNoLstm(torch.autograd.Function):
         mc = proc.config
         vp = ops.pack_level(proc)
         cont = lambda t: t.contiguous() if t is not None else None
-        tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+        no_agg = d_logits is None and d_ctx_out is None          # (see LevelFn.backward; here Z = alpha X + hctx still reaches the next level)
+        if no_agg:
+            tg, d_ctx_prev = None, None
+            d_tok = torch.zeros_like(tr["tokens"])
+        else:
+            tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
         sg, d_state_prev = bw.selection_backward_nolstm(mc, vp, sel, d_tok, cont(d_state_out))
         v = lambda t, shape: t.view(shape) if t is not None else None
-        grads = [sg["w1"], sg["b1"], v(sg["w2"], (1, -1)), sg["b2"], sg["wh1"], sg["bh1"], sg["wh2"], sg["bh2"], sg["wp"], sg["bp"], sg["special"]]
-        for l, g in enumerate(tg["layers"]):
-            grads += [g[key] for _, key in LAYER_ORDER]
-        grads += [tg["lnfg"], tg["lnfb"]]
-        grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]
+        grads = [sg["w1"], sg["b1"], v(sg["w2"], (1, -1)), sg["b2"], sg["wh1"], sg["bh1"], sg["wh2"], sg["bh2"]]
+        if no_agg:
+            grads += [None] * (3 + len(LAYER_ORDER) * mc.trans_layers + 4)
+        else:
+            grads += [sg["wp"], sg["bp"], sg["special"]]
+            for l, g in enumerate(tg["layers"]):
+                grads += [g[key] for _, key in LAYER_ORDER]
+            grads += [tg["lnfg"], tg["lnfb"]]
+            grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]
         return (None, None, None, None, d_state_prev if (ctx.has_state and d_state_prev is not None) else None,
                 d_ctx_prev if ctx.has_ctx else None, *grads)
 

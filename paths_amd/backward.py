@@ -25,7 +25,7 @@ TN_SPLIT2 = int(os.environ.get("PATHS_TN_SPLIT2", "2"))
 TN_MODE = os.environ.get("PATHS_TN_MODE", "x6")
 # dX / recompute GEMMs go to the split-operand kernel when the output width is a multiple of this (128: the d = 128 products too)
 NT_X6_MIN_N = int(os.environ.get("PATHS_NT_X6_MIN_N", "128"))
-# attention backward: "x6q" = dQ on the split-bf16 kernel (csrc/attn_bwd_x6.hip), "f32" = all of it on the f32 MFMA (csrc/attn_bwd.hip)
+# attention backward: "x6q" = the split-bf16 kernels (csrc/attn_bwd_x6.hip: dQ, and dK / dV unless PATHS_ATTN_BWD_KV_X6=0), "f32" = all of it on the f32 MFMA (csrc/attn_bwd.hip)
 ATTN_BWD_MODE = os.environ.get("PATHS_ATTN_BWD_MODE", "x6q")
 
 
@@ -667,7 +667,7 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev, drop, l)
         dqkv = torch.zeros((B, T, 3 * d), **f32)
         ws = torch.empty((B * H * T,), **f32)
-        if ATTN_BWD_MODE == "x6q":      # dQ on the split-bf16 kernel (csrc/attn_bwd_x6.hip), dK / dV on the f32 MFMA
+        if ATTN_BWD_MODE == "x6q":      # dQ, dK and dV on the split-bf16 kernels (csrc/attn_bwd_x6.hip; PATHS_ATTN_BWD_KV_X6=0 in the C library keeps dK / dV on the f32 MFMA)
             img = torch.empty((int(_lib.load().paths_attention_bwd_x6_workspace(B, T, H, hd)),), device=dqkv.device, dtype=torch.uint8)
             _lib.call("paths_attention_bwd_x6_dropout", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
                       P(num_ims), P(dqkv), P(ws), P(img), B, T, H, hd, *dk(l), st)

@@ -418,12 +418,8 @@ int paths_attention_bwd_x6_launch(const float* q, const float* k, const float* v
   char* kr = qr + img; char* vr = kr + img; char* gr = vr + img; char* ktp = gr + img; char* qtp = ktp + img; char* gtp = qtp + img;
   hipLaunchKernelGGL(attn_bwd_x6_prep_kernel, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, d_o, qr, kr, vr, gr, ktp, qtp, gtp, num_ims, T, Tp, H);
   PATHS_LAUNCH_CHECK("attention_bwd_x6(prep)");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STEP);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KV_STEP + 512);
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN(attn_bwd_q_x6_kernel, 2 * STEP, "attention_bwd_x6(dq)");
+  PATHS_LDS_OPT_IN(attn_bwd_kv_x6_kernel, KV_STEP + 512, "attention_bwd_x6(dk, dv)");
   const int npairs = H * B;
   if (kv_too) {
     const int nkb = (T + 127) / 128;

@@ -471,12 +471,8 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   static const int depth_env = getenv("PATHS_ATTN_DEPTH") ? atoi(getenv("PATHS_ATTN_DEPTH")) : 0;   // experiment
   const int depth = depth_env ? depth_env : ATTN_OCC >= 3 ? (nblk <= 256 ? 1 : nblk <= 512 ? 2 : 3) : nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
   const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_x6_kernel<NP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN((attn_x6_kernel<NP, false>), 96 * 1024, "attention_x6");
+  PATHS_LDS_OPT_IN((attn_x6_kernel<NP, true>), 96 * 1024, "attention_x6(dropout)");
   const int nqb = (nq + 64 * QT - 1) / (64 * QT), npairs = H * B;
   const DropSite site = paths_make_drop_site(drop_key, drop_p);
   // 1-D grid walked in XCD-aware order (see the kernel)

@@ -28,6 +28,21 @@ int paths_set_error(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// Opt a kernel in to `bytes` of dynamic LDS (> the 64 KiB default), once per DEVICE (the attribute is per device: a process that
+// drives several GPUs must set it on each), with the return code checked: a failure here would otherwise only surface as a generic
+// launch error.  Use inside a function that returns the int error code.
+#define PATHS_LDS_OPT_IN(kernel_ptr, bytes, name)                                                                              \
+  do {                                                                                                                         \
+    static unsigned char done_[64] = {0};                                                                                      \
+    int dev_ = 0;                                                                                                              \
+    if (hipGetDevice(&dev_) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "%s: hipGetDevice failed", name);            \
+    if (dev_ < 0 || dev_ >= 64 || !done_[dev_]) {                                                                              \
+      const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      if (e_ != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "%s: hipFuncSetAttribute(%d bytes of LDS): %s", name, (int)(bytes), hipGetErrorString(e_)); \
+      if (dev_ >= 0 && dev_ < 64) done_[dev_] = 1;                                                                             \
+    }                                                                                                                          \
+  } while (0)
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) - indices stay constants without relying on the unroller
 // Residuals of a packed fp16 pair: ra = a - (float)h.lo, rb = b - (float)h.hi, one v_fma_mix_f32 each (the mixed-precision FMA reads
 // the half straight out of the packed register; written as a - (float)h hipcc emits v_cvt_f32_f16 + v_sub_f32, and turns an

@@ -175,11 +175,7 @@ int launch_gemm(const GemmOperands& g, int Npad, const Epi& epi, hipStream_t str
   PATHS_REQUIRE(g.lda0 % 4 == 0 && g.lda1 % 4 == 0 && g.ldb % 4 == 0, "%s: leading dims must be multiples of 4 floats", name);
   PATHS_REQUIRE(((uintptr_t)g.A0 % 16 == 0) && ((uintptr_t)g.A1 % 16 == 0) && ((uintptr_t)g.Bt % 16 == 0), "%s: operands must be 16-byte aligned", name);
   auto kern = gemm_f32_kernel<WTM, WTN, WGM, WGN, Epi>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN(kern, lds, name);
   dim3 grid(Npad / BN, (g.M + BM - 1) / BM);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGN), lds, stream, g, epi);
   PATHS_LAUNCH_CHECK(name);

@@ -289,16 +289,13 @@ reduce_slabs_x6_kernel(const float* __restrict__ slabs, int splits, int64_t n, f
 }
 
 template <int WT1, int WT2>
-void launch_tn(const TnX6Operands& g, hipStream_t stream) {
+int launch_tn(const TnX6Operands& g, hipStream_t stream) {
   constexpr int lds = 2 * 3 * ((64 * WT1 + 127) / 128 + (64 * WT2 + 127) / 128) * IMG;
   auto kern = gemm_tn_x6_kernel<WT1, WT2, (WT1 * WT2 < 16 ? 2 : 1)>;
-  static bool once = false;
-  if (!once) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    once = true;
-  }
+  PATHS_LDS_OPT_IN(kern, lds, "gemm_tn_x6");
   const int nblk = (g.N1 / (64 * WT1)) * (g.N2 / (64 * WT2)) * g.splits;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, stream, g);
+  return PATHS_OK;
 }
 
 }  // namespace
@@ -328,8 +325,8 @@ int paths_gemm_tn_x6(const float* a, int64_t lda, const float* b0, int64_t ldb0,
   const bool direct = nsplit == 1 && !accumulate;
   TnX6Operands g{a, lda, (uint32_t)a_bytes, b0, ldb0, nb0e, (uint32_t)b0_bytes, b1, ldb1, (uint32_t)b1_bytes, M, N1, N2,
                  direct ? out : workspace, direct ? ldo : (int64_t)N2, rps, nsplit};
-  if (big) launch_tn<4, 4>(g, stream);
-  else launch_tn<2, 2>(g, stream);
+  const int rc_ = big ? launch_tn<4, 4>(g, stream) : launch_tn<2, 2>(g, stream);
+  if (rc_ != PATHS_OK) return rc_;
   PATHS_LAUNCH_CHECK("gemm_tn_x6");
   if (!direct) {
     const int64_t n = (int64_t)N1 * N2;

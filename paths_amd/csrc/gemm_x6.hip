@@ -443,11 +443,7 @@ int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stre
   PATHS_REQUIRE(ROWS == (g.A0rows != nullptr) && (!ROWS || g.K1 == 0), "%s: row-pointer form is single-panel", name);
   PATHS_REQUIRE((int64_t)g.M * (g.lda0 > g.lda1 ? (g.lda0 > g.ldadd ? g.lda0 : g.ldadd) : (g.lda1 > g.ldadd ? g.lda1 : g.ldadd)) * 4 < (int64_t)1 << 32, "%s: A panel larger than 4 GiB", name);
   auto kern = gemm_x6_kernel<NP, WTM, WTN, PF, ADD, ROWS, Epi, OCC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN(kern, lds, name);
   PATHS_REQUIRE(g.ksplit == 1 || (g.ksplit > 1 && g.K1 == 0 && g.K0 % (32 * g.ksplit) == 0 && g.K0 / g.ksplit >= 128), "%s: split-K needs a single panel and k windows that are multiples of 32, >= 128", name);
   dim3 grid(Npad / BN, (g.M + BM - 1) / BM, g.ksplit);
 #ifdef PATHS_X6_DEBUG
@@ -677,12 +673,8 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
         // the dispatcher packs a CU to its limit before it moves on: ask for LDS that spreads the blocks over all CUs
         const int fblk = (M + 63) / 64, fdepth = (fblk + 255) / 256;
         const int flds = fdepth == 1 ? 84 * 1024 : fdepth == 2 ? 54 * 1024 : fdepth == 3 ? 41 * 1024 : 1024;
-        static bool fattr = false;
-        if (!fattr) {
-          hipFuncSetAttribute(reinterpret_cast<const void*>(x6_finish_kernel<2, decltype(epi)>), hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
-          hipFuncSetAttribute(reinterpret_cast<const void*>(x6_finish_kernel<1, decltype(epi)>), hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024);
-          fattr = true;
-        }
+        PATHS_LDS_OPT_IN((x6_finish_kernel<2, decltype(epi)>), 84 * 1024, "importance_proj_x6(finish)");
+        PATHS_LDS_OPT_IN((x6_finish_kernel<1, decltype(epi)>), 84 * 1024, "importance_proj_x6(finish)");
         if (IP_TILE128)
           hipLaunchKernelGGL((x6_finish_kernel<1, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
                              skip_padding ? num_ims : nullptr, rows_per_slide, e);

@@ -19,11 +19,17 @@ int paths_abi_version(void) { return 1; }
 
 // ---- stream plumbing for the launch tape (paths_amd/utils.py:TapedRecursion): the recorded launch sequence of a recursion is
 // replayed as a flat list of C calls, so its cross-stream joins and zero fills are C calls too.
-// An event handle for paths_stream_wait (host object, created once per join of a tape; never destroyed before process exit).
+// An event handle for paths_stream_wait (host object, created once per join of a tape, destroyed by paths_event_destroy).
 void* paths_event_create(void) {
   hipEvent_t ev = nullptr;
   if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { paths_set_error(PATHS_ELAUNCH, "event_create failed"); return nullptr; }
   return ev;
+}
+// Destroy an event made by paths_event_create (the launch tape destroys its events when it is closed / collected).
+int paths_event_destroy(void* event) {
+  PATHS_REQUIRE(event != nullptr, "event_destroy: null event");
+  if (hipEventDestroy(static_cast<hipEvent_t>(event)) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "event_destroy: hipEventDestroy failed");
+  return PATHS_OK;
 }
 // dst waits for everything enqueued on src so far (hipEventRecord + hipStreamWaitEvent: no host synchronisation)
 int paths_stream_wait(hipStream_t dst, hipStream_t src, void* event) {

@@ -90,11 +90,7 @@ static int launch_topk(const float* scores, int64_t ld, const int64_t* num_ims, 
                        int* keep_count, const float* row_base, int64_t row_ld, int64_t slide_rows, int64_t* kept_rows,
                        const float* zero_row, hipStream_t stream) {
   const size_t lds = (size_t)(((n_max + 7) & ~7) + 2) * 8 + 4 * 64 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((TOPK_MAX + 2) * 8 + 1024));
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN(topk_rank_kernel, (TOPK_MAX + 2) * 8 + 1024, "topk");
   // x covers every element AND every position of the kept-row table (ldk may exceed n_max only through padding; both <= TOPK_MAX)
   const int cover = (int)(ldk > n_max ? ldk : n_max);
   hipLaunchKernelGGL(topk_rank_kernel, dim3((cover + 63) / 64, B), dim3(256), lds, stream, scores, ld, num_ims, keep, keep_idx, ldk,

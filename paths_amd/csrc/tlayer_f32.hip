@@ -487,11 +487,7 @@ int paths_token_layer_f32(const float* x_in, const float* attn, float* x_out,
                  q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps};
   constexpr size_t lds_min = (2ull * CHUNK_FLOATS + DFF + 3 * DM) * sizeof(float);      // 77,312 B: two workgroups per CU
   constexpr size_t lds_solo = 84 * 1024;                                                 // > 80 KiB: one workgroup per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solo);
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN(tlayer_f32_kernel, lds_solo, "token_layer");
   // max_tokens > 0: only token rows [0, max_tokens) are needed (last layer: only token 0 is read downstream)
   const int nt = max_tokens > 0 && max_tokens < T ? max_tokens : T;
   const int nblk = ((nt + 63) / 64) * B;

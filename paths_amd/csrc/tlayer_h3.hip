@@ -394,11 +394,7 @@ int paths_token_layer_h3(const float* x_in, const float* attn, float* x_out, con
                    q, k, v, num_ims, T, H, do_post, do_qkv, skip_padding, qscale, eps, reinterpret_cast<char*>(qkv_images), (T + 63) / 64 * 64};
   constexpr size_t lds_min = 2ull * CHUNK + (DFF + 3 * DM + 9 * DM) * sizeof(float);     // 73,728 B: two workgroups per CU
   constexpr size_t lds_solo = 84 * 1024;                                                 // > 80 KiB: one workgroup per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solo);
-    attr_set = true;
-  }
+  PATHS_LDS_OPT_IN(tlayer_h3_kernel, lds_solo, "token_layer_h3");
   const int nt = max_tokens > 0 && max_tokens < T ? max_tokens : T;
   const int nblk = ((nt + TOK_WG - 1) / TOK_WG) * B;
   const size_t lds = nblk <= (NWAVES == 8 ? 256 : 2 * 256) ? lds_solo : lds_min;      // spread small grids one workgroup per CU (see tlayer_f32.hip)

@@ -511,16 +511,7 @@ size_t ws_lds_bytes(bool post, bool qkv) {
 template <int DM, bool POST, bool QKV>
 int launch_ws(const WsParams& p, hipStream_t stream) {
   const size_t lds = ws_lds_bytes<DM>(POST, QKV);
-  // per-device opt-in for > 64 KiB of dynamic LDS (checked: a failure here would otherwise surface as a launch error)
-  static int attr_dev[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "token_layer_ws: hipGetDevice failed");
-  if (dev < 0 || dev >= 64 || !attr_dev[dev]) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tlayer_ws_kernel<DM, POST, QKV>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    if (e != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "token_layer_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    if (dev >= 0 && dev < 64) attr_dev[dev] = 1;
-  }
+  PATHS_LDS_OPT_IN((tlayer_ws_kernel<DM, POST, QKV>), 160 * 1024, "token_layer_ws");
   // (> 80 KiB per workgroup: one workgroup per CU, so a grid of ~one workgroup per CU spreads over the whole chip)
   const size_t ask = lds > 84 * 1024 ? lds : 84 * 1024;
   hipLaunchKernelGGL((tlayer_ws_kernel<DM, POST, QKV>), dim3((p.T + TOK - 1) / TOK, p.B), dim3(64 * NW), ask, stream, p);

@@ -4,7 +4,8 @@ Same constructor / ``process(data, lstm=None)`` / ``ctx_dim()`` surface and stat
 ``process`` issues the HIP launch sequence of paths_amd/ops.py:level_forward and returns the reference's
 dict {"logits", "ctx_slide", "ctx_patch", "importance"} (model/paths.py:141-146).
 
-Round-1 limits (rejected loudly, never silently approximated): trans_dim=128 / 4 heads / importance hidden 128, dropout inactive (eval or dropout=0).
+Limits (rejected loudly, never silently approximated): the aggregator kernels are built for trans_dim=128 / 4 heads / importance hidden
+128 (paths_amd/ops.py:check_supported).  Dropout > 0 is active in train mode (counter-based masks, paths_amd/backward.py:Drop).
 """
 from __future__ import annotations
 

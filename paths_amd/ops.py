@@ -369,7 +369,7 @@ def pack_level(proc) -> Dict[str, object]:
 def check_supported(mc, nhead_dim_ok: bool = True):
     """Configurations this build runs on the HIP path; everything else is rejected loudly."""
     if mc.trans_dim != 128 or mc.trans_heads != 4 or mc.importance_mlp_hidden_dim != 128:
-        raise NotImplementedError("paths_amd round 1 kernels are specialised for trans_dim=128, trans_heads=4, "
+        raise NotImplementedError("the aggregator kernels of this build are specialised for trans_dim=128, trans_heads=4, "
                                   f"importance_mlp_hidden_dim=128 (got {mc.trans_dim}, {mc.trans_heads}, {mc.importance_mlp_hidden_dim})")
     if mc.patch_embed_dim % 128 or mc.hierarchical_ctx_mlp_hidden_dim % 64:
         raise NotImplementedError("patch_embed_dim must be a multiple of 128 and hierarchical_ctx_mlp_hidden_dim of 64")

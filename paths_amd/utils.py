@@ -78,7 +78,6 @@ class GraphedRecursion:
         return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
 
     def capture(self):
-        assert not torch.is_grad_enabled() or not any(p.requires_grad for p in self.model.parameters()) or True
         dev = self.batch.device
         with torch.no_grad():
             # warm-up outside the capture: builds every cached image / table (some of which sync) and the side streams
@@ -139,6 +138,23 @@ class TapedRecursion:
 
     def _param_versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def close(self):
+        """Drop the tape and destroy the HIP events of its stream joins (a service that records one tape per batch would otherwise
+        accumulate about a dozen events per tape).  Called by __del__; the tape can be recorded again afterwards."""
+        evs, self._events = self._events[0], [[], 0]
+        self.tape = None
+        if evs:
+            try:
+                torch.cuda.synchronize(self.batch.device)       # no replay in flight still waits on them
+                lib = _lib.load()
+                for ev in evs:
+                    lib.paths_event_destroy(ev)
+            except Exception:                                    # interpreter shutdown: the runtime may be gone already
+                pass
+
+    def __del__(self):
+        self.close()
 
     def record(self):
         global STREAM_LANE

@@ -39,6 +39,31 @@ def test_concordance_index_matches_definition():
     assert concordance_index_censored(e, t, np.zeros(4)) == 0.5
 
 
+def test_concordance_index_hand_computed_sksurv_cases():
+    """Known answers worked out by hand from the definition sksurv.metrics.concordance_index_censored documents (pair (i, j) is
+    comparable iff i had an event and t_i < t_j, or t_i == t_j and j is censored; a pair counts 1 if risk_i > risk_j, 1/2 if the
+    risks are within tied_tol; sksurv itself is not installed here)."""
+    from paths_amd.eval import concordance_index_censored as ci
+    # events at t = 1, 2, 4; censored at t = 2, 3.  Comparable: 0 -> {1, 2, 3, 4} (4 concordant); 1 -> {3 (conc), 4 (disc), 2 (same
+    # time, censored: risk tie -> 1/2)}; the last event has nobody after it.  (4 + 1 + 0.5) / 7
+    t = np.array([1.0, 2, 2, 3, 4]); e = np.array([1, 1, 0, 0, 1], bool); r = np.array([0.9, 0.5, 0.5, 0.1, 0.7])
+    assert abs(ci(e, t, r) - 5.5 / 7.0) < 1e-15
+    # tied times: two events at the same time are NOT comparable with each other; an event and a censored sample at that time are
+    assert ci(np.array([1, 0], bool), np.array([5.0, 5.0]), np.array([0.2, 0.8])) == 0.0
+    assert ci(np.array([1, 0], bool), np.array([5.0, 5.0]), np.array([0.8, 0.2])) == 1.0
+    assert abs(ci(np.array([1, 1, 0], bool), np.array([5.0, 5.0, 7.0]), np.array([0.3, 0.9, 0.5])) - 0.5) < 1e-15      # pairs 0->2 (disc), 1->2 (conc)
+    # a censored sample never opens a pair, even when it is the earliest
+    assert ci(np.array([0, 1, 1], bool), np.array([1.0, 2.0, 3.0]), np.array([0.0, 0.9, 0.1])) == 1.0                  # only 1 -> 2
+    # risk ties inside tied_tol count one half, outside it they are ordered
+    e3, t3 = np.array([1, 1], bool), np.array([1.0, 2.0])
+    assert ci(e3, t3, np.array([0.5, 0.5 + 5e-9])) == 0.5 and ci(e3, t3, np.array([0.5, 0.5 + 5e-8])) == 0.0
+    assert ci(e3, t3, np.array([0.5, 0.5 + 5e-8]), tied_tol=1e-7) == 0.5
+    # no comparable pair at all: all censored, or every event tied in time with only events
+    for ev, tt in ((np.zeros(3, bool), np.array([1.0, 2, 3])), (np.ones(3, bool), np.array([5.0, 5, 5]))):
+        with pytest.raises(ValueError):
+            ci(ev, tt, np.array([0.1, 0.2, 0.3]))
+
+
 def test_binary_auroc_matches_pair_counting():
     from paths_amd.eval import binary_auroc
     rng = np.random.RandomState(1)

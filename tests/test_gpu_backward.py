@@ -334,8 +334,14 @@ def test_recursion_gradients_at_headline_size_vs_oracle_autograd(dev):
     assert live > 100, (live, worst)
 
 
+def _is_dead(k: str) -> bool:
+    """The reference's dead nn.Transformer parameters (encoder, cross-attention matrices): zero gradients there, SURVEY 3.3."""
+    return ".encoder." in k or "multihead_attn.in_proj" in k or "multihead_attn.out_proj.weight" in k
+
+
 @pytest.mark.parametrize("over", [{"lstm": False}, {"slide_ctx_mode": "concat"}, {"lstm": False, "slide_ctx_mode": "concat"},
-                                  {"slide_ctx_mode": "none"}], ids=["nolstm", "concat", "nolstm_concat", "ctx_none"])
+                                  {"slide_ctx_mode": "none"}, {"importance_mode": "none"}, {"lstm": False, "slide_ctx_mode": "none"}],
+                         ids=["nolstm", "concat", "nolstm_concat", "ctx_none", "imp_none", "nolstm_ctx_none"])
 def test_variant_training_gradients_vs_oracle_autograd(dev, over):
     """the non-default model variants train on the HIP path too (reference model/paths.py:49-54,101-109: RNN
     hierarchical context instead of the LSTM; :34-37,134-137: slide contexts concatenated into the classifier): 5-level training
@@ -360,13 +366,26 @@ def test_variant_training_gradients_vs_oracle_autograd(dev, over):
             # unused by the oracle's graph: either really unused (grad None) or one of the reference's dead nn.Transformer
             # parameters, which forward_backward fills with the reference's zero gradients
             assert g is None or float(g.abs().max()) == 0.0, k
+            # a parameter WITHOUT a path to the loss keeps grad None, as in the reference (torch autograd through the oracle): AdamW
+            # must not touch it, weight decay included (importance MLP under importance_mode "none", the earlier levels'
+            # aggregators under slide_ctx_mode "none", the classifiers of the non-final levels)
+            if ref.grad is None and not _is_dead(k):
+                assert g is None, k
             continue
         assert g is not None, k
         assert rel_err(g, ref.grad) < 2e-3, (k, rel_err(g, ref.grad))
         live += 1
-    assert live > (40 if over.get("slide_ctx_mode") == "none" else 90)      # ("none": the earlier levels' aggregators do not reach the loss)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    assert live > (15 if over.get("slide_ctx_mode") == "none" else 80)      # ("none": the earlier levels' aggregators do not reach the loss)
+    # one AdamW step: parameters the reference leaves alone (grad None) are bit-unchanged, weight decay included; and the fixed
+    # all-reduce list is exactly the set of non-dead parameters that got a gradient
+    from paths_amd import autograd as pag
+    assert {id(q) for q in pag.live_grad_params(model, 5)} == {id(q) for k, q in sd.items() if q.grad is not None and not _is_dead(k)}
+    untouched = {k: q.detach().clone() for k, q in sd.items() if p[k].grad is None and not _is_dead(k)}
+    assert untouched
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
     assert np.isfinite(float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)))
+    for k, before in untouched.items():
+        assert torch.equal(sd[k].detach(), before), k
 
 
 def test_training_on_zero_children_slides_takes_the_fallback(dev):

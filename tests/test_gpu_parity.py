@@ -749,6 +749,7 @@ def test_qkv_images_written_by_token_layer_equal_the_rewrite(dev, monkeypatch, n
     if ops.GEMM_MODE != "h3":
         pytest.skip("operand images written by the token layer are a default-mode (two-plane split) feature")
     assert ops.QKV_IMAGES
+    monkeypatch.setattr(ops, "TLAYER_WS", False)          # (the chunk-streaming token layer: its image writer and the re-write launch)
     g, info, out_direct = run_single(dev, name)
     monkeypatch.setattr(ops, "QKV_IMAGES", False)
     _, _, out_rewrite = run_single(dev, name)

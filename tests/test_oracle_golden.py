@@ -144,6 +144,20 @@ def test_compare_recursion_checker_detects_differences():
     assert not compare_recursion(bad, tr, hz, hz, raise_on_mismatch=False)["parent_pairs_identical"]
     with pytest.raises(AssertionError):
         compare_recursion(as_gpu(tr), tr, hz + 1e-3, hz)
+    # the kept SEQUENCE: swapping two kept entries whose scores differ by more than 1e-6 keeps the set but is reported
+    assert res["sequence_identical"] and res["sequence_positions_moved"] == 0
+    bad = as_gpu(tr)
+    a, b = int(bad[1]["keep_idx"][0, 0]), int(bad[1]["keep_idx"][0, 1])
+    bad[1]["keep_idx"][0, 0], bad[1]["keep_idx"][0, 1] = b, a
+    r2 = compare_recursion(bad, tr, hz, hz, raise_on_mismatch=False)
+    gap = abs(float(tr[1]["importance"][0, a] - tr[1]["importance"][0, b]))
+    assert gap > 1e-6 and r2["index_sets_identical"] and not r2["sequence_identical"] and r2["sequence_positions_moved"] == 2
+    assert abs(r2["sequence_max_gap"] - gap) < 1e-12 and any("kept sequence" in p_ for p_ in r2["problems"])
+    # ... while a swap inside the tolerance only shows in the counters
+    r3 = compare_recursion(bad, tr, hz, hz, raise_on_mismatch=False, seq_tol=gap * 2)
+    assert r3["sequence_positions_moved"] == 2 and not any("kept sequence" in p_ for p_ in r3["problems"])
+    # (the next level's parent_inds of this hand-made trace still index the un-swapped order: only that is reported)
+    assert all("(child -> parent)" in p_ for p_ in r3["problems"])
 
 
 def test_importance_map_equals_reference_overlay_g11():
