@@ -39,6 +39,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.
 MFMA_PER_PRODUCT = {3: 6, 2: 3}   # 16-bit MFMAs issued per fp32 product block: 3 bf16 planes ("x6") / 2 fp16 planes ("h3")
 BASE_SHAPES = {2048: (32, 64), 1024: (32, 32), 256: (16, 16)}
 PMC_PROFILE_H3 = "r02a_pmc_traffic.json"     # separate --pmc passes of the default build (tools/refresh_profiles.sh)
+ROOFLINE_FILE = "roofline.json"               # measured MFMA issue peak / stream bandwidth of the pool's boxes (tools/peaks.hip)
 CPU_DSEED = 1234
 # slide ids of the cpu_baseline / parity sample: screened here with the oracle so that every level's top-K boundary gap
 # (score[k-1] - score[k]) is >= 1e-5 with the bench weights (seed 0) - the reference's own selection is thread-count
@@ -49,6 +50,15 @@ CPU_SLIDE_IDS = {2048: [10003, 10004, 10005, 10002], 1024: [10000, 10001, 10003,
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def measured_peaks():
+    """profiles/roofline.json: the denominators measured on the box next to the spec values."""
+    try:
+        with open(os.path.join(ROOT, "profiles", ROOFLINE_FILE)) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
 
 
 def host_cpu_share() -> int:
@@ -375,6 +385,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
     ap.add_argument("--fp8", action="store_true", help="stress mode: also run the opt-in e4m3 attention variant and report its speed and "
                     "its logit distance from the fp32-accurate path")
+    ap.add_argument("--rotate", type=int, default=3, help="infer mode: distinct resident slide batches (21 GiB each at K=2048) cycled "
+                    "through the timed region, one recorded launch tape each; the headline is measured on the rotation (every step works "
+                    "on different rows than the step before), the single-batch replay figure is reported beside it")
     ap.add_argument("--train-steps", type=int, default=5, help="infer mode: timed steps of the short training measurement added to the "
                     "line as 'train' (0 = skip); 3 warm-up steps")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "stress"],
@@ -424,35 +437,48 @@ def main():
         train_bench(args, cfg, model, slides, rank, world, dev_reduce, pdist, putils, None)
         return
 
-    def step(trace=None):
+    # --rotate distinct resident batches (slide ids disjoint across batches and ranks)
+    nrot = max(1, args.rotate)
+    batches = [slides]
+    for r in range(1, nrot):
+        batches.append(DeviceSlideBatch([DeviceSlide.synthetic(1234, 100000 * r + rank * spg + i, BASE_SHAPES[K], device=dev) for i in range(spg)]))
+    if nrot > 1:
+        torch.cuda.synchronize()
+        log(f"{nrot} distinct batches resident ({torch.cuda.memory_allocated() / 2**30:.1f} GiB)")
+
+    def step(trace=None, batch=None):
         with torch.no_grad():
-            return putils.recurse(model, slides, cfg.top_k_patches, cfg.num_levels, trace=trace, check_status=False)
+            return putils.recurse(model, slides if batch is None else batch, cfg.top_k_patches, cfg.num_levels, trace=trace, check_status=False)
 
     # --graph: the whole recursion (5 levels, 3 streams, ~70 launches) captured once into a HIP graph and replayed per step
     # (paths_amd.utils.GraphedRecursion); default: the eager launch sequence (faster on this stack, see --graph's help)
     # default: the recursion recorded once as a flat launch tape and replayed (same three streams and joins as the eager pass,
     # Python's per-launch work gone: paths_amd.utils.TapedRecursion); --eager: every launch through the Python launch path
-    graphed, launch_mode = None, "eager"
+    graphed, launch_mode, replays = None, "eager", None
     if args.graph:
-        graphed = putils.GraphedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).capture()
-        launch_mode = "hip_graph_replay"
+        replays = [putils.GraphedRecursion(model, b, cfg.top_k_patches, cfg.num_levels).capture() for b in batches]
+        graphed, launch_mode = replays[0], "hip_graph_replay"
         log("recursion captured into a HIP graph")
     elif not args.eager:
-        graphed = putils.TapedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).record()
-        launch_mode = "launch_tape_replay"
-        log(f"recursion recorded as a launch tape ({len(graphed.tape)} C calls per step)")
+        replays = [putils.TapedRecursion(model, b, cfg.top_k_patches, cfg.num_levels).record() for b in batches]
+        graphed, launch_mode = replays[0], "launch_tape_replay"
+        log(f"recursion recorded as a launch tape ({len(graphed.tape)} C calls per step, one tape per resident batch)")
 
-    def timed_step():
-        return graphed.replay() if graphed is not None else step()
+    def timed_step(i=0):
+        return replays[i % nrot].replay() if replays is not None else step(batch=batches[i % nrot])
 
-    for i in range(args.warmup):
-        timed_step()
+    for i in range(max(args.warmup, nrot)):
+        timed_step(i)
         torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     # ---- timed region; the dominant kernel and the aggregator span are bracketed by events on their launch streams
     events = []
 
     def timer(name, launch, meta):
+        # An event recorded right behind a kernel launch is attached to THAT kernel and reads its start time (measured: a start
+        # event behind the memory-cell GEMM made the output-gate figure the sum of both, 187 us).  A throw-away record in front
+        # takes that attachment; the real start event then gets a marker of its own, stamped when everything before it has ended.
+        torch.cuda.Event(enable_timing=True).record()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out_ = launch()
@@ -465,8 +491,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     out = None
-    for _ in range(args.steps):
-        out = timed_step()
+    for i in range(args.steps):
+        out = timed_step(i)
     t_enqueued = time.perf_counter() - t0          # host side done (diagnostic: is the Python launch path ahead of the GPU?)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -475,6 +501,17 @@ def main():
     status = int(out["status"].item())
     assert status == 0, f"recursion status {status}"
     elapsed = pdist.max_over_ranks(elapsed, dev_reduce)
+    single = None
+    if nrot > 1:
+        # the same K steps on ONE batch (the round-2 headline): every step re-reads the rows the previous one touched
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out = timed_step(0)
+        barrier()
+        el1 = pdist.max_over_ranks(time.perf_counter() - t1, dev_reduce)
+        single = {"slides_per_s": round(spg * world * args.steps / el1, 2), "ms_per_step": round(el1 / args.steps * 1e3, 3),
+                  "note": "same launch mode, one resident batch replayed (warm L2 / Infinity Cache for its rows)"}
     eager = None
     if graphed is not None:
         # kernel-level event timing needs launches issued one by one (events inside a captured graph cannot be timed): the same
@@ -504,8 +541,8 @@ def main():
         n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-4)) + 1)
         barrier()
         t1 = time.perf_counter()
-        for _ in range(n_sus):
-            out = timed_step()
+        for i in range(n_sus):
+            out = timed_step(i)
         barrier()
         el2 = pdist.max_over_ranks(time.perf_counter() - t1, dev_reduce)
         sustained = {"steps": n_sus, "seconds": round(el2, 3), "slides_per_s": round(spg * world * n_sus / el2, 2),
@@ -593,6 +630,13 @@ def main():
                     "vs_f32_matrix_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 3),
                     "avg_launch_us": round(ms * 1e3 / n_launch, 2), "launches": n_launch,
                     "algorithmic_gflop_per_launch": round(flop / n_launch / 1e9, 3)}
+        mp = measured_peaks()
+        if mp is not None and planes == 2:
+            pm = mp["derived"]["h3_fp32_equivalent_tflops"]
+            roofline["peak_measured"] = pm
+            roofline["frac_of_measured_peak"] = round(achieved / pm, 4)
+            roofline["peak_measured_basis"] = ("profiles/roofline.json: back-to-back v_mfma_f32_32x32x16_f16 issue on random operands, all "
+                                               f"CUs = {mp['derived']['mfma_f16_issue_tflops']} TFLOP/s (tools/peaks.hip) / 3")
         if ser_span.get("lstm_gate_o"):
             f2, ms2, n2 = gemm_o_roofline(ser_span["lstm_gate_o"])
             roofline["serialized_us"] = round(ms2 * 1e3 / n2, 2)          # measured in this run (breakdown pass), not from a file
@@ -629,6 +673,12 @@ def main():
             fl2, ms2, n2 = agg_roofline(ser_span["aggregator"])
             roofline_attn["serialized_span_us"] = round(ms2 * 1e3 / n2, 2)
             roofline_attn["serialized_frac"] = round(fl2 / (ms2 * 1e-3) / 1e12 / peak, 4)
+            mp = measured_peaks()
+            if mp is not None and planes == 2:
+                pm = mp["derived"]["h3_16x16x32_fp32_equivalent_tflops"]
+                roofline_attn["peak_measured"] = pm
+                roofline_attn["serialized_frac_of_measured_peak"] = round(fl2 / (ms2 * 1e-3) / 1e12 / pm, 4)
+                roofline_attn["frac_of_measured_peak"] = round(ach / pm, 4)
 
     train = None
     if args.train_steps > 0:
@@ -648,6 +698,7 @@ def main():
                                    f"{BASE_SHAPES[K][0]}x{BASE_SHAPES[K][1]}, top_k {K // 4}, 10% background), D=1024 "
                                    f"features, trans_dim 128 x 4 heads x 2 layers, LSTM ctx 256; {spg} HBM-resident slides per GPU",
                        "slides_per_gpu": spg, "global_batch": spg * world, "levels": cfg.num_levels,
+                       "resident_batches_rotated": nrot,
                        "parallelism": f"slide-sharded x{world} (no data-path collective)",
                        "gemm_mode": ("h3: GEMM, attention and token-layer operands split into 2 fp16 planes (22 bits), 3 fp16 MFMAs per "
                                      "product block, fp32 accumulate, power-of-two scaling of weights / GEMM activations (error of the "
@@ -661,6 +712,8 @@ def main():
                      "note": "roofline / roofline_attn_ffn event timings come from the eager instrumented pass of the same K steps "
                              "(the replayed launch sequence carries no events)" if graphed is not None else None},
         }
+        if single is not None:
+            line["single_batch"] = single
         if train is not None:
             line["train"] = train
         if sustained is not None:

@@ -278,6 +278,29 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
                          float* ctx_out, float* logits, float* partials, int* counters, int B, int T, int d, int H,
                          float eps, float eps_final, paths_stream_t stream);
 
+/* ---- shape-generic kernels (csrc/generic.hip): any trans_dim (multiple of 32, <= 1024), head_dim in {16, 32, 48, 64}, any
+ * importance_mlp_hidden_dim - e.g. the reference's dataclass defaults trans_dim 192 / 4 heads (config.py:30-36).  With
+ * paths_gemm_nt_f32 for the products they evaluate model/paths.py:95-98,119-139 and model/aggregator.py:37-76 in exact fp32; the
+ * shipped 128 / 4 / 128 geometry runs on the specialised kernels above instead.
+ *   paths_attention_any   softmax(q k^T / sqrt(hd)) v, keys >= num_ims[b] + 1 masked; qkv [B*T, 3 d] token-major (in_proj output),
+ *                         qscale = log2(e) / sqrt(head_dim), o [B, T, d]; max_queries > 0: only queries [0, max_queries)
+ *   paths_layernorm_rows  y = LayerNorm(x (+ add [d])) * gamma + beta per row (row strides ldx / ldy)
+ *   paths_importance_rows importance[m] = valid ? sigmoid(hid[m] . w2 + b2) : 0 from hid = relu(Y W1^T + b1)  (utils.py:106-115)
+ *   paths_tokens_assemble tokens[b, 0] = special, tokens[b, 1 + n] = alpha P[b n] + bp + PE  (aggregator.py:37-65, utils.py:16-23,47-67)
+ *   paths_final_head_any  paths_final_head for any trans_dim */
+int paths_attention_any(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
+                        int max_queries, paths_stream_t stream);
+int paths_layernorm_rows(const float* x, int64_t ldx, const float* add, const float* gamma, const float* beta, float* y, int64_t ldy,
+                         int64_t rows, int d, float eps, paths_stream_t stream);
+int paths_importance_rows(const float* hid, int64_t ldh, const float* w2, const float* b2, const int64_t* num_ims, int rows_per_slide,
+                          int64_t M, int Hi, float* importance, paths_stream_t stream);
+int paths_tokens_assemble(const float* P, int64_t ldp, const float* importance, int imp_mul, const float* bp, const float* special,
+                          const float* div_term, const int64_t* locs, int rows_per_slide, int patch_size, int pe_mode, int d, int B,
+                          float* tokens, paths_stream_t stream);
+int paths_final_head_any(const float* x, int64_t slide_stride, const float* lng, const float* lnb, const float* ctx_prev, int64_t ctx_stride,
+                         const float* ctx_all, int ctx_depth, const float* wcls, const float* bcls, int num_logits, int cls_in,
+                         float* ctx_out, float* logits, int B, int d, float eps, paths_stream_t stream);
+
 /* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
  * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only
  * out[:, 0] of the final layer is read: it needs K/V of every token (q,k,v as written by paths_token_layer_f32 for

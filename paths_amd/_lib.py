@@ -55,6 +55,11 @@ SIGNATURES = {
     "paths_token_layer_ws": [_vp] * 17 + [_f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp],
     "paths_token0_pack_ws": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp],
     "paths_token0_tail_ws": [_vp] * 16 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
+    "paths_attention_any": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "paths_layernorm_rows": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
+    "paths_importance_rows": [_vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
+    "paths_tokens_assemble": [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "paths_final_head_any": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
     "paths_attention_h3_img": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "paths_token_layer_f32": [_vp] * 21 + [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "paths_token0_tail": [_vp] * 20 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],

@@ -366,11 +366,22 @@ def pack_level(proc) -> Dict[str, object]:
     return packed
 
 
-def check_supported(mc, nhead_dim_ok: bool = True):
+def fast_path(mc) -> bool:
+    """The shipped aggregator geometry (trans_dim 128, 4 heads, importance hidden 128): specialised, tuned kernels.  Anything
+    else the reference's config surface allows runs on the shape-generic kernels (csrc/generic.hip + the f32 GEMM)."""
+    return mc.trans_dim == 128 and mc.trans_heads == 4 and mc.importance_mlp_hidden_dim == 128
+
+
+def check_supported(mc, training: bool = False):
     """Configurations this build runs on the HIP path; everything else is rejected loudly."""
-    if mc.trans_dim != 128 or mc.trans_heads != 4 or mc.importance_mlp_hidden_dim != 128:
-        raise NotImplementedError("the aggregator kernels of this build are specialised for trans_dim=128, trans_heads=4, "
-                                  f"importance_mlp_hidden_dim=128 (got {mc.trans_dim}, {mc.trans_heads}, {mc.importance_mlp_hidden_dim})")
+    if not fast_path(mc):
+        d, H, Hi = mc.trans_dim, mc.trans_heads, mc.importance_mlp_hidden_dim
+        if d % 32 or d > 1024 or H < 1 or d % H or (d // H) not in (16, 32, 48, 64) or Hi < 1 or Hi > 1024:
+            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 1024), head_dim in {16, 32, 48, 64} and "
+                                      f"importance_mlp_hidden_dim <= 1024 (got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
+        if training:
+            raise NotImplementedError("training (the hand-written backward kernels) is built for trans_dim=128, trans_heads=4, "
+                                      f"importance_mlp_hidden_dim=128 (got {d}, {H}, {Hi}); inference runs on the generic kernels")
     if mc.patch_embed_dim % 128 or mc.hierarchical_ctx_mlp_hidden_dim % 64:
         raise NotImplementedError("patch_embed_dim must be a multiple of 128 and hierarchical_ctx_mlp_hidden_dim of 64")
     if mc.pos_encoding_mode not in ("1d", "2d"):
@@ -378,6 +389,102 @@ def check_supported(mc, nhead_dim_ok: bool = True):
         raise RuntimeError(f"pos_encoding_mode '{mc.pos_encoding_mode}' skips proj_in in the reference and fails there too")
     if mc.slide_ctx_mode not in ("residual", "concat", "none") or mc.importance_mode not in ("mul", "none"):
         raise ValueError("unknown slide_ctx_mode / importance_mode")
+
+
+def _pad_rows(w: torch.Tensor, mult: int = 128) -> torch.Tensor:
+    """[N, K] -> [ceil(N / mult) * mult, K] with zero rows (the f32 GEMM kernels read whole 128-row weight tiles)."""
+    n = w.shape[0]
+    n_pad = (n + mult - 1) // mult * mult
+    if n_pad == n:
+        return w.contiguous()
+    out = torch.zeros((n_pad, w.shape[1]), device=w.device, dtype=w.dtype)
+    out[:n] = w
+    return out
+
+
+def generic_pack(lvl_pack: Dict[str, object], mc) -> Dict[str, object]:
+    """Zero-padded fp32 weight copies for the generic path (cached in the level's pack dict, rebuilt with it)."""
+    if "generic" not in lvl_pack:
+        Hi = mc.importance_mlp_hidden_dim
+        g = {"w1": _pad_rows(lvl_pack["w_ip"][:Hi]), "wp": _pad_rows(lvl_pack["w_ip"][Hi:]), "layers": []}
+        for lay in lvl_pack["layers"]:
+            g["layers"].append({k: _pad_rows(lay[k]) for k in ("wqkv", "wo", "w1", "w2")})
+        lvl_pack["generic"] = g
+    return lvl_pack["generic"]
+
+
+def gemm_f32(a, lda: int, w_pad: torch.Tensor, bias, out, ldo: int, M: int, N: int, K: int, act: int = 0, residual=None, ldr: int = 0):
+    """out[M, N] = act(a[M, K] w^T + bias) (+ residual) on the f32-input matrix cores (exact fp32 FMA chains)."""
+    ptr = lambda t: t if isinstance(t, int) or t is None else t.data_ptr()
+    _lib.call("paths_gemm_nt_f32", ptr(a), lda, ptr(w_pad), K, ptr(bias), ptr(out), ldo, M, N, w_pad.shape[0], K, act,
+              ptr(residual), ldr, None, 0, 0, _lib.stream())
+
+
+def importance_proj_generic(mc, lvl_pack, src, ld_src: int, locs, num_ims, B: int, N: int, D: int, imp_mul: int, imp_out, tokens):
+    """importance MLP + masked sigmoid + alpha * proj_in + positional encoding + special token for any (trans_dim, hidden) widths
+    (reference model/paths.py:95-98,119-124; model/aggregator.py:37-65): two GEMMs and two row kernels."""
+    gp = generic_pack(lvl_pack, mc)
+    d, Hi, M = mc.trans_dim, mc.importance_mlp_hidden_dim, B * N
+    dev = locs.device
+    st = _lib.stream()
+    p = _lib.ptr
+    hid = torch.empty((M, Hi), device=dev, dtype=torch.float32)
+    gemm_f32(src, ld_src, gp["w1"], lvl_pack["b1"], hid, Hi, M, Hi, D, act=1)
+    _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), st)
+    proj = torch.empty((M, d), device=dev, dtype=torch.float32)
+    gemm_f32(src, ld_src, gp["wp"], None, proj, d, M, d, D)
+    pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+    _lib.call("paths_tokens_assemble", p(proj), d, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
+              p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
+
+
+def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
+    """The aggregator for any (trans_dim, heads): generic GEMMs + csrc/generic.hip (reference model/aggregator.py:58-76 with torch's
+    post-LN decoder layers, model/paths.py:130-139).  The last layer is evaluated at token 0 only (its other rows are never read)."""
+    gp = generic_pack(lvl_pack, mc)
+    B, T, d = tokens.shape
+    H, L = mc.trans_heads, mc.trans_layers
+    hd = d // H
+    dev = tokens.device
+    st = _lib.stream()
+    p = _lib.ptr
+    f32 = dict(device=dev, dtype=torch.float32)
+    qscale = LOG2E / math.sqrt(hd)
+    M = B * T
+    x = tokens.view(M, d)
+    qkv = torch.empty((M, 3 * d), **f32)
+    attn = torch.empty((B, T, d), **f32)
+    rows, ldx = M, d                      # the current activation: `rows` rows, row stride ldx (the last layer keeps token 0 of every slide)
+    for l in range(L):
+        lay, gl = lvl_pack["layers"][l], gp["layers"][l]
+        last = l == L - 1
+        gemm_f32(x, d, gl["wqkv"], lay["bqkv"], qkv, 3 * d, M, 3 * d, d)
+        _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
+        if last:
+            rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
+        y1 = torch.empty((rows, d), **f32)
+        gemm_f32(attn, ldx, gl["wo"], lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx)
+        x1 = torch.empty((rows, d), **f32)
+        _lib.call("paths_layernorm_rows", p(y1), d, None, p(lay["ln1g"]), p(lay["ln1b"]), p(x1), d, rows, d, lay["eps"], st)
+        x2 = y1                           # (re-used)
+        _lib.call("paths_layernorm_rows", p(x1), d, p(lay["cab"]), p(lay["ln2g"]), p(lay["ln2b"]), p(x2), d, rows, d, lay["eps"], st)
+        hff = torch.empty((rows, 4 * d), **f32)
+        gemm_f32(x2, d, gl["w1"], lay["b1"], hff, 4 * d, rows, 4 * d, d, act=1)
+        y2 = x1                           # (re-used)
+        gemm_f32(hff, 4 * d, gl["w2"], lay["b2"], y2, d, rows, d, 4 * d, residual=x2, ldr=d)
+        x3 = torch.empty((rows, d), **f32)
+        _lib.call("paths_layernorm_rows", p(y2), d, None, p(lay["ln3g"]), p(lay["ln3b"]), p(x3), d, rows, d, lay["eps"], st)
+        x, ldx = x3, d
+    nlog = lvl_pack["wcls"].shape[0]
+    ctx_out = torch.empty((B, d), **f32)
+    logits = torch.empty((B, nlog), **f32)
+    res = ctx_prev if mc.slide_ctx_mode == "residual" else None
+    cat = ctx_all.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_all is not None and ctx_all.shape[1] > 0) else None
+    # x: [B, d] if the loop ended on the last layer's token-0 rows (L >= 1), row stride d
+    _lib.call("paths_final_head_any", p(x), d if L >= 1 else T * d, p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
+              res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, cat.shape[1] if cat is not None else 0,
+              p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], p(ctx_out), p(logits), B, d, lvl_pack["lnf_eps"], st)
+    return {"logits": logits, "ctx_slide": ctx_out}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -431,12 +538,17 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     tokens = torch.empty((B, T, d), **f32)
 
     x6 = use_x6(D, lstm_pack["Hc"] if mc.lstm else 64)
-    assert x_rows is None or (x6 and split_planes() == 2 and mc.lstm), "row pointers need the default split mode and lstm=true"
+    assert x_rows is None or (x6 and split_planes() == 2 and mc.lstm and fast_path(mc)), "row pointers need the default split mode, lstm=true and the 128-wide aggregator"
     pe_rows = N if pe_mode == 1 else int(max_pos)
     pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
 
+    generic = not fast_path(mc)
+
     def importance_proj(src, imp_mul, imp_out, add=None):
         """tokens / importance from ``src`` (+ ``add``: x6 only, the GEMM input is src + add, row stride of add arbitrary)."""
+        if generic:
+            assert add is None and src is not None
+            return importance_proj_generic(mc, lvl_pack, src, D, locs, num_ims, B, N, D, imp_mul, imp_out, tokens)
         common = (p(lvl_pack["b1"]), p(lvl_pack["w2"]), p(lvl_pack["b2"]),
                   p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]),
                   p(pe_tab), pe_tab.shape[0] if pe_tab is not None else 0, p(locs),
@@ -464,7 +576,8 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         Hc = lstm_pack["Hc"]
         Dp = D + Hc
         state_out = torch.empty((B, N, Dp), **f32)
-        y = None if x6 else torch.empty((B, N, D), **f32)   # x6: Y = X + h1 is summed inside the importance/proj GEMM's staging
+        # x6: Y = X + h1 is summed inside the importance/proj GEMM's staging (the generic importance / projection GEMMs read a stored Y)
+        y = None if (x6 and not generic) else torch.empty((B, N, D), **f32)
         ws_o = torch.empty(((M + 255) // 256 * 256, D), **f32)       # gate scratch: whole 256-row tiles (raw accumulator layout)
         hp, hp_row = None, None
         if parent is not None:
@@ -499,7 +612,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             timed("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D, "parent_partials": parent is not None,
                                                    "x6": x6, "planes": split_planes() if x6 else 0}, detail=False)
             timed("lstm_mem_to_out", lambda: lstm(4))
-        if x6:
+        if x6 and not generic:
             timed("importance_proj", lambda: importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out))
         else:
             timed("importance_proj", lambda: importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance))
@@ -633,6 +746,8 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
 
 def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
     _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
+    if not fast_path(mc):
+        return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all)
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
     st = _lib.stream()

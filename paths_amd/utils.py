@@ -214,6 +214,24 @@ class TapedRecursion:
 
 
 OVERLAP_AGGREGATOR = os.environ.get("PATHS_OVERLAP_AGGREGATOR", "1") != "0"
+ROCTX_RANGES = os.environ.get("PATHS_ROCTX", "0") != "0"     # roctx ranges "level i: selection / aggregator / expansion" around the launches
+                                                             # of each level (rocprofv3 --marker-trace; torch.cuda.nvtx = roctx on ROCm)
+
+
+class _Range:
+    """roctx range around a group of launches (host side: marks where the launches were ENQUEUED); a no-op unless PATHS_ROCTX=1."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if ROCTX_RANGES:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *exc):
+        if ROCTX_RANGES:
+            torch.cuda.nvtx.range_pop()
+        return False
 ROWS_IN_PLACE = os.environ.get("PATHS_ROWS_IN_PLACE", "1") != "0"
 _STREAMS: Dict[int, tuple] = {}
 
@@ -293,7 +311,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
     # default split mode: feature rows are read in place in the resident grids (row-pointer GEMM operands) instead of being
     # copied (level 0) or gathered (children)
-    rows_in_place = share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE
+    rows_in_place = share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE and ops.fast_path(mc)
     zero_row = torch.zeros((D,), **f32) if rows_in_place else None
     fts = None if rows_in_place else torch.empty((B, N, D), **f32)
     x_rows = torch.empty((B, N), **i64) if rows_in_place else None
@@ -329,8 +347,9 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
             _lib.stream_wait(main_stream, par_stream)     # this level's rows / bookkeeping from the expansion branch are ready
             fork_pending = False
         imp_buf = imp_all[imp_off[i]:imp_off[i] + B * N].view(B, N) if N == sizes[i] else None
-        sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
-                                    max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf)
+        with _Range(f"level {i}: selection chain (LSTM gates, importance, projection)"):
+            sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
+                                        max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf)
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
@@ -339,10 +358,11 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         if overlap:
             _lib.stream_wait(side_stream, main_stream)    # tokens / num_ims of this level are ready
             keepalive.append((sel["tokens"], sel["num_ims"]))
-            with torch.cuda.stream(side_stream):
+            with torch.cuda.stream(side_stream), _Range(f"level {i}: aggregator (second stream)"):
                 agg = aggregate()
         else:
-            agg = aggregate()
+            with _Range(f"level {i}: aggregator"):
+                agg = aggregate()
         out = {"logits": agg["logits"], "ctx_slide": agg["ctx_slide"], "ctx_patch": sel["ctx_patch"], "importance": sel["importance"]}
         ctx_hist.append(out["ctx_slide"])
         rec = None
@@ -453,7 +473,7 @@ def recurse_train(model, slides, keep_patches: Sequence[int], num_levels: int, c
 def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
     from . import autograd as pag
     mc = model.procs[0].config
-    ops.check_supported(mc)
+    ops.check_supported(mc, training=True)
     B, dev, D = len(batch), batch.device, batch.dim
     st = _lib.stream()
     p = _lib.ptr

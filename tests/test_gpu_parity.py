@@ -84,17 +84,65 @@ def test_single_level_variants(dev, tag):
     np.testing.assert_allclose(out["ctx_patch"].numpy(), g["ctx_patch"], atol=STATE_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("tag", ["td192", "td192_pe1d", "h8_hi64", "td64_h2_l3"])
+def test_single_level_other_aggregator_geometries(dev, tag):
+    """g12 (reference config.py:30-36: the dataclass DEFAULT is trans_dim 192 = head_dim 48 with the 1-D encoding): aggregator
+    geometries other than the shipped 128 / 4 / 128 run on the shape-generic kernels (csrc/generic.hip + the f32 GEMM), same bars."""
+    import paths_amd.ops as O
+    calls = []
+    orig = O._lib.call
+    O._lib.call = lambda cname, *a: (calls.append(cname), orig(cname, *a))[1]
+    try:
+        g, info, out = run_single(dev, f"g12_{tag}_level1")
+    finally:
+        O._lib.call = orig
+    assert {"paths_attention_any", "paths_layernorm_rows", "paths_tokens_assemble", "paths_importance_rows", "paths_final_head_any"} <= set(calls)
+    np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["importance"].numpy(), g["importance"], atol=STATE_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_patch"].numpy(), g["ctx_patch"], atol=STATE_TOL, rtol=0)
+
+
+def test_recursion_trans_dim_192_vs_reference_golden(dev):
+    """g12 recursion: 5 levels at the reference's default trans_dim 192 through the device recursion (sync-free pass, launch tape
+    included) - per-level num_ims / locations / kept sets / parents exact, hazards within the bar."""
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    g, info = load_golden("g12_recursion_td192_6x7_top5")
+    cfg, model, _ = build_model(dev, info["wseed"], info["cfg_over"], top_k_patches=[info["top_k"]] * 4)
+    assert model.procs[0].config.trans_dim == 192
+    slides = [DeviceSlide.synthetic(info["dseed"], sid, tuple(info["base_shape"]), p_bg=info["p_bg"], device=dev) for sid in info["slide_ids"]]
+    B = len(slides)
+    trace = []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, cfg.top_k_patches, cfg.num_levels, trace=trace)
+    res = compare_recursion(trace, H.golden_trace(g, B, cfg.num_levels), torch.sigmoid(out["logits"]).cpu(), g["hazards"],
+                            imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["index_sets_identical"] and res["parent_pairs_identical"] and not res["near_tie_slides"]
+    taped = putils.TapedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).run()
+    assert torch.equal(taped["logits"], out["logits"]) and torch.equal(taped["importance"], out["importance"])
+
+
 def test_unsupported_config_rejected(dev):
-    """Configurations outside this build's kernel specialisation fail loudly (never approximated)."""
+    """Configurations outside what the kernels cover fail loudly (never approximated): a head_dim the generic attention does not
+    have, and TRAINING at a geometry other than the shipped one (the backward kernels are 128-wide)."""
     from paths_amd.data_utils.patch_batch import PatchBatch
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
     g, info = load_golden("g1_level0_b2_k256")
     cfg, model, _ = build_model(dev, info["wseed"], None)
-    model.procs[0].config.trans_heads = 8          # same tensors, unsupported head count
+    model.procs[0].config.trans_heads = 16         # head_dim 8: not built
     inp = H.single_level_inputs(info, H.oracle_config())
     pb = PatchBatch(**{k: torch.from_numpy(v).to(dev) for k, v in inp.items()})
     with pytest.raises(NotImplementedError):
         model(0, pb)
     model.procs[0].config.trans_heads = 4
+    g2, info2 = load_golden("g12_recursion_td192_6x7_top5")
+    cfg2, model2, _ = build_model(dev, info2["wseed"], info2["cfg_over"], top_k_patches=[info2["top_k"]] * 4)
+    slides = [DeviceSlide.synthetic(info2["dseed"], sid, tuple(info2["base_shape"]), p_bg=info2["p_bg"], device=dev) for sid in info2["slide_ids"]]
+    with pytest.raises(NotImplementedError):
+        putils.recurse_train(model2.train(), slides, cfg2.top_k_patches, cfg2.num_levels)
 
 
 @pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])
@@ -841,6 +889,29 @@ def test_taped_recursion_replays_bit_identically(dev):
         assert all(torch.equal(out["ctx_patch"][b, :n], ref["ctx_patch"][b, :n]) for b, n in enumerate(n_last))
     n_calls = len(t.tape)
     assert 60 <= n_calls <= 140 and sum(1 for _, _, name in t.tape if name == "paths_stream_wait") >= 10
+    # A replay must REGENERATE every value: poison the tape's outputs and every cached (freed) block of its private pool - the
+    # intermediates of the recorded pass live there - with NaN / garbage, replay, and compare again.  An operation missing from the
+    # tape (e.g. a torch-side kernel added to the path later) would leave poison behind instead of a stale correct value.
+    torch.cuda.synchronize()
+    pool_id = tuple(t._pool.id)
+    sizes = [b["size"] for seg in torch.cuda.memory_snapshot() if tuple(seg.get("segment_pool_id", ())) == pool_id
+             for b in seg["blocks"] if b["state"] == "inactive"]
+    assert sizes, "the tape's pool holds no cached blocks?"
+    with torch.cuda.use_mem_pool(t._pool, device=dev):
+        bufs = [torch.empty((sz,), dtype=torch.uint8, device=dev) for sz in sorted(sizes, reverse=True)]
+    poisoned = 0
+    for buf in bufs:
+        buf[: buf.numel() // 4 * 4].view(torch.float32).fill_(float("nan"))
+        poisoned += buf.numel()
+    del bufs
+    for key in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        t.out[key].fill_(float("nan"))
+    t.out["status"].fill_(7)
+    torch.cuda.synchronize()
+    out = t.run()
+    assert poisoned > (1 << 20) and int(out["status"].item()) == 0
+    assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"]) and torch.equal(out["ctx_slide"], ref["ctx_slide"])
+    assert all(torch.equal(out["ctx_patch"][b, :n], ref["ctx_patch"][b, :n]) for b, n in enumerate(n_last))
     with torch.no_grad():
         model.procs[4].classification_layer.bias.add_(0.25)
         ref2 = putils.recurse(model, slides, cfg.top_k_patches, 5)

@@ -44,6 +44,15 @@ def test_single_level_variants(tag):
         np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["td192", "td192_pe1d", "h8_hi64", "td64_h2_l3"])
+def test_single_level_other_aggregator_geometries(tag):
+    """g12: the oracle on aggregator geometries other than the shipped 128 / 4 / 128 (the reference dataclass default trans_dim 192,
+    head_dim 48; 8 heads with a 64-wide importance MLP; trans_dim 64 x 2 heads x 3 layers) against the reference's outputs."""
+    g, info, out = _run_single(f"g12_{tag}_level1")
+    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])
 def test_single_level_k2048(name):
     g, info, out = _run_single(name)

@@ -483,6 +483,17 @@ def main():
             "subtype": {"task": "subtype_classification", "filter_to_subtypes": ["a", "b"]},
         }.items():
             single_level(ref, f"g5_{tag}_level1", 1, 2, 64, [64, 50], wseed=4, dseed=15, cfg_over=over)
+    if want("g12"):
+        # other aggregator geometries than the shipped 128 / 4 / 128: the reference dataclass DEFAULT (trans_dim 192, head_dim 48,
+        # 1-D positional encoding: config.py:30-36), the same with the 2-D encoding, and free trans_heads / importance hidden dims
+        for tag, over in {
+            "td192": {"model_config": {"trans_dim": 192}},
+            "td192_pe1d": {"model_config": {"trans_dim": 192, "pos_encoding_mode": "1d"}},
+            "h8_hi64": {"model_config": {"trans_heads": 8, "importance_mlp_hidden_dim": 64}},
+            "td64_h2_l3": {"model_config": {"trans_dim": 64, "trans_heads": 2, "trans_layers": 3, "importance_mlp_hidden_dim": 32}},
+        }.items():
+            single_level(ref, f"g12_{tag}_level1", 1, 2, 64, [64, 50], wseed=4, dseed=15, cfg_over=over)
+        recursion(ref, "g12_recursion_td192_6x7_top5", (6, 7), 5, 2, wseed=2, dseed=13, p_bg=0.2, cfg_over={"model_config": {"trans_dim": 192}})
     if want("g6"):
         training(ref, "g6_train_16x16_top64", (16, 16), 64, 4, wseed=3, dseed=14)
     if want("g7"):
