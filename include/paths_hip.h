@@ -264,18 +264,21 @@ int paths_attention_h3_img(void* o_img, const int64_t* num_ims, int B, int T, in
  * x1 [B,T,128].  img: image built once per weight version by paths_token0_pack_ws (A_h = c Wk_h^T Wq_h, a0_h = c Wk_h^T bq_h and
  * 16-byte-transposed Wv, Wo, W1, W2; qscale c = log2(e)/sqrt(head_dim)); bv = in_proj_bias + 2 d.  Workgroups = (token split, head)
  * pairs per slide; each publishes a (max, sum, z[128]) partial, the LAST arriver of a slide (agent-scope release / acquire around an
- * arrival ticket) runs the row chain.  partials: paths_token0_ws_partials(B, T) floats of scratch; counters: B int32 words, zero
- * on entry, left zero (paths_token_layer_ws can zero them on the same stream).  Exact fp32 FMA chains. */
+ * arrival ticket) runs the row chain - or, when all workgroups of the launch fit the chip at once (<= 192), the DISTRIBUTED form:
+ * every workgroup pushes its partial through its head's Wv / Wo slices before the ticket and carries a slice of the feed-forward
+ * after a flag hop, so that no CU pulls more than ~100 KB of weights.  partials: paths_token0_ws_partials(B, T) floats of scratch;
+ * counters: 3 B int32 words, zero on entry, left zero; status (optional): bit 4 set if a bounded hand-off wait gave up.
+ * Exact fp32 FMA chains. */
 int64_t paths_token0_ws_image_bytes(void);
 int64_t paths_token0_ws_partials(int B, int T);
-int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* w1, const float* w2, float qscale, void* out,
-                         paths_stream_t stream);
+int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
+                         void* out, paths_stream_t stream);
 int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* img, const float* bv, const float* bo,
                          const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
                          const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,
                          const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
                          const float* wcls, const float* bcls, int num_logits, int cls_in,
-                         float* ctx_out, float* logits, float* partials, int* counters, int B, int T, int d, int H,
+                         float* ctx_out, float* logits, float* partials, int* counters, int* status, int B, int T, int d, int H,
                          float eps, float eps_final, paths_stream_t stream);
 
 /* ---- shape-generic kernels (csrc/generic.hip): any trans_dim (multiple of 32, <= 1024), head_dim in {16, 32, 48, 64}, any

@@ -33,7 +33,8 @@ constexpr int OFF_WV = OFF_A0 + NH * DM;                 // [32 k4][128 f][4]
 constexpr int OFF_WO = OFF_WV + DM * DM;                 // [32 k4][128 f][4]
 constexpr int OFF_W1 = OFF_WO + DM * DM;                 // [32 k4][512 n][4]
 constexpr int OFF_W2 = OFF_W1 + DFF * DM;                // [128 k4][128 f][4]
-constexpr int IMG_FLOATS = OFF_W2 + DM * DFF;
+constexpr int OFF_OB = OFF_W2 + DM * DFF;                // [128] Wo bv + bo  (distributed form: the bias of out_proj(attention output))
+constexpr int IMG_FLOATS = OFF_OB + DM;
 
 #ifdef PATHS_T0_STAMPS
 #define T0_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (p.stamps && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -50,7 +51,8 @@ struct T0Params {
   const float* wcls; const float* bcls; int num_logits, cls_in;
   float* ctx_out; float* logits;
   float* partials;                 // [B][4][nts][REC]
-  int* counters;                   // [B] arrival tickets, zero on entry, left zero
+  int* counters;                   // [3 B] per slide: arrival ticket 1, "x is published" flag, arrival ticket 2; zero on entry, left zero
+  int* status;                     // optional: bit 4 is set when a bounded hand-off wait of the distributed form gives up
   int T, nts; float eps, eps_f;
 #ifdef PATHS_T0_STAMPS
   unsigned long long* stamps;
@@ -190,13 +192,13 @@ token0_ws_kernel(T0Params p) {
   __syncthreads();
   if (tid == 0) {
     const int total = NH * p.nts;
-    const int t = __hip_atomic_fetch_add(p.counters + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(p.counters + 3 * b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == total - 1) ? 1 : 0;
     if (last) {
       // (every load of the records below is an sc1 load, which bypasses this CU's L1: the invalidate is issued for good measure
       // and not waited for - guide, Guideline 16 "Valid forms": sc1 stores drained before the ticket, sc1 loads after it)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(p.counters + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // left zero for the next launch
+      __hip_atomic_store(p.counters + 3 * b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // left zero for the next launch
     }
     *sFlag = last;
   }
@@ -317,10 +319,283 @@ token0_ws_kernel(T0Params p) {
   T0_STAMP(9);
 }
 
+
+// ================================================================================================================================
+// DISTRIBUTED form of the same launch (the default whenever its workgroups fit the chip at once).  The row chain above makes ONE
+// workgroup per slide pull 640 KB of weights through its CU (~45 GB/s per CU from beyond L2: >= 13 us).  Here every workgroup of a
+// slide (G = 4 heads x nts token splits) carries a slice instead, prefetched into registers when the kernel starts:
+//   before the barrier  its partial z is pushed through its head's Wv_h (32 x 128) and Wo[:, head] (128 x 32): u = Wo_h Wv_h z is
+//                       linear in z, so a slide's (m, l, u) records merge into a = sum_h (sum_ts w u) / den_h + (Wo bv + bo)
+//   arrival barrier     of the slide's G workgroups (one counter; they are all part of this launch and at most 192 workgroups
+//                       are launched, so they are co-resident once the chip has room); then EVERY workgroup merges the records
+//                       and runs norm1, + cross-attention bias, norm2 itself: x (redundant, 8 KB of sc1 loads + two LayerNorms,
+//                       cheaper than a publish-x hop from one workgroup)
+//   feed-forward slice  hidden units [j 512/G, (j+1) 512/G): h_j = relu(W1_j x + b1_j), y_j = W2[:, j] h_j -> record, ticket 2
+//   last arriver        sums the y_j, adds b2 + x, norm3, decoder.norm, slide-context residual, classifier.
+// No workgroup pulls more than ~100 KB.  The barrier wait is bounded: a timeout sets status bit 4 instead of hanging.  All
+// hand-offs: sc1 (write-through) stores drained before the counter add, sc1 loads after it (guide, Guideline 16 "Valid forms").
+// ================================================================================================================================
+constexpr int SPIN_LIMIT = 1 << 22;
+
+__global__ void __launch_bounds__(NT)
+token0_dist_kernel(T0Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[SLOTS * DM + 4 * DFF + 8 * DM + 64];
+  float* const sZ = smem;                    // phase 1: [16 slots][128]
+  float* const sRed = smem + SLOTS * DM;     // [2048] k-split partial sums
+  float* const sV = sRed + 4 * DFF;
+  float* const sX0 = sV, *const sQ = sV + DM, *const sNum = sV + 2 * DM, *const sXa = sV + 3 * DM, *const sH = sV + 4 * DM;
+  float* const sML = sV + 5 * DM;            // [16][2] slot (m, l); then [0] = M, [1] = den
+  float* const sVv = sV + 5 * DM + 2 * SLOTS + 8;      // [32]
+  int* const sFlag = reinterpret_cast<int*>(sV + 5 * DM + 2 * SLOTS);
+  const int G = NH * p.nts, HS = DFF / G, nld = HS / 16;               // HS in {16, 32, 64, 128}
+  const int b = blockIdx.y, j = blockIdx.x, head = j & 3, ts = j >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = p.x1 + (int64_t)b * p.T * DM;
+  const float* W = p.img;
+
+  // ---- this workgroup's weight slices, issued first: Wv_head / Wo[:, head] (2 + 2 loads), W1 / W2 slices (nld + nld loads)
+  const int o5 = tid & 31, kq5 = tid >> 5;             // 32 outputs x 16 k-groups of 8
+  const int f7 = tid & 127, kq7 = tid >> 7;            // 128 outputs x 4 k-groups
+  const int n1 = tid % HS, kq1 = tid / HS;             // HS outputs x (512 / HS) k-groups of HS / 4
+  f32x4 wv[2], wo[2], w1[8], w2[8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    wv[i] = ldg_f32x4(W + OFF_WV + ((2 * kq5 + i) * DM + 32 * head + o5) * 4);
+    wo[i] = ldg_f32x4(W + OFF_WO + ((8 * head + 2 * kq7 + i) * DM + f7) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < nld) {
+      w1[i] = ldg_f32x4(W + OFF_W1 + ((kq1 * nld + i) * DFF + j * HS + n1) * 4);
+      w2[i] = ldg_f32x4(W + OFF_W2 + (((j * HS) / 4 + kq7 * nld + i) * DM + f7) * 4);
+    }
+
+  T0_STAMP(0);
+  // ---- phase 0: qt = A_head x0 + a0_head
+  if (tid < DM) sX0[tid] = xb[tid];
+  __syncthreads();
+  {
+    const float* A = W + OFF_A + (int64_t)head * DM * DM;
+    f32x4 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = ldg_f32x4(A + ((8 * kq7 + i) * DM + f7) * 4);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += dot4(w[i], *reinterpret_cast<const f32x4*>(sX0 + 32 * kq7 + 4 * i));
+    sRed[kq7 * DM + f7] = acc;
+  }
+  __syncthreads();
+  if (tid < DM) sQ[tid] = ((sRed[tid] + sRed[DM + tid]) + (sRed[2 * DM + tid] + sRed[3 * DM + tid])) + W[OFF_A0 + head * DM + tid];
+  __syncthreads();
+
+  T0_STAMP(1);
+  // ---- phase 1 (as in token0_ws_kernel): online softmax over this workgroup's tokens, z = sum p x
+  const int len = min((int)p.num_ims[b] + 1, p.T);
+  const int chunk = (len + p.nts - 1) / p.nts;
+  const int k0 = ts * chunk, k1 = min(len, k0 + chunk);
+  const int l5 = lane & 31, slot = wave * 2 + (lane >> 5);
+  const f32x4 qv = *reinterpret_cast<const f32x4*>(sQ + 4 * l5);
+  float m = -1e30f, l = 0.f;
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // rounds of 8 tokens per half-wave; the row pieces of round r + 1 are in flight while round r is reduced (two register sets)
+  f32x4 xa[8], xn[8];
+  auto fetch = [&](f32x4 (&dst)[8], int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dst[u] = ldg_f32x4(xb + (int64_t)max(min(base + u * SLOTS + slot, k1 - 1), 0) * DM + 4 * l5);
+  };
+  auto reduce = [&](const f32x4 (&x)[8], int base) __attribute__((always_inline)) {
+    float s[8];
+    bool ok[8];
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      ok[u] = base + u * SLOTS + slot < k1;
+      s[u] = ok[u] ? half_sum32(dot4(qv, x[u])) : -1e30f;
+      mx = fmaxf(mx, s[u]);
+    }
+    const float alpha = __builtin_amdgcn_exp2f(m - mx);
+    float ps = 0.f;
+    z = z * alpha;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float pu = ok[u] ? __builtin_amdgcn_exp2f(s[u] - mx) : 0.f;
+      ps += pu;
+      z = z + x[u] * pu;
+    }
+    l = l * alpha + ps;
+    m = mx;
+  };
+  if (k0 < k1) fetch(xa, k0);
+  for (int base = k0; base < k1; base += 16 * SLOTS) {
+    if (base + 8 * SLOTS < k1) fetch(xn, base + 8 * SLOTS);
+    reduce(xa, base);
+    if (base + 8 * SLOTS < k1) {
+      if (base + 16 * SLOTS < k1) fetch(xa, base + 16 * SLOTS);
+      reduce(xn, base + 8 * SLOTS);
+    }
+  }
+  *reinterpret_cast<f32x4*>(sZ + slot * DM + 4 * l5) = z;
+  if (l5 == 0) { sML[2 * slot] = m; sML[2 * slot + 1] = l; }
+  __syncthreads();
+  T0_STAMP(2);
+  float Mloc = -1e30f;
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) Mloc = fmaxf(Mloc, sML[2 * sl]);
+  if (tid < DM) {
+    float num = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) num = fmaf(sZ[sl * DM + tid], __builtin_amdgcn_exp2f(sML[2 * sl] - Mloc), num);
+    sNum[tid] = num;
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int sl = 0; sl < SLOTS; ++sl) den = fmaf(sML[2 * sl + 1], __builtin_amdgcn_exp2f(sML[2 * sl] - Mloc), den);
+  __syncthreads();
+  // ---- v = Wv_head z (32 values), u = Wo[:, head] v (128 values): this workgroup's record is (M, den, u)
+  sRed[kq5 * 32 + o5] = dot4(wv[0], *reinterpret_cast<const f32x4*>(sNum + 8 * kq5)) + dot4(wv[1], *reinterpret_cast<const f32x4*>(sNum + 8 * kq5 + 4));
+  __syncthreads();
+  if (tid < 32) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += sRed[k * 32 + tid];
+    sVv[tid] = acc;
+  }
+  __syncthreads();
+  sRed[1024 + kq7 * DM + f7] = dot4(wo[0], *reinterpret_cast<const f32x4*>(sVv + 8 * kq7)) + dot4(wo[1], *reinterpret_cast<const f32x4*>(sVv + 8 * kq7 + 4));
+  __syncthreads();
+  float* rec = p.partials + ((int64_t)b * G + j) * REC;
+  if (tid < DM) {
+    const float* r4 = sRed + 1024 + tid;
+    st_agent(rec + 4 + tid, (r4[0] + r4[DM]) + (r4[2 * DM] + r4[3 * DM]));
+    if (tid == 0) { st_agent(rec, Mloc); st_agent(rec + 1, den); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* cnt = p.counters + 3 * b;
+  // ---- arrival barrier of the slide's G workgroups: every one of them then merges the G records itself (8 KB of sc1 loads and
+  // two LayerNorms, redundantly) - cheaper than publishing x from the last arriver (a store drain, a flag and a load: three more
+  // memory round trips on the critical path).  The waited-for workgroups are the slide's own, all part of this launch.
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT) {                      // give up loudly rather than hang: results of this slide are garbage
+        if (p.status) atomicOr(p.status, 4);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  T0_STAMP(3);
+  {
+    const int h = kq7;
+    const float* hp = p.partials + (int64_t)b * G * REC;
+    float pm[8], pl[8], pu[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int tc = min(t, p.nts - 1);
+      const float* r = hp + (tc * NH + h) * REC;
+      pm[t] = ld_agent(r); pl[t] = ld_agent(r + 1); pu[t] = ld_agent(r + 4 + f7);
+    }
+    float M = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) if (t < p.nts) M = fmaxf(M, pm[t]);
+    float num = 0.f, dn = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (t < p.nts) {
+        const float w = __builtin_amdgcn_exp2f(pm[t] - M);
+        num = fmaf(pu[t], w, num);
+        dn = fmaf(pl[t], w, dn);
+      }
+    sRed[h * DM + f7] = num / dn;
+  }
+  __syncthreads();
+  if (tid < DM) sXa[tid] = sX0[tid] + (((sRed[tid] + sRed[DM + tid]) + (sRed[2 * DM + tid] + sRed[3 * DM + tid])) + W[OFF_OB + tid]);
+  __syncthreads();
+  block_layernorm(sXa, p.ln1g, p.ln1b, p.eps, tid);
+  if (tid < DM) sXa[tid] += p.cab[tid];
+  __syncthreads();
+  block_layernorm(sXa, p.ln2g, p.ln2b, p.eps, tid);
+  T0_STAMP(4);
+  // ---- feed-forward slice j: h = relu(W1[j HS .., :] x + b1), y_j = W2[:, j HS ..] h
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nld) acc += dot4(w1[i], *reinterpret_cast<const f32x4*>(sXa + (kq1 * nld + i) * 4));
+    sRed[kq1 * HS + n1] = acc;
+  }
+  __syncthreads();
+  if (tid < HS) {
+    float acc = 0.f;
+    const int ng = NT / HS;
+    for (int k = 0; k < ng; ++k) acc += sRed[k * HS + tid];
+    sH[tid] = fmaxf(acc + p.b1[j * HS + tid], 0.f);
+  }
+  __syncthreads();
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nld) acc += dot4(w2[i], *reinterpret_cast<const f32x4*>(sH + (kq7 * nld + i) * 4));
+    sRed[1024 + kq7 * DM + f7] = acc;
+  }
+  __syncthreads();
+  float* rec2 = p.partials + (int64_t)gridDim.y * (G * REC + DM) + ((int64_t)b * G + j) * DM;
+  if (tid < DM) {
+    const float* r4 = sRed + 1024 + tid;
+    st_agent(rec2 + tid, (r4[0] + r4[DM]) + (r4[2 * DM] + r4[3 * DM]));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) *sFlag = (__hip_atomic_fetch_add(cnt + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1) ? 1 : 0;
+  __syncthreads();
+  T0_STAMP(5);
+  if (*sFlag == 0) return;
+  // ---- last arriver of ticket 2: x = norm3(x + sum_j y_j + b2), decoder.norm, slide-context residual, classifier
+  if (tid == 0) {
+    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);            // (every workgroup of the slide is past its barrier wait)
+    __hip_atomic_store(cnt + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  {
+    // 4 groups of G / 4 records per feature
+    const float* r2 = p.partials + (int64_t)gridDim.y * (G * REC + DM) + (int64_t)b * G * DM;
+    float acc = 0.f;
+    for (int g = kq7; g < G; g += 4) acc += ld_agent(r2 + g * DM + f7);
+    sRed[kq7 * DM + f7] = acc;
+  }
+  __syncthreads();
+  if (tid < DM) sXa[tid] = sXa[tid] + (((sRed[tid] + sRed[DM + tid]) + (sRed[2 * DM + tid] + sRed[3 * DM + tid])) + p.b2[tid]);
+  __syncthreads();
+  block_layernorm(sXa, p.ln3g, p.ln3b, p.eps, tid);
+  block_layernorm(sXa, p.lnfg, p.lnfb, p.eps_f, tid);
+  if (tid < DM) {
+    float v = sXa[tid];
+    if (p.ctx_prev) v += p.ctx_prev[(int64_t)b * p.ctx_stride + tid];
+    sXa[tid] = v;
+    p.ctx_out[(int64_t)b * DM + tid] = v;
+  }
+  __syncthreads();
+  for (int jj = wave; jj < p.num_logits; jj += NT / 64) {
+    const float* w = p.wcls + (int64_t)jj * p.cls_in;
+    float acc = 0.f;
+    if (p.ctx_all) {
+      for (int i = lane; i < p.ctx_depth * DM; i += 64) acc += w[i] * p.ctx_all[(int64_t)b * p.ctx_depth * DM + i];
+      w += p.ctx_depth * DM;
+    }
+    acc += w[lane] * sXa[lane] + w[lane + 64] * sXa[lane + 64];
+    acc = wave_sum64(acc);
+    if (lane == 0) p.logits[(int64_t)b * p.num_logits + jj] = acc + p.bcls[jj];
+  }
+  T0_STAMP(9);
+}
+
 // ---- packing: A_h = c Wk_h^T Wq_h (fp32 FMA chains over the 32 head dims), a0_h = c Wk_h^T bq_h, and the T4 transposes
 // out[(k4 * N + n) * 4 + e] = W[n][4 k4 + e]
 __global__ void __launch_bounds__(256)
-token0_pack_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv, const float* __restrict__ wo,
+token0_pack_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv, const float* __restrict__ wo, const float* __restrict__ bo,
                    const float* __restrict__ w1, const float* __restrict__ w2, float qscale, float* __restrict__ out) {
   const int job = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -339,6 +614,11 @@ token0_pack_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqk
     float acc = 0.f;
     for (int r = 0; r < HD; ++r) acc = fmaf(wk[r * DM], bqkv[HD * h + r], acc);
     out[OFF_A0 + i] = acc * qscale;
+  } else if (job == 6) {             // ob[f] = Wo[f] . bv + bo[f]
+    if (i >= DM) return;
+    float acc = 0.f;
+    for (int k = 0; k < DM; ++k) acc = fmaf(wo[(int64_t)i * DM + k], bqkv[2 * DM + k], acc);
+    out[OFF_OB + i] = acc + bo[i];
   } else {                           // T4 transposes: Wv (rows 2 DM.. of wqkv), Wo, W1, W2
     const float* src; int N, K, off;
     if (job == 2) { src = wqkv + 2 * DM * DM; N = DM; K = DM; off = OFF_WV; }
@@ -362,19 +642,34 @@ extern "C" {
 
 int64_t paths_token0_ws_image_bytes(void) { return (int64_t)IMG_FLOATS * 4; }
 
+// token splits of the distributed form: the largest nts in {8, 4, 2, 1} with 128-token splits and at most 192 workgroups in the
+// launch (all of them must be able to run at once: one 512-thread workgroup per CU); 0 = use the single-chain form
+static int dist_splits(int B, int T) {
+  static const bool off = getenv("PATHS_T0_DIST") != nullptr && atoi(getenv("PATHS_T0_DIST")) == 0;
+  if (off) return 0;
+  for (int nts = 8; nts >= 1; nts >>= 1)
+    if (NH * nts * B <= 192 && (nts == 1 || (nts - 1) * TS_TOKENS < T)) return nts;
+  return 0;
+}
+static int chain_splits(int T) {
+  int nts = (T + TS_TOKENS - 1) / TS_TOKENS;
+  return nts < 1 ? 1 : nts > MAX_TS ? MAX_TS : nts;
+}
+
 // floats of the partials scratch of paths_token0_tail_ws
 int64_t paths_token0_ws_partials(int B, int T) {
-  int nts = (T + TS_TOKENS - 1) / TS_TOKENS;
-  nts = nts < 1 ? 1 : nts > MAX_TS ? MAX_TS : nts;
-  return (int64_t)B * NH * nts * REC;
+  const int64_t chain = (int64_t)B * NH * chain_splits(T) * REC;
+  const int nd = dist_splits(B, T);
+  const int64_t dist = nd ? (int64_t)B * (NH * nd * (REC + DM) + DM) : 0;
+  return chain > dist ? chain : dist;
 }
 
 // Weight image of paths_token0_tail_ws for one (last) decoder layer: wqkv [384,128], bqkv [384], wo [128,128], w1 [512,128],
-// w2 [128,512]; qscale = log2(e) / sqrt(head_dim).  Rebuilt whenever the weights change.
-int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* w1, const float* w2, float qscale, void* out,
-                         hipStream_t stream) {
-  PATHS_REQUIRE(wqkv && bqkv && wo && w1 && w2 && out && (uintptr_t)out % 16 == 0, "token0_pack_ws: bad arguments");
-  hipLaunchKernelGGL(token0_pack_kernel, dim3(256, 6), dim3(256), 0, stream, wqkv, bqkv, wo, w1, w2, qscale, reinterpret_cast<float*>(out));
+// bo [128], w2 [128,512]; qscale = log2(e) / sqrt(head_dim).  Rebuilt whenever the weights change.
+int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
+                         void* out, hipStream_t stream) {
+  PATHS_REQUIRE(wqkv && bqkv && wo && bo && w1 && w2 && out && (uintptr_t)out % 16 == 0, "token0_pack_ws: bad arguments");
+  hipLaunchKernelGGL(token0_pack_kernel, dim3(256, 7), dim3(256), 0, stream, wqkv, bqkv, wo, bo, w1, w2, qscale, reinterpret_cast<float*>(out));
   PATHS_LAUNCH_CHECK("token0_pack_ws");
   return PATHS_OK;
 }
@@ -382,13 +677,16 @@ int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, 
 // The last decoder layer at token 0 (reference model/aggregator.py:70-75) + decoder.norm + slide-context residual / concat +
 // classifier (model/paths.py:130-139) from the layer's INPUT rows x1 [B,T,128]: no K / V projection, one launch.
 // img: paths_token0_pack_ws image; bv = in_proj_bias + 256; partials: paths_token0_ws_partials(B, T) floats of scratch;
-// counters: B int32 words that are ZERO on entry (they are left zero: the last arriver of a slide resets its word).
+// counters: 3 B int32 words that are ZERO on entry (they are left zero: the last arrivers reset them); status (optional): an int32
+// word whose bit 4 is set if a bounded hand-off wait of the distributed form gave up (never observed; the result is then invalid).
+// Two forms, same results to fp32 rounding: up to 192 workgroups in the launch -> the DISTRIBUTED form (every workgroup of a slide
+// carries a slice of the row chain's weights); larger batches -> one row-chain workgroup per slide (PATHS_T0_DIST=0 forces it).
 int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* img, const float* bv, const float* bo,
                          const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
                          const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,
                          const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
                          const float* wcls, const float* bcls, int num_logits, int cls_in,
-                         float* ctx_out, float* logits, float* partials, int* counters, int B, int T, int d, int H,
+                         float* ctx_out, float* logits, float* partials, int* counters, int* status, int B, int T, int d, int H,
                          float eps, float eps_final, hipStream_t stream) {
   PATHS_REQUIRE(d == DM && H == NH, "token0_tail_ws: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && x1 && num_ims && img && bv && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b && lnfg && lnfb,
@@ -396,15 +694,16 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
   PATHS_REQUIRE(wcls && bcls && ctx_out && logits && partials && counters, "token0_tail_ws: null output / scratch");
   PATHS_REQUIRE(num_logits > 0 && cls_in == (ctx_all ? (ctx_depth + 1) * DM : DM), "token0_tail_ws: bad classifier shape");
   PATHS_REQUIRE(((uintptr_t)x1 | (uintptr_t)img) % 16 == 0, "token0_tail_ws: buffers must be 16-byte aligned");
-  int nts = (T + TS_TOKENS - 1) / TS_TOKENS;
-  nts = nts < 1 ? 1 : nts > MAX_TS ? MAX_TS : nts;
+  const int nd = dist_splits(B, T);
+  const int nts = nd ? nd : chain_splits(T);
   T0Params p{x1, num_ims, reinterpret_cast<const float*>(img), bv, bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, lnfg, lnfb,
-             ctx_prev, ctx_stride, ctx_all, ctx_depth, wcls, bcls, num_logits, cls_in, ctx_out, logits, partials, counters, T, nts, eps, eps_final
+             ctx_prev, ctx_stride, ctx_all, ctx_depth, wcls, bcls, num_logits, cls_in, ctx_out, logits, partials, counters, status, T, nts, eps, eps_final
 #ifdef PATHS_T0_STAMPS
              , g_t0_stamps
 #endif
   };
-  hipLaunchKernelGGL(token0_ws_kernel, dim3(NH * nts, B), dim3(NT), 0, stream, p);
+  if (nd) hipLaunchKernelGGL(token0_dist_kernel, dim3(NH * nts, B), dim3(NT), 0, stream, p);
+  else hipLaunchKernelGGL(token0_ws_kernel, dim3(NH * nts, B), dim3(NT), 0, stream, p);
   PATHS_LAUNCH_CHECK("token0_tail_ws");
   return PATHS_OK;
 }

@@ -206,8 +206,8 @@ def token0_ws_image(layer: Dict[str, object], qscale: float) -> torch.Tensor:
     """Weight image of paths_token0_tail_ws for the LAST decoder layer (cached in the layer's pack dict)."""
     if "t0_image" not in layer:
         img = torch.empty((int(_lib.load().paths_token0_ws_image_bytes()),), device=layer["wo"].device, dtype=torch.uint8)
-        _lib.call("paths_token0_pack_ws", _lib.ptr(layer["wqkv"]), _lib.ptr(layer["bqkv"]), _lib.ptr(layer["wo"]), _lib.ptr(layer["w1"]),
-                  _lib.ptr(layer["w2"]), qscale, _lib.ptr(img), _lib.stream())
+        _lib.call("paths_token0_pack_ws", _lib.ptr(layer["wqkv"]), _lib.ptr(layer["bqkv"]), _lib.ptr(layer["wo"]), _lib.ptr(layer["bo"]),
+                  _lib.ptr(layer["w1"]), _lib.ptr(layer["w2"]), qscale, _lib.ptr(img), _lib.stream())
         layer["t0_image"] = img
     return layer["t0_image"]
 
@@ -216,12 +216,12 @@ _T0_COUNTERS: Dict[tuple, torch.Tensor] = {}
 
 
 def token0_counters(dev, B: int) -> torch.Tensor:
-    """Arrival tickets of paths_token0_tail_ws: int32 words that are zero between launches (the last arriver of a slide resets its
-    word).  One buffer per (device, stream): tails of different streams may be in flight together."""
+    """Arrival tickets / flags of paths_token0_tail_ws: 3 int32 words per slide that are zero between launches (the last arrivers
+    reset them).  One buffer per (device, stream): tails of different streams may be in flight together."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.stream())
     t = _T0_COUNTERS.get(key)
-    if t is None or t.numel() < B:
-        t = _T0_COUNTERS[key] = torch.zeros((max(256, B),), device=dev, dtype=torch.int32)
+    if t is None or t.numel() < 3 * B:
+        t = _T0_COUNTERS[key] = torch.zeros((max(768, 3 * B),), device=dev, dtype=torch.int32)
     return t
 
 
@@ -671,15 +671,16 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
     return hp
 
 
-def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
+def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None) -> Dict[str, torch.Tensor]:
     """The transformer aggregator + classifier of a level (reference model/aggregator.py:58-76, model/paths.py:126-139).
-    Nothing here feeds the next level's patch selection, so the device recursion runs it on a second HIP stream."""
-    return timed("aggregator", lambda: _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all),
+    Nothing here feeds the next level's patch selection, so the device recursion runs it on a second HIP stream.
+    ``status`` (optional int32 [1] device tensor): bit 4 is set if a bounded in-launch hand-off wait gave up (csrc/token0_ws.hip)."""
+    return timed("aggregator", lambda: _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status),
                  {"T": tokens.shape[1], "d": tokens.shape[2], "L": mc.trans_layers, "planes": split_planes() if GEMM_MODE != "f32" else 0},
                  detail=False)
 
 
-def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_img, q, k, v, xb, ctx_out, logits, token_layer_old):
+def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_img, q, k, v, xb, ctx_out, logits, token_layer_old, status=None):
     """Default-mode aggregator on the weight-stationary token-layer kernel (csrc/tlayer_ws.hip): in_proj writes the attention
     operand images, attention writes its output as the out_proj operand image, the chain kernel keeps weights in registers and
     shares only activations through LDS."""
@@ -723,7 +724,7 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
             p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
             res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
             p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), logits.shape[1], lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
-            p(part), p(cnt), B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
+            p(part), p(cnt), p(status) if status is not None else None, B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
 
     if TAIL_WS:
         timed("agg_token0_tail", tail_ws)
@@ -744,7 +745,7 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
     return {"logits": logits, "ctx_slide": ctx_out}
 
 
-def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
+def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None) -> Dict[str, torch.Tensor]:
     _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
     if not fast_path(mc):
         return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all)
@@ -798,7 +799,7 @@ def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dic
     # (no fp32 q, k, v round trip, no re-write launch); the last layer's q, k, v stay fp32 for the token-0 tail
     direct = GEMM_MODE == "h3" and attn_ws is not None and QKV_IMAGES and not fp8
     if direct and TLAYER_WS:
-        return _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, attn_ws, q, k, v, xb, ctx_out, logits, token_layer)
+        return _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, attn_ws, q, k, v, xb, ctx_out, logits, token_layer, status)
     timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0], qkv_images=attn_ws if direct else None))
     for l in range(L - 1):
         if fp8:

@@ -51,6 +51,8 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
         code = int(out["status"].item()) & ~1
     if code & 2:
         raise RecursionError_("child capacity exceeded (internal error)")
+    if code & 4:
+        raise RecursionError_("a bounded in-launch hand-off wait of the token-0 tail gave up (csrc/token0_ws.hip): results invalid")
     return out
 
 
@@ -353,7 +355,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
-            return ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
+            return ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status)
 
         if overlap:
             _lib.stream_wait(side_stream, main_stream)    # tokens / num_ims of this level are ready

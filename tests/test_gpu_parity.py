@@ -448,6 +448,28 @@ def test_headline_recursion_vs_oracle(dev, K, base, ids):
     np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
 
 
+def test_recursion_trans_dim_192_at_k1024_vs_oracle(dev):
+    """The reference's default aggregator width (trans_dim 192, head_dim 48) at a BASELINE size: 5 levels at K = 1024 patches/level on
+    the generic kernels against the oracle (the selection chain - LSTM, importance MLP - does not depend on trans_dim, so the
+    screened bench slides apply)."""
+    from oracle import paths_oracle as orc
+    from oracle.compare import compare_recursion
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    K, over = 1024, {"model_config": {"trans_dim": 192}}
+    cfg, model, params = build_model(dev, 0, over, top_k_patches=[K // 4] * 4)
+    ocfg = H.oracle_config(over, top_k_patches=[K // 4] * 4)
+    slides = [DeviceSlide.synthetic(1234, sid, (32, 32), device=dev) for sid in (10000, 10001)]
+    trace, otrace = [], []
+    with torch.no_grad():
+        out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=trace)
+        hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
+    res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
+    assert res["index_sets_identical"] and res["parent_pairs_identical"] and res["near_tie_slides"] == []
+    assert res["kept_indices_compared"] == 2 * 4 * (K // 4)
+    np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
+
+
 def test_stress_shape_k8192_d1536_single_level_vs_oracle(dev):
     """BASELINE configs[4] geometry (K = 8192 patches on ONE level = full quadratic attention over 8193 tokens, d = 1536 features)
     on the split-operand fp32-accurate path, against the oracle.  (The fp8 MFMA variant that config names is not built: DESIGN.md §6.)"""
@@ -761,7 +783,7 @@ def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens):
     lvl = {"layers": layers, "lnfg": 1 + rnd(d) * 0.1, "lnfb": rnd(d) * 0.1, "lnf_eps": 1e-5, "wcls": rnd(4, d) * 0.1, "bcls": rnd(4) * 0.1}
 
     class MC:
-        trans_dim, trans_heads, trans_layers, slide_ctx_mode = d, Hh, 2, "residual"
+        trans_dim, trans_heads, trans_layers, slide_ctx_mode, importance_mlp_hidden_dim = d, Hh, 2, "residual", 128
     tokens = rnd(B, T, d)
     num_ims = torch.tensor([n - 1 for n in lens], device=dev, dtype=torch.int64)
     ctx_prev = rnd(B, d)

@@ -31,7 +31,7 @@ if hasattr(lib, "paths_t0_stamp_buffer"):
 def run():
     _lib.call("paths_token0_tail_ws", p(x1), p(num_ims), p(img), w["bqkv"].data_ptr() + 8 * d, p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
               p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["b1"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]), p(lvl["lnfg"]), p(lvl["lnfb"]),
-              p(res), res.stride(0), None, 0, p(lvl["wcls"]), p(lvl["bcls"]), 4, 128, p(ctx_out), p(logits), p(part), p(cnt), B, T, d, H,
+              p(res), res.stride(0), None, 0, p(lvl["wcls"]), p(lvl["bcls"]), 4, 128, p(ctx_out), p(logits), p(part), p(cnt), None, B, T, d, H,
               w["eps"], lvl["lnf_eps"], st)
 run(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,10 +42,11 @@ print(f"{os.environ.get('PATHS_HIP_LIB', 'default')}: token0_tail_ws {e0.elapsed
 if stamps is not None:
     stamps.zero_(); run(); torch.cuda.synchronize()
     s = stamps.cpu(); s = s[s[:, 0] > 0]
-    names = ["start", "phase0 qt", "phase1", "publish", "merge", "o", "outproj+ln", "ffn1", "ffn2", "end"]
+    names = ["start", "phase0 qt", "phase1", "ticket1", "x ready", "ticket2", "-", "-", "-", "end"] if os.environ.get("PATHS_T0_DIST", "1") != "0" else ["start", "phase0 qt", "phase1", "publish", "merge", "o", "outproj+ln", "ffn1", "ffn2", "end"]
     last = s[s[:, 9] > 0]
     print("   workgroups", len(s), "last arrivers", len(last))
     for i, n in enumerate(names):
-        rows = last if i > 3 else s
+        rows = last if (i > 3 and os.environ.get("PATHS_T0_DIST", "1") == "0") or i == 9 else s
+        if rows[:, i].max() == 0: continue
         rel = (rows[:, i] - rows[:, 0]).float()
         print(f"   {n:12s} median +{int(rel.median()):7d} cycles   max +{int(rel.max()):7d}")
