@@ -304,6 +304,37 @@ int paths_final_head_any(const float* x, int64_t slide_stride, const float* lng,
                          const float* ctx_all, int ctx_depth, const float* wcls, const float* bcls, int num_logits, int cls_in,
                          float* ctx_out, float* logits, int B, int d, float eps, paths_stream_t stream);
 
+/* Shape-generic TRAINING kernels (csrc/generic_bwd.hip + the TRAIN form of the generic attention): what autograd applies in the
+ * reference train step (train.py:65) to nn.LayerNorm, the importance MLP / scaling / proj_in (model/paths.py:95-98,119-124) and the
+ * masked multi-head self-attention incl. its dropout (model/aggregator.py:25-33,70-72), for any trans_dim % 32 == 0 (<= 1024), head_dim
+ * 16 / 32 / 48 / 64 and any importance hidden width; the shipped 128 / 4 / 128 geometry trains on the specialised entry points below.
+ *   paths_attention_any_train      paths_attention_any + lse [B,H,T] (log2 domain, un-dropped softmax; may be null) + dropout p on the
+ *                                  probabilities (mask element ((b*H + h)*T + q)*T + k of site drop_key; p = 0: none)
+ *   paths_attention_bwd_any        dqkv [B*T, 3d] = [dq | dk | dv] (token-major, ZERO on entry) from qkv (q unscaled), o, d_o, lse;
+ *                                  ws_dsum: B*H*T floats of scratch; max_queries > 0: only those queries carry an output gradient
+ *   paths_layernorm_fwd_stats_any  y (may be null), xhat, rstd of LayerNorm(x (+ add [d])) over contiguous [rows, d]
+ *   paths_layernorm_bwd_any        dx and dy * xhat
+ *   paths_layernorm_bwd_sums_any   dx and one slab [sum dy*xhat | sum dy | sum dx] (3 d floats) per rows_per_block rows
+ *   paths_importance_bwd_any       du [M, ldu] = [dhid (Hi) | dP (d) | zeros], da [M], dah [M, Hi] = da * hid
+ *   paths_importance_rows_bwd_any  lstm = false (model/paths.py:95-109): the importance MLP's backward through Z = alpha X, any Hi */
+int paths_attention_any_train(const float* qkv, int64_t ld, float* o, float* lse, const int64_t* num_ims, int B, int T, int H, int head_dim,
+                              float qscale, int max_queries, uint64_t drop_key, float drop_p, paths_stream_t stream);
+int paths_attention_bwd_any(const float* qkv, int64_t ld, const float* o, const float* d_o, const float* lse, const int64_t* num_ims,
+                            float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, float qscale, int max_queries,
+                            uint64_t drop_key, float drop_p, paths_stream_t stream);
+int paths_layernorm_fwd_stats_any(const float* x, const float* add, const float* gamma, const float* beta, float* y, float* xhat,
+                                  float* rstd, int64_t rows, int d, float eps, paths_stream_t stream);
+int paths_layernorm_bwd_any(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* dyxhat,
+                            int64_t rows, int d, paths_stream_t stream);
+int paths_layernorm_bwd_sums_any(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* slabs,
+                                 int64_t rows, int d, int rows_per_block, paths_stream_t stream);
+int paths_importance_rows_bwd_any(const float* dz_rows, const float* x, int D, const float* hid, const float* alpha, const float* w2,
+                                  const int64_t* num_ims, int rows_per_slide, int64_t M, int Hi, float* dh, float* da, float* dah,
+                                  paths_stream_t stream);
+int paths_importance_bwd_any(const float* dtok, const float* pproj, const float* hid, const float* alpha, const float* w2,
+                             const int64_t* num_ims, int rows_per_slide, int64_t M, int imp_mul, int Hi, int d, int64_t ldu, float* du,
+                             float* da, float* dah, paths_stream_t stream);
+
 /* LAST decoder layer evaluated at token 0 only + decoder.norm + slide-context residual / concat + classifier, one
  * launch (reference model/aggregator.py:70-75 for the final layer, model/paths.py:130-139).  Legal because only
  * out[:, 0] of the final layer is read: it needs K/V of every token (q,k,v as written by paths_token_layer_f32 for

@@ -56,6 +56,13 @@ SIGNATURES = {
     "paths_token0_pack_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp],
     "paths_token0_tail_ws": [_vp] * 16 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "paths_attention_any": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "paths_attention_any_train": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _u64, _f32, _vp],
+    "paths_layernorm_fwd_stats_any": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
+    "paths_layernorm_bwd_any": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
+    "paths_layernorm_bwd_sums_any": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "paths_importance_bwd_any": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
+    "paths_importance_rows_bwd_any": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
+    "paths_attention_bwd_any": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _u64, _f32, _vp],
     "paths_layernorm_rows": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
     "paths_importance_rows": [_vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp],
     "paths_tokens_assemble": [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],

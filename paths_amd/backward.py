@@ -42,31 +42,41 @@ def _splits(M: int, n_tiles: int) -> int:
     return max(1, min(64, (512 + n_tiles - 1) // n_tiles, M // 256 if M >= 256 else 1))
 
 
-def transpose(w: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0) -> torch.Tensor:
-    """out[cols, rows] = w[rows, offset:offset+cols]^T  (w row-major with leading dimension ld)."""
-    out = torch.empty((cols, rows), **_f32(w.device))
+def transpose(w: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0, pad_to: Optional[int] = None) -> torch.Tensor:
+    """out[cols, rows] = w[rows, offset:offset+cols]^T  (w row-major with leading dimension ld); pad_to > rows: out is [cols, pad_to]
+    with zeros behind column ``rows`` (a K dimension padded for the GEMM kernels)."""
+    if pad_to is not None and pad_to > rows:
+        out = torch.zeros((cols, pad_to), **_f32(w.device))
+    else:
+        out = torch.empty((cols, rows), **_f32(w.device))
     _lib.call("paths_transpose_f32", w.data_ptr() + 4 * offset, ld if ld is not None else w.stride(0), rows, cols,
-              P(out), rows, _lib.stream())
+              P(out), out.shape[1], _lib.stream())
     return out
 
 
 def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=0, mask=None, ldm=0, accumulate=False,
             ldw=None):
     """out[M,N] (+)= maskop(act(a[M,K] wt[N,K]^T + bias)) + residual; a/out/residual/mask may be raw pointers."""
-    assert N % 128 == 0 and K % 32 == 0
+    assert K % 32 == 0
     ap = a if isinstance(a, int) else a.data_ptr()
     op = out if isinstance(out, int) else out.data_ptr()
     rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
     mp = None if mask is None else (mask if isinstance(mask, int) else mask.data_ptr())
     ldw = ldw if ldw is not None else K
-    if ops.GEMM_MODE != "f32" and N % NT_X6_MIN_N == 0 and K >= 128 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
+    if ops.GEMM_MODE != "f32" and N % NT_X6_MIN_N == 0 and K >= 128 and K % 128 == 0 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
             and wt.shape[0] >= N and wt.stride(0) == ldw and wt.stride(1) == 1:
         # split-bf16 GEMM: the (transposed) weight is re-imaged per call - 6 N K bytes, microseconds next to an M >= 1024 product
         wx, wx_s = ops.x6_pack(wt[:N, :K], planes=ops.TRAIN_PLANES)
         _lib.call("paths_gemm_nt_x6", ap, lda, P(wx), K, 0, P(bias), op, ldo, M, N, N, K, act, rp, ldr, mp, ldm,
                   1 if accumulate else 0, ops.TRAIN_PLANES, wx_s, 1.0, _lib.stream())
         return
-    _lib.call("paths_gemm_nt_f32", ap, lda, P(wt), ldw, P(bias), op, ldo, M, N, N, K, act, rp, ldr,
+    n_pad = N
+    if N % 128:                        # the f32 GEMM reads whole 128-row weight tiles: zero rows behind the last output feature
+        assert isinstance(wt, torch.Tensor) and wt.stride(1) == 1 and wt.stride(0) == ldw
+        n_pad = (N + 127) // 128 * 128
+        if wt.shape[0] < n_pad:
+            wt = ops._pad_rows(wt[:N])
+    _lib.call("paths_gemm_nt_f32", ap, lda, P(wt), ldw, P(bias), op, ldo, M, N, n_pad, K, act, rp, ldr,
               mp, ldm, 1 if accumulate else 0, _lib.stream())
 
 
@@ -81,7 +91,7 @@ def _splits_x6(M: int, N1: int, N2: int, nb0: int) -> int:
 def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, accumulate=False):
     """out[N1,N2] (+)= a[M,N1]^T [b0 | b1][M,N2]."""
     dev = out.device
-    if TN_MODE == "x6" and M >= 512 and M * 4 * max(lda, ldb0, ldb1) < (1 << 31):
+    if TN_MODE == "x6" and M >= 512 and N1 % 128 == 0 and N2 % 128 == 0 and M * 4 * max(lda, ldb0, ldb1) < (1 << 31):
         splits = _splits_x6(M, N1, N2, nb0 if b1 is not None else 0)
         ws = torch.empty((splits * N1 * N2,), **_f32(dev))
         ap = a if isinstance(a, int) else a.data_ptr()
@@ -90,7 +100,7 @@ def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, 
         _lib.call("paths_gemm_tn_x6", ap, lda, b0p, ldb0, nb0, b1p, ldb1, P(out), ldo if ldo is not None else N2, M, N1, N2,
                   splits, 1 if accumulate else 0, P(ws), _lib.stream())
         return
-    splits = _splits(M, (N1 // 128) * (N2 // 128))
+    splits = _splits(M, ((N1 + 127) // 128) * ((N2 + 127) // 128))
     ws = torch.empty((splits * N1 * N2,), **_f32(dev))
     ap = a if isinstance(a, int) else a.data_ptr()
     b0p = b0 if isinstance(b0, int) else b0.data_ptr()
@@ -148,9 +158,21 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
                   P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
     sv["importance"] = torch.empty((B, N), **f32)
     sv["tokens"] = torch.empty((B, T, d), **f32)
-    sv["hid"] = torch.empty((B, N, 128), **f32)
-    sv["pproj"] = torch.empty((B, N, 128), **f32)
+    Hi = mc.importance_mlp_hidden_dim
+    sv["hid"] = torch.empty((B, N, Hi), **f32)
+    sv["pproj"] = torch.empty((B, N, d), **f32)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+    if not ops.fast_path(mc):
+        # any (trans_dim, hidden) widths: two generic GEMMs + the row kernels of csrc/generic.hip, keeping hid = relu(Y W1^T + b1)
+        # and P = Y Wp^T for the backward (reference model/paths.py:95-98,119-124; model/aggregator.py:37-65)
+        gp = ops.generic_pack(lvl_pack, mc)
+        ops.gemm_f32(sv["y"], D, gp["w1"], lvl_pack["b1"], sv["hid"], Hi, M, Hi, D, act=1)
+        _lib.call("paths_importance_rows", P(sv["hid"]), Hi, P(lvl_pack["w2"]), P(lvl_pack["b2"]), P(num_ims), N, M, Hi, P(sv["importance"]), st)
+        ops.gemm_f32(sv["y"], D, gp["wp"], None, sv["pproj"], d, M, d, D)
+        _lib.call("paths_tokens_assemble", P(sv["pproj"]), d, P(sv["importance"]), 1 if mc.importance_mode == "mul" else 0, P(lvl_pack["bp"]),
+                  P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), P(locs), N, mc.patch_size, pe_mode, d, B,
+                  P(sv["tokens"]), st)
+        return sv
     tail = (P(lvl_pack["b1"]), P(lvl_pack["w2"]), P(lvl_pack["b2"]),
             P(lvl_pack["bp"]), P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), None, 0, P(locs),
             P(num_ims), N, mc.patch_size, pe_mode, 1 if mc.importance_mode == "mul" else 0, P(sv["importance"]),
@@ -179,24 +201,30 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     grads: Dict[str, torch.Tensor] = {}
 
     # ---- importance MLP + scaling + proj_in
-    du = torch.empty((M, 256), **f32)
+    d, Hi = mc.trans_dim, mc.importance_mlp_hidden_dim
+    U = (Hi + d + 31) // 32 * 32                     # dU = [dhid (Hi) | dP (d) | zero pad]: the K dimension of dY = dU W_ip
+    du = torch.empty((M, U), **f32)
     da = torch.empty((M,), **f32)
-    dah = torch.empty((M, 128), **f32)
-    _lib.call("paths_importance_bwd", P(d_tokens), P(sv["pproj"]), P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]),
-              P(num_ims), N, M, 1 if mc.importance_mode == "mul" else 0, P(du), P(da), P(dah), st)
-    grads["w2"] = colsum(dah, 128, M, 128)
+    dah = torch.empty((M, Hi), **f32)
+    if ops.fast_path(mc):
+        _lib.call("paths_importance_bwd", P(d_tokens), P(sv["pproj"]), P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]),
+                  P(num_ims), N, M, 1 if mc.importance_mode == "mul" else 0, P(du), P(da), P(dah), st)
+    else:
+        _lib.call("paths_importance_bwd_any", P(d_tokens), P(sv["pproj"]), P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]),
+                  P(num_ims), N, M, 1 if mc.importance_mode == "mul" else 0, Hi, d, U, P(du), P(da), P(dah), st)
+    grads["w2"] = colsum(dah, Hi, M, Hi)
     grads["b2"] = colsum(da, 1, M, 1)
-    grads["b1"] = colsum(du, 256, M, 128)
-    grads["special"] = colsum(d_tokens, T * 128, B, 128)
+    grads["b1"] = colsum(du, U, M, Hi)
+    grads["special"] = colsum(d_tokens, T * d, B, d)
     # proj_in.bias: sum of token gradients over the valid patch rows = colsum of dP / alpha is not usable (alpha may
     # be 0), so sum d_tokens rows 1..N directly; padded token rows carry exact zeros (masked keys, unused queries)
     # = (sum over all B*T token rows) - (sum over the B special-token rows): two launches instead of 2 B
-    grads["bp"] = colsum(d_tokens, 128, B * T, 128) - grads["special"]
-    grads["w_ip"] = torch.empty((256, D), **f32)
-    gemm_tn(du, 256, sv["y"], D, grads["w_ip"], M, 256, D)
+    grads["bp"] = colsum(d_tokens, d, B * T, d) - grads["special"]
+    grads["w_ip"] = torch.empty((Hi + d, D), **f32)
+    gemm_tn(du, U, sv["y"], D, grads["w_ip"], M, Hi + d, D)
     dy = torch.empty((M, D), **f32)
-    w_ip_t = transpose(lvl_pack["w_ip"], 256, D)                       # [D, 256]
-    gemm_nt(du, 256, w_ip_t, dy, D, M, D, 256)
+    w_ip_t = transpose(lvl_pack["w_ip"], Hi + d, D, pad_to=U)          # [D, U]
+    gemm_nt(du, U, w_ip_t, dy, D, M, D, U)
 
     # ---- LSTM cell.  Y = X + h1  =>  dh1 = dY (+ gradient arriving at the h half of state_out)
     dG = torch.empty((M, G), **f32)
@@ -248,6 +276,14 @@ def selection_forward_train_nolstm(mc, lvl_pack, fts, locs, num_ims, state_prev)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
 
     def imp_proj(src, imp_out, hid_out, pproj_out):
+        if not ops.fast_path(mc):      # any widths: generic GEMMs + row kernels (tokens = P + bp + PE: src is already scaled)
+            gp = ops.generic_pack(lvl_pack, mc)
+            ops.gemm_f32(src, D, gp["w1"], lvl_pack["b1"], hid_out, Hi, M, Hi, D, act=1)
+            _lib.call("paths_importance_rows", P(hid_out), Hi, P(lvl_pack["w2"]), P(lvl_pack["b2"]), P(num_ims), N, M, Hi, P(imp_out), st)
+            ops.gemm_f32(src, D, gp["wp"], None, pproj_out, d, M, d, D)
+            _lib.call("paths_tokens_assemble", P(pproj_out), d, P(imp_out), 0, P(lvl_pack["bp"]), P(lvl_pack["special"]),
+                      P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), P(locs), N, mc.patch_size, pe_mode, d, B, P(sv["tokens"]), st)
+            return
         _lib.call("paths_importance_proj", P(src), D, P(lvl_pack["w_ip_fwd"]), P(lvl_pack["b1"]), P(lvl_pack["w2"]), P(lvl_pack["b2"]),
                   P(lvl_pack["bp"]), P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), None, 0, P(locs),
                   P(num_ims), N, mc.patch_size, pe_mode, 0, P(imp_out), P(sv["tokens"]), P(hid_out), P(pproj_out), M, D, Hi, d, 0, st)
@@ -276,20 +312,21 @@ def selection_backward_nolstm(mc, lvl_pack, sv, d_tokens: torch.Tensor, d_state_
     fts, state_prev, num_ims = sv["fts"], sv["state_prev"], sv["num_ims"]
     B, N, D = fts.shape
     M, T = B * N, N + 1
+    d, Hi = mc.trans_dim, mc.importance_mlp_hidden_dim
     dev = fts.device
     f32 = _f32(dev)
     st = _lib.stream()
     g: Dict[str, Optional[torch.Tensor]] = {k: None for k in ("w1", "b1", "w2", "b2", "wh1", "bh1", "wh2", "bh2")}
     Z = sv["state_out"]
     # tokens[:, 1:] = Z Wp^T + bp + PE on valid rows (padded token rows carry exact zero gradients: masked keys, unused queries)
-    dpp = d_tokens[:, 1:, :].contiguous().view(M, 128)
-    g["special"] = colsum(d_tokens, T * 128, B, 128)
-    g["bp"] = colsum(dpp, 128, M, 128)
-    wp = lvl_pack["w_ip"][128:]                                          # [128, D] proj_in.weight
-    g["wp"] = torch.empty((128, D), **f32)
-    gemm_tn(dpp, 128, Z, D, g["wp"], M, 128, D)
+    dpp = d_tokens[:, 1:, :].contiguous().view(M, d)
+    g["special"] = colsum(d_tokens, T * d, B, d)
+    g["bp"] = colsum(dpp, d, M, d)
+    wp = lvl_pack["w_ip"][Hi:]                                           # [d, D] proj_in.weight
+    g["wp"] = torch.empty((d, D), **f32)
+    gemm_tn(dpp, d, Z, D, g["wp"], M, d, D)
     dZ = torch.empty((M, D), **f32)
-    gemm_nt(dpp, 128, transpose(wp, 128, D), dZ, D, M, D, 128, residual=d_state_out, ldr=D)
+    gemm_nt(dpp, d, transpose(wp, d, D), dZ, D, M, D, d, residual=d_state_out, ldr=D)
     d_state_prev = None
     if sv["has_hctx"]:
         # hctx = Wh2 relu(Wh1 s + bh1) + bh2 added on valid rows; dZ is exactly zero on padded rows (no token, never kept)
@@ -306,16 +343,20 @@ def selection_backward_nolstm(mc, lvl_pack, sv, d_tokens: torch.Tensor, d_state_
         d_state_prev = torch.empty((B, N, D), **f32)
         gemm_nt(dhh, Hh, transpose(lvl_pack["wh1"], Hh, D), d_state_prev, D, M, D, Hh)
     if mc.importance_mode == "mul":
-        dh = torch.empty((M, 128), **f32)
+        dh = torch.empty((M, Hi), **f32)
         da = torch.empty((M,), **f32)
-        dah = torch.empty((M, 128), **f32)
-        _lib.call("paths_importance_rows_bwd", P(dZ), P(fts), D, P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]), P(num_ims), N, M,
-                  P(dh), P(da), P(dah), st)
-        g["w2"] = colsum(dah, 128, M, 128)
+        dah = torch.empty((M, Hi), **f32)
+        if ops.fast_path(mc):
+            _lib.call("paths_importance_rows_bwd", P(dZ), P(fts), D, P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]), P(num_ims), N, M,
+                      P(dh), P(da), P(dah), st)
+        else:
+            _lib.call("paths_importance_rows_bwd_any", P(dZ), P(fts), D, P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]), P(num_ims), N, M,
+                      Hi, P(dh), P(da), P(dah), st)
+        g["w2"] = colsum(dah, Hi, M, Hi)
         g["b2"] = colsum(da, 1, M, 1)
-        g["b1"] = colsum(dh, 128, M, 128)
-        g["w1"] = torch.empty((128, D), **f32)
-        gemm_tn(dh, 128, fts, D, g["w1"], M, 128, D)
+        g["b1"] = colsum(dh, Hi, M, Hi)
+        g["w1"] = torch.empty((Hi, D), **f32)
+        gemm_tn(dh, Hi, fts, D, g["w1"], M, Hi, D)
     return g, d_state_prev
 
 
@@ -369,34 +410,36 @@ def dropout_rows(x, ldx, M, N, key, p, out=None, ldo=None, resid=None, ldr=0, ve
     return out
 
 
-def _ln_fwd(x, add, g, b, rows, eps, want_y=True):
+def _ln_fwd(x, add, g, b, rows, eps, want_y=True, d=128):
     f32 = _f32(x.device)
-    y = torch.empty((rows, 128), **f32) if want_y else None
-    xh = torch.empty((rows, 128), **f32)
+    y = torch.empty((rows, d), **f32) if want_y else None
+    xh = torch.empty((rows, d), **f32)
     rs = torch.empty((rows,), **f32)
-    _lib.call("paths_layernorm_fwd_stats", P(x), P(add), P(g), P(b), P(y), P(xh), P(rs), rows, 128, eps, _lib.stream())
+    _lib.call("paths_layernorm_fwd_stats" if d == 128 else "paths_layernorm_fwd_stats_any", P(x), P(add), P(g), P(b), P(y), P(xh), P(rs),
+              rows, d, eps, _lib.stream())
     return y, xh, rs
 
 
-def _ln_bwd(dy, xh, rs, g, rows):
+def _ln_bwd(dy, xh, rs, g, rows, d=128):
     f32 = _f32(dy.device)
-    dx = torch.empty((rows, 128), **f32)
-    dyx = torch.empty((rows, 128), **f32)
-    _lib.call("paths_layernorm_bwd", P(dy), P(xh), P(rs), P(g), P(dx), P(dyx), rows, 128, _lib.stream())
+    dx = torch.empty((rows, d), **f32)
+    dyx = torch.empty((rows, d), **f32)
+    _lib.call("paths_layernorm_bwd" if d == 128 else "paths_layernorm_bwd_any", P(dy), P(xh), P(rs), P(g), P(dx), P(dyx), rows, d, _lib.stream())
     return dx, dyx
 
 
-def _ln_bwd_sums(dy, xh, rs, g, rows):
+def _ln_bwd_sums(dy, xh, rs, g, rows, d=128):
     """LayerNorm backward + affine gradients + column sums of dx in two launches: (dx, dgamma, dbeta, colsum(dx))."""
     f32 = _f32(dy.device)
-    dx = torch.empty((rows, 128), **f32)
+    dx = torch.empty((rows, d), **f32)
     rpb = 64
     nblk = (rows + rpb - 1) // rpb
-    slabs = torch.empty((nblk, 384), **f32)
-    _lib.call("paths_layernorm_bwd_sums", P(dy), P(xh), P(rs), P(g), P(dx), P(slabs), rows, 128, rpb, _lib.stream())
-    gb = torch.empty((384,), **f32)
-    _lib.call("paths_reduce_slabs_f32", P(slabs), nblk, 384, P(gb), 0, _lib.stream())
-    return dx, gb[:128], gb[128:256], gb[256:]
+    slabs = torch.empty((nblk, 3 * d), **f32)
+    _lib.call("paths_layernorm_bwd_sums" if d == 128 else "paths_layernorm_bwd_sums_any", P(dy), P(xh), P(rs), P(g), P(dx), P(slabs), rows, d, rpb,
+              _lib.stream())
+    gb = torch.empty((3 * d,), **f32)
+    _lib.call("paths_reduce_slabs_f32", P(slabs), nblk, 3 * d, P(gb), 0, _lib.stream())
+    return dx, gb[:d], gb[d:2 * d], gb[2 * d:]
 
 
 def chain_forward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dev, drop: Optional[Drop] = None, layer: int = 0,
@@ -407,34 +450,35 @@ def chain_forward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, d
     dropout, dropout3); without it this is the plain chain.  Mask element index = row * width + column of the [M, width] matrix."""
     f32 = _f32(dev)
     eps = w["eps"]
+    d, F = w["wo"].shape[0], w["w1"].shape[0]            # trans_dim, dim_feedforward (= 4 trans_dim, reference model/aggregator.py:30)
     c: Dict[str, object] = {}
     if drop is None:
-        u1 = torch.empty((M, 128), **f32)
-        gemm_nt(attn_ptr, lda, w["wo"], u1, 128, M, 128, 128, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
-        n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps)
-        n2, c["xh2"], c["rs2"] = _ln_fwd(n1, w["cab"], w["ln2g"], w["ln2b"], M, eps)
-        hid = torch.empty((M, 512), **f32)
-        gemm_nt(n2, 128, w["w1"], hid, 512, M, 512, 128, bias=w["b1"], act=1)
-        u3 = torch.empty((M, 128), **f32)
-        gemm_nt(hid, 512, w["w2"], u3, 128, M, 128, 512, bias=w["b2"], residual=n2, ldr=128)
+        u1 = torch.empty((M, d), **f32)
+        gemm_nt(attn_ptr, lda, w["wo"], u1, d, M, d, d, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
+        n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps, d=d)
+        n2, c["xh2"], c["rs2"] = _ln_fwd(n1, w["cab"], w["ln2g"], w["ln2b"], M, eps, d=d)
+        hid = torch.empty((M, F), **f32)
+        gemm_nt(n2, d, w["w1"], hid, F, M, F, d, bias=w["b1"], act=1)
+        u3 = torch.empty((M, d), **f32)
+        gemm_nt(hid, F, w["w2"], u3, d, M, d, F, bias=w["b2"], residual=n2, ldr=d)
         c["hid"], c["hid_used"] = hid, hid
     else:
         p = drop.p
-        sa = torch.empty((M, 128), **f32)
-        gemm_nt(attn_ptr, lda, w["wo"], sa, 128, M, 128, 128, bias=w["bo"])
-        u1 = dropout_rows(sa, 128, M, 128, drop.key(layer, Drop.SA_OUT), p, out=sa, ldo=128, resid=x_in_ptr, ldr=ldx)       # x + dropout1(sa)
-        n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps)
-        u2 = dropout_rows(None, 0, M, 128, drop.key(layer, Drop.CA_OUT), p, resid=n1, ldr=128, vec=w["cab"])                 # n1 + dropout2(cab)
-        n2, c["xh2"], c["rs2"] = _ln_fwd(u2, None, w["ln2g"], w["ln2b"], M, eps)
-        hid = torch.empty((M, 512), **f32)
-        gemm_nt(n2, 128, w["w1"], hid, 512, M, 512, 128, bias=w["b1"], act=1)
-        hd = dropout_rows(hid, 512, M, 512, drop.key(layer, Drop.FF_INNER), p)                                             # dropout(relu(linear1))
-        ffo = torch.empty((M, 128), **f32)
-        gemm_nt(hd, 512, w["w2"], ffo, 128, M, 128, 512, bias=w["b2"])
-        u3 = dropout_rows(ffo, 128, M, 128, drop.key(layer, Drop.FF_OUT), p, out=ffo, ldo=128, resid=n2, ldr=128)           # n2 + dropout3(ffo)
+        sa = torch.empty((M, d), **f32)
+        gemm_nt(attn_ptr, lda, w["wo"], sa, d, M, d, d, bias=w["bo"])
+        u1 = dropout_rows(sa, d, M, d, drop.key(layer, Drop.SA_OUT), p, out=sa, ldo=d, resid=x_in_ptr, ldr=ldx)       # x + dropout1(sa)
+        n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps, d=d)
+        u2 = dropout_rows(None, 0, M, d, drop.key(layer, Drop.CA_OUT), p, resid=n1, ldr=d, vec=w["cab"])                 # n1 + dropout2(cab)
+        n2, c["xh2"], c["rs2"] = _ln_fwd(u2, None, w["ln2g"], w["ln2b"], M, eps, d=d)
+        hid = torch.empty((M, F), **f32)
+        gemm_nt(n2, d, w["w1"], hid, F, M, F, d, bias=w["b1"], act=1)
+        hd = dropout_rows(hid, F, M, F, drop.key(layer, Drop.FF_INNER), p)                                             # dropout(relu(linear1))
+        ffo = torch.empty((M, d), **f32)
+        gemm_nt(hd, F, w["w2"], ffo, d, M, d, F, bias=w["b2"])
+        u3 = dropout_rows(ffo, d, M, d, drop.key(layer, Drop.FF_OUT), p, out=ffo, ldo=d, resid=n2, ldr=d)           # n2 + dropout3(ffo)
         c["hid"], c["hid_used"] = hid, hd
     c["n2"] = n2
-    x3, c["xh3"], c["rs3"] = _ln_fwd(u3, None, w["ln3g"], w["ln3b"], M, eps, want_y=want_out)
+    x3, c["xh3"], c["rs3"] = _ln_fwd(u3, None, w["ln3g"], w["ln3b"], M, eps, want_y=want_out, d=d)
     c["x3"] = x3
     return c
 
@@ -445,55 +489,61 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
     (:func:`chain_forward`, same dropout masks as the forward), then differentiate.
     Returns (grads, dx_in [M,128], dattn [M,128])."""
     f32 = _f32(dev)
+    d, F = w["wo"].shape[0], w["w1"].shape[0]
     g: Dict[str, torch.Tensor] = {}
     c = chain_forward(w, x_in_ptr, ldx, attn_ptr, lda, M, dev, drop, layer, want_out=False)
     hid, hd, n2 = c["hid"], c["hid_used"], c["n2"]
     p = drop.p if drop is not None else 0.0
     # ---- backward
-    du3, g["ln3g"], g["ln3b"], cs3 = _ln_bwd_sums(dx_out, c["xh3"], c["rs3"], w["ln3g"], M)
+    du3, g["ln3g"], g["ln3b"], cs3 = _ln_bwd_sums(dx_out, c["xh3"], c["rs3"], w["ln3g"], M, d)
     if drop is None:
         dffo, g["b2"] = du3, cs3
     else:
-        dffo = dropout_rows(du3, 128, M, 128, drop.key(layer, Drop.FF_OUT), p)
-        g["b2"] = colsum(dffo, 128, M, 128)
-    dhid = torch.empty((M, 512), **f32)
-    gemm_nt(dffo, 128, transpose(w["w2"], 128, 512), dhid, 512, M, 512, 128, mask=hid, ldm=512)
+        dffo = dropout_rows(du3, d, M, d, drop.key(layer, Drop.FF_OUT), p)
+        g["b2"] = colsum(dffo, d, M, d)
+    dhid = torch.empty((M, F), **f32)
+    gemm_nt(dffo, d, transpose(w["w2"], d, F), dhid, F, M, F, d, mask=hid, ldm=F)
     if drop is not None:
-        dropout_rows(dhid, 512, M, 512, drop.key(layer, Drop.FF_INNER), p, out=dhid, ldo=512)
-    g["w2"] = torch.empty((128, 512), **f32)
-    gemm_tn(dffo, 128, hd, 512, g["w2"], M, 128, 512)
-    dn2 = torch.empty((M, 128), **f32)
-    gemm_nt(dhid, 512, transpose(w["w1"], 512, 128), dn2, 128, M, 128, 512, residual=du3, ldr=128)
-    g["w1"] = torch.empty((512, 128), **f32)
-    gemm_tn(dhid, 512, n2, 128, g["w1"], M, 512, 128)
-    g["b1"] = colsum(dhid, 512, M, 512)
-    du2, g["ln2g"], g["ln2b"], cs2 = _ln_bwd_sums(dn2, c["xh2"], c["rs2"], w["ln2g"], M)
-    g["cab"] = cs2 if drop is None else colsum(dropout_rows(du2, 128, M, 128, drop.key(layer, Drop.CA_OUT), p), 128, M, 128)
-    du1, g["ln1g"], g["ln1b"], cs1 = _ln_bwd_sums(du2, c["xh1"], c["rs1"], w["ln1g"], M)
+        dropout_rows(dhid, F, M, F, drop.key(layer, Drop.FF_INNER), p, out=dhid, ldo=F)
+    g["w2"] = torch.empty((d, F), **f32)
+    gemm_tn(dffo, d, hd, F, g["w2"], M, d, F)
+    dn2 = torch.empty((M, d), **f32)
+    gemm_nt(dhid, F, transpose(w["w1"], F, d), dn2, d, M, d, F, residual=du3, ldr=d)
+    g["w1"] = torch.empty((F, d), **f32)
+    gemm_tn(dhid, F, n2, d, g["w1"], M, F, d)
+    g["b1"] = colsum(dhid, F, M, F)
+    du2, g["ln2g"], g["ln2b"], cs2 = _ln_bwd_sums(dn2, c["xh2"], c["rs2"], w["ln2g"], M, d)
+    g["cab"] = cs2 if drop is None else colsum(dropout_rows(du2, d, M, d, drop.key(layer, Drop.CA_OUT), p), d, M, d)
+    du1, g["ln1g"], g["ln1b"], cs1 = _ln_bwd_sums(du2, c["xh1"], c["rs1"], w["ln1g"], M, d)
     if drop is None:
         dsa, g["bo"] = du1, cs1
     else:
-        dsa = dropout_rows(du1, 128, M, 128, drop.key(layer, Drop.SA_OUT), p)
-        g["bo"] = colsum(dsa, 128, M, 128)
-    dattn = torch.empty((M, 128), **f32)
-    gemm_nt(dsa, 128, transpose(w["wo"], 128, 128), dattn, 128, M, 128, 128)
-    g["wo"] = torch.empty((128, 128), **f32)
-    gemm_tn(dsa, 128, attn_ptr, lda, g["wo"], M, 128, 128)
+        dsa = dropout_rows(du1, d, M, d, drop.key(layer, Drop.SA_OUT), p)
+        g["bo"] = colsum(dsa, d, M, d)
+    dattn = torch.empty((M, d), **f32)
+    gemm_nt(dsa, d, transpose(w["wo"], d, d), dattn, d, M, d, d)
+    g["wo"] = torch.empty((d, d), **f32)
+    gemm_tn(dsa, d, attn_ptr, lda, g["wo"], M, d, d)
     return g, du1, dattn
 
 
-def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: float, dx_accum: torch.Tensor):
-    """in_proj backward.  dqkv [M,384] = [dq_scaled | dk | dv]; dx_accum [M,128] += dqkv_pre W_in."""
+def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: float, dx_accum: torch.Tensor, fold_qscale: bool = True):
+    """in_proj backward.  dqkv [M,3d] = [dq | dk | dv]; dx_accum [M,d] += dqkv W_in.  fold_qscale (the 128-wide kernels, whose
+    q is stored pre-scaled): dq is the gradient of the SCALED q, so d(q_scaled)/d(q) is folded into the weight copy and into the
+    q rows of the weight / bias gradients; the shape-generic attention backward returns the gradient of the unscaled q."""
     f32 = _f32(x_in.device)
+    d = w["wo"].shape[0]
     g: Dict[str, torch.Tensor] = {}
-    wt = transpose(w["wqkv"], 384, 128)                       # [128, 384]
-    wt[:, :128] *= qscale                                     # fold d(q_scaled)/d(q) into the weight copy
-    gemm_nt(dqkv, 384, wt, dx_accum, 128, M, 128, 384, accumulate=True)
-    g["wqkv"] = torch.empty((384, 128), **f32)
-    gemm_tn(dqkv, 384, x_in, 128, g["wqkv"], M, 384, 128)
-    g["bqkv"] = colsum(dqkv, 384, M, 384)
-    g["wqkv"][:128] *= qscale
-    g["bqkv"][:128] *= qscale
+    wt = transpose(w["wqkv"], 3 * d, d)                       # [d, 3d]
+    if fold_qscale:
+        wt[:, :d] *= qscale
+    gemm_nt(dqkv, 3 * d, wt, dx_accum, d, M, d, 3 * d, accumulate=True)
+    g["wqkv"] = torch.empty((3 * d, d), **f32)
+    gemm_tn(dqkv, 3 * d, x_in, d, g["wqkv"], M, 3 * d, d)
+    g["bqkv"] = colsum(dqkv, 3 * d, M, 3 * d)
+    if fold_qscale:
+        g["wqkv"][:d] *= qscale
+        g["bqkv"][:d] *= qscale
     return g
 
 
@@ -520,6 +570,8 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
     """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output).
     ``drop`` (train mode with dropout > 0): the fused row-chain kernels have no dropout sites, so the chain of every layer runs
     on the generic kernels of :func:`chain_forward` - the very sequence the backward recomputes - with the masks applied."""
+    if not ops.fast_path(mc):
+        return _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, drop, ctx_all)
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
     hd = d // H
@@ -589,10 +641,65 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
     return sv
 
 
+def _attention_generic(qkv, attn, lse, num_ims, B, T, H, hd, qscale, max_queries, drop: Optional[Drop], layer: int):
+    key, p = (drop.key(layer, Drop.ATTN), drop.p) if drop is not None else (0, 0.0)
+    _lib.call("paths_attention_any_train", P(qkv), qkv.stride(0), P(attn), P(lse), P(num_ims), B, T, H, hd, qscale, max_queries, key, p,
+              _lib.stream())
+
+
+def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Optional[Drop], ctx_all: Optional[torch.Tensor]):
+    """:func:`transformer_forward_train` for any (trans_dim, heads): every product on the generic GEMMs, attention on the shape-generic
+    kernel (csrc/generic.hip, TRAIN form: lse + dropout), the row chains on :func:`chain_forward` - the sequence the backward
+    recomputes.  q, k, v stay token-major ([B*T, 3d], q unscaled: the attention kernels scale it on load)."""
+    B, T, d = tokens.shape
+    H, L = mc.trans_heads, mc.trans_layers
+    hd = d // H
+    dev = tokens.device
+    f32 = _f32(dev)
+    qscale = LOG2E / math.sqrt(hd)
+    layers = lvl_pack["layers"]
+    M = B * T
+    assert ctx_prev is None or ctx_all is None
+    cdepth = ctx_all.shape[1] if ctx_all is not None else 0
+    sv = {"layers": [], "num_ims": num_ims, "tokens": tokens, "ctx_prev": ctx_prev, "ctx_all": ctx_all if cdepth > 0 else None,
+          "drop": drop}
+
+    def in_proj(x, w):
+        qkv = torch.empty((M, 3 * d), **f32)
+        gemm_nt(x.view(M, d), d, w["wqkv"], qkv, 3 * d, M, 3 * d, d, bias=w["bqkv"])
+        return qkv
+
+    x = tokens
+    qkv = in_proj(x, layers[0])
+    for l in range(L - 1):
+        attn = torch.zeros((B, T, d), **f32)
+        lse = torch.zeros((B, H, T), **f32)
+        _attention_generic(qkv, attn, lse, num_ims, B, T, H, hd, qscale, 0, drop, l)
+        x_out = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, M, dev, drop, l)["x3"].view(B, T, d)
+        sv["layers"].append({"x_in": x, "qkv": qkv, "attn": attn, "lse": lse})
+        x, qkv = x_out, in_proj(x_out, layers[l + 1])
+    # last layer: only token 0 of its output is read (reference model/aggregator.py:75)
+    w = layers[L - 1]
+    attn0 = torch.zeros((B, T, d), **f32)
+    lse0 = torch.zeros((B, H, T), **f32)
+    _attention_generic(qkv, attn0, lse0, num_ims, B, T, H, hd, qscale, 1, drop, L - 1)
+    x3 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)["x3"]
+    nlog = lvl_pack["wcls"].shape[0]
+    ctx_out = torch.empty((B, d), **f32)
+    logits = torch.empty((B, nlog), **f32)
+    _lib.call("paths_final_head_any", P(x3), d, P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev),
+              ctx_prev.stride(0) if ctx_prev is not None else 0, P(ctx_all) if cdepth > 0 else None, cdepth, P(lvl_pack["wcls"]),
+              P(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), B, d, lvl_pack["lnf_eps"], _lib.stream())
+    sv["last"] = {"x_in": x, "qkv": qkv, "attn0": attn0, "lse0": lse0}
+    sv["ctx_out"], sv["logits"] = ctx_out, logits
+    return sv
+
+
 def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_ctx_out: Optional[torch.Tensor]):
-    """Returns (grads, d_tokens [B,T,128], d_ctx): d_ctx = gradient of ctx_prev [B,128] (residual mode), of ctx_all [B,depth,128]
+    """Returns (grads, d_tokens [B,T,d], d_ctx): d_ctx = gradient of ctx_prev [B,d] (residual mode), of ctx_all [B,depth,d]
     (concat mode) or None.  grads: {"layers": [per-layer dict], "lnfg", "lnfb", "wcls", "bcls"}.  d_logits / d_ctx_out may be
-    None (zero)."""
+    None (zero).  The shipped geometry (ops.fast_path) differentiates its attention with the 128-wide kernels (q, k, v head-major,
+    q pre-scaled); every other geometry with csrc/generic_bwd.hip (token-major qkv)."""
     tokens, num_ims, ctx_prev = sv["tokens"], sv["num_ims"], sv["ctx_prev"]
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
@@ -604,59 +711,72 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     layers = lvl_pack["layers"]
     grads = {"layers": [None] * L}
     nlog = lvl_pack["wcls"].shape[0]
+    fast = ops.fast_path(mc)
+    assert nlog <= 128
 
-    # ---- head: logits = F Wcls^T + bcls, F = decoder.norm(x3) (+ ctx_prev);  only residual / none modes in training
+    # ---- head: logits = F Wcls^T + bcls, F = decoder.norm(x3) (+ ctx_prev)
     wl = layers[L - 1]
     last = sv["last"]
     x_last = last["x_in"]
     drop: Optional[Drop] = sv.get("drop")
     dk = lambda l: (drop.key(l, Drop.ATTN), drop.p) if drop is not None else (0, 0.0)
-    # recompute token 0 of the last layer up to x3 (its attention output first)
-    attn0 = torch.zeros((B, T, d), **f32)
-    attention(last["q"], last["k"], last["v"], attn0, None, num_ims, B, T, H, hd, 1, *dk(L - 1))
+    # recompute token 0 of the last layer up to x3 (its attention output first; the generic path kept it)
+    if fast:
+        attn0 = torch.zeros((B, T, d), **f32)
+        attention(last["q"], last["k"], last["v"], attn0, None, num_ims, B, T, H, hd, 1, *dk(L - 1))
+    else:
+        attn0 = last["attn0"]
     x3 = chain_forward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)["x3"]
-    xf, xhf, rsf = _ln_fwd(x3, None, lvl_pack["lnfg"], lvl_pack["lnfb"], B, lvl_pack["lnf_eps"])
-    feat = xf + ctx_prev if ctx_prev is not None else xf                     # [B,128] (8 rows: bookkeeping)
+    xf, xhf, rsf = _ln_fwd(x3, None, lvl_pack["lnfg"], lvl_pack["lnfb"], B, lvl_pack["lnf_eps"], d=d)
+    feat = xf + ctx_prev if ctx_prev is not None else xf                     # [B,d] (8 rows: bookkeeping)
     ctx_all = sv.get("ctx_all")
     cdepth = ctx_all.shape[1] if ctx_all is not None else 0
-    dF = torch.zeros((B, 128), **f32)
-    d_ctx_all = torch.zeros((B, cdepth, 128), **f32) if cdepth > 0 else None
+    dF = torch.zeros((B, d), **f32)
+    d_ctx_all = torch.zeros((B, cdepth, d), **f32) if cdepth > 0 else None
     if d_ctx_out is not None:
         dF += d_ctx_out
     if d_logits is not None:
-        dl = torch.zeros((B, 128), **f32)
+        dl = torch.zeros((B, 128), **f32)                                    # logits padded to one 128-wide k panel
         dl[:, :nlog] = d_logits
-        wcls = lvl_pack["wcls"]                                              # [nlog, (cdepth + 1) * 128]: blocks = [ctx levels | F]
+        wcls = lvl_pack["wcls"]                                              # [nlog, (cdepth + 1) * d]: blocks = [ctx levels | F]
+        dpad = (d + 127) // 128 * 128
         for kb in range(cdepth + 1):
-            wc = torch.zeros((128, 128), **f32)
-            wc[:, :nlog] = wcls[:, kb * 128:(kb + 1) * 128].t()              # [in=128, out padded]
+            wc = torch.zeros((dpad, 128), **f32)
+            wc[:d, :nlog] = wcls[:, kb * d:(kb + 1) * d].t()                 # [in = d (padded rows), out padded]
             if kb == cdepth:
-                gemm_nt(dl, 128, wc, dF, 128, B, 128, 128, accumulate=True)  # dF += dlogits Wcls[:, F block]
+                gemm_nt(dl, 128, wc, dF, d, B, d, 128, accumulate=True)      # dF += dlogits Wcls[:, F block]
             else:
-                blk = torch.empty((B, 128), **f32)
-                gemm_nt(dl, 128, wc, blk, 128, B, 128, 128)                  # gradient of the concatenated context of level kb
+                blk = torch.empty((B, d), **f32)
+                gemm_nt(dl, 128, wc, blk, d, B, d, 128)                      # gradient of the concatenated context of level kb
                 d_ctx_all[:, kb] = blk
-        cat_in = torch.cat((ctx_all.reshape(B, cdepth * 128), feat), dim=1).contiguous() if cdepth > 0 else feat
-        gw = torch.empty((128, (cdepth + 1) * 128), **f32)
-        gemm_tn(dl, 128, cat_in, (cdepth + 1) * 128, gw, B, 128, (cdepth + 1) * 128)     # (dlogits^T [ctx | F]), rows >= nlog are zero
+        cat_in = torch.cat((ctx_all.reshape(B, cdepth * d), feat), dim=1).contiguous() if cdepth > 0 else feat
+        gw = torch.empty((128, (cdepth + 1) * d), **f32)
+        gemm_tn(dl, 128, cat_in, (cdepth + 1) * d, gw, B, 128, (cdepth + 1) * d)         # (dlogits^T [ctx | F]), rows >= nlog are zero
         grads["wcls"] = gw[:nlog].contiguous()
         grads["bcls"] = colsum(dl, 128, B, 128)[:nlog].contiguous()
     else:
         grads["wcls"] = torch.zeros_like(lvl_pack["wcls"])
         grads["bcls"] = torch.zeros_like(lvl_pack["bcls"])
     d_ctx_prev = dF.clone() if ctx_prev is not None else d_ctx_all
-    dx3, dyxf = _ln_bwd(dF, xhf, rsf, lvl_pack["lnfg"], B)
-    grads["lnfg"], grads["lnfb"] = colsum(dyxf, 128, B, 128), colsum(dF, 128, B, 128)
+    dx3, dyxf = _ln_bwd(dF, xhf, rsf, lvl_pack["lnfg"], B, d)
+    grads["lnfg"], grads["lnfb"] = colsum(dyxf, d, B, d), colsum(dF, d, B, d)
 
     # ---- last layer, token 0 only
     g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dx3, dev, drop, L - 1)
     dqkv = torch.zeros((B, T, 3 * d), **f32)
-    a0 = attn0[:, 0, :].contiguous()
-    _lib.call("paths_attention_token0_bwd_dropout", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(num_ims), P(dqkv),
-              B, T, H, hd, *dk(L - 1), st)
+    if fast:
+        a0 = attn0[:, 0, :].contiguous()
+        _lib.call("paths_attention_token0_bwd_dropout", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(num_ims), P(dqkv),
+                  B, T, H, hd, *dk(L - 1), st)
+    else:
+        d_o = torch.zeros((B, T, d), **f32)                                  # only token 0 carries an output gradient
+        d_o[:, 0, :] = da0
+        ws = torch.empty((B * H * T,), **f32)
+        _lib.call("paths_attention_bwd_any", P(last["qkv"]), 3 * d, P(attn0), P(d_o), P(last["lse0"]), P(num_ims), P(dqkv), P(ws),
+                  B, T, H, hd, qscale, 1, *dk(L - 1), st)
     dx = torch.zeros((B, T, d), **f32)                                       # gradient of the last layer's input
     dx[:, 0, :] = dx0
-    g.update(qkv_backward(wl, x_last, dqkv, B * T, qscale, dx))
+    g.update(qkv_backward(wl, x_last, dqkv, B * T, qscale, dx, fold_qscale=fast))
     grads["layers"][L - 1] = g
 
     # ---- full layers
@@ -667,14 +787,17 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev, drop, l)
         dqkv = torch.zeros((B, T, 3 * d), **f32)
         ws = torch.empty((B * H * T,), **f32)
-        if ATTN_BWD_MODE == "x6q":      # dQ, dK and dV on the split-bf16 kernels (csrc/attn_bwd_x6.hip; PATHS_ATTN_BWD_KV_X6=0 in the C library keeps dK / dV on the f32 MFMA)
+        if not fast:
+            _lib.call("paths_attention_bwd_any", P(lv["qkv"]), 3 * d, P(lv["attn"]), P(dattn), P(lv["lse"]), P(num_ims), P(dqkv), P(ws),
+                      B, T, H, hd, qscale, 0, *dk(l), st)
+        elif ATTN_BWD_MODE == "x6q":    # dQ, dK and dV on the split-bf16 kernels (csrc/attn_bwd_x6.hip; PATHS_ATTN_BWD_KV_X6=0 in the C library keeps dK / dV on the f32 MFMA)
             img = torch.empty((int(_lib.load().paths_attention_bwd_x6_workspace(B, T, H, hd)),), device=dqkv.device, dtype=torch.uint8)
             _lib.call("paths_attention_bwd_x6_dropout", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
                       P(num_ims), P(dqkv), P(ws), P(img), B, T, H, hd, *dk(l), st)
         else:
             _lib.call("paths_attention_bwd_f32_dropout", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
                       P(num_ims), P(dqkv), P(ws), B, T, H, hd, *dk(l), st)
-        g.update(qkv_backward(w, lv["x_in"], dqkv, M, qscale, dx_in))
+        g.update(qkv_backward(w, lv["x_in"], dqkv, M, qscale, dx_in, fold_qscale=fast))
         grads["layers"][l] = g
         dx = dx_in.view(B, T, d)
     return grads, dx, d_ctx_prev

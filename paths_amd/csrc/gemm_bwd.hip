@@ -44,9 +44,13 @@ gemm_tn_kernel(TnOperands g) {
   const float* Bp = second ? g.B1 + (n2_0 - g.NB0) : g.B0 + n2_0;
   const int64_t ldb = second ? g.ldb1 : g.ldb0;
   const float* Ap = g.A + n1_0;
+  // ragged edge tiles (N1 / N2 not multiples of 128): columns past the end are read from the tile's first column instead (their
+  // products only reach accumulator rows / columns the epilogue never stores)
+  const int bcols = (second ? g.N2 : g.NB0) - n2_0;
 
   // staging: 32 rows x 32 float4 per operand -> 4 float4 per thread per operand (8 chunks per k-tile)
   const int c4 = tid & 31, r0 = tid >> 5;          // r0 in [0,8): rows r0 + 8p
+  const int ca = n1_0 + 4 * c4 < g.N1 ? 4 * c4 : 0, cb = 4 * c4 < bcols ? 4 * c4 : 0;
   f32x4 ra[4], rb[4];
   // one chunk (compile-time index after unrolling); rows past the end are read clamped and zeroed by a select, not a
   // branch: the k-tile body must stay one basic block so its instruction order can be pinned (see gemm_f32.hip)
@@ -54,8 +58,8 @@ gemm_tn_kernel(TnOperands g) {
     const int p = idx & 3;
     const int m = m0 + r0 + 8 * p;
     const int mc = min(m, m_end - 1);
-    if (idx < 4) ra[p] = ldg_f32x4(Ap + (int64_t)mc * g.lda + 4 * c4);
-    else rb[p] = ldg_f32x4(Bp + (int64_t)mc * ldb + 4 * c4);
+    if (idx < 4) ra[p] = ldg_f32x4(Ap + (int64_t)mc * g.lda + ca);
+    else rb[p] = ldg_f32x4(Bp + (int64_t)mc * ldb + cb);
   };
   // the zeroing of rows past the end happens HERE (8 groups after the load was issued): touching the loaded value
   // earlier would put an s_waitcnt vmcnt(0) right behind every load
@@ -264,19 +268,18 @@ int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0
                       hipStream_t stream) {
   PATHS_REQUIRE(M > 0 && N1 > 0 && N2 > 0 && splits > 0 && a && b0 && out && workspace, "gemm_tn: bad arguments");
   PATHS_REQUIRE(N1 % 4 == 0 && N2 % 4 == 0 && lda % 4 == 0 && ldb0 % 4 == 0 && (b1 == nullptr || ldb1 % 4 == 0), "gemm_tn: dims must be multiples of 4");
-  PATHS_REQUIRE(N1 % 128 == 0 && N2 % 128 == 0, "gemm_tn: N1 (%d) and N2 (%d) must be multiples of 128", N1, N2);
-  PATHS_REQUIRE(b1 == nullptr || (nb0 % 128 == 0 && nb0 < N2), "gemm_tn: panel split must be a multiple of 128");
+  PATHS_REQUIRE(b1 == nullptr || (nb0 % 128 == 0 && nb0 > 0 && nb0 < N2), "gemm_tn: panel split must be a multiple of 128");
   PATHS_REQUIRE(((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
   int rps = (M + splits - 1) / splits;
   rps = (rps + TK - 1) / TK * TK;
   if (splits == 1 && !accumulate) {      // enough tiles to fill the chip: write the result in place, no slab pass
     TnOperands g1{a, lda, b0, ldb0, b1 ? nb0 : N2, b1, ldb1, M, N1, N2, out, ldo, rps};
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(N2 / 128, N1 / 128, 1), dim3(256), 0, stream, g1);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N2 + 127) / 128, (N1 + 127) / 128, 1), dim3(256), 0, stream, g1);
     PATHS_LAUNCH_CHECK("gemm_tn");
     return PATHS_OK;
   }
   TnOperands g{a, lda, b0, ldb0, b1 ? nb0 : N2, b1, ldb1, M, N1, N2, workspace, (int64_t)N2, rps};
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(N2 / 128, N1 / 128, splits), dim3(256), 0, stream, g);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((N2 + 127) / 128, (N1 + 127) / 128, splits), dim3(256), 0, stream, g);
   PATHS_LAUNCH_CHECK("gemm_tn");
   const int64_t n = (int64_t)N1 * N2;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, splits, n, out, ldo, N2, accumulate);

@@ -6,6 +6,9 @@
 // Exact fp32 arithmetic throughout (f32-input MFMA = a k-ordered fp32 FMA chain); written for correctness and reasonable speed,
 // not tuned like the 128-wide path.
 #include "common.h"
+#include "dropout.h"
+
+DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
 
 namespace {
 
@@ -17,11 +20,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- fused masked self-attention, fp32 MFMA (the scheme of attn_f32.hip), templated on the head dim; q, k, v are read in place
 // from the token-major in_proj output [B*T, 3d] (q | k | v blocks of d columns, head h at columns h*HD), q scaled here.
+// TRAIN (paths_attention_any_train): also writes the log2-domain log-sum-exp of the un-dropped softmax and multiplies the probabilities
+// that enter the PV product by the regenerated dropout mask / (1 - p) (element ((slide*H + head)*T + query)*T + key, csrc/dropout.h).
 constexpr int KT = 64;
-template <int HD>
+template <int HD, bool TRAIN>
 __global__ void __launch_bounds__(256)
 attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, float* __restrict__ o,
-                const int64_t* __restrict__ num_ims, int T, int H) {
+                const int64_t* __restrict__ num_ims, int T, int H, float* __restrict__ lse, DropSite drop) {
   constexpr int NU = HD / 16, LDKs = HD + 8, LDVs = HD + 4, C4 = HD / 4;
   __shared__ __attribute__((aligned(16))) float sK[2][KT * LDKs];
   __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVs];
@@ -111,6 +116,15 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
       }
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if constexpr (TRAIN) {
+      if (drop.thr != 0u) {
+        const uint64_t rowi = (((uint64_t)b * H + head) * T + (uint64_t)min(q0 + wave * 16 + ql, T - 1)) * T + (uint64_t)(kt * KT + 4 * g4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult(drop, rowi + (uint64_t)(16 * t + r));
+      }
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) oacc[u] *= alpha;
 #pragma unroll
@@ -133,6 +147,9 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
     float* op = o + ((int64_t)b * T + qi) * d + head * HD + 4 * g4;
 #pragma unroll
     for (int u = 0; u < NU; ++u) *reinterpret_cast<f32x4*>(op + 16 * u) = oacc[u] * inv;
+    if constexpr (TRAIN) {
+      if (lse != nullptr && g4 == 0) lse[((int64_t)b * H + head) * T + qi] = m_run + __builtin_amdgcn_logf(l_run);
+    }
   }
 }
 
@@ -276,14 +293,37 @@ int paths_attention_any(const float* qkv, int64_t ld, float* o, const int64_t* n
   const int d = H * head_dim;
   const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
   dim3 grid((nq + 63) / 64, H, B);
+  const DropSite none{0u, 0u, 0u, 1.f};
   switch (head_dim) {
-    case 16: hipLaunchKernelGGL(attn_any_kernel<16>, grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H); break;
-    case 32: hipLaunchKernelGGL(attn_any_kernel<32>, grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H); break;
-    case 48: hipLaunchKernelGGL(attn_any_kernel<48>, grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H); break;
-    case 64: hipLaunchKernelGGL(attn_any_kernel<64>, grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H); break;
+    case 16: hipLaunchKernelGGL((attn_any_kernel<16, false>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, nullptr, none); break;
+    case 32: hipLaunchKernelGGL((attn_any_kernel<32, false>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, nullptr, none); break;
+    case 48: hipLaunchKernelGGL((attn_any_kernel<48, false>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, nullptr, none); break;
+    case 64: hipLaunchKernelGGL((attn_any_kernel<64, false>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, nullptr, none); break;
     default: return paths_set_error(PATHS_EUNSUPPORTED, "attention_any: head_dim %d (supported: 16, 32, 48, 64)", head_dim);
   }
   PATHS_LAUNCH_CHECK("attention_any");
+  return PATHS_OK;
+}
+
+// paths_attention_any for the training forward: also lse [B, H, T] (log2 domain, un-dropped softmax; may be null) and dropout p on the
+// probabilities (site key drop_key; p = 0: none).  Rows >= max_queries of o / lse are not written.
+int paths_attention_any_train(const float* qkv, int64_t ld, float* o, float* lse, const int64_t* num_ims, int B, int T, int H, int head_dim,
+                              float qscale, int max_queries, uint64_t drop_key, float drop_p, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && qkv && o && num_ims, "attention_any_train: bad arguments");
+  PATHS_REQUIRE(ld % 4 == 0 && ((uintptr_t)qkv | (uintptr_t)o) % 16 == 0, "attention_any_train: buffers must be 16-byte aligned, ld a multiple of 4");
+  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention_any_train: p must be in [0, 1)");
+  const int d = H * head_dim;
+  const int nq = max_queries > 0 && max_queries < T ? max_queries : T;
+  dim3 grid((nq + 63) / 64, H, B);
+  const DropSite site = paths_make_drop_site(drop_key, drop_p);
+  switch (head_dim) {
+    case 16: hipLaunchKernelGGL((attn_any_kernel<16, true>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, lse, site); break;
+    case 32: hipLaunchKernelGGL((attn_any_kernel<32, true>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, lse, site); break;
+    case 48: hipLaunchKernelGGL((attn_any_kernel<48, true>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, lse, site); break;
+    case 64: hipLaunchKernelGGL((attn_any_kernel<64, true>), grid, dim3(256), 0, stream, qkv, ld, d, qscale, o, num_ims, T, H, lse, site); break;
+    default: return paths_set_error(PATHS_EUNSUPPORTED, "attention_any_train: head_dim %d (supported: 16, 32, 48, 64)", head_dim);
+  }
+  PATHS_LAUNCH_CHECK("attention_any_train");
   return PATHS_OK;
 }
 

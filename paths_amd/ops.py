@@ -379,9 +379,9 @@ def check_supported(mc, training: bool = False):
         if d % 32 or d > 1024 or H < 1 or d % H or (d // H) not in (16, 32, 48, 64) or Hi < 1 or Hi > 1024:
             raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 1024), head_dim in {16, 32, 48, 64} and "
                                       f"importance_mlp_hidden_dim <= 1024 (got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
-        if training:
-            raise NotImplementedError("training (the hand-written backward kernels) is built for trans_dim=128, trans_heads=4, "
-                                      f"importance_mlp_hidden_dim=128 (got {d}, {H}, {Hi}); inference runs on the generic kernels")
+        if training and Hi % 4:
+            raise NotImplementedError("training at aggregator geometries other than trans_dim=128 / 4 heads / importance hidden 128 needs "
+                                      f"importance_mlp_hidden_dim % 4 == 0 (got {Hi}); inference runs")
     if mc.patch_embed_dim % 128 or mc.hierarchical_ctx_mlp_hidden_dim % 64:
         raise NotImplementedError("patch_embed_dim must be a multiple of 128 and hierarchical_ctx_mlp_hidden_dim of 64")
     if mc.pos_encoding_mode not in ("1d", "2d"):

@@ -81,3 +81,24 @@ def golden_trace(g, B, L):
                    "importance": g[f"L{l}_importance"], "logits": g[f"L{l}_logits"],
                    "keep_inds": [g[f"L{l}_keep_{j}"] for j in range(B)] if l < L - 1 else []})
     return tr
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def spy_calls():
+    """Names of the C entry points (paths_amd._lib.call) a block of code goes through."""
+    from paths_amd import _lib
+    calls = []
+    orig = _lib.call
+
+    def spy(cname, *a):
+        calls.append(cname)
+        return orig(cname, *a)
+
+    _lib.call = spy
+    try:
+        yield calls
+    finally:
+        _lib.call = orig

@@ -65,6 +65,29 @@ def test_gemm_tn_colsum_transpose(dev):
         assert rel_err(o_s, ref_s) < 2e-6, (Ms, Ks, Ns)
 
 
+@pytest.mark.parametrize("M,N1,N2", [(1000, 192, 576), (5000, 320, 1024), (8, 128, 576), (700, 96, 64), (2049, 768, 192)])
+def test_gemm_tn_and_nt_ragged_widths(dev, M, N1, N2):
+    """Widths that are not multiples of 128 (trans_dim 192: 192 / 576 / 768 columns): the f32 TN kernel's edge tiles and the NT
+    wrapper's zero-padded weight rows, plain and accumulating, against float64."""
+    from paths_amd import backward as bw
+    g = torch.Generator().manual_seed(M + N1)
+    a, b = torch.randn(M, N1, generator=g), torch.randn(M, N2, generator=g)
+    ad, bd = a.to(dev), b.to(dev)
+    out = torch.full((N1, N2), 3.0, device=dev)
+    bw.gemm_tn(ad, N1, bd, N2, out, M, N1, N2)
+    ref = a.double().t() @ b.double()
+    assert rel_err(out, ref) < 2e-6
+    bw.gemm_tn(ad, N1, bd, N2, out, M, N1, N2, accumulate=True)
+    assert rel_err(out, 2 * ref) < 2e-6
+    if N1 % 32 == 0:
+        w, bias = torch.randn(N2, N1, generator=g), torch.randn(N2, generator=g)
+        o = torch.full((M, N2), 1.0, device=dev)
+        bw.gemm_nt(ad, N1, w.to(dev), o, N2, M, N2, N1, bias=bias.to(dev), act=1, accumulate=True)
+        assert rel_err(o, torch.relu(a.double() @ w.double().t() + bias.double()) + 1.0) < 2e-6
+        wt = bw.transpose(w.to(dev), N2, N1, pad_to=N2 + 32)                 # [N1, N2 + 32], zero padded K
+        assert torch.equal(wt[:, :N2].cpu(), w.t()) and float(wt[:, N2:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,N1,N2,nb0,pad", [(4096, 256, 512, 256, 0), (1000, 256, 384, 256, 0), (2500, 512, 512, 0, 0),
                                              (777, 128, 128, 0, 0), (5003, 256, 768, 512, 64), (16384, 1792, 2048, 1024, 256)])
 def test_gemm_tn_x6_matches_fp64(dev, M, N1, N2, nb0, pad):
@@ -388,6 +411,48 @@ def test_variant_training_gradients_vs_oracle_autograd(dev, over):
         assert torch.equal(sd[k].detach(), before), k
 
 
+@pytest.mark.parametrize("over", [{"trans_dim": 192}, {"trans_dim": 64, "trans_heads": 2, "importance_mlp_hidden_dim": 64},
+                                  {"trans_dim": 192, "trans_heads": 3, "importance_mlp_hidden_dim": 96, "slide_ctx_mode": "concat"},
+                                  {"trans_dim": 96, "trans_heads": 6, "importance_mode": "none", "pos_encoding_mode": "1d"},
+                                  {"trans_dim": 192, "lstm": False}, {"trans_dim": 64, "trans_heads": 1, "importance_mlp_hidden_dim": 36, "lstm": False}],
+                         ids=["td192_default", "td64_h2_hi64", "td192_h3_hi96_concat", "td96_h6_impnone_pe1d", "td192_nolstm", "td64_h1_hi36_nolstm"])
+def test_training_other_aggregator_geometries_vs_oracle_autograd(dev, over):
+    """the reference's config surface (config.py:30-36) trains too - trans_dim 192 / head_dim 48 is its dataclass
+    default.  5-level training forward / backward on the shape-generic kernels (csrc/generic.hip TRAIN attention, csrc/generic_bwd.hip)
+    vs torch autograd through the oracle, every live parameter; then one AdamW step."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    cfg_over = {"model_config": dict(over)}
+    cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3, cfg_over=cfg_over)
+    model.train()
+    with H.spy_calls() as calls:
+        _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
+    assert "paths_attention_bwd_any" in calls and "paths_attention_any_train" in calls
+    assert ("paths_importance_rows_bwd_any" if over.get("lstm") is False else "paths_importance_bwd_any") in calls
+    assert not {"paths_attention_bwd_x6_dropout", "paths_importance_bwd", "paths_importance_rows_bwd", "paths_importance_proj"} & set(calls)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(cfg_over, top_k_patches=[16] * 4)
+    labels = {"survival_bin": batch["survival_bin"], "censored": batch["censored"]}
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], labels)
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5
+    sd = dict(model.named_parameters())
+    live = 0
+    for k, ref in p.items():
+        g = sd[k].grad
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, k
+            if ref.grad is None and not _is_dead(k):
+                assert g is None, k
+            continue
+        assert g is not None, k
+        assert rel_err(g, ref.grad) < 2e-3, (k, rel_err(g, ref.grad))
+        live += 1
+    assert live > 80
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+    assert np.isfinite(float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)))
+
+
 def test_training_on_zero_children_slides_takes_the_fallback(dev):
     """the training path reads the recursion's status word too.  Slides whose kept patches have no tissue children
     (reference fallback to all cells with zero parent state, data_utils/slide.py:336-352) train through the careful
@@ -420,13 +485,16 @@ def test_training_on_zero_children_slides_takes_the_fallback(dev):
     assert live > 100
 
 
-def test_three_adamw_steps_match_reference_g6(dev):
-    """Reference train-step semantics (train.py:49-50,59-68): losses of 3 AdamW steps vs the fixture captured from the
-    reference (G6), dead parameters included in weight decay, unused classifiers left with grad None."""
+@pytest.mark.parametrize("name", ["g6_train_16x16_top64", "g13_train_td192_8x8_top16", "g13_train_td64_h2_hi32_8x8_top16"])
+def test_three_adamw_steps_match_reference_g6(dev, name):
+    """Reference train-step semantics (train.py:49-50,59-68): losses of 3 AdamW steps vs the fixtures captured from the
+    reference (G6: the shipped geometry; G13: its dataclass-default trans_dim 192 and a small free geometry, on the shape-generic
+    training kernels), dead parameters included in weight decay, unused classifiers left with grad None."""
     from paths_amd import utils as putils
     from tests.conftest import load_golden
-    g, info = load_golden("g6_train_16x16_top64")
-    cfg, model, params, slides, batch = _train_setup(dev, info["wseed"], info["dseed"], info["top_k"], tuple(info["base_shape"]), info["B"])
+    g, info = load_golden(name)
+    cfg, model, params, slides, batch = _train_setup(dev, info["wseed"], info["dseed"], info["top_k"], tuple(info["base_shape"]), info["B"],
+                                                     cfg_over=info.get("cfg_over") or None)
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=info["lr"], weight_decay=info["weight_decay"])
     losses = []
@@ -552,27 +620,33 @@ def test_dropout_mask_statistics(dev):
     assert float(_mask(dev, d0.key(0, 0), 1000, 0.0).min()) == 1.0                         # p = 0: everything kept
 
 
-def test_dropout_forward_backward_vs_fp64_with_exported_masks(dev):
+@pytest.mark.parametrize("geo", [{}, {"trans_dim": 192}, {"trans_dim": 128, "trans_heads": 2}, {"trans_dim": 64, "trans_heads": 4}],
+                         ids=["shipped_128x4", "td192_hd48", "td128_hd64", "td64_hd16"])
+def test_dropout_forward_backward_vs_fp64_with_exported_masks(dev, geo):
     """All five dropout sites of both decoder layers (the last one at token 0 only): forward outputs and every gradient of the HIP
-    training path against float64 autograd through a reference that multiplies by the SAME masks (exported by paths_dropout_mask)."""
+    training path against float64 autograd through a reference that multiplies by the SAME masks (exported by paths_dropout_mask).
+    The shipped geometry runs the 128-wide kernels, the others the shape-generic ones (csrc/generic.hip TRAIN attention,
+    csrc/generic_bwd.hip): same mask element indices at every site."""
     from paths_amd import ops as _ops
     if _ops.GEMM_MODE == "f32":
         pytest.skip("dropout needs the split-operand attention kernel: PATHS_GEMM_MODE=f32 rejects it loudly (backward.py)")
     from paths_amd import backward as bw, ops
-    cfg, model, params = build_model(dev, 33)
+    cfg, model, params = build_model(dev, 33, {"model_config": dict(geo)} if geo else None)
     mc = cfg.model_config
-    depth, B, N, H, pd = 1, 3, 150, 4, 0.1
+    depth, B, N, H, pd = 1, 3, 150, mc.trans_heads, 0.1
+    d = mc.trans_dim
+    hd = d // H
     num_ims = torch.tensor([150, 97, 31])
     T = N + 1
     g = torch.Generator().manual_seed(5)
     tokvalid = torch.arange(T)[None, :] < (num_ims + 1)[:, None]
-    tokens = torch.randn(B, T, 128, generator=g) * tokvalid[..., None]
-    ctx_prev = torch.randn(B, 128, generator=g)
+    tokens = torch.randn(B, T, d, generator=g) * tokvalid[..., None]
+    ctx_prev = torch.randn(B, d, generator=g)
     vp = ops.pack_level(model.procs[depth])
     drop = bw.Drop(pd, 0xC0FFEE, depth)
     sv = bw.transformer_forward_train(mc, vp, tokens.to(dev), num_ims.to(dev), ctx_prev.to(dev), drop)
     G_log = torch.randn(B, 4, generator=g)
-    G_ctx = torch.randn(B, 128, generator=g)
+    G_ctx = torch.randn(B, d, generator=g)
     grads, d_tok, d_ctx = bw.transformer_backward(mc, vp, sv, G_log.to(dev), G_ctx.to(dev))
 
     sc = 1.0 / (1.0 - pd)
@@ -584,26 +658,26 @@ def test_dropout_forward_backward_vs_fp64_with_exported_masks(dev):
     t = pre + "global_agg.transformer.decoder."
 
     def layer(l, S, rows_q):
-        """S [B,T,128]; returns the layer output for query rows rows_q (slice(None) = all, or [0]); masks indexed like the kernels"""
+        """S [B,T,d]; returns the layer output for query rows rows_q (slice(None) = all, or [0]); masks indexed like the kernels"""
         q_ = t + f"layers.{l}."
         qkv = F.linear(S, p[q_ + "self_attn.in_proj_weight"], p[q_ + "self_attn.in_proj_bias"])
-        qq, kk, vv = [x.view(B, T, H, 32).transpose(1, 2) for x in qkv.split(128, dim=-1)]
-        scores = (qq @ kk.transpose(-1, -2)) / np.sqrt(32.0)
+        qq, kk, vv = [x.view(B, T, H, hd).transpose(1, 2) for x in qkv.split(d, dim=-1)]
+        scores = (qq @ kk.transpose(-1, -2)) / np.sqrt(float(hd))
         scores = scores.masked_fill(~tokvalid[:, None, None, :], float("-inf"))
         A = torch.softmax(scores, dim=-1) * mk(l, bw.Drop.ATTN, (B, H, T, T))
-        att = (A @ vv).transpose(1, 2).reshape(B, T, 128)[:, rows_q]
+        att = (A @ vv).transpose(1, 2).reshape(B, T, d)[:, rows_q]
         x = S[:, rows_q]
         R = x.shape[1]
         sa = F.linear(att, p[q_ + "self_attn.out_proj.weight"], p[q_ + "self_attn.out_proj.bias"])
-        x = F.layer_norm(x + sa * mk(l, bw.Drop.SA_OUT, (B, R, 128)), (128,), p[q_ + "norm1.weight"], p[q_ + "norm1.bias"])
-        x = F.layer_norm(x + p[q_ + "multihead_attn.out_proj.bias"] * mk(l, bw.Drop.CA_OUT, (B, R, 128)), (128,), p[q_ + "norm2.weight"], p[q_ + "norm2.bias"])
-        hid = torch.relu(F.linear(x, p[q_ + "linear1.weight"], p[q_ + "linear1.bias"])) * mk(l, bw.Drop.FF_INNER, (B, R, 512))
+        x = F.layer_norm(x + sa * mk(l, bw.Drop.SA_OUT, (B, R, d)), (d,), p[q_ + "norm1.weight"], p[q_ + "norm1.bias"])
+        x = F.layer_norm(x + p[q_ + "multihead_attn.out_proj.bias"] * mk(l, bw.Drop.CA_OUT, (B, R, d)), (d,), p[q_ + "norm2.weight"], p[q_ + "norm2.bias"])
+        hid = torch.relu(F.linear(x, p[q_ + "linear1.weight"], p[q_ + "linear1.bias"])) * mk(l, bw.Drop.FF_INNER, (B, R, 4 * d))
         ff = F.linear(hid, p[q_ + "linear2.weight"], p[q_ + "linear2.bias"])
-        return F.layer_norm(x + ff * mk(l, bw.Drop.FF_OUT, (B, R, 128)), (128,), p[q_ + "norm3.weight"], p[q_ + "norm3.bias"])
+        return F.layer_norm(x + ff * mk(l, bw.Drop.FF_OUT, (B, R, d)), (d,), p[q_ + "norm3.weight"], p[q_ + "norm3.bias"])
 
     S1 = layer(0, tk, slice(None))
     x3 = layer(1, S1, slice(0, 1))[:, 0]                 # the last layer is only read at token 0 (reference model/aggregator.py:75)
-    F_ = F.layer_norm(x3, (128,), p[t + "norm.weight"], p[t + "norm.bias"]) + cp
+    F_ = F.layer_norm(x3, (d,), p[t + "norm.weight"], p[t + "norm.bias"]) + cp
     logits = F.linear(F_, p[pre + "classification_layer.weight"], p[pre + "classification_layer.bias"])
     assert rel_err(sv["logits"], logits.detach()) < 1e-5 and rel_err(sv["ctx_out"], F_.detach()) < 1e-5
     plain = bw.transformer_forward_train(mc, vp, tokens.to(dev), num_ims.to(dev), ctx_prev.to(dev))

@@ -126,7 +126,7 @@ def test_recursion_trans_dim_192_vs_reference_golden(dev):
 
 def test_unsupported_config_rejected(dev):
     """Configurations outside what the kernels cover fail loudly (never approximated): a head_dim the generic attention does not
-    have, and TRAINING at a geometry other than the shipped one (the backward kernels are 128-wide)."""
+    have (inference and training), and training with an importance hidden width the generic backward cannot address (% 4)."""
     from paths_amd.data_utils.patch_batch import PatchBatch
     from paths_amd import utils as putils
     from paths_amd.data_utils.slide import DeviceSlide
@@ -139,10 +139,11 @@ def test_unsupported_config_rejected(dev):
         model(0, pb)
     model.procs[0].config.trans_heads = 4
     g2, info2 = load_golden("g12_recursion_td192_6x7_top5")
-    cfg2, model2, _ = build_model(dev, info2["wseed"], info2["cfg_over"], top_k_patches=[info2["top_k"]] * 4)
     slides = [DeviceSlide.synthetic(info2["dseed"], sid, tuple(info2["base_shape"]), p_bg=info2["p_bg"], device=dev) for sid in info2["slide_ids"]]
-    with pytest.raises(NotImplementedError):
-        putils.recurse_train(model2.train(), slides, cfg2.top_k_patches, cfg2.num_levels)
+    for over in ({"trans_dim": 192, "trans_heads": 24}, {"trans_dim": 192, "importance_mlp_hidden_dim": 30}):
+        cfg2, model2, _ = build_model(dev, info2["wseed"], {"model_config": over}, top_k_patches=[info2["top_k"]] * 4)
+        with pytest.raises(NotImplementedError):
+            putils.recurse_train(model2.train(), slides, cfg2.top_k_patches, cfg2.num_levels)
 
 
 @pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])

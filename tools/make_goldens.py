@@ -261,10 +261,10 @@ def trace_one(ref, c, model, slides, synth):
     return {"levels": levels, "hazards": torch.sigmoid(out["logits"]) if c.task == "survival" else out["logits"]}, min_gap
 
 
-def training(ref, name, base_shape, top_k, B, wseed, dseed, steps=3):
-    """G6: reference train step semantics (train.py:49-50,59-68): AdamW on inference_end2end loss."""
+def training(ref, name, base_shape, top_k, B, wseed, dseed, steps=3, cfg_over=None):
+    """G6 / G13: reference train step semantics (train.py:49-50,59-68): AdamW on inference_end2end loss."""
     rcfg, rutils, patch_batch, rslide, rdataset, rloader = ref
-    c = make_config(rcfg)
+    c = make_config(rcfg, **copy.deepcopy(cfg_over or {}))
     c.top_k_patches = [top_k] * (c.num_levels - 1)
     model, _ = build_model(c, wseed)
     model.train()
@@ -288,7 +288,8 @@ def training(ref, name, base_shape, top_k, B, wseed, dseed, steps=3):
         losses.append(float(loss.item()))
     save(name, {"losses": np.asarray(losses, np.float64)},
          {"kind": "training", "base_shape": list(base_shape), "top_k": top_k, "B": B, "wseed": wseed, "dseed": dseed,
-          "grad_none": none_grads, "grad_norms": gnorms, "lr": c.lr, "weight_decay": c.weight_decay, "grad": True})
+          "grad_none": none_grads, "grad_norms": gnorms, "lr": c.lr, "weight_decay": c.weight_decay, "grad": True,
+          "cfg_over": cfg_over or {}})
 
 
 def nll_known(ref, name):
@@ -496,6 +497,11 @@ def main():
         recursion(ref, "g12_recursion_td192_6x7_top5", (6, 7), 5, 2, wseed=2, dseed=13, p_bg=0.2, cfg_over={"model_config": {"trans_dim": 192}})
     if want("g6"):
         training(ref, "g6_train_16x16_top64", (16, 16), 64, 4, wseed=3, dseed=14)
+    if want("g13"):
+        # training at the reference's dataclass-default aggregator geometry (trans_dim 192 = head_dim 48) and at a small free one
+        training(ref, "g13_train_td192_8x8_top16", (8, 8), 16, 3, wseed=5, dseed=21, cfg_over={"model_config": {"trans_dim": 192}})
+        training(ref, "g13_train_td64_h2_hi32_8x8_top16", (8, 8), 16, 3, wseed=6, dseed=22,
+                 cfg_over={"model_config": {"trans_dim": 64, "trans_heads": 2, "importance_mlp_hidden_dim": 32}})
     if want("g7"):
         nll_known(ref, "g7_nll")
     if want("g8"):
