@@ -179,9 +179,17 @@ int paths_reduce_slabs_f32(const float* slabs, int splits, int n, float* out, in
 int paths_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                             const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim,
                             paths_stream_t stream);
-/* Same for the last decoder layer, where only token 0 is a query: a0 / da0 [B,128]. */
-int paths_attention_token0_bwd(const float* q, const float* k, const float* v, const float* a0, const float* da0,
-                               const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, paths_stream_t stream);
+/* The last decoder layer is read at token 0 only (model/aggregator.py:75): single-query attention of the TRAINING path, keys split
+ * over workgroups (csrc/attn_token0.hip).  a0 / da0 [B, H*32] = attention output of token 0 and its gradient, lse0 [B, H] (log2
+ * domain, un-dropped softmax), dropout p on the probabilities (mask element ((b*H + h)*T + 0)*T + key of site drop_key; p = 0: none);
+ * ws: paths_attention_token0_workspace(B, T, H) floats.  The backward writes dk / dv of every valid key and dq of row 0 into dqkv
+ * [B, T, 3*H*32] (zero on entry). */
+int64_t paths_attention_token0_workspace(int B, int T, int H);
+int paths_attention_token0_fwd(const float* q, const float* k, const float* v, const int64_t* num_ims, float* a0, float* lse0, float* ws,
+                               int B, int T, int H, int head_dim, uint64_t drop_key, float drop_p, paths_stream_t stream);
+int paths_attention_token0_bwd(const float* q, const float* k, const float* v, const float* a0, const float* da0, const float* lse0,
+                               const int64_t* num_ims, float* dqkv, float* ws, int B, int T, int H, int head_dim, uint64_t drop_key,
+                               float drop_p, paths_stream_t stream);
 
 /* Generic out = act(a W^T + b) on the fp32 matrix cores (W rows zero-padded to Npad, a multiple of 128). */
 int paths_linear_f32(const float* a, int64_t lda, const float* w, const float* b, float* out, int64_t ldo,
@@ -468,9 +476,6 @@ int64_t paths_attention_bwd_x6_workspace(int B, int T, int H, int head_dim);
 int paths_attention_bwd_x6_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                                    const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
                                    uint64_t drop_key, float drop_p, paths_stream_t stream);
-int paths_attention_token0_bwd_dropout(const float* q, const float* k, const float* v, const float* a0, const float* da0,
-                                       const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, uint64_t drop_key,
-                                       float drop_p, paths_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -484,14 +484,16 @@ def chain_forward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, d
 
 
 def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, dx_out: torch.Tensor, dev,
-                   drop: Optional[Drop] = None, layer: int = 0):
+                   drop: Optional[Drop] = None, layer: int = 0, saved: Optional[Dict[str, object]] = None):
     """Row chain of one decoder layer (out_proj .. norm3): recompute its intermediates with the generic kernels
-    (:func:`chain_forward`, same dropout masks as the forward), then differentiate.
+    (:func:`chain_forward`, same dropout masks as the forward) unless the forward's own are handed in, then differentiate.
     Returns (grads, dx_in [M,128], dattn [M,128])."""
     f32 = _f32(dev)
     d, F = w["wo"].shape[0], w["w1"].shape[0]
     g: Dict[str, torch.Tensor] = {}
-    c = chain_forward(w, x_in_ptr, ldx, attn_ptr, lda, M, dev, drop, layer, want_out=False)
+    # ``saved``: the dict the training forward's chain_forward returned (kept when the forward ran on these very kernels: dropout
+    # on, or a shape-generic geometry); otherwise the fused forward kept nothing and the chain is recomputed here
+    c = saved if saved is not None else chain_forward(w, x_in_ptr, ldx, attn_ptr, lda, M, dev, drop, layer, want_out=False)
     hid, hd, n2 = c["hid"], c["hid_used"], c["n2"]
     p = drop.p if drop is not None else 0.0
     # ---- backward
@@ -565,6 +567,15 @@ def attention(q, k, v, out, lse, num_ims, B, T, H, hd, max_queries, drop_key: in
         _lib.call("paths_attention_f32", P(q), P(k), P(v), P(out), P(lse), P(num_ims), B, T, H, hd, max_queries, st)
 
 
+def attention_token0(q, k, v, num_ims, B, T, H, hd, drop_key: int = 0, drop_p: float = 0.0):
+    """Token-0 attention of the last layer (csrc/attn_token0.hip, keys split over workgroups): (a0 [B, H*hd], lse0 [B, H])."""
+    f32 = _f32(q.device)
+    a0, lse0 = torch.empty((B, H * hd), **f32), torch.empty((B, H), **f32)
+    ws = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), **f32)
+    _lib.call("paths_attention_token0_fwd", P(q), P(k), P(v), P(num_ims), P(a0), P(lse0), P(ws), B, T, H, hd, drop_key, drop_p, _lib.stream())
+    return a0, lse0
+
+
 def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Optional[Drop] = None,
                               ctx_all: Optional[torch.Tensor] = None):
     """Forward of the aggregator with the per-layer tensors the backward needs (q,k,v, lse, attention output).
@@ -609,9 +620,10 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
             token_layer(x, x_out, layers[l], layers[l + 1], attn, q2, k2, v2)
         else:
             attention(q, k, v, attn, lse, num_ims, B, T, H, hd, 0, drop.key(l, Drop.ATTN), drop.p)
-            x_out = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, B * T, tokens.device, drop, l)["x3"].view(B, T, d)
+            chain = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, B * T, tokens.device, drop, l)
+            x_out = chain["x3"].view(B, T, d)
             token_layer(x_out, None, None, layers[l + 1], None, q2, k2, v2)
-        sv["layers"].append({"x_in": x, "q": q, "k": k, "v": v, "attn": attn, "lse": lse})
+        sv["layers"].append({"x_in": x, "q": q, "k": k, "v": v, "attn": attn, "lse": lse, "chain": chain if drop is not None else None})
         x, q, k, v = x_out, q2, k2, v2
     # last layer at token 0 (+ decoder.norm, residual, classifier): one fused launch
     w = layers[L - 1]
@@ -621,13 +633,13 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
     if drop is not None:
         # the fused token-0 tail has no dropout sites either: single-query attention (rows > 0 of the output are not needed), the
         # row chain on the B token-0 rows, decoder.norm, slide-context residual and classifier with the generic kernels
-        attn0 = torch.zeros((B, T, d), **f32)
-        attention(q, k, v, attn0, None, num_ims, B, T, H, hd, 1, drop.key(L - 1, Drop.ATTN), drop.p)
-        x3 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, tokens.device, drop, L - 1)["x3"]
+        a0, lse0 = attention_token0(q, k, v, num_ims, B, T, H, hd, drop.key(L - 1, Drop.ATTN), drop.p)
+        chain0 = chain_forward(w, x.data_ptr(), T * d, a0.data_ptr(), d, B, tokens.device, drop, L - 1)
+        x3 = chain0["x3"]
         _lib.call("paths_final_head", P(x3), d, P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev),
                   ctx_prev.stride(0) if ctx_prev is not None else 0, cat_ptr, cdepth, P(lvl_pack["wcls"]), P(lvl_pack["bcls"]), nlog,
                   lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), B, d, lvl_pack["lnf_eps"], st)
-        sv["last"] = {"x_in": x, "q": q, "k": k, "v": v}
+        sv["last"] = {"x_in": x, "q": q, "k": k, "v": v, "a0": a0, "lse0": lse0, "chain": chain0}
         sv["ctx_out"], sv["logits"] = ctx_out, logits
         return sv
     ws = torch.empty((B * H * 16 * 36,), **f32)
@@ -675,22 +687,24 @@ def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, 
         attn = torch.zeros((B, T, d), **f32)
         lse = torch.zeros((B, H, T), **f32)
         _attention_generic(qkv, attn, lse, num_ims, B, T, H, hd, qscale, 0, drop, l)
-        x_out = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, M, dev, drop, l)["x3"].view(B, T, d)
-        sv["layers"].append({"x_in": x, "qkv": qkv, "attn": attn, "lse": lse})
+        chain = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, M, dev, drop, l)
+        x_out = chain["x3"].view(B, T, d)
+        sv["layers"].append({"x_in": x, "qkv": qkv, "attn": attn, "lse": lse, "chain": chain})
         x, qkv = x_out, in_proj(x_out, layers[l + 1])
     # last layer: only token 0 of its output is read (reference model/aggregator.py:75)
     w = layers[L - 1]
     attn0 = torch.zeros((B, T, d), **f32)
     lse0 = torch.zeros((B, H, T), **f32)
     _attention_generic(qkv, attn0, lse0, num_ims, B, T, H, hd, qscale, 1, drop, L - 1)
-    x3 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)["x3"]
+    chain0 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)
+    x3 = chain0["x3"]
     nlog = lvl_pack["wcls"].shape[0]
     ctx_out = torch.empty((B, d), **f32)
     logits = torch.empty((B, nlog), **f32)
     _lib.call("paths_final_head_any", P(x3), d, P(lvl_pack["lnfg"]), P(lvl_pack["lnfb"]), P(ctx_prev),
               ctx_prev.stride(0) if ctx_prev is not None else 0, P(ctx_all) if cdepth > 0 else None, cdepth, P(lvl_pack["wcls"]),
               P(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], P(ctx_out), P(logits), B, d, lvl_pack["lnf_eps"], _lib.stream())
-    sv["last"] = {"x_in": x, "qkv": qkv, "attn0": attn0, "lse0": lse0}
+    sv["last"] = {"x_in": x, "qkv": qkv, "attn0": attn0, "lse0": lse0, "chain": chain0}
     sv["ctx_out"], sv["logits"] = ctx_out, logits
     return sv
 
@@ -720,13 +734,20 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     x_last = last["x_in"]
     drop: Optional[Drop] = sv.get("drop")
     dk = lambda l: (drop.key(l, Drop.ATTN), drop.p) if drop is not None else (0, 0.0)
-    # recompute token 0 of the last layer up to x3 (its attention output first; the generic path kept it)
+    # token 0 of the last layer up to x3: kept by the forward when it ran on the generic kernels (dropout on, or a shape-generic
+    # geometry); the fused token-0 tail keeps nothing, so its attention output and row chain are recomputed
+    chain0 = last.get("chain")
     if fast:
-        attn0 = torch.zeros((B, T, d), **f32)
-        attention(last["q"], last["k"], last["v"], attn0, None, num_ims, B, T, H, hd, 1, *dk(L - 1))
+        a0, lse0 = last.get("a0"), last.get("lse0")           # [B, d] / [B, H]
+        if a0 is None:
+            a0, lse0 = attention_token0(last["q"], last["k"], last["v"], num_ims, B, T, H, hd, *dk(L - 1))
+        a0_ptr, a0_ld = a0.data_ptr(), d
     else:
-        attn0 = last["attn0"]
-    x3 = chain_forward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)["x3"]
+        attn0 = last["attn0"]                                  # [B, T, d], row 0 of every slide filled
+        a0_ptr, a0_ld = attn0.data_ptr(), T * d
+    if chain0 is None:
+        chain0 = chain_forward(wl, x_last.data_ptr(), T * d, a0_ptr, a0_ld, B, dev, drop, L - 1)
+    x3 = chain0["x3"]
     xf, xhf, rsf = _ln_fwd(x3, None, lvl_pack["lnfg"], lvl_pack["lnfb"], B, lvl_pack["lnf_eps"], d=d)
     feat = xf + ctx_prev if ctx_prev is not None else xf                     # [B,d] (8 rows: bookkeeping)
     ctx_all = sv.get("ctx_all")
@@ -762,11 +783,11 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     grads["lnfg"], grads["lnfb"] = colsum(dyxf, d, B, d), colsum(dF, d, B, d)
 
     # ---- last layer, token 0 only
-    g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dx3, dev, drop, L - 1)
+    g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, a0_ptr, a0_ld, B, dx3, dev, drop, L - 1, saved=chain0)
     dqkv = torch.zeros((B, T, 3 * d), **f32)
     if fast:
-        a0 = attn0[:, 0, :].contiguous()
-        _lib.call("paths_attention_token0_bwd_dropout", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(num_ims), P(dqkv),
+        ws = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), **f32)
+        _lib.call("paths_attention_token0_bwd", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(lse0), P(num_ims), P(dqkv), P(ws),
                   B, T, H, hd, *dk(L - 1), st)
     else:
         d_o = torch.zeros((B, T, d), **f32)                                  # only token 0 carries an output gradient
@@ -784,7 +805,8 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         lv = sv["layers"][l]
         w = layers[l]
         M = B * T
-        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev, drop, l)
+        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev, drop, l,
+                                         saved=lv.get("chain"))
         dqkv = torch.zeros((B, T, 3 * d), **f32)
         ws = torch.empty((B * H * T,), **f32)
         if not fast:

@@ -13,7 +13,7 @@
 //                          accumulator layout [q rows][key lane] are directly the B operands)
 //   attn_bwd_q_kernel      one wave = 16 queries, loops over all keys:   dQ_s^T += K^T ds^T                 (transposed form,
 //                          as the forward: per-lane query state)
-//   attn_token0_bwd_kernel last layer: a single query (token 0) per head, VALU only
+//   (the last layer's single-query form lives in attn_token0.hip)
 #include <cstdlib>
 
 #include "common.h"
@@ -246,85 +246,6 @@ attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, cons
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Last layer: one query (token 0) per (slide, head).  a0 / da0: [B, 128] attention output of token 0 and its gradient.
-// Writes dk, dv for every key and dq for row 0 of dqkv (dq rows > 0 must be zero-initialised by the caller).
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-attn_token0_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                       const float* __restrict__ a0, const float* __restrict__ da0, const int64_t* __restrict__ num_ims,
-                       float* __restrict__ dqkv, int T, int H, DropSite drop) {
-  __shared__ float red[4][34];
-  const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int len = (int)num_ims[b] + 1;
-  const int64_t base = ((int64_t)b * H + head) * T * HD;
-  float qv[32], gv[32];
-  float dsumv = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    qv[i] = q[base + i];
-    gv[i] = da0[(int64_t)b * H * HD + head * HD + i];
-    dsumv += gv[i] * a0[(int64_t)b * H * HD + head * HD + i];
-  }
-  // pass 1: log-sum-exp over the keys (log2 domain)
-  float m = -INFINITY;
-  for (int key = tid; key < len; key += 256) {
-    float sc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) sc += k[base + (int64_t)key * HD + i] * qv[i];
-    m = fmaxf(m, sc);
-  }
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if (lane == 0) red[wave][0] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
-  __syncthreads();
-  float l = 0.f;
-  for (int key = tid; key < len; key += 256) {
-    float sc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) sc += k[base + (int64_t)key * HD + i] * qv[i];
-    l += exp2f(sc - m);
-  }
-  l = wsum(l);
-  if (lane == 0) red[wave][1] = l;
-  __syncthreads();
-  const float lse = m + log2f(red[0][1] + red[1][1] + red[2][1] + red[3][1]);
-  __syncthreads();
-  // pass 2: gradients
-  float dq[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) dq[i] = 0.f;
-  for (int key = tid; key < len; key += 256) {
-    float sc = 0.f, dp = 0.f;
-    float kk[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      kk[i] = k[base + (int64_t)key * HD + i];
-      sc += kk[i] * qv[i];
-      dp += v[base + (int64_t)key * HD + i] * gv[i];
-    }
-    const float p = exp2f(sc - lse);
-    const float m = drop.thr ? drop_mult(drop, (((uint64_t)b * H + head) * (uint64_t)T) * (uint64_t)T + (uint64_t)key) : 1.0f;   // query 0
-    const float ds = LN2 * p * (dp * m - dsumv);
-    float* dst = dqkv + ((int64_t)b * T + key) * (3 * H * HD) + head * HD;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      dst[H * HD + i] = ds * qv[i];
-      dst[2 * H * HD + i] = p * m * gv[i];
-      dq[i] += ds * kk[i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const float t = wsum(dq[i]);
-    if (lane == 0) red[wave][2 + i] = t;
-  }
-  __syncthreads();
-  if (tid < 32) dqkv[((int64_t)b * T) * (3 * H * HD) + head * HD + tid] = red[0][2 + tid] + red[1][2 + tid] + red[2][2 + tid] + red[3][2 + tid];
-}
-
 }  // namespace
 
 extern "C" {
@@ -373,23 +294,6 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(q)");
   return PATHS_OK;
-}
-
-int paths_attention_token0_bwd_dropout(const float* q, const float* k, const float* v, const float* a0, const float* da0,
-                                       const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, uint64_t drop_key,
-                                       float drop_p, hipStream_t stream) {
-  PATHS_REQUIRE(head_dim == HD && H == 4, "attention_token0_bwd: head_dim must be 32 and H 4");
-  PATHS_REQUIRE(B > 0 && T > 0 && q && k && v && a0 && da0 && num_ims && dqkv, "attention_token0_bwd: bad arguments");
-  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention_token0_bwd: p must be in [0, 1)");
-  hipLaunchKernelGGL(attn_token0_bwd_kernel, dim3(H, B), dim3(256), 0, stream, q, k, v, a0, da0, num_ims, dqkv, T, H,
-                     paths_make_drop_site(drop_key, drop_p));
-  PATHS_LAUNCH_CHECK("attention_token0_bwd");
-  return PATHS_OK;
-}
-
-int paths_attention_token0_bwd(const float* q, const float* k, const float* v, const float* a0, const float* da0,
-                               const int64_t* num_ims, float* dqkv, int B, int T, int H, int head_dim, hipStream_t stream) {
-  return paths_attention_token0_bwd_dropout(q, k, v, a0, da0, num_ims, dqkv, B, T, H, head_dim, 0, 0.f, stream);
 }
 
 }  // extern "C"

@@ -453,6 +453,31 @@ def test_training_other_aggregator_geometries_vs_oracle_autograd(dev, over):
     assert np.isfinite(float(putils.train_step(model, opt, batch, 5, cfg.top_k_patches)))
 
 
+def test_training_td192_at_k256_vs_oracle_autograd(dev):
+    """The shape-generic training kernels at sequence lengths that span many key / query blocks (K = 256: up to 1,025 tokens per slide,
+    ragged num_ims): loss and every live gradient of the reference-default geometry against torch autograd through the oracle."""
+    from oracle import paths_oracle as orc
+    from paths_amd import utils as putils
+    cfg_over = {"model_config": {"trans_dim": 192}}
+    cfg, model, params, slides, batch = _train_setup(dev, wseed=8, dseed=23, top_k=256, base=(18, 20), n_slides=2, cfg_over=cfg_over)
+    model.train()
+    _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ocfg = H.oracle_config(cfg_over, top_k_patches=[256] * 4)
+    labels = {"survival_bin": batch["survival_bin"], "censored": batch["censored"]}
+    hz, oloss = orc.inference_end2end(p, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], labels)
+    oloss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 2e-5
+    sd = dict(model.named_parameters())
+    live = 0
+    for k, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) == 0.0:
+            continue
+        assert sd[k].grad is not None and rel_err(sd[k].grad, ref.grad) < 2e-3, (k, rel_err(sd[k].grad, ref.grad))
+        live += 1
+    assert live > 100
+
+
 def test_training_on_zero_children_slides_takes_the_fallback(dev):
     """the training path reads the recursion's status word too.  Slides whose kept patches have no tissue children
     (reference fallback to all cells with zero parent state, data_utils/slide.py:336-352) train through the careful
