@@ -544,6 +544,17 @@ def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
     return {"logits": logits, "status": status}
 
 
+def _label_to(x, dev):
+    """A label vector on the device without a blocking copy: a pageable-memory upload would hold the host until everything already
+    enqueued on the stream (the whole forward) has run, and the backward could only be enqueued after that."""
+    t = torch.as_tensor(x)
+    if t.device == dev:
+        return t
+    if dev.type == "cuda" and not t.is_cuda:
+        return t.pin_memory().to(dev, non_blocking=True)
+    return t.to(dev)
+
+
 def loss_from_logits(logits, batch, task: str, global_batch: Optional[int] = None):
     """Loss of reference utils.py:263-279 on the last level's logits.  With ``global_batch`` the mean is taken over the
     GLOBAL batch (sum of local terms / global_batch) so that data-parallel shards add up exactly."""
@@ -552,10 +563,10 @@ def loss_from_logits(logits, batch, task: str, global_batch: Optional[int] = Non
     scale = 1.0 if global_batch is None else n / float(global_batch)
     if task == "survival":
         hazards = torch.sigmoid(logits)
-        loss = nll_loss(hazards, torch.as_tensor(batch["survival_bin"]).to(dev), torch.as_tensor(batch["censored"]).to(dev))
+        loss = nll_loss(hazards, _label_to(batch["survival_bin"], dev), _label_to(batch["censored"], dev))
         return hazards, loss * scale
     elif task == "subtype_classification":
-        return logits, F.cross_entropy(logits, torch.as_tensor(batch["subtype"]).to(dev)) * scale
+        return logits, F.cross_entropy(logits, _label_to(batch["subtype"], dev)) * scale
     raise ValueError(task)
 
 
