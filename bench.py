@@ -159,6 +159,7 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     cfg = Config.load(os.path.join(ROOT, "tests", "golden", "sample"), test_mode=True)
     cfg.model_config.patch_embed_dim, cfg.num_levels, cfg.top_k_patches = 1536, 1, []
+    cfg.model_config.trans_dim, cfg.model_config.trans_heads = args.trans_dim, args.trans_heads
     model = cfg.get_model()
     sd = syn.make_state_dict(0, {k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -199,11 +200,37 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
         ops.KERNEL_TIMER, ops.TIMER_ALL = None, False
         assert int(out_["status"].item()) == 0
         att = [e0.elapsed_time(e1) * 1e3 for n, e0, e1 in ev if n == "agg_attention"]
+        agg = [e0.elapsed_time(e1) * 1e3 for n, e0, e1 in ev if n == "aggregator"]
+        timed_run.agg_us = sum(agg) / len(agg) if agg else None
         return el, out_["logits"].clone(), (sum(att) / len(att) if att else None)
 
     elapsed, logits, attn_us = timed_run()
+    agg_us = timed_run.agg_us
+    T_, d_, L_ = 8193, args.trans_dim, cfg.model_config.trans_layers
+    # algorithmic FLOPs of the aggregator per step and GPU (24 T d^2 + 4 T^2 d per layer, degenerate cross-attention 0)
+    agg_flops = spg * L_ * (24 * T_ * d_ * d_ + 4 * T_ * T_ * d_)
+    fp8_agg = None
+    if args.fp8 and ops.fp8_supported(cfg.model_config):
+        # the whole aggregator's big products in e4m3 (csrc/gemm_fp8.hip + csrc/attn_fp8.hip): in_proj, the full layers' attention,
+        # out_proj and the feed-forward pair; the first (warm-up) step calibrates the hidden layer's scale
+        ops.AGG_FP8 = True
+        el8, logits8, _ = timed_run()
+        agg8_us = timed_run.agg_us
+        ops.AGG_FP8 = False
+        diff = float((logits8 - logits).abs().max())
+        fp8_agg = {"slides_per_s": round(spg * world * args.steps / el8, 2), "ms_per_step": round(el8 / args.steps * 1e3, 3),
+                   "aggregator_us": round(agg8_us, 1) if agg8_us else None, "aggregator_us_accurate_path": round(agg_us, 1) if agg_us else None,
+                   "max_logit_diff_vs_accurate_path": diff, "meets_1e-4_logit_bar": bool(diff <= 1e-4),
+                   "what": "in_proj, full-layer attention, out_proj, linear1 / linear2 with e4m3 operands and per-tensor scales "
+                           "(v_mfma_scale_f32_32x32x64_f8f6f4 GEMMs, 16x16x32 fp8 attention); LayerNorm, residuals, the last layer's "
+                           "token-0 row chain, the classifier and the whole selection chain (LSTM, importance, top-K) in fp32",
+                   "roofline": None if not agg8_us else {
+                       "bound": "mfma", "achieved": round(agg_flops / (agg8_us * 1e-6) / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                       "frac": round(agg_flops / (agg8_us * 1e-6) / 1e12 / 5000.0, 4),
+                       "note": "algorithmic aggregator FLOPs (L (24 T d^2 + 4 T^2 d) per slide) / event-timed aggregator span, against "
+                               "the dense fp8 MFMA peak; the last layer runs at token 0 only, so the executed share is smaller"}}
     fp8 = None
-    if args.fp8:
+    if args.fp8 and args.trans_dim == 128 and args.trans_heads == 4:
         # the e4m3 attention variant (csrc/attn_fp8.hip) on the same batch: its speed AND its distance from the fp32-accurate logits
         ops.ATTN_FP8 = True
         el8, logits8, attn8_us = timed_run()
@@ -220,8 +247,7 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
                                     "dense fp8 MFMA peak; head_dim 32 gives one 16x16x32 k-step per score tile, the loop is exp2 / "
                                     "conversion (VALU) bound"}}
     if rank == 0:
-        T, d, L = 8193, 128, 2
-        flops = spg * world * (L * (24 * T * d * d + 4 * T * T * d))          # attention + FFN, per step
+        flops = agg_flops * world                                             # attention + FFN, per step
         print(json.dumps({
             "metric": "stress_slides_per_sec_1level_K8192_D1536", "value": round(spg * world * args.steps / elapsed, 2),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -230,8 +256,10 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
                      "e4m3 attention variant of BASELINE configs[4], outside the 1e-4 logit bar",
             "data": "synthetic",
             "config": {"workload": f"single level, 8192 patches x 1536 features per slide, {spg} slides per GPU, full quadratic "
-                                   "attention over 8193 tokens (BASELINE.json configs[4] geometry)", "global_batch": spg * world},
-            "attn_ffn_flops_per_step": flops, "attention_us": round(attn_us, 1) if attn_us else None, "fp8_attention": fp8}), flush=True)
+                                   f"attention over 8193 tokens (BASELINE.json configs[4] geometry), trans_dim {args.trans_dim} / "
+                                   f"{args.trans_heads} heads", "global_batch": spg * world},
+            "attn_ffn_flops_per_step": flops, "attention_us": round(attn_us, 1) if attn_us else None,
+            "aggregator_us": round(agg_us, 1) if agg_us else None, "fp8_attention": fp8, "fp8_aggregator": fp8_agg}), flush=True)
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()
@@ -383,7 +411,10 @@ def main():
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra DVFS-steady loop (0 = skip)")
     ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
-    ap.add_argument("--fp8", action="store_true", help="stress mode: also run the opt-in e4m3 attention variant and report its speed and "
+    ap.add_argument("--trans-dim", type=int, default=128, help="stress mode: aggregator width (BASELINE configs[4] reports 128 and 1536; "
+                    "1536 runs with --trans-heads 24 = head_dim 64: the reference's 4 heads would be head_dim 384, which is not built)")
+    ap.add_argument("--trans-heads", type=int, default=4)
+    ap.add_argument("--fp8", action="store_true", help="stress mode: also run the opt-in e4m3 variants (attention only; the whole aggregator) and report speed and "
                     "its logit distance from the fp32-accurate path")
     ap.add_argument("--rotate", type=int, default=3, help="infer mode: distinct resident slide batches (21 GiB each at K=2048) cycled "
                     "through the timed region, one recorded launch tape each; the headline is measured on the rotation (every step works "

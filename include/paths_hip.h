@@ -461,6 +461,29 @@ int paths_dropout_mask(float* mask, int64_t n, uint64_t key, float p, paths_stre
 int64_t paths_attention_fp8_workspace(int B, int T, int H, int head_dim);
 int paths_attention_fp8(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims, int B, int T, int H,
                         int head_dim, void* workspace, paths_stream_t stream);
+/* The same on the token-major in_proj output qkv [B*T, 3d] (row stride ld; q unscaled, qscale = log2(e)/sqrt(head_dim) applied while the
+ * operand images are written); head_dim 32 or 64. */
+int paths_attention_fp8_qkv(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
+                            void* workspace, paths_stream_t stream);
+
+/* e4m3 GEMM of the stress variant (csrc/gemm_fp8.hip: v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales, per-tensor scales) for the
+ * aggregator's products over all tokens (reference model/aggregator.py:25-33: in_proj, out_proj, linear1, linear2).  Opt-in, NOT a parity
+ * path (4 significant bits per operand).
+ *   paths_fp8_scale        *scale = 448 / max|x| over an fp32 [M, K] matrix, on the device (scratch: one zeroed uint32, left zero)
+ *   paths_fp8_pack_weight  w8 [ceil(N/256)*256, K] = e4m3(W * *scale) (zero rows behind N), *scale = 448 / max|W|; K % 64 == 0
+ *   paths_fp8_quantize     x8 [ceil(M/256)*256, K] = e4m3(x * *scale) of an fp32 [M, K] matrix (zero rows behind M)
+ *   paths_gemm_nt_fp8      out[M,N] = act(A W^T + bias) (+ residual) from the two e4m3 images and their scales; K % 128 == 0 */
+int paths_fp8_scale(const float* x, int64_t ld, int64_t M, int K, float* scale, unsigned int* scratch, paths_stream_t stream);
+int paths_fp8_pack_weight(const float* w, int64_t ldw, int N, int K, uint8_t* w8, float* scale, unsigned int* scratch, paths_stream_t stream);
+int paths_fp8_quantize(const float* x, int64_t ld, int M, int K, const float* scale, uint8_t* x8, paths_stream_t stream);
+int paths_gemm_nt_fp8(const uint8_t* a8, const uint8_t* w8, const float* a_scale, const float* w_scale, const float* bias,
+                      float* out, int64_t ldo, int M, int N, int K, int act, const float* residual, int64_t ldr, paths_stream_t stream);
+/* The same product handed on in e4m3 (the A image of the next GEMM): out8 [ceil(M/256)*256, N] = e4m3(act(A W^T + bias) * *out_scale),
+ * rows >= M zero on entry; *out_scale is a calibrated per-tensor scale, out_absmax (optional) receives max|result| as float bits. */
+int paths_gemm_nt_fp8_out8(const uint8_t* a8, const uint8_t* w8, const float* a_scale, const float* w_scale, const float* bias,
+                           uint8_t* out8, const float* out_scale, unsigned int* out_absmax, int M, int N, int K, int act,
+                           paths_stream_t stream);
+
 /* paths_attention_x6 with dropout on the softmax probabilities: O = (softmax(S) * mask / (1 - p)) V, lse un-dropped; mask element
  * ((b * H + h) * T + q) * T + k.  q, k, v fp32 (no pre-built images). */
 int paths_attention_x6_dropout(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B,

@@ -19,7 +19,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int HD = 32;
 constexpr int F8 = 512;                    // bytes of one 16-row x 32-k fp8 fragment (64 lanes x 8 bytes)
 constexpr int KSTEP = 64;                  // keys per LDS buffer
 constexpr int QT = 2;                      // 16-query tiles per wave
@@ -40,52 +39,65 @@ __device__ __forceinline__ f32x4 mfma8(long a, long b, f32x4 c) { return __built
 __device__ __forceinline__ float rows_max(float x) { x = fmaxf(x, __shfl_xor(x, 16)); return fmaxf(x, __shfl_xor(x, 32)); }
 __device__ __forceinline__ float rows_sum(float x) { x += __shfl_xor(x, 16); return x + __shfl_xor(x, 32); }
 
-// Fragment images per (slide, head), Tp = T rounded up to 64 (the lane maps of attn_x6.hip, 8 bytes per lane):
-//   Q8 / K8 : [Tp/16 tiles][64 lanes][8 fp8]         lane (r = l&15, g = l>>4): token 16 tile + r, dims 8g .. 8g+7
-//   V8      : [Tp/32 groups][2 dv tiles][64 lanes][8] lane (dv = l&15, g): dim 16 dvt + dv, keys 32 grp + 4g + (j&3) + 16 (j>>2)
+// Fragment images per (slide, head), Tp = T rounded up to 64 (the lane maps of attn_x6.hip, 8 bytes per lane), NK = HD / 32 k-steps,
+// NDV = HD / 16 output-dim tiles:
+//   Q8 / K8 : [Tp/16 tiles][NK][64 lanes][8 fp8]      lane (r = l&15, g = l>>4): token 16 tile + r, dims 32 kk + 8g .. + 7
+//   V8      : [Tp/32 groups][NDV][64 lanes][8]         lane (dv = l&15, g): dim 16 dvt + dv, keys 32 grp + 4g + (j&3) + 16 (j>>2)
+// Element (b, head, token, c) of q / k / v sits at base + b * bstride + head * hstride + token * ld + c: head-major [B][H][T][HD]
+// (ld = HD, the layout paths_token_layer_f32 writes, q pre-scaled: qmul = 1) or token-major in_proj output [B*T, 3d] (ld = 3d, hstride = HD,
+// q unscaled: qmul = log2(e) / sqrt(HD)).
+template <int HD>
 __global__ void __launch_bounds__(256)
-attn_fp8_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                     char* __restrict__ q8, char* __restrict__ k8, char* __restrict__ v8,
+attn_fp8_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld, int64_t hstride,
+                     int64_t bstride, float qmul, char* __restrict__ q8, char* __restrict__ k8, char* __restrict__ v8,
                      const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
+  constexpr int NK = HD / 32, NDV = HD / 16;
   __shared__ float sv[KSTEP][HD + 1];
   const int b = blockIdx.z, head = blockIdx.y, t0 = blockIdx.x * KSTEP;
   const int len = min((int)num_ims[b] + 1, T);
   const int tid = threadIdx.x;
-  const int64_t base = ((int64_t)b * H + head) * T * HD;
+  const int64_t base = (int64_t)b * bstride + (int64_t)head * hstride;
   const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD;
   {
     const int tl = tid >> 2, g = tid & 3, tok = t0 + tl;
-    float xq[8], xk[8];
     const bool kvalid = tok < len, qvalid = tok < T;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      xk[i] = kvalid ? k[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
-      xq[i] = qvalid ? q[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
+    for (int kk = 0; kk < NK; ++kk) {
+      float xq[8], xk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xk[i] = kvalid ? k[base + (int64_t)tok * ld + 32 * kk + 8 * g + i] : 0.f;
+        xq[i] = qvalid ? q[base + (int64_t)tok * ld + 32 * kk + 8 * g + i] : 0.f;
+      }
+      const int64_t off = ibase + ((int64_t)(tok >> 4) * NK + kk) * F8 + ((tok & 15) + 16 * g) * 8;
+      *reinterpret_cast<u32x2*>(k8 + off) = fp8x8(xk, 1.0f);
+      *reinterpret_cast<u32x2*>(q8 + off) = fp8x8(xq, qmul);
     }
-    const int64_t off = ibase + (int64_t)(tok >> 4) * F8 + ((tok & 15) + 16 * g) * 8;
-    *reinterpret_cast<u32x2*>(k8 + off) = fp8x8(xk, 1.0f);
-    *reinterpret_cast<u32x2*>(q8 + off) = fp8x8(xq, 1.0f);
   }
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int idx = tid + 256 * p, tl = idx >> 5, dcol = idx & 31, tok = t0 + tl;
-    sv[tl][dcol] = tok < len ? v[base + (int64_t)tok * HD + dcol] : 0.f;
+  for (int p = 0; p < KSTEP * HD / 256; ++p) {
+    const int idx = tid + 256 * p, tl = idx / HD, dcol = idx % HD, tok = t0 + tl;
+    sv[tl][dcol] = tok < len ? v[base + (int64_t)tok * ld + dcol] : 0.f;
   }
   __syncthreads();
-  {
-    const int kg = tid >> 7, dvt = (tid >> 6) & 1, l = tid & 63, dv = l & 15, g = l >> 4;
+#pragma unroll
+  for (int job = tid; job < 2 * NDV * 64; job += 256) {
+    const int kg = job / (NDV * 64), dvt = (job / 64) % NDV, l = job & 63, dv = l & 15, g = l >> 4;
     float xv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) xv[j] = sv[32 * kg + 4 * g + (j & 3) + 16 * (j >> 2)][16 * dvt + dv];
-    const int64_t off = ibase + (int64_t)(((t0 >> 5) + kg) * 2 + dvt) * F8 + l * 8;
+    const int64_t off = ibase + (int64_t)(((t0 >> 5) + kg) * NDV + dvt) * F8 + l * 8;
     *reinterpret_cast<u32x2*>(v8 + off) = fp8x8(xv, 1.0f);
   }
 }
 
+template <int HD>
 __global__ void __launch_bounds__(256, 2)
 attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const char* __restrict__ v8,
                 float* __restrict__ o, const int64_t* __restrict__ num_ims, int T, int Tp, int H, int npairs, int nqb) {
-  __shared__ __attribute__((aligned(16))) char sKb[2][4 * F8], sVb[2][4 * F8];
+  constexpr int NK = HD / 32, NDV = HD / 16;
+  constexpr int KB = 4 * NK * F8, VB = 2 * NDV * F8;      // bytes of K / V^T fragments per 64-key step
+  __shared__ __attribute__((aligned(16))) char sKb[2][KB], sVb[2][VB];
   // XCD-aware placement as in attn_x6.hip: pair p only ever runs on the XCD group p % 8
   const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
   const int cnt = (npairs - xg + 7) >> 3;
@@ -100,39 +112,48 @@ attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const 
   const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD;
   const int qw = q0 + wave * 16 * QT;
 
-  long qf[QT];
+  long qf[QT][NK];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt)
-    qf[qt] = *reinterpret_cast<const long*>(q8 + ibase + (int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * F8 + lane * 8);
-  f32x4 oacc[2][QT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int kk = 0; kk < NK; ++kk)
+      qf[qt][kk] = *reinterpret_cast<const long*>(q8 + ibase + ((int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * NK + kk) * F8 + lane * 8);
+  f32x4 oacc[NDV][QT];
+#pragma unroll
+  for (int i = 0; i < NDV; ++i)
 #pragma unroll
     for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run[QT], l_run[QT];
 #pragma unroll
   for (int j = 0; j < QT; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
 
-  // staging: a 64-key step is 2 KiB of K fragments + 2 KiB of V^T fragments: threads 0-127 carry K (one step ahead), 128-255 V
+  // staging: threads 0-127 carry the K fragments of a 64-key step (one step ahead), 128-255 its V^T fragments: NK 16-byte pieces each
   const int nkt = (len + KSTEP - 1) / KSTEP;
   const bool carriesK = tid < 128;
   const int chunk = (tid & 127) * 16;
-  u32x4 st;
+  u32x4 st[NK];
   auto gload = [&](int ktk, int ktv) {        // K of step ktk / V of step ktv (the caller checks the ranges)
-    const char* src = carriesK ? k8 + ibase + (int64_t)ktk * (4 * F8) : v8 + ibase + (int64_t)ktv * (4 * F8);
-    st = *reinterpret_cast<const u32x4*>(src + chunk);
+    const char* src = carriesK ? k8 + ibase + (int64_t)ktk * KB : v8 + ibase + (int64_t)ktv * VB;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) st[c] = *reinterpret_cast<const u32x4*>(src + chunk + 2048 * c);
   };
   auto swrite = [&](int ktk, int ktv, bool dok, bool dov) {
-    if (carriesK) { if (dok) *reinterpret_cast<u32x4*>(&sKb[ktk & 1][chunk]) = st; }
-    else if (dov) *reinterpret_cast<u32x4*>(&sVb[ktv & 1][chunk]) = st;
+#pragma unroll
+    for (int c = 0; c < NK; ++c) {
+      if (carriesK) { if (dok) *reinterpret_cast<u32x4*>(&sKb[ktk & 1][chunk + 2048 * c]) = st[c]; }
+      else if (dov) *reinterpret_cast<u32x4*>(&sVb[ktv & 1][chunk + 2048 * c]) = st[c];
+    }
   };
   auto qk = [&](int kt, f32x4 (&s)[QT][4]) __attribute__((always_inline)) {
     const char* sK = &sKb[kt & 1][lane * 8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const long kf = *reinterpret_cast<const long*>(sK + t * F8);
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma8(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int kk = 0; kk < NK; ++kk) {
+        const long kf = *reinterpret_cast<const long*>(sK + (t * NK + kk) * F8);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma8(kf, qf[qt][kk], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : s[qt][t]);
+      }
     }
   };
   gload(0, 0);
@@ -181,14 +202,14 @@ attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const 
       }
       l_run[qt] = l_run[qt] * alpha + psum;
       m_run[qt] = m_new;
-      oacc[0][qt] *= alpha;
-      oacc[1][qt] *= alpha;
+#pragma unroll
+      for (int dvt = 0; dvt < NDV; ++dvt) oacc[dvt][qt] *= alpha;
     }
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-      for (int dvt = 0; dvt < 2; ++dvt) {
-        const long vf = *reinterpret_cast<const long*>(sV + (kg * 2 + dvt) * F8);
+      for (int dvt = 0; dvt < NDV; ++dvt) {
+        const long vf = *reinterpret_cast<const long*>(sV + (kg * NDV + dvt) * F8);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) oacc[dvt][qt] = mfma8(vf, pf[qt][kg], oacc[dvt][qt]);
       }
@@ -211,10 +232,27 @@ attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const 
     const int qi = qw + 16 * qt + ql;
     if (qi < T) {
       float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * g4;
-      *reinterpret_cast<f32x4*>(op) = oacc[0][qt] * inv;
-      *reinterpret_cast<f32x4*>(op + 16) = oacc[1][qt] * inv;
+#pragma unroll
+      for (int dvt = 0; dvt < NDV; ++dvt) *reinterpret_cast<f32x4*>(op + 16 * dvt) = oacc[dvt][qt] * inv;
     }
   }
+}
+
+template <int HD>
+int launch_fp8(const float* q, const float* k, const float* v, int64_t ld, int64_t hstride, int64_t bstride, float qmul, float* o,
+               const int64_t* num_ims, int B, int T, int H, void* workspace, hipStream_t stream) {
+  const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
+  const int64_t img = (int64_t)B * H * Tp * HD;
+  char* q8 = reinterpret_cast<char*>(workspace);
+  char* k8 = q8 + img;
+  char* v8 = k8 + img;
+  hipLaunchKernelGGL(attn_fp8_prep_kernel<HD>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, ld, hstride, bstride, qmul, q8, k8, v8,
+                     num_ims, T, Tp, H);
+  PATHS_LAUNCH_CHECK("attention_fp8(prep)");
+  const int nqb = (T + 64 * QT - 1) / (64 * QT), npairs = H * B;
+  hipLaunchKernelGGL(attn_fp8_kernel<HD>, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 0, stream, q8, k8, v8, o, num_ims, T, Tp, H, npairs, nqb);
+  PATHS_LAUNCH_CHECK("attention_fp8");
+  return PATHS_OK;
 }
 
 }  // namespace
@@ -227,24 +265,29 @@ int64_t paths_attention_fp8_workspace(int B, int T, int H, int head_dim) {
   return 3 * (int64_t)B * H * Tp * head_dim;
 }
 
-// o[B, T, H*32] = softmax(q_s k^T) v with e4m3 operands (see the file header: opt-in, outside the 1e-4 logit bar).
-// q, k, v head-major [B][H][T][32] fp32, q pre-scaled by log2(e)/sqrt(head_dim); keys >= num_ims[b] + 1 are masked.
+// o[B, T, H*hd] = softmax(q_s k^T) v with e4m3 operands (see the file header: opt-in, outside the 1e-4 logit bar), head_dim 32 or 64.
+// q, k, v head-major [B][H][T][hd] fp32, q pre-scaled by log2(e)/sqrt(head_dim); keys >= num_ims[b] + 1 are masked.
 int paths_attention_fp8(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims, int B, int T, int H,
                         int head_dim, void* workspace, hipStream_t stream) {
-  PATHS_REQUIRE(head_dim == HD, "attention_fp8: head_dim must be %d (got %d)", HD, head_dim);
+  PATHS_REQUIRE(head_dim == 32 || head_dim == 64, "attention_fp8: head_dim must be 32 or 64 (got %d)", head_dim);
   PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && q && k && v && o && num_ims && workspace, "attention_fp8: bad arguments B=%d T=%d H=%d", B, T, H);
   PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_fp8: buffers must be 16-byte aligned");
-  const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
-  const int64_t img = (int64_t)B * H * Tp * HD;
-  char* q8 = reinterpret_cast<char*>(workspace);
-  char* k8 = q8 + img;
-  char* v8 = k8 + img;
-  hipLaunchKernelGGL(attn_fp8_prep_kernel, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, q8, k8, v8, num_ims, T, Tp, H);
-  PATHS_LAUNCH_CHECK("attention_fp8(prep)");
-  const int nqb = (T + 64 * QT - 1) / (64 * QT), npairs = H * B;
-  hipLaunchKernelGGL(attn_fp8_kernel, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 0, stream, q8, k8, v8, o, num_ims, T, Tp, H, npairs, nqb);
-  PATHS_LAUNCH_CHECK("attention_fp8");
-  return PATHS_OK;
+  const int64_t hs = (int64_t)T * head_dim, bs = (int64_t)H * T * head_dim;
+  return head_dim == 32 ? launch_fp8<32>(q, k, v, head_dim, hs, bs, 1.0f, o, num_ims, B, T, H, workspace, stream)
+                        : launch_fp8<64>(q, k, v, head_dim, hs, bs, 1.0f, o, num_ims, B, T, H, workspace, stream);
+}
+
+// The same on the token-major in_proj output qkv [B*T, 3d] (row stride ld; q | k | v blocks of d = H * head_dim columns, q UNscaled:
+// qscale = log2(e) / sqrt(head_dim) is applied while the operand images are written).
+int paths_attention_fp8_qkv(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
+                            void* workspace, hipStream_t stream) {
+  PATHS_REQUIRE(head_dim == 32 || head_dim == 64, "attention_fp8_qkv: head_dim must be 32 or 64 (got %d)", head_dim);
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && qkv && o && num_ims && workspace && ld >= 3 * H * head_dim, "attention_fp8_qkv: bad arguments B=%d T=%d H=%d", B, T, H);
+  PATHS_REQUIRE(((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_fp8_qkv: buffers must be 16-byte aligned");
+  const int d = H * head_dim;
+  const int64_t bs = (int64_t)T * ld;
+  return head_dim == 32 ? launch_fp8<32>(qkv, qkv + d, qkv + 2 * d, ld, head_dim, bs, qscale, o, num_ims, B, T, H, workspace, stream)
+                        : launch_fp8<64>(qkv, qkv + d, qkv + 2 * d, ld, head_dim, bs, qscale, o, num_ims, B, T, H, workspace, stream);
 }
 
 }  // extern "C"

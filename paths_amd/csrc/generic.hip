@@ -153,17 +153,17 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
   }
 }
 
-// ---- y[row] = LayerNorm(x[row] (+ add)) * gamma + beta over d <= 1024 features, one wave per row (two-pass statistics in registers)
+// ---- y[row] = LayerNorm(x[row] (+ add)) * gamma + beta over d <= 2048 features, one wave per row (two-pass statistics in registers)
 __global__ void __launch_bounds__(256)
 layernorm_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ add, const float* __restrict__ g,
                       const float* __restrict__ bta, float* __restrict__ y, int64_t ldy, int64_t rows, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  f32x4 v[4];
+  f32x4 v[8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int c = 4 * lane + 256 * i;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < d) {
@@ -175,14 +175,14 @@ layernorm_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __r
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
     if (4 * lane + 256 * i < d) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float c = v[i][e] - mean; q += c * c; }
     }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int c = 4 * lane + 256 * i;
     if (c < d) {
       const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c), bb = *reinterpret_cast<const f32x4*>(bta + c);
@@ -244,13 +244,13 @@ tokens_assemble_kernel(const float* __restrict__ P, int64_t ldp, const float* __
   }
 }
 
-// ---- final head for any d <= 1024: decoder.norm(token 0) + slide-context residual -> ctx_out ; classifier over [concat ctx | f]
+// ---- final head for any d <= 2048: decoder.norm(token 0) + slide-context residual -> ctx_out ; classifier over [concat ctx | f]
 __global__ void __launch_bounds__(64)
 final_head_any_kernel(const float* __restrict__ x, int64_t slide_stride, const float* __restrict__ lng, const float* __restrict__ lnb,
                       const float* __restrict__ ctx_prev, int64_t ctx_stride, const float* __restrict__ ctx_all, int ctx_depth,
                       const float* __restrict__ wcls, const float* __restrict__ bcls, int num_logits, int cls_in,
                       float* __restrict__ ctx_out, float* __restrict__ logits, int d, float eps) {
-  __shared__ float f[1024];
+  __shared__ float f[2048];
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* row = x + (int64_t)b * slide_stride;
   float s = 0.f;
@@ -327,10 +327,10 @@ int paths_attention_any_train(const float* qkv, int64_t ld, float* o, float* lse
   return PATHS_OK;
 }
 
-// y[rows, d] (ldy) = LayerNorm(x (ldx) (+ add [d])) * gamma + beta, d <= 1024 and a multiple of 4 (torch native_layer_norm, biased variance)
+// y[rows, d] (ldy) = LayerNorm(x (ldx) (+ add [d])) * gamma + beta, d <= 2048 and a multiple of 4 (torch native_layer_norm, biased variance)
 int paths_layernorm_rows(const float* x, int64_t ldx, const float* add, const float* gamma, const float* beta, float* y, int64_t ldy,
                          int64_t rows, int d, float eps, hipStream_t stream) {
-  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 1024 && d % 4 == 0 && x && gamma && beta && y, "layernorm_rows: bad arguments (d = %d)", d);
+  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 2048 && d % 4 == 0 && x && gamma && beta && y, "layernorm_rows: bad arguments (d = %d)", d);
   PATHS_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, "layernorm_rows: alignment");
   hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, ldx, add, gamma, beta, y, ldy, rows, d, eps);
   PATHS_LAUNCH_CHECK("layernorm_rows");
@@ -359,11 +359,11 @@ int paths_tokens_assemble(const float* P, int64_t ldp, const float* importance, 
   return PATHS_OK;
 }
 
-// paths_final_head for any trans_dim <= 1024 (reference model/aggregator.py:75, model/paths.py:130-139)
+// paths_final_head for any trans_dim <= 2048 (reference model/aggregator.py:75, model/paths.py:130-139)
 int paths_final_head_any(const float* x, int64_t slide_stride, const float* lng, const float* lnb, const float* ctx_prev, int64_t ctx_stride,
                          const float* ctx_all, int ctx_depth, const float* wcls, const float* bcls, int num_logits, int cls_in,
                          float* ctx_out, float* logits, int B, int d, float eps, hipStream_t stream) {
-  PATHS_REQUIRE(B > 0 && d > 0 && d <= 1024 && num_logits > 0 && cls_in == (ctx_all ? (ctx_depth + 1) * d : d), "final_head_any: bad shape");
+  PATHS_REQUIRE(B > 0 && d > 0 && d <= 2048 && num_logits > 0 && cls_in == (ctx_all ? (ctx_depth + 1) * d : d), "final_head_any: bad shape");
   hipLaunchKernelGGL(final_head_any_kernel, dim3(B), dim3(64), 0, stream, x, slide_stride, lng, lnb, ctx_prev, ctx_stride, ctx_all, ctx_depth,
                      wcls, bcls, num_logits, cls_in, ctx_out, logits, d, eps);
   PATHS_LAUNCH_CHECK("final_head_any");

@@ -46,6 +46,7 @@ def timed(name: str, fn, meta=None, detail: bool = True):
 #   "f32" : f32-input MFMA (csrc/gemm_f32.hip, csrc/attn_f32.hip)
 GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "h3")
 A_SCALE = float(os.environ.get("PATHS_H3_A_SCALE", "16"))      # a power of two
+AGG_FP8 = os.environ.get("PATHS_AGG_FP8", "0") != "0"       # the whole aggregator's big products (in_proj, attention, out_proj, FFN) with e4m3 operands: the BASELINE configs[4] stress variant (opt-in, NOT a parity path: csrc/gemm_fp8.hip)
 ATTN_FP8 = os.environ.get("PATHS_ATTN_FP8", "0") != "0"     # inference attention with e4m3 operands (opt-in, see csrc/attn_fp8.hip)
 TRAIN_PLANES = 3        # training re-images weights every step: the bf16 split needs no scale, i.e. no host sync on max|w|
 # forward GEMMs / attention of the TRAINING step: 2 = the inference split (fp16 planes) with lagged weight scales, 3 = exact bf16
@@ -376,8 +377,8 @@ def check_supported(mc, training: bool = False):
     """Configurations this build runs on the HIP path; everything else is rejected loudly."""
     if not fast_path(mc):
         d, H, Hi = mc.trans_dim, mc.trans_heads, mc.importance_mlp_hidden_dim
-        if d % 32 or d > 1024 or H < 1 or d % H or (d // H) not in (16, 32, 48, 64) or Hi < 1 or Hi > 1024:
-            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 1024), head_dim in {16, 32, 48, 64} and "
+        if d % 32 or d > 2048 or H < 1 or d % H or (d // H) not in (16, 32, 48, 64) or Hi < 1 or Hi > 1024 or (training and d > 1024):
+            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 2048; <= 1024 for training), head_dim in {16, 32, 48, 64} and "
                                       f"importance_mlp_hidden_dim <= 1024 (got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
         if training and Hi % 4:
             raise NotImplementedError("training at aggregator geometries other than trans_dim=128 / 4 heads / importance hidden 128 needs "
@@ -438,9 +439,87 @@ def importance_proj_generic(mc, lvl_pack, src, ld_src: int, locs, num_ims, B: in
               p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
 
 
-def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all) -> Dict[str, torch.Tensor]:
+def fp8_pack(lvl_pack: Dict[str, object], mc) -> Dict[str, object]:
+    """e4m3 images + per-tensor scales (device scalars) of the aggregator's four weight matrices per layer (cached in the level's pack
+    dict, rebuilt with it), plus the scratch words the scale kernels use."""
+    if "fp8" not in lvl_pack:
+        dev = lvl_pack["wcls"].device
+        st = _lib.stream()
+        scratch = torch.zeros((1,), device=dev, dtype=torch.int32)
+        g = {"layers": [], "scratch": scratch, "a_scale": torch.ones((1,), device=dev, dtype=torch.float32)}
+        for lay in lvl_pack["layers"]:
+            e = {}
+            for k in ("wqkv", "wo", "w1", "w2"):
+                w = lay[k].contiguous()
+                N, K = w.shape
+                w8 = torch.empty(((N + 255) // 256 * 256, K), device=dev, dtype=torch.uint8)
+                sc = torch.empty((1,), device=dev, dtype=torch.float32)
+                _lib.call("paths_fp8_pack_weight", w.data_ptr(), K, N, K, w8.data_ptr(), sc.data_ptr(), scratch.data_ptr(), st)
+                e[k] = (w8, sc)
+            g["layers"].append(e)
+        lvl_pack["fp8"] = g
+    return lvl_pack["fp8"]
+
+
+def _fp8_image(fp, key: str, nbytes: int, dev, zero: bool = False) -> torch.Tensor:
+    buf = fp.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = fp[key] = (torch.zeros if zero else torch.empty)((nbytes,), device=dev, dtype=torch.uint8)
+    return buf
+
+
+def gemm_fp8(fp, a, lda: int, w8sc, bias, out, ldo: int, M: int, N: int, K: int, act: int = 0, residual=None, ldr: int = 0):
+    """out[M, N] = act(a[M, K] w^T + bias) (+ residual) with e4m3 operands (csrc/gemm_fp8.hip): per-tensor activation scale from a
+    device-side max|a| (no host sync), the activation image from one quantisation pass, the weight image and its scale from :func:`fp8_pack`."""
+    ptr = lambda t: t if isinstance(t, int) or t is None else t.data_ptr()
+    st = _lib.stream()
+    _lib.call("paths_fp8_scale", ptr(a), lda, M, K, fp["a_scale"].data_ptr(), fp["scratch"].data_ptr(), st)
+    a8 = _fp8_image(fp, "a8", (M + 255) // 256 * 256 * K, w8sc[0].device)
+    _lib.call("paths_fp8_quantize", ptr(a), lda, M, K, fp["a_scale"].data_ptr(), a8.data_ptr(), st)
+    _lib.call("paths_gemm_nt_fp8", a8.data_ptr(), w8sc[0].data_ptr(), fp["a_scale"].data_ptr(), w8sc[1].data_ptr(), ptr(bias), ptr(out), ldo,
+              M, N, K, act, ptr(residual), ldr, st)
+
+
+def ffn_fp8(fp, lay8, x2, d: int, b1, b2, y2, M: int):
+    """y2 = x2 + linear2(relu(linear1(x2))) with e4m3 operands and the hidden layer [M, 4d] handed from the first GEMM to the second
+    as an e4m3 image (never as fp32: 1.6 GB written, read twice for max|.| and quantisation, at the stress shape).  Its per-tensor
+    scale is CALIBRATED: the first call of a layer runs the fp32 hand-over and records 448 / (2 max|hidden|) (a factor 2 of head
+    room; values beyond saturate), later calls reuse it; max|hidden| of every call lands in lay8["h_amax"] (float bits) for checks."""
+    F = 4 * d
+    dev = x2.device
+    st = _lib.stream()
+    if "h_scale" not in lay8:
+        hff = torch.empty((M, F), device=dev, dtype=torch.float32)
+        gemm_fp8(fp, x2, d, lay8["w1"], b1, hff, F, M, F, d, act=1)
+        sc = torch.empty((1,), device=dev, dtype=torch.float32)
+        _lib.call("paths_fp8_scale", hff.data_ptr(), F, M, F, sc.data_ptr(), fp["scratch"].data_ptr(), st)
+        sc *= 0.5
+        lay8["h_scale"] = sc
+        lay8["h_amax"] = torch.zeros((1,), device=dev, dtype=torch.int32)
+        gemm_fp8(fp, hff, F, lay8["w2"], b2, y2, d, M, d, F, residual=x2, ldr=d)
+        return
+    _lib.call("paths_fp8_scale", x2.data_ptr(), d, M, d, fp["a_scale"].data_ptr(), fp["scratch"].data_ptr(), st)
+    a8 = _fp8_image(fp, "a8", (M + 255) // 256 * 256 * d, dev)
+    _lib.call("paths_fp8_quantize", x2.data_ptr(), d, M, d, fp["a_scale"].data_ptr(), a8.data_ptr(), st)
+    h8 = _fp8_image(fp, "h8", (M + 255) // 256 * 256 * F, dev, zero=True)
+    lay8["h_amax"].zero_()
+    _lib.call("paths_gemm_nt_fp8_out8", a8.data_ptr(), lay8["w1"][0].data_ptr(), fp["a_scale"].data_ptr(), lay8["w1"][1].data_ptr(), b1.data_ptr(),
+              h8.data_ptr(), lay8["h_scale"].data_ptr(), lay8["h_amax"].data_ptr(), M, F, d, 1, st)
+    _lib.call("paths_gemm_nt_fp8", h8.data_ptr(), lay8["w2"][0].data_ptr(), lay8["h_scale"].data_ptr(), lay8["w2"][1].data_ptr(), b2.data_ptr(),
+              y2.data_ptr(), d, M, d, F, 0, x2.data_ptr(), d, st)
+
+
+def fp8_supported(mc) -> bool:
+    d, H = mc.trans_dim, mc.trans_heads
+    return d % 64 == 0 and d % H == 0 and (d // H) in (32, 64)
+
+
+def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8: bool = False) -> Dict[str, torch.Tensor]:
     """The aggregator for any (trans_dim, heads): generic GEMMs + csrc/generic.hip (reference model/aggregator.py:58-76 with torch's
-    post-LN decoder layers, model/paths.py:130-139).  The last layer is evaluated at token 0 only (its other rows are never read)."""
+    post-LN decoder layers, model/paths.py:130-139).  The last layer is evaluated at token 0 only (its other rows are never read).
+    ``fp8`` (ops.AGG_FP8, the BASELINE configs[4] stress variant, NOT a parity path): the products over all tokens - in_proj, the full
+    layers' attention, out_proj and both feed-forward GEMMs - run with e4m3 operands (csrc/gemm_fp8.hip, csrc/attn_fp8.hip); LayerNorm,
+    residuals, the last layer's token-0 attention and row chain and the classifier stay in fp32."""
     gp = generic_pack(lvl_pack, mc)
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
@@ -451,6 +530,10 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     f32 = dict(device=dev, dtype=torch.float32)
     qscale = LOG2E / math.sqrt(hd)
     M = B * T
+    if fp8 and not fp8_supported(mc):
+        raise NotImplementedError(f"the e4m3 aggregator needs trans_dim % 64 == 0 and head_dim 32 or 64 (got {d} / {H} heads)")
+    fp = fp8_pack(lvl_pack, mc) if fp8 else None
+    ws8 = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if (fp8 and L > 1) else None
     x = tokens.view(M, d)
     qkv = torch.empty((M, 3 * d), **f32)
     attn = torch.empty((B, T, d), **f32)
@@ -458,20 +541,34 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     for l in range(L):
         lay, gl = lvl_pack["layers"][l], gp["layers"][l]
         last = l == L - 1
-        gemm_f32(x, d, gl["wqkv"], lay["bqkv"], qkv, 3 * d, M, 3 * d, d)
-        _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
+        big = fp8 and not last            # products over all tokens of a full layer
+
+        def gemm(a, lda, key, bias, out, ldo, m, n, kdim, act=0, residual=None, ldr=0, low=False):
+            if low:
+                gemm_fp8(fp, a, lda, fp["layers"][l][key], bias, out, ldo, m, n, kdim, act, residual, ldr)
+            else:
+                gemm_f32(a, lda, gl[key], bias, out, ldo, m, n, kdim, act, residual, ldr)
+
+        gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
+        if big:
+            _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
+        else:
+            _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
         if last:
             rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
         y1 = torch.empty((rows, d), **f32)
-        gemm_f32(attn, ldx, gl["wo"], lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx)
+        gemm(attn, ldx, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx, low=big)
         x1 = torch.empty((rows, d), **f32)
         _lib.call("paths_layernorm_rows", p(y1), d, None, p(lay["ln1g"]), p(lay["ln1b"]), p(x1), d, rows, d, lay["eps"], st)
         x2 = y1                           # (re-used)
         _lib.call("paths_layernorm_rows", p(x1), d, p(lay["cab"]), p(lay["ln2g"]), p(lay["ln2b"]), p(x2), d, rows, d, lay["eps"], st)
-        hff = torch.empty((rows, 4 * d), **f32)
-        gemm_f32(x2, d, gl["w1"], lay["b1"], hff, 4 * d, rows, 4 * d, d, act=1)
         y2 = x1                           # (re-used)
-        gemm_f32(hff, 4 * d, gl["w2"], lay["b2"], y2, d, rows, d, 4 * d, residual=x2, ldr=d)
+        if big:
+            ffn_fp8(fp, fp["layers"][l], x2, d, lay["b1"], lay["b2"], y2, rows)
+        else:
+            hff = torch.empty((rows, 4 * d), **f32)
+            gemm(x2, d, "w1", lay["b1"], hff, 4 * d, rows, 4 * d, d, act=1)
+            gemm(hff, 4 * d, "w2", lay["b2"], y2, d, rows, d, 4 * d, residual=x2, ldr=d)
         x3 = torch.empty((rows, d), **f32)
         _lib.call("paths_layernorm_rows", p(y2), d, None, p(lay["ln3g"]), p(lay["ln3b"]), p(x3), d, rows, d, lay["eps"], st)
         x, ldx = x3, d
@@ -747,6 +844,8 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
 
 def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None) -> Dict[str, torch.Tensor]:
     _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
+    if AGG_FP8:
+        return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8=True)
     if not fast_path(mc):
         return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all)
     B, T, d = tokens.shape

@@ -1011,6 +1011,81 @@ def test_fp8_attention_variant_error_is_measured(dev, monkeypatch):
     assert torch.equal(out_fp8["importance"], out_def["importance"])           # the selection chain does not depend on the aggregator
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(256, 256, 128, 0, True), (1000, 640, 256, 0, True), (300, 100, 128, 1, False), (4097, 1536, 1536, 0, True),
+                                           (513, 384, 512, 1, False)])
+def test_gemm_fp8_matches_float64_on_the_same_quantised_operands(dev, M, N, K, act, res):
+    """csrc/gemm_fp8.hip (v_mfma_scale_f32_32x32x64_f8f6f4, opt-in stress variant): device-side per-tensor scales = 448 / max|.|, and the
+    product equals float64 arithmetic on the SAME e4m3-quantised operands to accumulation accuracy (the operand lane map is right,
+    edge tiles and padding rows are handled); against the UNquantised product it is percent-level - not a parity path, and pinned so."""
+    from paths_amd import _lib
+    p = _lib.ptr
+    st = _lib.stream()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w, bias = torch.randn(M, K, generator=g) * 1.7, torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    rd = r.to(dev) if res else None
+    scratch = torch.zeros(1, dtype=torch.int32, device=dev)
+    sa, sw = torch.empty(1, device=dev), torch.empty(1, device=dev)
+    w8 = torch.empty(((N + 255) // 256 * 256, K), dtype=torch.uint8, device=dev)
+    a8 = torch.empty(((M + 255) // 256 * 256, K), dtype=torch.uint8, device=dev)
+    _lib.call("paths_fp8_pack_weight", p(wd), K, N, K, p(w8), p(sw), p(scratch), st)
+    _lib.call("paths_fp8_scale", p(ad), K, M, K, p(sa), p(scratch), st)
+    _lib.call("paths_fp8_quantize", p(ad), K, M, K, p(sa), p(a8), st)
+    out = torch.full((M, N), 7.0, device=dev)
+    _lib.call("paths_gemm_nt_fp8", p(a8), p(w8), p(sa), p(sw), p(bd), p(out), N, M, N, K, act, p(rd) if res else None, N if res else 0, st)
+    fsa, fsw = float(sa), float(sw)
+    assert abs(fsa * float(a.abs().max()) - 448) < 0.5 and abs(fsw * float(w.abs().max()) - 448) < 0.5 and int(scratch) == 0
+    q8 = lambda x, s_: (x * s_).clamp(-448, 448).to(torch.float8_e4m3fn).double()
+    assert torch.equal(a8[:M].cpu().view(torch.float8_e4m3fn).double(), q8(a, fsa)) and float(a8[M:].float().abs().max() if a8.shape[0] > M else 0) == 0
+    fin = lambda y: (torch.relu(y) if act else y) + (r.double() if res else 0)
+    same = fin(q8(a, fsa) @ q8(w, fsw).t() / (fsa * fsw) + bias.double())
+    exact = fin(a.double() @ w.double().t() + bias.double())
+    o = out.cpu().double()
+    assert float((o - same).abs().max() / same.abs().max()) < 1e-4       # (the e4m3 matrix-core path does not keep full fp32 accumulation: measured 2e-5)
+    err = float((o - exact).abs().max() / exact.abs().max())
+    assert 1e-3 < err < 0.1, err
+    # the e4m3 hand-over form: the same product quantised in the epilogue with a given scale, and its max|result| reported
+    if not res:
+        so = torch.tensor([448.0 / float(exact.abs().max()) * 0.5], device=dev)
+        o8 = torch.zeros(((M + 255) // 256 * 256, N), dtype=torch.uint8, device=dev)
+        amax = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("paths_gemm_nt_fp8_out8", p(a8), p(w8), p(sa), p(sw), p(bd), p(o8), p(so), p(amax), M, N, K, act, st)
+        got = o8[:M].cpu().view(torch.float8_e4m3fn).double() / float(so)
+        assert float((got - o).abs().max() / o.abs().max()) < 0.07           # one more e4m3 rounding (2^-4 relative) on top of `out`
+        assert abs(float(amax.view(torch.float32)) - float(o.abs().max())) < 1e-4 * float(o.abs().max())
+
+
+@pytest.mark.parametrize("over", [{}, {"trans_heads": 2}, {"trans_dim": 256, "trans_heads": 4}], ids=["td128_hd32", "td128_hd64", "td256_hd64"])
+def test_fp8_aggregator_variant_error_is_measured(dev, monkeypatch, over):
+    """ops.AGG_FP8 (BASELINE configs[4]: "fp8 (e4m3, per-tensor scale) on K3-K5"): the aggregator's products over all tokens with e4m3
+    operands.  NOT a parity test - it pins the error band (finite, logits within a coarse band of the fp32-accurate path and far
+    outside the 1e-4 bar), that the SECOND call (calibrated e4m3 hidden layer instead of the fp32 hand-over) stays in the band, and that
+    the selection outputs do not depend on the variant; a geometry it cannot serve is rejected."""
+    from paths_amd import ops
+    from paths_amd.data_utils.patch_batch import PatchBatch
+    g, info = load_golden("g9_level1_b2_k2048")
+    cfg, model, _ = build_model(dev, info["wseed"], {"model_config": dict(over)} if over else info["cfg_over"])
+    inp = H.single_level_inputs(info, H.oracle_config({"model_config": dict(over)} if over else info["cfg_over"]))
+    pb = PatchBatch(**{k: torch.from_numpy(v).to(dev) for k, v in inp.items()})
+    with torch.no_grad():
+        ref = {k: v.clone() for k, v in model(info["depth"], pb).items()}
+        monkeypatch.setattr(ops, "AGG_FP8", True)
+        with H.spy_calls() as calls:
+            first = {k: v.clone() for k, v in model(info["depth"], pb).items()}
+        assert "paths_gemm_nt_fp8" in calls and "paths_attention_fp8_qkv" in calls and "paths_gemm_nt_fp8_out8" not in calls
+        with H.spy_calls() as calls:
+            second = {k: v.clone() for k, v in model(info["depth"], pb).items()}
+        assert "paths_gemm_nt_fp8_out8" in calls
+    for out in (first, second):
+        err = float((out["logits"] - ref["logits"]).abs().max())
+        assert torch.isfinite(out["logits"]).all() and 1e-4 < err < 0.3, err
+        assert torch.equal(out["importance"], ref["importance"]) and torch.equal(out["ctx_patch"], ref["ctx_patch"])
+    model.procs[info["depth"]].config.trans_heads = 8 if not over.get("trans_dim") else 16       # head_dim 16: no e4m3 attention
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        model(info["depth"], pb)
+
+
 @pytest.mark.parametrize("case", range(24))
 def test_random_small_recursions_vs_oracle(dev, case):
     """A seeded sweep over the driver's shape space - grid shape, background rate (down to slides whose kept patches have no tissue
