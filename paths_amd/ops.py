@@ -414,9 +414,25 @@ def generic_pack(lvl_pack: Dict[str, object], mc) -> Dict[str, object]:
     return lvl_pack["generic"]
 
 
-def gemm_f32(a, lda: int, w_pad: torch.Tensor, bias, out, ldo: int, M: int, N: int, K: int, act: int = 0, residual=None, ldr: int = 0):
-    """out[M, N] = act(a[M, K] w^T + bias) (+ residual) on the f32-input matrix cores (exact fp32 FMA chains)."""
+GENERIC_SPLIT = os.environ.get("PATHS_GENERIC_SPLIT", "1") != "0"   # shape-generic INFERENCE: big GEMMs on the split-fp16 matrix-core kernel
+
+
+def gemm_f32(a, lda: int, w_pad: torch.Tensor, bias, out, ldo: int, M: int, N: int, K: int, act: int = 0, residual=None, ldr: int = 0,
+             split=None):
+    """out[M, N] = act(a[M, K] w^T + bias) (+ residual) on the f32-input matrix cores (exact fp32 FMA chains).
+    ``split`` = (cache dict, key) (inference only: the image costs one host sync per weight version): products with M >= 1024 rows run
+    on the split-operand kernel of the tuned path instead (csrc/gemm_x6.hip: two fp16 planes per operand in the default mode, 22-bit
+    products, fp32 accumulate - the arithmetic of every big product of the shipped geometry), 3x the f32-MFMA rate."""
     ptr = lambda t: t if isinstance(t, int) or t is None else t.data_ptr()
+    if split is not None and GENERIC_SPLIT and GEMM_MODE != "f32" and M >= 1024 and K >= 128 and K % 32 == 0:
+        cache, key = split
+        k6 = f"{key}_x6_{split_planes()}"
+        if k6 not in cache:
+            cache[k6] = x6_pack(w_pad[:N].contiguous(), n_pad=(N + 255) // 256 * 256)
+        img, ws = cache[k6]
+        _lib.call("paths_gemm_nt_x6", ptr(a), lda, img.data_ptr(), K, 0, ptr(bias), ptr(out), ldo, M, N, (N + 255) // 256 * 256, K, act,
+                  ptr(residual), ldr, None, 0, 0, split_planes(), ws, a_scale(), _lib.stream())
+        return
     _lib.call("paths_gemm_nt_f32", ptr(a), lda, ptr(w_pad), K, ptr(bias), ptr(out), ldo, M, N, w_pad.shape[0], K, act,
               ptr(residual), ldr, None, 0, 0, _lib.stream())
 
@@ -430,10 +446,10 @@ def importance_proj_generic(mc, lvl_pack, src, ld_src: int, locs, num_ims, B: in
     st = _lib.stream()
     p = _lib.ptr
     hid = torch.empty((M, Hi), device=dev, dtype=torch.float32)
-    gemm_f32(src, ld_src, gp["w1"], lvl_pack["b1"], hid, Hi, M, Hi, D, act=1)
+    gemm_f32(src, ld_src, gp["w1"], lvl_pack["b1"], hid, Hi, M, Hi, D, act=1, split=(gp, "w1"))
     _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), st)
     proj = torch.empty((M, d), device=dev, dtype=torch.float32)
-    gemm_f32(src, ld_src, gp["wp"], None, proj, d, M, d, D)
+    gemm_f32(src, ld_src, gp["wp"], None, proj, d, M, d, D, split=(gp, "wp"))
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
     _lib.call("paths_tokens_assemble", p(proj), d, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
               p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
@@ -547,7 +563,7 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             if low:
                 gemm_fp8(fp, a, lda, fp["layers"][l][key], bias, out, ldo, m, n, kdim, act, residual, ldr)
             else:
-                gemm_f32(a, lda, gl[key], bias, out, ldo, m, n, kdim, act, residual, ldr)
+                gemm_f32(a, lda, gl[key], bias, out, ldo, m, n, kdim, act, residual, ldr, split=(gl, key))
 
         gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
         if big:
