@@ -713,8 +713,12 @@ def main():
 
     train = None
     if args.train_steps > 0:
-        train = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 3)
-        log(f"train probe: {train['ms_per_step']} ms per step, all-reduce {train['allreduce_ms']} ms")
+        try:
+            train = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 3)
+            log(f"train probe: {train['ms_per_step']} ms per step, all-reduce {train['allreduce_ms']} ms")
+        except Exception as e:       # the headline (already measured above) must not be lost to a failure of the secondary probe
+            train = {"error": f"{type(e).__name__}: {e}"[:400]}
+            log(f"train probe FAILED: {train['error']}")
     if rank == 0:
         total_slides = spg * world * args.steps
         line = {
