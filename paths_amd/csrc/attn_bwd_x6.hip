@@ -144,6 +144,7 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
   if (qb >= nqb) return;
   const int b = pair / H, head = pair - b * H, q0 = qb * 64 * QT;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 15, g4 = lane >> 4;
@@ -224,7 +225,7 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
         for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) = key 4 g4 + (j & 3) + 16 (j >> 2) of the group
           const int key = kt_ * KSTEP + 32 * kg + 16 * (j >> 2) + 4 * g4 + (j & 3);
           const float p = key < len ? __builtin_amdgcn_exp2f(s[qt][j >> 2][j & 3] - my_lse[qt]) : 0.f;
-          const float m = drop.thr ? drop_mult(drop, drow + (uint64_t)min(key, T - 1)) : 1.0f;
+          const float m = drop.thr ? drop_mult_w(drop, dwin, drow + (uint64_t)min(key, T - 1)) : 1.0f;
           dsv[j] = LN2 * p * (dp[qt][j >> 2][j & 3] * m - my_d[qt]);
         }
         split8(dsv, dsf[qt]);
@@ -275,6 +276,7 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
   if (kb >= nkb) return;
   const int b = pair / H, head = pair - b * H, k0 = kb * 128;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   if (k0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kl = lane & 15, g4 = lane >> 4;
@@ -364,7 +366,7 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
           const int qloc = 32 * qg + 16 * (j >> 2) + 4 * g4 + (j & 3), qi = qs * KSTEP + qloc;
           const bool ok = key_ok && qi < len;
           const float pr = ok ? __builtin_amdgcn_exp2f(s[j >> 2][t][j & 3] - sL[qloc]) : 0.f;
-          const float m = drop.thr ? drop_mult(drop, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)min(qi, T - 1)) * (uint64_t)T + (uint64_t)min(key, T - 1)) : 1.0f;
+          const float m = drop.thr ? drop_mult_w(drop, dwin, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)min(qi, T - 1)) * (uint64_t)T + (uint64_t)min(key, T - 1)) : 1.0f;
           dsv[j] = LN2 * pr * (dp[j >> 2][t][j & 3] * m - sD[qloc]);
           pv[j] = pr * m;
         }

@@ -45,6 +45,7 @@ token0_fwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
   __shared__ float sred[4];
   const int part = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   int k0, k1;
   split_range(len, S, part, k0, k1);
   const int64_t base = ((int64_t)b * H + head) * T * HD;
@@ -87,7 +88,7 @@ token0_fwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
     if (key < k1) {
       const float p = __builtin_amdgcn_exp2f(sc[j] - m);
       l += p;                                                      // the normaliser is the un-dropped softmax's
-      sP[tid + 256 * j] = drop.thr != 0u ? p * drop_mult(drop, row + (uint64_t)key) : p;
+      sP[tid + 256 * j] = drop.thr != 0u ? p * drop_mult_w(drop, dwin, row + (uint64_t)key) : p;
     }
   }
   l = wave_sum(l);
@@ -137,6 +138,7 @@ token0_bwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
   __shared__ float red[4][HD];
   const int part = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   int k0, k1;
   split_range(len, S, part, k0, k1);
   const int64_t base = ((int64_t)b * H + head) * T * HD;
@@ -167,7 +169,7 @@ token0_bwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
       dp += (vv[i][0] * gv[i][0] + vv[i][1] * gv[i][1]) + (vv[i][2] * gv[i][2] + vv[i][3] * gv[i][3]);
     }
     const float p = __builtin_amdgcn_exp2f(s - L);
-    const float mk = drop.thr != 0u ? drop_mult(drop, row + (uint64_t)key) : 1.f;
+    const float mk = drop.thr != 0u ? drop_mult_w(drop, dwin, row + (uint64_t)key) : 1.f;
     const float pd = p * mk;
     const float ds = LN2 * p * (dp * mk - dsum);
     float* dkp = dqkv + ((int64_t)b * T + key) * (3 * H * HD) + H * HD + head * HD;

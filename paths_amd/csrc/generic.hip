@@ -32,6 +32,7 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
   __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVs];
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
   const float* qb = qkv + (int64_t)b * T * ld + head * HD;
@@ -122,7 +123,7 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult(drop, rowi + (uint64_t)(16 * t + r));
+          for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult_w(drop, dwin, rowi + (uint64_t)(16 * t + r));
       }
     }
 #pragma unroll

@@ -240,6 +240,7 @@ attn_bwd_any_kv_kernel(const float* __restrict__ qkv, int64_t ld, int d, float q
   __shared__ float red[64 * (HD + 1)];
   const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 64;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   if (k0 >= len) return;
   const int nq = max_q > 0 ? min(len, max_q) : len;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -282,7 +283,7 @@ attn_bwd_any_kv_kernel(const float* __restrict__ qkv, int64_t ld, int d, float q
 #pragma unroll
       for (int c = 0; c < HD; ++c) { s = fmaf(qrow[c], kr[c], s); dp = fmaf(grow[c], vr[c], dp); }
       const float p = key_ok ? __builtin_amdgcn_exp2f(s - sL[r]) : 0.f;
-      const float m = drop.thr != 0u ? drop_mult(drop, (site_row + (uint64_t)(q0 + r)) * T + (uint64_t)key) : 1.f;
+      const float m = drop.thr != 0u ? drop_mult_w(drop, dwin, (site_row + (uint64_t)(q0 + r)) * T + (uint64_t)key) : 1.f;
       const float pd = p * m;
       const float ds = LN2 * p * (dp * m - sD[r]);
 #pragma unroll
@@ -324,6 +325,7 @@ attn_bwd_any_q_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qs
   __shared__ float red[64 * (HD + 1)];
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
   const int len = min((int)num_ims[b] + 1, T);
+  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
   const int nq = max_q > 0 ? min(len, max_q) : len;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,7 +363,7 @@ attn_bwd_any_q_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qs
 #pragma unroll
       for (int c = 0; c < HD; ++c) { s = fmaf(qr[c], krow[c], s); dp = fmaf(gr[c], vrow[c], dp); }
       const float p = __builtin_amdgcn_exp2f(s - L);
-      const float m = drop.thr != 0u ? drop_mult(drop, site_row + (uint64_t)(k0 + r)) : 1.f;
+      const float m = drop.thr != 0u ? drop_mult_w(drop, dwin, site_row + (uint64_t)(k0 + r)) : 1.f;
       const float ds = LN2 * p * (dp * m - Dv);
 #pragma unroll
       for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, krow[c], dq[c]);
