@@ -894,6 +894,28 @@ def test_graphed_recursion_replays_bit_identically(dev):
     assert torch.equal(out3["logits"], ref3["logits"])
 
 
+@pytest.mark.parametrize("over", [{"trans_dim": 192}, {"trans_dim": 64, "trans_heads": 2, "importance_mlp_hidden_dim": 32, "lstm": False}],
+                         ids=["td192", "td64_h2_hi32_nolstm"])
+def test_taped_recursion_other_geometries(dev, over):
+    """The launch tape on the shape-generic path (no torch-side kernel may hide in it): replays equal the eager pass bit for bit, also
+    after the tape's outputs were poisoned."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 5, {"model_config": dict(over)}, top_k_patches=[24] * 4)
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(98, sid, (9, 11), p_bg=0.15, device=dev) for sid in range(3)])
+    with torch.no_grad():
+        ref = putils.recurse(model, slides, cfg.top_k_patches, 5)
+    t = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5)
+    for rep in range(3):
+        if rep == 2:
+            for key in ("logits", "ctx_slide", "importance"):
+                t.out[key].fill_(float("nan"))
+        out = t.run()
+        assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
+        assert torch.equal(out["ctx_slide"], ref["ctx_slide"])
+    t.close()
+
+
 def test_taped_recursion_replays_bit_identically(dev):
     """paths_amd.utils.TapedRecursion: the recorded launch tape (C calls + stream joins + zero fills on three streams) replays to
     the eager pass's results bit for bit, is re-recorded when a weight changes, and hands fallback batches to the eager path."""
