@@ -301,6 +301,12 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
  *   paths_final_head_any  paths_final_head for any trans_dim */
 int paths_attention_any(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
                         int max_queries, paths_stream_t stream);
+/* The same attention on the 16-bit matrix cores with fp32-accurate operands (csrc/attn_h3_any.hip: two fp16 planes per operand, three
+ * MFMAs per product block - the arithmetic of the tuned head_dim-32 kernel - for head_dim 16 / 32 / 48 / 64); all queries;
+ * workspace: paths_attention_h3_any_workspace(B, T, H, head_dim) bytes. */
+int64_t paths_attention_h3_any_workspace(int B, int T, int H, int head_dim);
+int paths_attention_h3_any(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
+                           void* workspace, paths_stream_t stream);
 int paths_layernorm_rows(const float* x, int64_t ldx, const float* add, const float* gamma, const float* beta, float* y, int64_t ldy,
                          int64_t rows, int d, float eps, paths_stream_t stream);
 int paths_importance_rows(const float* hid, int64_t ldh, const float* w2, const float* b2, const int64_t* num_ims, int rows_per_slide,

@@ -550,6 +550,10 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
         raise NotImplementedError(f"the e4m3 aggregator needs trans_dim % 64 == 0 and head_dim 32 or 64 (got {d} / {H} heads)")
     fp = fp8_pack(lvl_pack, mc) if fp8 else None
     ws8 = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if (fp8 and L > 1) else None
+    # full layers' attention on the split-fp16 matrix-core kernel for any head_dim (the arithmetic of the tuned path), unless the
+    # f32 mode is selected; the last layer's single query stays on the f32-input kernel
+    h3 = (not fp8) and GENERIC_SPLIT and GEMM_MODE == "h3" and L > 1
+    wsh = torch.empty((int(_lib.load().paths_attention_h3_any_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if h3 else None
     x = tokens.view(M, d)
     qkv = torch.empty((M, 3 * d), **f32)
     attn = torch.empty((B, T, d), **f32)
@@ -568,6 +572,8 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
         gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
         if big:
             _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
+        elif h3 and not last:
+            _lib.call("paths_attention_h3_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(wsh), st)
         else:
             _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
         if last:

@@ -1033,6 +1033,37 @@ def test_fp8_attention_variant_error_is_measured(dev, monkeypatch):
     assert torch.equal(out_fp8["importance"], out_def["importance"])           # the selection chain does not depend on the aggregator
 
 
+@pytest.mark.parametrize("hd,H", [(16, 4), (32, 3), (48, 4), (64, 2)])
+def test_attention_h3_any_matches_fp64(dev, hd, H):
+    """csrc/attn_h3_any.hip: the split-fp16 attention for any head_dim on the token-major in_proj output (ragged batch, masked keys,
+    several key steps) against float64: the error of an fp32 chain, like the tuned head_dim-32 kernel."""
+    from paths_amd import _lib
+    B, T = 3, 333
+    d = H * hd
+    g = torch.Generator().manual_seed(hd)
+    qkv = torch.randn(B * T, 3 * d, generator=g)
+    num_ims = torch.tensor([332, 150, 64])
+    qd, nd = qkv.to(dev), num_ims.to(dev)
+    o = torch.full((B, T, d), float("nan"), device=dev)
+    ws = torch.empty((int(_lib.load().paths_attention_h3_any_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8)
+    _lib.call("paths_attention_h3_any", qd.data_ptr(), 3 * d, o.data_ptr(), nd.data_ptr(), B, T, H, hd, math.log2(math.e) / math.sqrt(hd),
+              ws.data_ptr(), _lib.stream())
+    torch.cuda.synchronize()
+    q, k, v = (x.view(B, T, H, hd).transpose(1, 2).double() for x in qkv.split(d, dim=1))
+    s_ = torch.einsum("bhqd,bhkd->bhqk", q, k) / math.sqrt(hd)
+    mask = torch.arange(T)[None, :] > num_ims[:, None]
+    s_ = s_.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bhqk,bhkd->bqhd", torch.softmax(s_, -1), v).reshape(B, T, d)
+    valid = torch.arange(T)[None, :] <= num_ims[:, None]
+    out = o.cpu().double()
+    assert torch.isfinite(out[valid]).all()
+    assert float((out[valid] - ref[valid]).abs().max()) < 5e-6
+    # and against the f32-input kernel of the same contract
+    o2 = torch.zeros((B, T, d), device=dev)
+    _lib.call("paths_attention_any", qd.data_ptr(), 3 * d, o2.data_ptr(), nd.data_ptr(), B, T, H, hd, math.log2(math.e) / math.sqrt(hd), 0, _lib.stream())
+    assert float((o2.cpu().double()[valid] - out[valid]).abs().max()) < 5e-6
+
+
 @pytest.mark.parametrize("M,N,K,act,res", [(256, 256, 128, 0, True), (1000, 640, 256, 0, True), (300, 100, 128, 1, False), (4097, 1536, 1536, 0, True),
                                            (513, 384, 512, 1, False)])
 def test_gemm_fp8_matches_float64_on_the_same_quantised_operands(dev, M, N, K, act, res):
