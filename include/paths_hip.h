@@ -185,6 +185,8 @@ int paths_attention_bwd_f32(const float* q, const float* k, const float* v, cons
  * ws: paths_attention_token0_workspace(B, T, H) floats.  The backward writes dk / dv of every valid key and dq of row 0 into dqkv
  * [B, T, 3*H*32] (zero on entry). */
 int64_t paths_attention_token0_workspace(int B, int T, int H);
+int paths_attention_token0_any(const float* qkv, int64_t ld, const int64_t* num_ims, float* a0, float* ws, int B, int T, int H, int head_dim,
+                               float qscale, paths_stream_t stream);      /* inference form for any head_dim on the token-major in_proj output */
 int paths_attention_token0_fwd(const float* q, const float* k, const float* v, const int64_t* num_ims, float* a0, float* lse0, float* ws,
                                int B, int T, int H, int head_dim, uint64_t drop_key, float drop_p, paths_stream_t stream);
 int paths_attention_token0_bwd(const float* q, const float* k, const float* v, const float* a0, const float* da0, const float* lse0,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "paths_importance_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "paths_layernorm_fwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp],
     "paths_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "paths_attention_token0_any": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "paths_attention_token0_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_attention_token0_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],

@@ -203,6 +203,107 @@ token0_bwd_combine_kernel(const float* __restrict__ dq_part, float* __restrict__
   dqkv[((int64_t)b * T) * (3 * H * HD) + head * HD + lane] = t;      // row 0 of slide b, q block
 }
 
+// ---- the same single-query attention for any head_dim (multiple of 4, <= 64) on the token-major in_proj output qkv [B*T, 3d]
+// (inference of the shape-generic path: no dropout, no lse): partials (m, l, o[HD]) per key split, then the combine
+template <int HD>
+__global__ void __launch_bounds__(256)
+token0_any_partial_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, const int64_t* __restrict__ num_ims,
+                          float* __restrict__ partials, int T, int H, int S) {
+  constexpr int PS = HD + 4;
+  __shared__ float sP[1024];
+  __shared__ float red[8][HD + 1];
+  __shared__ float sred[4];
+  const int part = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = min((int)num_ims[b] + 1, T);
+  int k0, k1;
+  split_range(len, S, part, k0, k1);
+  const float* qp = qkv + (int64_t)b * T * ld + head * HD;          // token 0 of slide b
+  const float* kb = qp + d;
+  const float* vb = qp + 2 * d;
+  float* dst = partials + (((int64_t)b * H + head) * S + part) * PS;
+  if (k0 >= k1) {
+    if (tid < PS) dst[tid] = tid == 0 ? -INFINITY : 0.f;
+    return;
+  }
+  f32x4 qv[HD / 4];
+#pragma unroll
+  for (int i = 0; i < HD / 4; ++i) qv[i] = *reinterpret_cast<const f32x4*>(qp + 4 * i) * qscale;
+  float sc[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = k0 + tid + 256 * j;
+    sc[j] = -INFINITY;
+    if (key < k1) {
+      const float* kp = kb + (int64_t)key * ld;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < HD / 4; ++i) {
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+        s += (kk[0] * qv[i][0] + kk[1] * qv[i][1]) + (kk[2] * qv[i][2] + kk[3] * qv[i][3]);
+      }
+      sc[j] = s;
+      m = fmaxf(m, s);
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) sred[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  __syncthreads();
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int key = k0 + tid + 256 * j;
+    if (key < k1) {
+      const float p = __builtin_amdgcn_exp2f(sc[j] - m);
+      l += p;
+      sP[tid + 256 * j] = p;
+    }
+  }
+  l = wave_sum(l);
+  if (lane == 0) sred[wave] = l;
+  __syncthreads();
+  l = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+  // o[c] = sum_key p[key] v[key][c]: thread (c = tid % 64, g = tid / 64) walks keys g, g + 4, ... (c < HD active)
+  const int c = tid & 63, g = tid >> 6;
+  float o = 0.f;
+  if (c < HD)
+    for (int kk = g; kk < k1 - k0; kk += 4) o = fmaf(sP[kk], vb[(int64_t)(k0 + kk) * ld + c], o);
+  if (c < HD) red[g][c] = o;
+  __syncthreads();
+  if (tid < HD) dst[4 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  if (tid == 0) { dst[0] = m; dst[1] = l; }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(64)
+token0_any_combine_kernel(const float* __restrict__ partials, float* __restrict__ a0 /*[B, H*HD]*/, int H, int S) {
+  constexpr int PS = HD + 4;
+  const int head = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* sp = partials + ((int64_t)b * H + head) * S * PS;
+  float M = -INFINITY;
+  for (int pt = 0; pt < S; ++pt) M = fmaxf(M, sp[pt * PS]);
+  float num = 0.f, den = 0.f;
+  for (int pt = 0; pt < S; ++pt) {
+    const float mp = sp[pt * PS];
+    const float w = mp == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mp - M);
+    den += w * sp[pt * PS + 1];
+    if (lane < HD) num += w * sp[pt * PS + 4 + lane];
+  }
+  if (lane < HD) a0[((int64_t)b * H + head) * HD + lane] = num / den;
+}
+
+template <int HD>
+int launch_token0_any(const float* qkv, int64_t ld, int d, float qscale, const int64_t* num_ims, float* a0, float* ws, int B, int T, int H, int S,
+                      hipStream_t stream) {
+  hipLaunchKernelGGL(token0_any_partial_kernel<HD>, dim3(S, H, B), dim3(256), 0, stream, qkv, ld, d, qscale, num_ims, ws, T, H, S);
+  PATHS_LAUNCH_CHECK("attention_token0_any(partials)");
+  hipLaunchKernelGGL(token0_any_combine_kernel<HD>, dim3(H, B), dim3(64), 0, stream, ws, a0, H, S);
+  PATHS_LAUNCH_CHECK("attention_token0_any(combine)");
+  return PATHS_OK;
+}
+
 int pick_splits(int B, int T, int H) {
   int S = 1;
   while (S < S_MAX && B * H * S < 512 && (T + 2 * S - 1) / (2 * S) >= 64) S *= 2;
@@ -215,7 +316,24 @@ int pick_splits(int B, int T, int H) {
 extern "C" {
 
 // floats of scratch for the two entry points below (split partials)
-int64_t paths_attention_token0_workspace(int B, int T, int H) { return (int64_t)B * H * 64 * PSTRIDE; }
+int64_t paths_attention_token0_workspace(int B, int T, int H) { return (int64_t)B * H * 64 * 68; }     // (68 >= PSTRIDE, head_dim 64 + 4)
+
+// a0 [B, H*hd] = attention output of token 0 per head for any head_dim in {16, 32, 48, 64} on the token-major in_proj output qkv
+// [B*T, 3d] (row stride ld, q unscaled: qscale = log2(e) / sqrt(hd)); inference form (no dropout); ws as above
+int paths_attention_token0_any(const float* qkv, int64_t ld, const int64_t* num_ims, float* a0, float* ws, int B, int T, int H, int head_dim,
+                               float qscale, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && qkv && num_ims && a0 && ws && ld % 4 == 0 && (uintptr_t)qkv % 16 == 0, "attention_token0_any: bad arguments");
+  const int S = pick_splits(B, T, H);
+  PATHS_REQUIRE(S <= 64 && (((T + S - 1) / S + 63) & ~63) <= 1024, "attention_token0_any: T = %d is too long", T);
+  const int d = H * head_dim;
+  switch (head_dim) {
+    case 16: return launch_token0_any<16>(qkv, ld, d, qscale, num_ims, a0, ws, B, T, H, S, stream);
+    case 32: return launch_token0_any<32>(qkv, ld, d, qscale, num_ims, a0, ws, B, T, H, S, stream);
+    case 48: return launch_token0_any<48>(qkv, ld, d, qscale, num_ims, a0, ws, B, T, H, S, stream);
+    case 64: return launch_token0_any<64>(qkv, ld, d, qscale, num_ims, a0, ws, B, T, H, S, stream);
+    default: return paths_set_error(PATHS_EUNSUPPORTED, "attention_token0_any: head_dim %d (supported: 16, 32, 48, 64)", head_dim);
+  }
+}
 
 // a0 [B, H*32] = token-0 attention output per head (dropout p on the probabilities, site drop_key), lse0 [B, H] (log2 domain,
 // un-dropped softmax); q, k, v head-major [B, H, T, 32] with q pre-scaled (as paths_token_layer_f32 writes them)

@@ -574,12 +574,20 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
         elif h3 and not last:
             _lib.call("paths_attention_h3_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(wsh), st)
+        elif last and GENERIC_SPLIT:
+            # single query per (slide, head), keys split over workgroups (csrc/attn_token0.hip): [B, d] instead of row 0 of [B, T, d]
+            a0 = torch.empty((B, d), **f32)
+            ws0 = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), **f32)
+            _lib.call("paths_attention_token0_any", p(qkv), 3 * d, p(num_ims), p(a0), p(ws0), B, T, H, hd, qscale, st)
         else:
             _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
         if last:
             rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
         y1 = torch.empty((rows, d), **f32)
-        gemm(attn, ldx, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx, low=big)
+        if last and GENERIC_SPLIT:
+            gemm(a0, d, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx)
+        else:
+            gemm(attn, ldx, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx, low=big)
         x1 = torch.empty((rows, d), **f32)
         _lib.call("paths_layernorm_rows", p(y1), d, None, p(lay["ln1g"]), p(lay["ln1b"]), p(x1), d, rows, d, lay["eps"], st)
         x2 = y1                           # (re-used)

@@ -96,7 +96,8 @@ def test_single_level_other_aggregator_geometries(dev, tag):
         g, info, out = run_single(dev, f"g12_{tag}_level1")
     finally:
         O._lib.call = orig
-    assert {"paths_attention_any", "paths_layernorm_rows", "paths_tokens_assemble", "paths_importance_rows", "paths_final_head_any"} <= set(calls)
+    attn = {"paths_attention_h3_any", "paths_attention_token0_any"} if (O.GEMM_MODE == "h3" and O.GENERIC_SPLIT) else {"paths_attention_any"}
+    assert attn | {"paths_layernorm_rows", "paths_tokens_assemble", "paths_importance_rows", "paths_final_head_any"} <= set(calls)
     np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out["importance"].numpy(), g["importance"], atol=STATE_TOL, rtol=0)
@@ -1062,6 +1063,12 @@ def test_attention_h3_any_matches_fp64(dev, hd, H):
     o2 = torch.zeros((B, T, d), device=dev)
     _lib.call("paths_attention_any", qd.data_ptr(), 3 * d, o2.data_ptr(), nd.data_ptr(), B, T, H, hd, math.log2(math.e) / math.sqrt(hd), 0, _lib.stream())
     assert float((o2.cpu().double()[valid] - out[valid]).abs().max()) < 5e-6
+    # the single-query form of the last layer (token 0 of every slide, keys split over workgroups)
+    a0 = torch.full((B, d), float("nan"), device=dev)
+    ws0 = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), device=dev)
+    _lib.call("paths_attention_token0_any", qd.data_ptr(), 3 * d, nd.data_ptr(), a0.data_ptr(), ws0.data_ptr(), B, T, H, hd,
+              math.log2(math.e) / math.sqrt(hd), _lib.stream())
+    assert float((a0.cpu().double() - ref[:, 0]).abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(256, 256, 128, 0, True), (1000, 640, 256, 0, True), (300, 100, 128, 1, False), (4097, 1536, 1536, 0, True),
