@@ -521,7 +521,7 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
 }
 
 #ifndef PATHS_H_OCC
-#define PATHS_H_OCC 2
+#define PATHS_H_OCC 3
 #endif
 constexpr int H_OCC = PATHS_H_OCC;
 static const bool IP_TILE128 = getenv("PATHS_IP_TILE128") != nullptr && atoi(getenv("PATHS_IP_TILE128")) != 0;   // measured: 69 us vs 58 (split-K)
