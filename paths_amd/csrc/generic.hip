@@ -195,6 +195,63 @@ layernorm_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __r
   }
 }
 
+// ---- y[row] = LayerNorm2(LayerNorm1(x[row]) + add) for d <= 2048: the post-attention norm1 -> (+ cross-attention bias) -> norm2 pair of a
+// decoder layer over an empty memory (reference model/aggregator.py:25-33) in one pass, the intermediate row stays in registers
+__global__ void __launch_bounds__(256)
+layernorm2_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ g1, const float* __restrict__ b1,
+                       const float* __restrict__ add, const float* __restrict__ g2, const float* __restrict__ b2, float* __restrict__ y,
+                       int64_t ldy, int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v[8];
+  const float inv_d = 1.0f / (float)d;
+  auto stats = [&](float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (4 * lane + 256 * i < d) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (4 * lane + 256 * i < d) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float c = v[i][e] - mean; q += c * c; }
+      }
+    rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = 4 * lane + 256 * i;
+    v[i] = c < d ? *reinterpret_cast<const f32x4*>(x + row * ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float mean, rstd;
+  stats(mean, rstd);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g1 + c), bb = *reinterpret_cast<const f32x4*>(b1 + c);
+      const f32x4 aa = add ? *reinterpret_cast<const f32x4*>(add + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = ((v[i][e] - mean) * rstd * gg[e] + bb[e]) + aa[e];
+    }
+  }
+  stats(mean, rstd);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g2 + c), bb = *reinterpret_cast<const f32x4*>(b2 + c);
+      f32x4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) out[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+      *reinterpret_cast<f32x4*>(y + row * ldy + c) = out;
+    }
+  }
+}
+
 // ---- importance[m] = valid ? sigmoid(hid[m] . w2 + b2) : 0   (hid = relu(Y W1^T + b1) from the GEMM), one wave per row
 __global__ void __launch_bounds__(256)
 importance_rows_kernel(const float* __restrict__ hid, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ b2,
@@ -335,6 +392,17 @@ int paths_layernorm_rows(const float* x, int64_t ldx, const float* add, const fl
   PATHS_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, "layernorm_rows: alignment");
   hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, ldx, add, gamma, beta, y, ldy, rows, d, eps);
   PATHS_LAUNCH_CHECK("layernorm_rows");
+  return PATHS_OK;
+}
+
+// y = LayerNorm(LayerNorm(x) * g1 + b1 + add) * g2 + b2 per row (norm1 -> + cross-attention bias -> norm2 of a decoder layer), d <= 2048
+int paths_layernorm2_rows(const float* x, int64_t ldx, const float* g1, const float* b1, const float* add, const float* g2, const float* b2,
+                          float* y, int64_t ldy, int64_t rows, int d, float eps, hipStream_t stream) {
+  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 2048 && d % 4 == 0 && x && g1 && b1 && g2 && b2 && y, "layernorm2_rows: bad arguments (d = %d)", d);
+  PATHS_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x | (uintptr_t)y | (uintptr_t)add | (uintptr_t)g1 | (uintptr_t)b1 | (uintptr_t)g2 | (uintptr_t)b2) % 16 == 0,
+                "layernorm2_rows: alignment");
+  hipLaunchKernelGGL(layernorm2_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, ldx, g1, b1, add, g2, b2, y, ldy, rows, d, eps);
+  PATHS_LAUNCH_CHECK("layernorm2_rows");
   return PATHS_OK;
 }
 

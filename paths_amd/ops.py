@@ -589,9 +589,9 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
         else:
             gemm(attn, ldx, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx, low=big)
         x1 = torch.empty((rows, d), **f32)
-        _lib.call("paths_layernorm_rows", p(y1), d, None, p(lay["ln1g"]), p(lay["ln1b"]), p(x1), d, rows, d, lay["eps"], st)
-        x2 = y1                           # (re-used)
-        _lib.call("paths_layernorm_rows", p(x1), d, p(lay["cab"]), p(lay["ln2g"]), p(lay["ln2b"]), p(x2), d, rows, d, lay["eps"], st)
+        x2 = y1                           # (in place: every wave reads its row before it writes it)
+        _lib.call("paths_layernorm2_rows", p(y1), d, p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]), p(lay["ln2g"]), p(lay["ln2b"]), p(x2), d,
+                  rows, d, lay["eps"], st)
         y2 = x1                           # (re-used)
         if big:
             ffn_fp8(fp, fp["layers"][l], x2, d, lay["b1"], lay["b2"], y2, rows)
