@@ -556,7 +556,9 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     wsh = torch.empty((int(_lib.load().paths_attention_h3_any_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if h3 else None
     x = tokens.view(M, d)
     qkv = torch.empty((M, 3 * d), **f32)
-    attn = torch.empty((B, T, d), **f32)
+    # rows of padded queries are never written by the attention kernels: harmless row-wise garbage on the accurate path, but the e4m3
+    # path takes max|.| over WHOLE activation matrices for its per-tensor scales - there they must be defined (zero)
+    attn = (torch.zeros if fp8 else torch.empty)((B, T, d), **f32)
     rows, ldx = M, d                      # the current activation: `rows` rows, row stride ldx (the last layer keeps token 0 of every slide)
     for l in range(L):
         lay, gl = lvl_pack["layers"][l], gp["layers"][l]
