@@ -479,11 +479,13 @@ int paths_attention_fp8_qkv(const float* qkv, int64_t ld, float* o, const int64_
 /* e4m3 GEMM of the stress variant (csrc/gemm_fp8.hip: v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales, per-tensor scales) for the
  * aggregator's products over all tokens (reference model/aggregator.py:25-33: in_proj, out_proj, linear1, linear2).  Opt-in, NOT a parity
  * path (4 significant bits per operand).
- *   paths_fp8_scale        *scale = 448 / max|x| over an fp32 [M, K] matrix, on the device (scratch: one zeroed uint32, left zero)
+ *   paths_fp8_scale        *scale = 448 / max|x| over an fp32 [M, K] matrix, on the device (scratch: one zeroed uint32, left zero);
+ *                          with num_ims / rows_per_slide only the valid token rows of a token-major activation count
  *   paths_fp8_pack_weight  w8 [ceil(N/256)*256, K] = e4m3(W * *scale) (zero rows behind N), *scale = 448 / max|W|; K % 64 == 0
  *   paths_fp8_quantize     x8 [ceil(M/256)*256, K] = e4m3(x * *scale) of an fp32 [M, K] matrix (zero rows behind M)
  *   paths_gemm_nt_fp8      out[M,N] = act(A W^T + bias) (+ residual) from the two e4m3 images and their scales; K % 128 == 0 */
-int paths_fp8_scale(const float* x, int64_t ld, int64_t M, int K, float* scale, unsigned int* scratch, paths_stream_t stream);
+int paths_fp8_scale(const float* x, int64_t ld, int64_t M, int K, float* scale, unsigned int* scratch, const int64_t* num_ims,
+                    int rows_per_slide, paths_stream_t stream);
 int paths_fp8_pack_weight(const float* w, int64_t ldw, int N, int K, uint8_t* w8, float* scale, unsigned int* scratch, paths_stream_t stream);
 int paths_fp8_quantize(const float* x, int64_t ld, int M, int K, const float* scale, uint8_t* x8, paths_stream_t stream);
 int paths_gemm_nt_fp8(const uint8_t* a8, const uint8_t* w8, const float* a_scale, const float* w_scale, const float* bias,

@@ -65,7 +65,7 @@ SIGNATURES = {
     "paths_importance_bwd_any": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
     "paths_importance_rows_bwd_any": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp, _vp],
     "paths_attention_bwd_any": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _u64, _f32, _vp],
-    "paths_fp8_scale": [_vp, _i64, _i64, _i32, _vp, _vp, _vp],
+    "paths_fp8_scale": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i32, _vp],
     "paths_fp8_pack_weight": [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp],
     "paths_fp8_quantize": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "paths_gemm_nt_fp8_out8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],

@@ -39,13 +39,17 @@ __device__ __forceinline__ uint32_t fp8x4(float a, float b, float c, float d) {
 }
 
 // ---- max |x| over a [M, K] fp32 matrix (row stride ld) as IEEE bits in *bits (non-negative floats order like unsigned ints)
+// num_ims != null: row r is token r % rows_per_slide of slide r / rows_per_slide and counts only if that token is valid (special token +
+// num_ims patches): rows of padded tokens may hold anything (tiles that are all padding are skipped by their producers)
 __global__ void __launch_bounds__(256)
-absmax_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int K, unsigned int* __restrict__ bits) {
+absmax_kernel(const float* __restrict__ x, int64_t ld, int64_t M, int K, unsigned int* __restrict__ bits, const int64_t* __restrict__ num_ims,
+              int rows_per_slide) {
   float m = 0.f;
   const int k4 = K / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < M * k4; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / k4;
     const int c = (int)(i - r * k4);
+    if (num_ims != nullptr && (r % rows_per_slide) > num_ims[r / rows_per_slide]) continue;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c);
     m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
@@ -234,12 +238,15 @@ gemm_fp8_kernel(Fp8Gemm g) {
 
 extern "C" {
 
-// *scale = 448 / max|x| over the [M, K] fp32 matrix (row stride ld); scratch: one zero-initialised uint32 on the device (left zero)
-int paths_fp8_scale(const float* x, int64_t ld, int64_t M, int K, float* scale, unsigned int* scratch, hipStream_t stream) {
+// *scale = 448 / max|x| over the [M, K] fp32 matrix (row stride ld); scratch: one zero-initialised uint32 on the device (left zero);
+// num_ims / rows_per_slide (optional): token-major activations [slides * rows_per_slide, K] - only valid token rows count
+int paths_fp8_scale(const float* x, int64_t ld, int64_t M, int K, float* scale, unsigned int* scratch, const int64_t* num_ims,
+                    int rows_per_slide, hipStream_t stream) {
   PATHS_REQUIRE(x && scale && scratch && M > 0 && K > 0 && K % 4 == 0 && ld % 4 == 0 && (uintptr_t)x % 16 == 0, "fp8_scale: bad arguments");
+  PATHS_REQUIRE(num_ims == nullptr || (rows_per_slide > 0 && M % rows_per_slide == 0), "fp8_scale: M must be slides x rows_per_slide with num_ims");
   const int64_t n4 = M * (K / 4);
   const unsigned blocks = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, ld, M, K, scratch);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, stream, x, ld, M, K, scratch, num_ims, rows_per_slide);
   PATHS_LAUNCH_CHECK("fp8_scale(absmax)");
   hipLaunchKernelGGL(scale_from_bits_kernel, dim3(1), dim3(1), 0, stream, scratch, scale);
   PATHS_LAUNCH_CHECK("fp8_scale");
@@ -249,7 +256,7 @@ int paths_fp8_scale(const float* x, int64_t ld, int64_t M, int K, float* scale, 
 // e4m3 image of a weight matrix W [N, K] (row stride ldw): w8 [Npad, K] bytes (Npad = N rounded up to 256, zero rows), *scale = 448 / max|W|
 int paths_fp8_pack_weight(const float* w, int64_t ldw, int N, int K, uint8_t* w8, float* scale, unsigned int* scratch, hipStream_t stream) {
   PATHS_REQUIRE(w && w8 && scale && scratch && N > 0 && K > 0 && K % 64 == 0 && ldw % 4 == 0, "fp8_pack_weight: K must be a multiple of 64 (got %d)", K);
-  const int rc = paths_fp8_scale(w, ldw, N, K, scale, scratch, stream);
+  const int rc = paths_fp8_scale(w, ldw, N, K, scale, scratch, nullptr, 0, stream);
   if (rc != PATHS_OK) return rc;
   const int Npad = (N + BN - 1) / BN * BN;
   const int64_t n4 = (int64_t)Npad * (K / 4);

@@ -484,19 +484,21 @@ def _fp8_image(fp, key: str, nbytes: int, dev, zero: bool = False) -> torch.Tens
     return buf
 
 
-def gemm_fp8(fp, a, lda: int, w8sc, bias, out, ldo: int, M: int, N: int, K: int, act: int = 0, residual=None, ldr: int = 0):
+def gemm_fp8(fp, a, lda: int, w8sc, bias, out, ldo: int, M: int, N: int, K: int, act: int = 0, residual=None, ldr: int = 0, tok=None):
     """out[M, N] = act(a[M, K] w^T + bias) (+ residual) with e4m3 operands (csrc/gemm_fp8.hip): per-tensor activation scale from a
     device-side max|a| (no host sync), the activation image from one quantisation pass, the weight image and its scale from :func:`fp8_pack`."""
     ptr = lambda t: t if isinstance(t, int) or t is None else t.data_ptr()
     st = _lib.stream()
-    _lib.call("paths_fp8_scale", ptr(a), lda, M, K, fp["a_scale"].data_ptr(), fp["scratch"].data_ptr(), st)
+    # tok = (num_ims, T): the rows are tokens of slides - only valid ones count for the scale (padded rows may hold anything)
+    _lib.call("paths_fp8_scale", ptr(a), lda, M, K, fp["a_scale"].data_ptr(), fp["scratch"].data_ptr(), tok[0].data_ptr() if tok else None,
+              tok[1] if tok else 0, st)
     a8 = _fp8_image(fp, "a8", (M + 255) // 256 * 256 * K, w8sc[0].device)
     _lib.call("paths_fp8_quantize", ptr(a), lda, M, K, fp["a_scale"].data_ptr(), a8.data_ptr(), st)
     _lib.call("paths_gemm_nt_fp8", a8.data_ptr(), w8sc[0].data_ptr(), fp["a_scale"].data_ptr(), w8sc[1].data_ptr(), ptr(bias), ptr(out), ldo,
               M, N, K, act, ptr(residual), ldr, st)
 
 
-def ffn_fp8(fp, lay8, x2, d: int, b1, b2, y2, M: int):
+def ffn_fp8(fp, lay8, x2, d: int, b1, b2, y2, M: int, tok=None):
     """y2 = x2 + linear2(relu(linear1(x2))) with e4m3 operands and the hidden layer [M, 4d] handed from the first GEMM to the second
     as an e4m3 image (never as fp32: 1.6 GB written, read twice for max|.| and quantisation, at the stress shape).  Its per-tensor
     scale is CALIBRATED: the first call of a layer runs the fp32 hand-over and records 448 / (2 max|hidden|) (a factor 2 of head
@@ -506,15 +508,17 @@ def ffn_fp8(fp, lay8, x2, d: int, b1, b2, y2, M: int):
     st = _lib.stream()
     if "h_scale" not in lay8:
         hff = torch.empty((M, F), device=dev, dtype=torch.float32)
-        gemm_fp8(fp, x2, d, lay8["w1"], b1, hff, F, M, F, d, act=1)
+        gemm_fp8(fp, x2, d, lay8["w1"], b1, hff, F, M, F, d, act=1, tok=tok)
         sc = torch.empty((1,), device=dev, dtype=torch.float32)
-        _lib.call("paths_fp8_scale", hff.data_ptr(), F, M, F, sc.data_ptr(), fp["scratch"].data_ptr(), st)
+        _lib.call("paths_fp8_scale", hff.data_ptr(), F, M, F, sc.data_ptr(), fp["scratch"].data_ptr(), tok[0].data_ptr() if tok else None,
+                  tok[1] if tok else 0, st)
         sc *= 0.5
         lay8["h_scale"] = sc
         lay8["h_amax"] = torch.zeros((1,), device=dev, dtype=torch.int32)
-        gemm_fp8(fp, hff, F, lay8["w2"], b2, y2, d, M, d, F, residual=x2, ldr=d)
+        gemm_fp8(fp, hff, F, lay8["w2"], b2, y2, d, M, d, F, residual=x2, ldr=d, tok=tok)
         return
-    _lib.call("paths_fp8_scale", x2.data_ptr(), d, M, d, fp["a_scale"].data_ptr(), fp["scratch"].data_ptr(), st)
+    _lib.call("paths_fp8_scale", x2.data_ptr(), d, M, d, fp["a_scale"].data_ptr(), fp["scratch"].data_ptr(), tok[0].data_ptr() if tok else None,
+              tok[1] if tok else 0, st)
     a8 = _fp8_image(fp, "a8", (M + 255) // 256 * 256 * d, dev)
     _lib.call("paths_fp8_quantize", x2.data_ptr(), d, M, d, fp["a_scale"].data_ptr(), a8.data_ptr(), st)
     h8 = _fp8_image(fp, "h8", (M + 255) // 256 * 256 * F, dev, zero=True)
@@ -567,7 +571,7 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
 
         def gemm(a, lda, key, bias, out, ldo, m, n, kdim, act=0, residual=None, ldr=0, low=False):
             if low:
-                gemm_fp8(fp, a, lda, fp["layers"][l][key], bias, out, ldo, m, n, kdim, act, residual, ldr)
+                gemm_fp8(fp, a, lda, fp["layers"][l][key], bias, out, ldo, m, n, kdim, act, residual, ldr, tok=(num_ims, T) if m == M else None)
             else:
                 gemm_f32(a, lda, gl[key], bias, out, ldo, m, n, kdim, act, residual, ldr, split=(gl, key))
 
@@ -596,7 +600,7 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
                   rows, d, lay["eps"], st)
         y2 = x1                           # (re-used)
         if big:
-            ffn_fp8(fp, fp["layers"][l], x2, d, lay["b1"], lay["b2"], y2, rows)
+            ffn_fp8(fp, fp["layers"][l], x2, d, lay["b1"], lay["b2"], y2, rows, tok=(num_ims, T))
         else:
             hff = torch.empty((rows, 4 * d), **f32)
             gemm(x2, d, "w1", lay["b1"], hff, 4 * d, rows, 4 * d, d, act=1)

@@ -1090,7 +1090,7 @@ def test_gemm_fp8_matches_float64_on_the_same_quantised_operands(dev, M, N, K, a
     w8 = torch.empty(((N + 255) // 256 * 256, K), dtype=torch.uint8, device=dev)
     a8 = torch.empty(((M + 255) // 256 * 256, K), dtype=torch.uint8, device=dev)
     _lib.call("paths_fp8_pack_weight", p(wd), K, N, K, p(w8), p(sw), p(scratch), st)
-    _lib.call("paths_fp8_scale", p(ad), K, M, K, p(sa), p(scratch), st)
+    _lib.call("paths_fp8_scale", p(ad), K, M, K, p(sa), p(scratch), None, 0, st)
     _lib.call("paths_fp8_quantize", p(ad), K, M, K, p(sa), p(a8), st)
     out = torch.full((M, N), 7.0, device=dev)
     _lib.call("paths_gemm_nt_fp8", p(a8), p(w8), p(sa), p(sw), p(bd), p(out), N, M, N, K, act, p(rd) if res else None, N if res else 0, st)
@@ -1105,6 +1105,17 @@ def test_gemm_fp8_matches_float64_on_the_same_quantised_operands(dev, M, N, K, a
     assert float((o - same).abs().max() / same.abs().max()) < 1e-4       # (the e4m3 matrix-core path does not keep full fp32 accumulation: measured 2e-5)
     err = float((o - exact).abs().max() / exact.abs().max())
     assert 1e-3 < err < 0.1, err
+    # token-major activations: rows of padded tokens (anything: here 1e30 / NaN) do not count for the scale
+    if M % 4 == 0:
+        T_ = M // 4
+        nims = torch.tensor([T_ - 1, T_ // 2, 0, T_ - 3])                   # valid rows per slide: num_ims + 1
+        pois = a.clone()
+        rowv = (torch.arange(T_)[None, :] <= nims[:, None]).reshape(-1)
+        pois[~rowv] = 1e30
+        pois[~rowv, 0] = float("nan")
+        sa2 = torch.empty(1, device=dev)
+        _lib.call("paths_fp8_scale", p(pois.to(dev)), K, M, K, p(sa2), p(scratch), p(nims.to(dev)), T_, st)
+        assert abs(float(sa2) * float(a[rowv].abs().max()) - 448) < 0.5
     # the e4m3 hand-over form: the same product quantised in the epilogue with a given scale, and its max|result| reported
     if not res:
         so = torch.tensor([448.0 / float(exact.abs().max()) * 0.5], device=dev)

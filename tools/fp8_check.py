@@ -25,7 +25,7 @@ def run(M, N, K, act=0, res=True, reps=0):
     sa, sw = torch.empty(1, device=dev), torch.empty(1, device=dev)
     w8 = torch.empty(((N + 255) // 256 * 256, K), dtype=torch.uint8, device=dev)
     _lib.call("paths_fp8_pack_weight", p(wd), K, N, K, p(w8), p(sw), p(scratch), st)
-    _lib.call("paths_fp8_scale", p(ad), K, M, K, p(sa), p(scratch), st)
+    _lib.call("paths_fp8_scale", p(ad), K, M, K, p(sa), p(scratch), None, 0, st)
     out = torch.full((M, N), 7.0, device=dev)
     a8 = torch.empty(((M + 255) // 256 * 256, K), dtype=torch.uint8, device=dev)
     _lib.call("paths_fp8_quantize", p(ad), K, M, K, p(sa), p(a8), st)
