@@ -89,6 +89,10 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const 
  *                      pre-scaled by powers of two: weights by w_scale when packed (max|w| w_scale < 65504), activations by
  *                      a_scale inside the kernel (|activation| a_scale < 65504; below 0.125 / a_scale the lo plane is
  *                      subnormal: absolute error 2^-25 / a_scale per element).  Accumulators are un-scaled in the epilogues.
+ *   planes = 4        (paths_gemm_nt_x6 / paths_x6_pack_weights only): TWO bf16 planes (hi + mid of the exact split: 16
+ *                      significant bits per operand, fp32's exponent range: no scales, nothing overflows); hi*hi + hi*mid + mid*hi,
+ *                      3 bf16 MFMAs per block, relative error of a product ~2e-5.  The gradient GEMMs of the training step
+ *                      (round 3; paths_gemm_tn_x6 has the same form as its planes = 2).
  * Activations stay fp32 in HBM; WEIGHTS are passed as the image produced once by paths_x6_pack_weights:
  *   [Npad/32][K/16][plane][k-half][32 rows][8 x 16 bit]   (paths_x6_packed_bytes(Npad, K, planes) = 2 planes Npad K bytes).
  * They replace the same reference code as their f32 twins (model/interface.py:31-58, model/paths.py:78-98,119-124). */
@@ -139,11 +143,12 @@ int64_t paths_gemm_tn_workspace(int N1, int N2, int splits);
 int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
                       float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
                       paths_stream_t stream);
-/* The same product on the bf16 matrix cores, three exact bf16 planes per operand split in registers (6 MFMAs per block, as
- * accurate as the f32 MFMA: see csrc/gemm_tn_x6.hip).  `splits` is an upper bound (>= 32 rows per split are kept); operands
- * must be smaller than 4 GiB each (32-bit buffer offsets). */
+/* The same product on the bf16 matrix cores, operands split in registers: planes = 3: three exact bf16 planes (6 MFMAs per block, as
+ * accurate as the f32 MFMA); planes = 2: hi | mid only (3 MFMAs, 16 significant bits per operand at fp32's exponent range, relative
+ * error of a product ~2e-5: the training step's default since round 3).  `splits` is an upper bound (>= 32 rows per split are kept);
+ * operands must be smaller than 4 GiB each (32-bit buffer offsets). */
 int paths_gemm_tn_x6(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
-                     float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
+                     float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace, int planes,
                      paths_stream_t stream);
 int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int splits, int accumulate, float* workspace,
                      paths_stream_t stream);

@@ -34,7 +34,7 @@ SIGNATURES = {
                          _i32, _f32, _f32, _vp],
     "paths_gemm_tn_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "paths_attention_fp8": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
-    "paths_gemm_tn_x6": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
+    "paths_gemm_tn_x6": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "paths_colsum_f32": [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "paths_transpose_f32": [_vp, _i64, _i32, _i32, _vp, _i64, _vp],
     "paths_lstm_bwd_a": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp],

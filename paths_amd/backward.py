@@ -98,7 +98,7 @@ def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, 
         b0p = b0 if isinstance(b0, int) else b0.data_ptr()
         b1p = None if b1 is None else (b1 if isinstance(b1, int) else b1.data_ptr())
         _lib.call("paths_gemm_tn_x6", ap, lda, b0p, ldb0, nb0, b1p, ldb1, P(out), ldo if ldo is not None else N2, M, N1, N2,
-                  splits, 1 if accumulate else 0, P(ws), _lib.stream())
+                  splits, 1 if accumulate else 0, P(ws), 2 if ops.TRAIN_PLANES == 4 else 3, _lib.stream())
         return
     splits = _splits(M, ((N1 + 127) // 128) * ((N2 + 127) // 128))
     ws = torch.empty((splits * N1 * N2,), **_f32(dev))

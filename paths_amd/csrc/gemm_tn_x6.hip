@@ -51,16 +51,21 @@ struct TnX6Operands {
   int splits;
 };
 
-template <int WT1, int WT2, int OCC>
+// PL = bf16 planes per operand: 3 (hi | mid | lo, six partial products: exact fp32 products) or 2 (hi | mid, three partial products
+// hi*hi + hi*mid + mid*hi: 16 significant bits per operand at fp32's exponent range, relative error of a product ~2e-5; half the
+// MFMAs, 7 instead of 12 split micro-steps, two thirds of the LDS traffic - the default of the training step since round 3)
+template <int WT1, int WT2, int OCC, int PL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 gemm_tn_x6_kernel(TnX6Operands g) {
+  static_assert(PL == 2 || PL == 3, "two or three bf16 planes");
+  constexpr int NPRD = PL == 3 ? 6 : 3;                   // partial products per operand pair
   constexpr int B1 = 64 * WT1, B2 = 64 * WT2;             // workgroup tile
   constexpr int NIA = (B1 + 127) / 128, NIB = (B2 + 127) / 128;   // 128-column images per plane
-  constexpr int OPA = 3 * NIA * IMG, STAGE = 3 * (NIA + NIB) * IMG;
+  constexpr int OPA = PL * NIA * IMG, STAGE = PL * (NIA + NIB) * IMG;
   constexpr int NCA = WT1, NCB = WT2, NC = NCA + NCB;     // fp32 chunks (4 floats) per thread per stage
-  constexpr int RG = WT2 * 6;                             // MFMA gaps per accumulator row
+  constexpr int RG = WT2 * NPRD;                          // MFMA gaps per accumulator row
   constexpr int NG = WT1 * RG, AG = (WT1 - 1) * RG;       // gaps per stage / before the barrier
-  constexpr int NS = 12;                                  // split micro-steps per chunk
+  constexpr int NS = PL == 3 ? 12 : 7;                    // split micro-steps per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
 
@@ -111,23 +116,31 @@ gemm_tn_x6_kernel(TnX6Operands g) {
   // split of one chunk in NS micro-steps of at most 2 VALU instructions; the last one is the three LDS writes
   auto a_step = [&](int q, int st, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[q];
+    const int ps = (q < NCA ? NIA : NIB) * IMG;           // plane stride of this operand
     if (st == 0) { hi[0] = pk_bf16(v[0], v[1]); hi[1] = pk_bf16(v[2], v[3]); }
     if (st == 1) { tf[0] = bf_lo(hi[0]); tf[1] = bf_hi(hi[0]); }
     if (st == 2) { v[0] -= tf[0]; v[1] -= tf[1]; }
     if (st == 3) { tf[0] = bf_lo(hi[1]); tf[1] = bf_hi(hi[1]); }
     if (st == 4) { v[2] -= tf[0]; v[3] -= tf[1]; }
     if (st == 5) { mid[0] = pk_bf16(v[0], v[1]); mid[1] = pk_bf16(v[2], v[3]); }
-    if (st == 6) { tf[0] = bf_lo(mid[0]); tf[1] = bf_hi(mid[0]); }
-    if (st == 7) { v[0] -= tf[0]; v[1] -= tf[1]; }
-    if (st == 8) { tf[0] = bf_lo(mid[1]); tf[1] = bf_hi(mid[1]); }
-    if (st == 9) { v[2] -= tf[0]; v[3] -= tf[1]; }
-    if (st == 10) { lo[0] = pk_bf16(v[0], v[1]); lo[1] = pk_bf16(v[2], v[3]); }
-    if (st == 11) {
-      char* d = smem + buf * STAGE + lwr[q];
-      const int ps = (q < NCA ? NIA : NIB) * IMG;         // plane stride of this operand
-      *reinterpret_cast<u32x2*>(d) = u32x2{hi[0], hi[1]};
-      *reinterpret_cast<u32x2*>(d + ps) = u32x2{mid[0], mid[1]};
-      *reinterpret_cast<u32x2*>(d + 2 * ps) = u32x2{lo[0], lo[1]};
+    if constexpr (PL == 2) {
+      if (st == 6) {
+        char* d = smem + buf * STAGE + lwr[q];
+        *reinterpret_cast<u32x2*>(d) = u32x2{hi[0], hi[1]};
+        *reinterpret_cast<u32x2*>(d + ps) = u32x2{mid[0], mid[1]};
+      }
+    } else {
+      if (st == 6) { tf[0] = bf_lo(mid[0]); tf[1] = bf_hi(mid[0]); }
+      if (st == 7) { v[0] -= tf[0]; v[1] -= tf[1]; }
+      if (st == 8) { tf[0] = bf_lo(mid[1]); tf[1] = bf_hi(mid[1]); }
+      if (st == 9) { v[2] -= tf[0]; v[3] -= tf[1]; }
+      if (st == 10) { lo[0] = pk_bf16(v[0], v[1]); lo[1] = pk_bf16(v[2], v[3]); }
+      if (st == 11) {
+        char* d = smem + buf * STAGE + lwr[q];
+        *reinterpret_cast<u32x2*>(d) = u32x2{hi[0], hi[1]};
+        *reinterpret_cast<u32x2*>(d + ps) = u32x2{mid[0], mid[1]};
+        *reinterpret_cast<u32x2*>(d + 2 * ps) = u32x2{lo[0], lo[1]};
+      }
     }
   };
 
@@ -157,7 +170,7 @@ gemm_tn_x6_kernel(TnX6Operands g) {
   auto tr_read = [&](uint32_t byte_off) -> u32x2 {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(smem + byte_off)));
   };
-  u32x4 fa[2][3], fb[2][WT2][3];
+  u32x4 fa[2][PL], fb[2][WT2][PL];
   auto read_a = [&](int buf, int i, int slot, int p) {
     const u32x2 x = tr_read(buf * STAGE + p * NIA * IMG + fra[i][0]), y = tr_read(buf * STAGE + p * NIA * IMG + fra[i][1]);
     fa[slot][p] = u32x4{x[0], x[1], y[0], y[1]};
@@ -176,17 +189,19 @@ gemm_tn_x6_kernel(TnX6Operands g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto one_mfma = [&](int gq, int sb) __attribute__((always_inline)) {
-    const int i = gq / RG, j = (gq % RG) / 6, t = gq % 6, sl = i & 1;
-    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][PA_[t]]), __builtin_bit_cast(bf16x8, fb[sb][j][PB_[t]]), acc[i][j], 0, 0, 0);
+    const int i = gq / RG, j = (gq % RG) / NPRD, t = gq % NPRD, sl = i & 1;
+    // smallest partial products first.  PL == 3: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi;  PL == 2: mid*hi, hi*mid, hi*hi
+    constexpr int PA3[6] = {2, 0, 1, 1, 0, 0}, PB3[6] = {0, 2, 1, 0, 1, 0}, PA2[3] = {1, 0, 0}, PB2[3] = {0, 1, 0};
+    const int pa = PL == 3 ? PA3[t] : PA2[t % 3], pb = PL == 3 ? PB3[t] : PB2[t % 3];
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][pa]), __builtin_bit_cast(bf16x8, fb[sb][j][pb]), acc[i][j], 0, 0, 0);
   };
 
   // staging slots: chunk q owns GPC consecutive gaps (SPG micro-steps each); its reload with stage kt+2 shares the last one
   constexpr auto fits = [](int spg) constexpr { return ((NS + spg - 1) / spg) * NC <= AG; };
-  constexpr int SPG = fits(1) ? 1 : fits(2) ? 2 : fits(3) ? 3 : 4;
+  constexpr int SPG = fits(1) ? 1 : fits(2) ? 2 : fits(3) ? 3 : fits(4) ? 4 : fits(6) ? 6 : NS;   // (128 x 128 tiles at two planes: few gaps)
   static_assert(fits(SPG), "staging does not fit before the barrier");
   constexpr int GPC = (NS + SPG - 1) / SPG;
-  constexpr int AR0 = RG / 2;                            // gaps AR0 .. AR0+2 of row i: fragment reads of A row i+1
+  constexpr int AR0 = RG / 2;                            // gaps AR0 .. AR0+PL-1 of row i: fragment reads of A row i+1
   auto staging_slot = [&](auto sc, int kt, auto bufc, auto m1c, auto m2c) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value, buf = decltype(bufc)::value;
     constexpr bool more1 = decltype(m1c)::value, more2 = decltype(m2c)::value;
@@ -206,7 +221,7 @@ gemm_tn_x6_kernel(TnX6Operands g) {
     static_for<0, AG>([&](auto gc) __attribute__((always_inline)) {
       constexpr int gq = decltype(gc)::value, i = gq / RG, gr = gq % RG;
       one_mfma(gq, sb);
-      if constexpr (gr >= AR0 && gr < AR0 + 3) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
+      if constexpr (gr >= AR0 && gr < AR0 + PL) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
       staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -218,14 +233,14 @@ gemm_tn_x6_kernel(TnX6Operands g) {
       if constexpr (more1) {
         static_for<2 * gr, 2 * gr + 2>([&](auto fc) __attribute__((always_inline)) {
           constexpr int f = decltype(fc)::value;
-          if constexpr (f < 3) read_a(buf ^ 1, 0, 0, f);
-          else if constexpr (f < 3 + 3 * WT2) read_b(buf ^ 1, (f - 3) / 3, sb ^ 1, (f - 3) % 3);
+          if constexpr (f < PL) read_a(buf ^ 1, 0, 0, f);
+          else if constexpr (f < PL + PL * WT2) read_b(buf ^ 1, (f - PL) / PL, sb ^ 1, (f - PL) % PL);
         });
       }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
-  static_assert(2 * RG >= 3 + 3 * WT2, "next stage's first fragments do not fit behind the barrier");
+  static_assert(2 * RG >= PL + PL * WT2, "next stage's first fragments do not fit behind the barrier");
   constexpr std::integral_constant<int, 0> I0{};
   constexpr std::integral_constant<int, 1> I1{};
   constexpr std::true_type T{};
@@ -242,11 +257,11 @@ gemm_tn_x6_kernel(TnX6Operands g) {
   }
   __syncthreads();
 #pragma unroll
-  for (int p = 0; p < 3; ++p) read_a(0, 0, 0, p);
+  for (int p = 0; p < PL; ++p) read_a(0, 0, 0, p);
 #pragma unroll
   for (int j = 0; j < WT2; ++j)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) read_b(0, j, 0, p);
+    for (int p = 0; p < PL; ++p) read_b(0, j, 0, p);
   for (int kt = 0; kt < nk - 2; kt += 2) {
     __builtin_amdgcn_sched_barrier(0);
     stage_body(kt, I0, T, T);
@@ -288,10 +303,10 @@ reduce_slabs_x6_kernel(const float* __restrict__ slabs, int splits, int64_t n, f
   *o = accumulate ? *o + s : s;
 }
 
-template <int WT1, int WT2>
+template <int WT1, int WT2, int PL>
 int launch_tn(const TnX6Operands& g, hipStream_t stream) {
-  constexpr int lds = 2 * 3 * ((64 * WT1 + 127) / 128 + (64 * WT2 + 127) / 128) * IMG;
-  auto kern = gemm_tn_x6_kernel<WT1, WT2, (WT1 * WT2 < 16 ? 2 : 1)>;
+  constexpr int lds = 2 * PL * ((64 * WT1 + 127) / 128 + (64 * WT2 + 127) / 128) * IMG;
+  auto kern = gemm_tn_x6_kernel<WT1, WT2, (WT1 * WT2 < 16 ? 2 : 1), PL>;
   PATHS_LDS_OPT_IN(kern, lds, "gemm_tn_x6");
   const int nblk = (g.N1 / (64 * WT1)) * (g.N2 / (64 * WT2)) * g.splits;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, stream, g);
@@ -302,12 +317,14 @@ int launch_tn(const TnX6Operands& g, hipStream_t stream) {
 
 extern "C" {
 
-// Same arguments as paths_gemm_tn_f32.  `splits` is an upper bound (the kernel needs >= 32 rows per split); `workspace` holds
+// Same arguments as paths_gemm_tn_f32 + planes: 3 = three bf16 planes per operand (exact fp32 products), 2 = two (16 significant bits
+// per operand, half the MFMAs).  `splits` is an upper bound (the kernel needs >= 32 rows per split); `workspace` holds
 // paths_gemm_tn_workspace(N1, N2, splits) floats.
 int paths_gemm_tn_x6(const float* a, int64_t lda, const float* b0, int64_t ldb0, int nb0, const float* b1, int64_t ldb1,
-                     float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace,
+                     float* out, int64_t ldo, int M, int N1, int N2, int splits, int accumulate, float* workspace, int planes,
                      hipStream_t stream) {
   PATHS_REQUIRE(M > 0 && N1 > 0 && N2 > 0 && splits > 0 && a && b0 && out && workspace, "gemm_tn_x6: bad arguments");
+  PATHS_REQUIRE(planes == 2 || planes == 3, "gemm_tn_x6: planes must be 2 or 3 (bf16 planes per operand)");
   PATHS_REQUIRE(N1 % 128 == 0 && N2 % 128 == 0, "gemm_tn_x6: N1 (%d) and N2 (%d) must be multiples of 128", N1, N2);
   PATHS_REQUIRE(lda % 4 == 0 && ldb0 % 4 == 0 && (b1 == nullptr || ldb1 % 4 == 0), "gemm_tn_x6: leading dimensions must be multiples of 4");
   PATHS_REQUIRE(b1 == nullptr || (nb0 % 128 == 0 && nb0 > 0 && nb0 < N2), "gemm_tn_x6: panel split must be a multiple of 128");
@@ -325,7 +342,8 @@ int paths_gemm_tn_x6(const float* a, int64_t lda, const float* b0, int64_t ldb0,
   const bool direct = nsplit == 1 && !accumulate;
   TnX6Operands g{a, lda, (uint32_t)a_bytes, b0, ldb0, nb0e, (uint32_t)b0_bytes, b1, ldb1, (uint32_t)b1_bytes, M, N1, N2,
                  direct ? out : workspace, direct ? ldo : (int64_t)N2, rps, nsplit};
-  const int rc_ = big ? launch_tn<4, 4>(g, stream) : launch_tn<2, 2>(g, stream);
+  const int rc_ = planes == 3 ? (big ? launch_tn<4, 4, 3>(g, stream) : launch_tn<2, 2, 3>(g, stream))
+                              : (big ? launch_tn<4, 4, 2>(g, stream) : launch_tn<2, 2, 2>(g, stream));
   if (rc_ != PATHS_OK) return rc_;
   PATHS_LAUNCH_CHECK("gemm_tn_x6");
   if (!direct) {

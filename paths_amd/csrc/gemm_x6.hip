@@ -56,8 +56,12 @@ __device__ __forceinline__ float h_lo(uint32_t p) { return (float)__builtin_bit_
 __device__ __forceinline__ float h_hi(uint32_t p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
 
 constexpr int FRAG = 1024;         // bytes of one 32-row x 16-k fragment of one plane (16-bit elements either way)
-// NP = planes per operand: 3 = bf16 hi|mid|lo, 6 MFMAs per product block ("x6"); 2 = fp16 hi|lo, 3 MFMAs ("h3")
-template <int NP> constexpr int subt() { return NP * FRAG; }    // one 32-row x 16-k sub-tile
+// NP = operand split: 3 = three bf16 planes hi|mid|lo, 6 MFMAs per product block ("x6", exact fp32 products); 2 = two fp16 planes
+// hi|lo, 3 MFMAs ("h3": 22 bits, operands pre-scaled by powers of two); 4 = TWO bf16 planes hi|mid, 3 MFMAs (hi*hi + hi*mid +
+// mid*hi: 16 significant bits per operand at fp32's exponent range - no scaling, no overflow: the gradient GEMMs of the training
+// step, whose operands span too many binades for a fixed-scale fp16 split; relative error of a product ~2e-5)
+template <int NP> constexpr int planes_of() { return NP == 4 ? 2 : NP; }
+template <int NP> constexpr int subt() { return planes_of<NP>() * FRAG; }    // one 32-row x 16-k sub-tile
 
 struct X6Operands {
   const float* A0; int64_t lda0; int K0;
@@ -88,14 +92,15 @@ uint64_t* g_x6_dbg = nullptr;
 template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi, int OCC = 1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 gemm_x6_kernel(X6Operands g, Epi epi) {
-  static_assert(NP == 2 || NP == 3, "two fp16 planes or three bf16 planes");
+  static_assert(NP == 2 || NP == 3 || NP == 4, "two fp16 planes, three bf16 planes or two bf16 planes");
+  constexpr int PL = planes_of<NP>();                  // planes per operand
   constexpr int SUBT = subt<NP>();
   constexpr int NPROD = NP == 3 ? 6 : 3;               // partial products kept per operand pair
   constexpr int BM = WTM * 64, BN = WTN * 64;
   constexpr int SA = 2 * WTM, SB = 2 * WTN;            // 32-row sub-tiles per block
   constexpr int STAGE = (SA + SB) * SUBT;
   constexpr int NA = BM / 64;                          // fp32 A chunks (4 floats) per thread per stage
-  constexpr int NPB = SB * NP, NB = (NPB + 3) / 4;     // 1-KiB W pieces per stage, per wave
+  constexpr int NPB = SB * PL, NB = (NPB + 3) / 4;     // 1-KiB W pieces per stage, per wave
   static_assert(WTM % 2 == 0, "A fragment register slots alternate per accumulator row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -153,13 +158,13 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   for (int i = 0; i < NB; ++i) {
     int pc = wave + 4 * i;
     if (pc >= NPB) pc -= 4;                            // re-stage this wave's previous piece (same bytes, same slot)
-    const int sub = pc / NP, pl = pc % NP;
+    const int sub = pc / PL, pl = pc % PL;
     bbase[i] = g.Wt + ((int64_t)(n0 >> 5) + sub) * g.w_group_stride + pl * FRAG;
     bwr[i] = (SA + sub) * SUBT + pl * FRAG + lane * 16;
   }
   static_assert(PF == 1 || PF == 2, "one or two register sets");
   f32x4 sa[PF][NA], sadd[ADD ? PF : 1][ADD ? NA : 1]; u32x4 sbr[PF][NB];
-  uint32_t hi[NA][2], mid[NP == 3 ? NA : 1][2], lo[NA][2];
+  uint32_t hi[NA][2], mid[NP != 2 ? NA : 1][2], lo[NA][2];
   // Loads go through buffer descriptors: a wave-uniform base (SGPRs), a scalar byte offset (stage, panel, W piece) and ONE
   // per-lane 32-bit offset computed once.  As 64-bit pointers hipcc strength-reduced each load's address into a VGPR pair it
   // then bumped with 3-4 VALU instructions per load; packed into the MFMA gaps of the 128-row tiles that stretched the first
@@ -198,7 +203,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // between two 32-cycle MFMAs hides about 24 cycles of other issue; the first version used 7 steps of 4 VALU + waits, every
   // such gap overflowed by ~15 cycles and idle gaps cannot win that back: ~500 cycles per stage (tools/x6_stages.py).
   //   NP == 3 (bf16): 12 micro-steps (+1 for the ADD sum);  NP == 2 (fp16): scale, hi, 2 x residuals (v_fma_mix), lo, writes = 6 (+1).
-  constexpr int NS = (NP == 3 ? 12 : 6) + (ADD ? 1 : 0);
+  constexpr int NS = (NP == 3 ? 12 : NP == 4 ? 7 : 6) + (ADD ? 1 : 0);
   float tf[NA][2];
   auto a_step = [&](int set, int q, int st0, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[set][q];
@@ -224,6 +229,18 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
         *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
         *reinterpret_cast<u32x2*>(d + 2 * FRAG) = u32x2{lo[q][0], lo[q][1]};
       }
+    } else if constexpr (NP == 4) {                     // hi | mid of the three-plane split: 16 significant bits, no scale
+      if (st == 0) { hi[q][0] = pk_bf16(v[0], v[1]); hi[q][1] = pk_bf16(v[2], v[3]); }
+      if (st == 1) { tf[q][0] = bf_lo(hi[q][0]); tf[q][1] = bf_hi(hi[q][0]); }
+      if (st == 2) { v[0] -= tf[q][0]; v[1] -= tf[q][1]; }
+      if (st == 3) { tf[q][0] = bf_lo(hi[q][1]); tf[q][1] = bf_hi(hi[q][1]); }
+      if (st == 4) { v[2] -= tf[q][0]; v[3] -= tf[q][1]; }
+      if (st == 5) { mid[q][0] = pk_bf16(v[0], v[1]); mid[q][1] = pk_bf16(v[2], v[3]); }
+      if (st == 6) {
+        char* d = smem + buf * STAGE + awr[q];
+        *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
+        *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
+      }
     } else {
       if (st == 0) v *= g.a_scale;                      // power of two: exact
       if (st == 1) { hi[q][0] = pk_f16(v[0], v[1]); hi[q][1] = pk_f16(v[2], v[3]); }
@@ -245,7 +262,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
 
   const char* sA = smem + (wm * WTM) * SUBT + lane * 16;
   const char* sB = smem + (SA + wn * WTN) * SUBT + lane * 16;
-  u32x4 fa[2][NP], fb[2][WTN][NP];                     // 8 x 16-bit per lane and plane
+  u32x4 fa[2][PL], fb[2][WTN][PL];                     // 8 x 16-bit per lane and plane
   auto read_a = [&](int buf, int i, int slot, int p) { fa[slot][p] = *reinterpret_cast<const u32x4*>(sA + buf * STAGE + i * SUBT + p * FRAG); };
   auto read_b = [&](int buf, int j, int slot, int p) { fb[slot][j][p] = *reinterpret_cast<const u32x4*>(sB + buf * STAGE + j * SUBT + p * FRAG); };
   constexpr int RG = WTN * NPROD;                      // MFMA gaps per accumulator row
@@ -253,6 +270,9 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     const int i = gq / RG, j = (gq % RG) / NPROD, t = gq % NPROD, sl = i & 1;
     if constexpr (NP == 3) {
       constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][PA_[t]]), __builtin_bit_cast(bf16x8, fb[sb][j][PB_[t]]), acc[i][j], 0, 0, 0);
+    } else if constexpr (NP == 4) {
+      constexpr int PA_[3] = {1, 0, 0}, PB_[3] = {0, 1, 0};                     // mid*hi, hi*mid, hi*hi
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[sl][PA_[t]]), __builtin_bit_cast(bf16x8, fb[sb][j][PB_[t]]), acc[i][j], 0, 0, 0);
     } else {
       constexpr int PA_[3] = {1, 0, 0}, PB_[3] = {0, 1, 0};                     // lo*hi, hi*lo, hi*hi
@@ -319,7 +339,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
     static_for<0, AG>([&](auto gc) __attribute__((always_inline)) {
       constexpr int gq = decltype(gc)::value, i = gq / RG, gr = gq % RG;
       one_mfma(gq, sb);
-      if constexpr (gr >= AR0 && gr < AR0 + NP) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
+      if constexpr (gr >= AR0 && gr < AR0 + PL) read_a(buf, i + 1, (i + 1) & 1, gr - AR0);
       staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -337,8 +357,8 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
       if constexpr (more1) {
         static_for<2 * gr, 2 * gr + 2>([&](auto fc) __attribute__((always_inline)) {
           constexpr int f = decltype(fc)::value;
-          if constexpr (f < NP) read_a(buf ^ 1, 0, 0, f);
-          else if constexpr (f < NP + NP * WTN) read_b(buf ^ 1, (f - NP) / NP, sb ^ 1, (f - NP) % NP);
+          if constexpr (f < PL) read_a(buf ^ 1, 0, 0, f);
+          else if constexpr (f < PL + PL * WTN) read_b(buf ^ 1, (f - PL) / PL, sb ^ 1, (f - PL) % PL);
         });
       }
       staging_slot(std::integral_constant<int, gq>{}, kt, bufc, m1c, m2c);   // (reload slots of the PF == 2 layout)
@@ -373,11 +393,11 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   }
   __syncthreads();
 #pragma unroll
-  for (int p = 0; p < NP; ++p) read_a(0, 0, 0, p);
+  for (int p = 0; p < PL; ++p) read_a(0, 0, 0, p);
 #pragma unroll
   for (int j = 0; j < WTN; ++j)
 #pragma unroll
-    for (int p = 0; p < NP; ++p) read_b(0, j, 0, p);
+    for (int p = 0; p < PL; ++p) read_b(0, j, 0, p);
 #ifdef PATHS_X6_DEBUG
   dbg_t1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -423,6 +443,10 @@ __global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, uint16_
     const __bf16 m = (__bf16)r1; const float r2 = r1 - (float)m;
     const __bf16 l = (__bf16)r2;
     o[0] = __builtin_bit_cast(uint16_t, h); o[FRAG / 2] = __builtin_bit_cast(uint16_t, m); o[FRAG] = __builtin_bit_cast(uint16_t, l);
+  } else if constexpr (NP == 4) {
+    const __bf16 h = (__bf16)v; const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    o[0] = __builtin_bit_cast(uint16_t, h); o[FRAG / 2] = __builtin_bit_cast(uint16_t, m);
   } else {
     const _Float16 h = (_Float16)v; const float r1 = v - (float)h;
     const _Float16 l = (_Float16)r1;
@@ -515,6 +539,9 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
     if (planes == 2) return launch_x6_np<2, WTM, WTN, PF, ADD, true>(g, Npad, epi, stream, name);
     return paths_set_error(PATHS_EUNSUPPORTED, "%s: row pointers need planes = 2", name);
   }
+  if constexpr (std::is_same<Epi, EpiBias>::value && !ADD) {      // two bf16 planes: the plain NT products only (training's dX GEMMs)
+    if (planes == 4) return launch_x6_np<4, WTM, WTN, PF, ADD, false>(g, Npad, epi, stream, name);
+  }
   if (planes == 3) return launch_x6_np<3, WTM, WTN, PF, ADD, false>(g, Npad, epi, stream, name);
   if (planes == 2) return launch_x6_np<2, WTM, WTN, PF, ADD, false>(g, Npad, epi, stream, name);
   return paths_set_error(PATHS_EINVAL, "%s: planes must be 3 (bf16 x6) or 2 (fp16 x3), got %d", name, planes);
@@ -528,7 +555,8 @@ static const bool IP_TILE128 = getenv("PATHS_IP_TILE128") != nullptr && atoi(get
 static const bool O_RAW = getenv("PATHS_O_RAW") == nullptr || atoi(getenv("PATHS_O_RAW")) != 0;
 static const bool H_SMALL_TILES = getenv("PATHS_H_SMALL_TILES") == nullptr || atoi(getenv("PATHS_H_SMALL_TILES")) != 0;
 
-inline int64_t group_stride(int planes, int Kpacked) { return (int64_t)(Kpacked / 16) * planes * FRAG; }
+inline int plane_count(int planes) { return planes == 4 ? 2 : planes; }      // API mode 4 = two bf16 planes
+inline int64_t group_stride(int planes, int Kpacked) { return (int64_t)(Kpacked / 16) * plane_count(planes) * FRAG; }
 inline bool pow2(float x) { int e; return x > 0.f && frexpf(x, &e) == 0.5f; }
 
 }  // namespace
@@ -544,7 +572,7 @@ void paths_x6_debug_buffer(uint64_t* p) { g_x6_dbg = p; }
 #endif
 
 // bytes of the packed image of an [Npad, K] weight: planes x 2 bytes per element
-int64_t paths_x6_packed_bytes(int Npad, int K, int planes) { return (int64_t)Npad * K * 2 * planes; }
+int64_t paths_x6_packed_bytes(int Npad, int K, int planes) { return (int64_t)Npad * K * 2 * plane_count(planes); }
 
 // w [N, K] fp32 (row stride ldw) -> out (paths_x6_packed_bytes bytes); Npad % 32 == 0, K % 16 == 0.
 // planes 3: exact bf16 hi|mid|lo (w_scale must be 1); planes 2: fp16 hi|lo of w * w_scale (w_scale a power of two chosen by
@@ -552,10 +580,11 @@ int64_t paths_x6_packed_bytes(int Npad, int K, int planes) { return (int64_t)Npa
 int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int planes, float w_scale, hipStream_t stream) {
   PATHS_REQUIRE(N > 0 && Npad >= N && Npad % 32 == 0 && K % 16 == 0, "x6_pack_weights: bad shape N=%d Npad=%d K=%d", N, Npad, K);
   PATHS_REQUIRE((uintptr_t)out % 16 == 0, "x6_pack_weights: out must be 16-byte aligned");
-  PATHS_REQUIRE((planes == 3 && w_scale == 1.0f) || (planes == 2 && pow2(w_scale)), "x6_pack_weights: planes 3 with w_scale 1, or planes 2 with a power-of-two w_scale");
+  PATHS_REQUIRE(((planes == 3 || planes == 4) && w_scale == 1.0f) || (planes == 2 && pow2(w_scale)), "x6_pack_weights: planes 3 / 4 (bf16) with w_scale 1, or planes 2 with a power-of-two w_scale");
   const int64_t n = (int64_t)Npad * K;
   const dim3 grid((unsigned)((n + 255) / 256));
-  if (planes == 3) hipLaunchKernelGGL(x6_pack_kernel<3>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, 1.0f);
+  if (planes == 4) hipLaunchKernelGGL(x6_pack_kernel<4>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, 1.0f);
+  else if (planes == 3) hipLaunchKernelGGL(x6_pack_kernel<3>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, 1.0f);
   else hipLaunchKernelGGL(x6_pack_kernel<2>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, w_scale);
   PATHS_LAUNCH_CHECK("x6_pack_weights");
   return PATHS_OK;
@@ -698,11 +727,12 @@ int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                      int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, hipStream_t stream) {
   PATHS_REQUIRE(k0 % 16 == 0 && k0 >= 0 && k0 + K <= Kpacked, "gemm_nt_x6: bad k window");
-  PATHS_REQUIRE(planes == 3 || (planes == 2 && pow2(w_scale) && pow2(a_scale)), "gemm_nt_x6: planes 3, or planes 2 with power-of-two scales");
-  if (planes == 3) w_scale = a_scale = 1.0f;
-  X6Operands g{a, lda, K, nullptr, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * planes * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
+  PATHS_REQUIRE(planes == 3 || planes == 4 || (planes == 2 && pow2(w_scale) && pow2(a_scale)), "gemm_nt_x6: planes 3 / 4 (bf16), or planes 2 with power-of-two scales");
+  if (planes != 2) w_scale = a_scale = 1.0f;
+  X6Operands g{a, lda, K, nullptr, nullptr, 0, 0, nullptr, 0, reinterpret_cast<const char*>(w_x6) + (int64_t)(k0 / 16) * plane_count(planes) * FRAG, group_stride(planes, Kpacked), M, nullptr, 0, a_scale};
   EpiBias e{b, out, ldo, N, act, residual, ldr, mask, ldm, accumulate, 1.0f / (w_scale * a_scale)};
   if (Npad % 256 != 0) {           // 128 / 384 output columns (the transformer layers' d = 128 products): 128 x 128 tiles, 2 workgroups per CU
+    if (planes == 4) return launch_x6_np<4, 2, 2, 2, false, false, EpiBias, 2>(g, Npad, e, stream, "gemm_nt_x6(n128, bf16 x 2)");
     if (planes == 3) return launch_x6_np<3, 2, 2, 2, false, false, EpiBias, 2>(g, Npad, e, stream, "gemm_nt_x6(n128)");
     return launch_x6_np<2, 2, 2, 2, false, false, EpiBias, 2>(g, Npad, e, stream, "gemm_nt_x6(n128)");
   }

@@ -48,7 +48,12 @@ GEMM_MODE = os.environ.get("PATHS_GEMM_MODE", "h3")
 A_SCALE = float(os.environ.get("PATHS_H3_A_SCALE", "16"))      # a power of two
 AGG_FP8 = os.environ.get("PATHS_AGG_FP8", "0") != "0"       # the whole aggregator's big products (in_proj, attention, out_proj, FFN) with e4m3 operands: the BASELINE configs[4] stress variant (opt-in, NOT a parity path: csrc/gemm_fp8.hip)
 ATTN_FP8 = os.environ.get("PATHS_ATTN_FP8", "0") != "0"     # inference attention with e4m3 operands (opt-in, see csrc/attn_fp8.hip)
-TRAIN_PLANES = 3        # training re-images weights every step: the bf16 split needs no scale, i.e. no host sync on max|w|
+# Operand split of the training step's GRADIENT GEMMs (dX = dY W, dW = dY^T X), bf16 planes (fp32's exponent range: gradients span too
+# many binades for a fixed-scale fp16 split, and re-imaging weights every step must not cost a host sync on max|w|):
+#   4 (default) = TWO planes (hi + mid, 16 significant bits per operand, 3 MFMAs per product block, relative error ~2e-5 per product);
+#   3           = three planes (exact fp32 products, 6 MFMAs).
+TRAIN_PLANES = int(os.environ.get("PATHS_TRAIN_PLANES", "4"))
+assert TRAIN_PLANES in (3, 4), "PATHS_TRAIN_PLANES must be 3 (exact) or 4 (two bf16 planes)"
 # forward GEMMs / attention of the TRAINING step: 2 = the inference split (fp16 planes) with lagged weight scales, 3 = exact bf16
 TRAIN_FWD_PLANES = int(os.environ.get("PATHS_TRAIN_FWD_PLANES", "2"))
 
@@ -113,7 +118,7 @@ def x6_pack(w: torch.Tensor, n_pad: Optional[int] = None, planes: Optional[int] 
         w_scale = 1.0
     elif w_scale is None:
         w_scale = _pow2_scale(w)
-    out = torch.empty((n_pad * K * 2 * planes,), device=w.device, dtype=torch.uint8)
+    out = torch.empty((n_pad * K * 2 * (2 if planes == 4 else planes),), device=w.device, dtype=torch.uint8)
     _lib.call("paths_x6_pack_weights", _lib.ptr(w), w.stride(0), _lib.ptr(out), N, n_pad, K, planes, w_scale, _lib.stream())
     return out, w_scale
 
