@@ -138,7 +138,17 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_FAST_STREAM = os.environ.get("PATHS_FAST_STREAM", "1") != "0"
+
+
 def stream() -> int:
+    """Handle of torch's current stream on the current device.  Called once per launch (~600 times per training step): the public
+    ``torch.cuda.current_stream()`` builds a Stream object through four Python layers (5 ms per step measured under cProfile); the
+    two C bindings below return the same handle directly."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None and _FAST_STREAM:
+        return _RAW_STREAM(_GET_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
