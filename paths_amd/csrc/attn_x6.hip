@@ -22,8 +22,20 @@
 #include "dropout.h"
 
 DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
+#if defined(PATHS_ATTN_STAMPS) && !defined(PATHS_ATTN_DEBUG)
+#define PATHS_ATTN_DEBUG 1
+#endif
 #ifdef PATHS_ATTN_DEBUG
 unsigned long long* g_attn_dbg = nullptr;
+#endif
+// PATHS_ATTN_STAMPS = n (diagnostic builds only, tools/attn_stamps.py): s_memtime stamps between the phases of a key step, summed
+// per wave 0 of every workgroup into the debug buffer (16 words per workgroup).  1: around the barrier only (the schedule of the
+// step stays hipcc's), 2: every phase (pins the phases apart: shares, never quoted as run time).
+#ifdef PATHS_ATTN_STAMPS
+#define ATTN_STAMP(i, lvl) do { if (PATHS_ATTN_STAMPS >= (lvl)) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    st_acc[i] += (unsigned)(t_ - st_prev); st_prev = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define ATTN_STAMP(i, lvl) do { } while (0)
 #endif
 
 namespace {
@@ -55,14 +67,17 @@ __device__ __forceinline__ uint32_t pk_f16(float a, float b) {
 }
 // 8 fp32 -> two planes of 8 fp16 (hi, lo): 22 significant bits
 __device__ __forceinline__ void split8h(const float (&x)[8], u32x4& hi, u32x4& lo) {
+  // residual + rounding of the lo plane: one v_fma_mixlo_f16 / v_fma_mixhi_f16 per value (common.h: f16_pair_residuals_pk), the four
+  // low halves first: a half-register write directly in front of the other half's costs a wait state each (16 s_nop per key step)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = x[2 * i], b = x[2 * i + 1];
-    const uint32_t h = pk_f16(a, b);
-    float ra, rb;
-    f16_pair_residuals(h, a, b, ra, rb);
-    hi[i] = h; lo[i] = pk_f16(ra, rb);
-  }
+  for (int i = 0; i < 4; ++i) hi[i] = pk_f16(x[2 * i], x[2 * i + 1]);
+  uint32_t r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[i]) : "v"(hi[i]), "v"(x[2 * i]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r[i]) : "v"(hi[i]), "v"(x[2 * i + 1]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) lo[i] = r[i];
 }
 // planes[0..NP) of 8 values
 template <int NP>
@@ -153,6 +168,9 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[3], const u32x4 (&b
   return c;
 }
 __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x4 c) {   // hi, lo: all but lo*lo
+#if PATHS_ATTN_WHATIF & 4
+  return mfma_f16(a[0], b[0], c);
+#endif
   c = mfma_f16(a[1], b[0], c);
   c = mfma_f16(a[0], b[1], c);
   c = mfma_f16(a[0], b[0], c);
@@ -187,6 +205,20 @@ constexpr bool ATTN_P1 = PATHS_ATTN_P1 != 0;      // P as one fp16 plane (see th
 #define PATHS_ATTN_DEFER 8
 #endif
 constexpr float ATTN_DEFER = (float)(PATHS_ATTN_DEFER);   // deferred-rescale threshold in log2 units (0 = rescale every step)
+#ifndef PATHS_ATTN_WHATIF
+#define PATHS_ATTN_WHATIF 0
+#endif
+// PATHS_ATTN_WHATIF (diagnostic builds, WRONG results, tools/attn_time.py): 1 no exp2, 2 no lo plane of P, 4 one MFMA per product
+// block, 8 no PV products, 16 no score products, 32 no LDS fragment reads (one fragment set re-used), 64 no staging (loads, LDS writes)
+constexpr int WHATIF = PATHS_ATTN_WHATIF;
+#ifndef PATHS_ATTN_FAST
+#define PATHS_ATTN_FAST 1
+#endif
+// FAST (two fp16 planes, no dropout): the running maximum is SUBTRACTED INSIDE the score product (the accumulators of S^T = K Q^T
+// start at -m_run instead of 0) and is only revised when a probability sum says it has to be: the common key step has no maximum
+// chain, no subtraction, no vote on the scores - exp2, the sum, the fp16 hi | lo split and nothing else (VALU instructions per
+// score element 6.7 -> ~4.5; the kernel is VALU-issue bound: round-4 measurement).
+constexpr bool ATTN_FAST = PATHS_ATTN_FAST != 0 && !ATTN_P1;
 template <int NP, bool DROP>
 __global__ void __launch_bounds__(256, ATTN_OCC)
 attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6,
@@ -234,9 +266,11 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < QT; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr bool FAST = ATTN_FAST && NP == 2 && !DROP;
   float m_run[QT], l_run[QT];
+  f32x4 negm[QT];                                       // FAST: -m_run in all four elements = the C operand of the score products
 #pragma unroll
-  for (int j = 0; j < QT; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
+  for (int j = 0; j < QT; ++j) { m_run[j] = FAST ? 0.f : -INFINITY; l_run[j] = 0.f; negm[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   // staging: one 64-key step = 4 NP KiB of K fragments + 4 NP KiB of V^T fragments, both contiguous in their images.
   // Software pipeline: S(k+1) = K(k+1) Q^T is issued BEFORE the softmax of S(k), so one wave's MFMAs run under its own VALU work
@@ -269,9 +303,12 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     for (int t = 0; t < 4; ++t) {
       u32x4 kf[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const u32x4*>(sK + (t * NP + p) * FRAG);
+      for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const u32x4*>(sK + (((WHATIF & 32) ? 0 : t) * NP + p) * FRAG);
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma_split(kf, qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int qt = 0; qt < QT; ++qt) {
+        if constexpr ((WHATIF & 16) != 0) { s[qt][t] = negm[qt]; asm("" : "+v"(s[qt][t])); }
+        else s[qt][t] = mfma_split(kf, qf[qt], negm[qt]);      // (zero outside FAST)
+      }
     }
   };
   gload_k(0); gload_v(0);
@@ -392,20 +429,136 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     if (kt + 1 < nkt) swrite_v(kt + 1);                 // over V(kt-1)
     __syncthreads();
   };
+  // FAST step.  Invariant on entry: s = S(kt) - m_run (per query tile), as the MFMA left it.  P = exp2(s) is taken optimistically;
+  // a lane whose 16-key probability sum exceeds 2^ATTN_DEFER (or is inf: a score far above the running maximum) sends the wave
+  // through the revision path: true maximum of the step, m_run += d, everything already computed relative to the old value
+  // (l, O^T, these scores and the next step's, which are in flight) re-based, probabilities recomputed.  The first key step always
+  // revises (m_run starts at 0; there d may be negative).  P <= 2^ATTN_DEFER keeps the fp16 planes far from their range.
+#ifdef PATHS_ATTN_STAMPS
+  unsigned st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
+  auto step_fast = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], auto lastc) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(lastc)::value;
+    if constexpr (PATHS_ATTN_PRIO_SHIFT >= 0) {
+      if ((((kt >> PATHS_ATTN_PRIO_SHIFT) ^ prio_parity) & 1) != 0) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    ATTN_STAMP(0, 1);
+    if constexpr ((WHATIF & 64) == 0) {
+    if (kt + 2 < nkt) gload_k(kt + 2);
+    if (kt + 1 < nkt) gload_v(kt + 1);
+    }
+    if constexpr (ATTN_OCC >= 3) qk(kt, s);
+    const char* sV = sVb + (kt & 1) * HALF + lane * 16;
+    if constexpr (LAST) {
+      const int kbase = kt * KSTEP + 4 * g4;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
+    }
+    if constexpr (ATTN_OCC < 3) qk(kt + 1, sn);
+    ATTN_STAMP(1, 2);
+    u32x4 pf[QT][2][2];
+    float psum[QT];
+    auto probs = [&](int qt) __attribute__((always_inline)) {
+      // four independent partial sums (a 16-deep dependent chain sat on the step's critical path: hipcc packed the two query tiles'
+      // chains into v_pk_add_f32, each followed by a wait state); the empty asm keeps them scalar
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) of the PV product = key 4 g4 + (j&3) + 16 (j>>2) of the group
+          pv[j] = (WHATIF & 1) ? s[qt][2 * kg + (j >> 2)][j & 3] : __builtin_amdgcn_exp2f(s[qt][2 * kg + (j >> 2)][j & 3]);
+          ps[j & 3] += pv[j];
+          asm("" : "+v"(ps[j & 3]));
+        }
+        if constexpr ((WHATIF & 2) != 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pf[qt][kg][0][i] = pf[qt][kg][1][i] = pk_f16(pv[2 * i], pv[2 * i + 1]);
+        } else split_planes<2>(pv, pf[qt][kg]);
+      }
+      psum[qt] = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) probs(qt);
+    ATTN_STAMP(2, 2);
+    float pmax = psum[0];
+#pragma unroll
+    for (int qt = 1; qt < QT; ++qt) pmax = fmaxf(pmax, psum[qt]);
+    if (kt == 0 || __any(!(pmax <= 256.0f))) {          // 2^8 (ATTN_DEFER); !(<=) also catches a NaN
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          mx = fmaxf(fmaxf(mx, s[qt][t][0]), s[qt][t][1]);
+          mx = fmaxf(fmaxf(mx, s[qt][t][2]), s[qt][t][3]);
+        }
+        mx = rows_max(mx);                              // finite: key 0 (special token) is valid for every query
+        const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+        l_run[qt] *= alpha;
+        oacc[0][qt] *= alpha;
+        oacc[1][qt] *= alpha;
+        m_run[qt] += d;
+        negm[qt] = f32x4{-m_run[qt], -m_run[qt], -m_run[qt], -m_run[qt]};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s[qt][t] -= f32x4{d, d, d, d};
+          if constexpr (ATTN_OCC < 3) sn[qt][t] -= f32x4{d, d, d, d};
+        }
+        probs(qt);
+      }
+    }
+    ATTN_STAMP(3, 2);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) l_run[qt] += psum[qt];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int dvt = 0; dvt < 2; ++dvt) {
+        u32x4 vf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + (((WHATIF & 32) ? 0 : (kg * 2 + dvt)) * NP + p) * FRAG);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          if constexpr ((WHATIF & 8) != 0) { oacc[dvt][qt] += __builtin_bit_cast(f32x4, pf[qt][kg][0]) + __builtin_bit_cast(f32x4, pf[qt][kg][1]) + __builtin_bit_cast(f32x4, vf[0]); }
+          else oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
+        }
+      }
+    ATTN_STAMP(4, 2);
+    if constexpr ((WHATIF & 64) == 0) {
+    if (kt + 2 < nkt) swrite_k(kt + 2);
+    if (kt + 1 < nkt) swrite_v(kt + 1);
+    }
+    ATTN_STAMP(5, 1);
+    __syncthreads();
+    ATTN_STAMP(6, 1);
+  };
+  auto stepx = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], auto lastc) __attribute__((always_inline)) {
+    if constexpr (FAST) step_fast(kt, s, sn, lastc);
+    else step(kt, s, sn, lastc);
+  };
   {
     constexpr std::false_type MID{};
     constexpr std::true_type END{};
     int kt = 0;
     if constexpr (ATTN_OCC >= 3) {
-      for (; kt + 1 < nkt; ++kt) step(kt, sA, sA, MID);
-      step(kt, sA, sA, END);
+      for (; kt + 1 < nkt; ++kt) stepx(kt, sA, sA, MID);
+      stepx(kt, sA, sA, END);
     } else {
       for (; kt + 2 < nkt; kt += 2) {
-        step(kt, sA, sB, MID);
-        step(kt + 1, sB, sA, MID);
+        stepx(kt, sA, sB, MID);
+        stepx(kt + 1, sB, sA, MID);
       }
-      if (kt + 1 < nkt) { step(kt, sA, sB, MID); step(kt + 1, sB, sA, END); }
-      else step(kt, sA, sB, END);
+      if (kt + 1 < nkt) { stepx(kt, sA, sB, MID); stepx(kt + 1, sB, sA, END); }
+      else stepx(kt, sA, sB, END);
     }
   }
 #pragma unroll
@@ -443,7 +596,14 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#ifdef PATHS_ATTN_STAMPS
+    unsigned long long* d = dbg + 16 * blockIdx.x;
+    d[0] = dbg_t0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = ((unsigned long long)xcc << 32) | hwid;
+    for (int i = 0; i < 8; ++i) d[3 + i] = st_acc[i];
+    d[11] = (unsigned long long)nkt;
+#else
     dbg[3 * blockIdx.x] = dbg_t0; dbg[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); dbg[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hwid;
+#endif
   }
 #endif
 }

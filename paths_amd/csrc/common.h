@@ -52,6 +52,16 @@ __device__ __forceinline__ void f16_pair_residuals(uint32_t h, float a, float b,
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
 }
 
+// The same residuals ROUNDED to fp16 and packed (the lo plane of the pair): v_fma_mixlo_f16 / v_fma_mixhi_f16 compute the fp32
+// FMA and write its fp16 rounding (nearest even, as v_cvt_pk_f16_f32) into one half of the destination - two instructions where
+// residuals + pack took three.
+__device__ __forceinline__ uint32_t f16_pair_residuals_pk(uint32_t h, float a, float b) {
+  uint32_t r;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(b));
+  return r;
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
