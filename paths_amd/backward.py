@@ -25,6 +25,10 @@ TN_SPLIT2 = int(os.environ.get("PATHS_TN_SPLIT2", "2"))
 TN_MODE = os.environ.get("PATHS_TN_MODE", "x6")
 # dX / recompute GEMMs go to the split-operand kernel when the output width is a multiple of this (128: the d = 128 products too)
 NT_X6_MIN_N = int(os.environ.get("PATHS_NT_X6_MIN_N", "128"))
+# Row counts from which the gradient GEMMs run on the split-bf16 kernels (below: the f32-input MFMA kernels, which are as fast there).
+# Module constants so that tests can force the split kernels onto the small shapes of the reference's trajectory fixtures.
+NT_X6_MIN_M = int(os.environ.get("PATHS_NT_X6_MIN_M", "1024"))
+TN_X6_MIN_M = int(os.environ.get("PATHS_TN_X6_MIN_M", "512"))
 # attention backward: "x6q" = the split-bf16 kernels (csrc/attn_bwd_x6.hip: dQ, and dK / dV unless PATHS_ATTN_BWD_KV_X6=0), "f32" = all of it on the f32 MFMA (csrc/attn_bwd.hip)
 ATTN_BWD_MODE = os.environ.get("PATHS_ATTN_BWD_MODE", "x6q")
 
@@ -63,7 +67,7 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
     rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
     mp = None if mask is None else (mask if isinstance(mask, int) else mask.data_ptr())
     ldw = ldw if ldw is not None else K
-    if ops.GEMM_MODE != "f32" and N % NT_X6_MIN_N == 0 and K >= 128 and K % 128 == 0 and M >= 1024 and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
+    if ops.GEMM_MODE != "f32" and N % NT_X6_MIN_N == 0 and K >= 128 and K % 128 == 0 and M >= NT_X6_MIN_M and isinstance(wt, torch.Tensor) and wt.dim() == 2 \
             and wt.shape[0] >= N and wt.stride(0) == ldw and wt.stride(1) == 1:
         # split-bf16 GEMM: the (transposed) weight is re-imaged per call - 6 N K bytes, microseconds next to an M >= 1024 product
         wx, wx_s = ops.x6_pack(wt[:N, :K], planes=ops.TRAIN_PLANES)
@@ -91,7 +95,7 @@ def _splits_x6(M: int, N1: int, N2: int, nb0: int) -> int:
 def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, accumulate=False):
     """out[N1,N2] (+)= a[M,N1]^T [b0 | b1][M,N2]."""
     dev = out.device
-    if TN_MODE == "x6" and M >= 512 and N1 % 128 == 0 and N2 % 128 == 0 and M * 4 * max(lda, ldb0, ldb1) < (1 << 31):
+    if TN_MODE == "x6" and M >= TN_X6_MIN_M and N1 % 128 == 0 and N2 % 128 == 0 and M * 4 * max(lda, ldb0, ldb1) < (1 << 31):
         splits = _splits_x6(M, N1, N2, nb0 if b1 is not None else 0)
         ws = torch.empty((splits * N1 * N2,), **_f32(dev))
         ap = a if isinstance(a, int) else a.data_ptr()

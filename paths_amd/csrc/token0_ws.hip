@@ -642,13 +642,28 @@ extern "C" {
 
 int64_t paths_token0_ws_image_bytes(void) { return (int64_t)IMG_FLOATS * 4; }
 
-// token splits of the distributed form: the largest nts in {8, 4, 2, 1} with 128-token splits and at most 192 workgroups in the
-// launch (all of them must be able to run at once: one 512-thread workgroup per CU); 0 = use the single-chain form
+// token splits of the distributed form: the largest nts in {8, 4, 2, 1} with 128-token splits whose launch fits the chip with room
+// to spare - every workgroup of a slide spins on its siblings' arrival, so ALL of them must be resident at once: at most 3/4 of
+// (CUs x resident 512-thread workgroups of this kernel per CU, both asked from the runtime per device; 192 on an MI355X in SPX
+// mode) - the rest of the chip may hold another stream's kernels; 0 = use the single-chain form
+static int dist_limit() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cached[dev] == 0) {
+    int cus = 0, occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(token0_dist_kernel), NT, 0) != hipSuccess || occ <= 0) return 0;
+    cached[dev] = cus * (occ > 1 ? 1 : occ) * 3 / 4;      // (counted at ONE workgroup per CU: a second one there would share its memory queue)
+  }
+  return cached[dev];
+}
 static int dist_splits(int B, int T) {
   static const bool off = getenv("PATHS_T0_DIST") != nullptr && atoi(getenv("PATHS_T0_DIST")) == 0;
   if (off) return 0;
+  const int limit = dist_limit();
   for (int nts = 8; nts >= 1; nts >>= 1)
-    if (NH * nts * B <= 192 && (nts == 1 || (nts - 1) * TS_TOKENS < T)) return nts;
+    if (NH * nts * B <= limit && (nts == 1 || (nts - 1) * TS_TOKENS < T)) return nts;
   return 0;
 }
 static int chain_splits(int T) {

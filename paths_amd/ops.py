@@ -219,6 +219,7 @@ def token0_ws_image(layer: Dict[str, object], qscale: float) -> torch.Tensor:
 
 
 _T0_COUNTERS: Dict[tuple, torch.Tensor] = {}
+_T0_RETIRED: List[torch.Tensor] = []
 
 
 def token0_counters(dev, B: int) -> torch.Tensor:
@@ -227,6 +228,8 @@ def token0_counters(dev, B: int) -> torch.Tensor:
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.stream())
     t = _T0_COUNTERS.get(key)
     if t is None or t.numel() < 3 * B:
+        if t is not None:
+            _T0_RETIRED.append(t)        # recorded launch tapes / captured graphs hold its address: never hand the block back
         t = _T0_COUNTERS[key] = torch.zeros((max(768, 3 * B),), device=dev, dtype=torch.int32)
     return t
 
@@ -536,7 +539,7 @@ def ffn_fp8(fp, lay8, x2, d: int, b1, b2, y2, M: int, tok=None):
 
 def fp8_supported(mc) -> bool:
     d, H = mc.trans_dim, mc.trans_heads
-    return d % 64 == 0 and d % H == 0 and (d // H) in (32, 64)
+    return d % 128 == 0 and d % H == 0 and (d // H) in (32, 64)      # paths_gemm_nt_fp8 needs K % 128 == 0 (one 64-k instruction pair per stage)
 
 
 def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8: bool = False) -> Dict[str, torch.Tensor]:
@@ -635,7 +638,12 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     state_prev: [B,N,>=D+Hc] view whose last dim holds (h|c) of the previous level (row stride arbitrary) or None;
     ctx_prev [B,d] (residual source) or None; ctx_all [B,depth,d] contiguous (concat mode) or None."""
     sel = selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding)
-    agg = aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all)
+    status = torch.zeros((1,), device=fts.device, dtype=torch.int32)
+    agg = aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status)
+    # the drop-in call is synchronous anyway (the range guard above it syncs): a token-0 tail whose bounded hand-off wait gave up
+    # (status bit 2, csrc/token0_ws.hip) must not hand back its logits
+    if int(status.item()) & 4:
+        raise _lib.PathsHipError("a bounded in-launch hand-off wait of the token-0 tail gave up (csrc/token0_ws.hip): results invalid")
     return {"logits": agg["logits"], "ctx_slide": agg["ctx_slide"], "ctx_patch": sel["ctx_patch"], "importance": sel["importance"]}
 
 

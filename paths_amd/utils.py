@@ -43,17 +43,26 @@ def recurse(model, slides, keep_patches: Sequence[int], num_levels: int,
     out = _recurse(model, slides, keep_patches, num_levels, trace, careful=False)
     if not check_status:
         return out
-    code = int(out["status"].item())            # the only host sync of the fast path, after the last level
-    if code & 1:
+    if check_status_word(out["status"]):        # the only host sync of the fast path, after the last level
         if trace is not None:
             trace.clear()
         out = _recurse(model, slides, keep_patches, num_levels, trace, careful=True)
-        code = int(out["status"].item()) & ~1
+        check_status_word(out["status"], fallback_done=True)
+    return out
+
+
+def check_status_word(status, fallback_done: bool = False) -> bool:
+    """Decode the device status word of one recursion (ONE host sync).  Returns True when the batch needs the careful re-run (bit 0:
+    some slide produced zero children, reference data_utils/slide.py:336-352); raises on the bits that invalidate the results - bit 1
+    (child capacity exceeded) and bit 2 (a bounded in-launch hand-off wait of the token-0 tail gave up, csrc/token0_ws.hip).  Every
+    path that returns recursion outputs goes through here: recurse(), GraphedRecursion.run(), TapedRecursion.run() and the
+    training forward (autograd.forward_backward)."""
+    code = int(status.item()) if torch.is_tensor(status) else int(status)
     if code & 2:
         raise RecursionError_("child capacity exceeded (internal error)")
     if code & 4:
         raise RecursionError_("a bounded in-launch hand-off wait of the token-0 tail gave up (csrc/token0_ws.hip): results invalid")
-    return out
+    return bool(code & 1) and not fallback_done
 
 
 class GraphedRecursion:
@@ -100,12 +109,9 @@ class GraphedRecursion:
     def run(self) -> Dict[str, torch.Tensor]:
         """replay + the status check of :func:`recurse` (one host sync after the last level)."""
         out = self.replay()
-        code = int(out["status"].item())
-        if code & 1:
+        if check_status_word(out["status"]):
             with torch.no_grad():
                 return recurse(self.model, self.batch, self.keep, self.levels)
-        if code & 2:
-            raise RecursionError_("child capacity exceeded (internal error)")
         return out
 
 
@@ -144,7 +150,8 @@ class TapedRecursion:
     def close(self):
         """Drop the tape and destroy the HIP events of its stream joins (a service that records one tape per batch would otherwise
         accumulate about a dozen events per tape).  Called by __del__; the tape can be recorded again afterwards."""
-        evs, self._events = self._events[0], [[], 0]
+        evs = (getattr(self, "_events", None) or [[], 0])[0]      # (__init__ may have raised before _events existed)
+        self._events = [[], 0]
         self.tape = None
         if evs:
             try:
@@ -206,12 +213,9 @@ class TapedRecursion:
     def run(self) -> Dict[str, torch.Tensor]:
         """replay + the status check of :func:`recurse` (one host sync after the last level)."""
         out = self.replay()
-        code = int(out["status"].item())
-        if code & 1:
+        if check_status_word(out["status"]):
             with torch.no_grad():
                 return recurse(self.model, self.batch, self.keep, self.levels)
-        if code & 2:
-            raise RecursionError_("child capacity exceeded (internal error)")
         return out
 
 
@@ -591,15 +595,12 @@ def forward_backward(model, batch, num_levels, keep_patches, task: str = "surviv
     outputs, loss = loss_from_logits(out["logits"], batch, task, global_batch)
     loss.backward()
     ev.synchronize()
-    code = int(host[0])
-    if code & 1:
+    if check_status_word(int(host[0])):
         model.zero_grad(set_to_none=True)
         out = recurse_train(model, batch["slide"], keep_patches, num_levels, careful=True)
         outputs, loss = loss_from_logits(out["logits"], batch, task, global_batch)
         loss.backward()
-        code = int(out["status"].item()) & ~1
-    if code & 2:
-        raise RecursionError_("child capacity exceeded (internal error)")
+        check_status_word(out["status"], fallback_done=True)
     pag.fill_dead_grads(model)
     return outputs, loss
 

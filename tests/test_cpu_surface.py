@@ -132,6 +132,16 @@ def test_cpu_inputs_are_rejected_loudly():
         cell(torch.zeros(2, 128), torch.zeros(2, 128), torch.zeros(2, 64))
 
 
+def test_status_word_decoding():
+    """paths_amd.utils.check_status_word: bit 0 asks for the careful re-run, bits 1 and 2 invalidate the results."""
+    from paths_amd import utils as putils
+    assert putils.check_status_word(0) is False and putils.check_status_word(torch.tensor([1])) is True
+    assert putils.check_status_word(1, fallback_done=True) is False
+    for code in (2, 4, 6, 3, 5):
+        with pytest.raises(putils.RecursionError_):
+            putils.check_status_word(code)
+
+
 def test_synthetic_generator_properties():
     from paths_amd import synthetic as syn
     s = syn.SyntheticSlide(7, 3, (4, 5), dim=64, num_levels=3, p_bg=0.25)

@@ -1,5 +1,6 @@
 """GPU tests of the hand-written backward kernels against torch autograd (float64) over the oracle's formulas."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -522,13 +523,63 @@ def test_training_on_zero_children_slides_takes_the_fallback(dev):
     assert live > 100
 
 
-@pytest.mark.parametrize("name", ["g6_train_16x16_top64", "g13_train_td192_8x8_top16", "g13_train_td64_h2_hi32_8x8_top16"])
-def test_three_adamw_steps_match_reference_g6(dev, name):
+@pytest.mark.parametrize("M,N,K", [(2048, 1024, 1792), (1500, 128, 512), (4099, 256, 128), (1024, 384, 128)])
+@pytest.mark.parametrize("planes", [3, 4])
+def test_gemm_nt_train_planes_matches_fp64(dev, monkeypatch, planes, M, N, K):
+    """dX = dY W on the split-bf16 kernel at BOTH training settings against float64 (the two-plane default of the dX
+    GEMM had no unit test): gradient rows spread over 24 binades, bias, relu, mask, residual, accumulate, ragged M.  planes 3 =
+    three exact bf16 planes (fp32-accurate), 4 = two planes (16 significant bits per operand: a product ~2e-5)."""
+    from paths_amd import backward as bw, ops
+    monkeypatch.setattr(ops, "TRAIN_PLANES", planes)
+    tol = 2e-6 if planes == 3 else 3e-5
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-28, -4, (M, 1), generator=g).float())
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 2.0 ** -16
+    res = torch.randn(M, N, generator=g) * 2.0 ** -16
+    mask = (torch.rand(M, N, generator=g) > 0.3).float()
+    dyd, wd = dy.to(dev), w.to(dev)
+    assert M >= bw.NT_X6_MIN_M and N % bw.NT_X6_MIN_N == 0 and K % 128 == 0      # (the split kernel is the one that runs)
+    o = torch.empty(M, N, device=dev)
+    bw.gemm_nt(dyd, K, wd, o, N, M, N, K)
+    ref = dy.double() @ w.double().t()
+    row_rel = ((o.cpu().double() - ref).abs().amax(1) / ref.abs().amax(1).clamp_min(1e-300)).max().item()      # PER ROW: small-gradient rows count
+    assert row_rel < 3 * tol, row_rel         # (max-norm per row: fp32 accumulation over K = 1792 alone is ~2.5e-6 there)
+    assert rel_err(o, ref) < tol
+    o2 = torch.full((M, N), 2.0 ** -16, device=dev)
+    bw.gemm_nt(dyd, K, wd, o2, N, M, N, K, bias=bias.to(dev), act=1, residual=res.to(dev), ldr=N, mask=mask.to(dev), ldm=N, accumulate=True)
+    ref2 = torch.relu(ref + bias.double()) * mask.double() + res.double() + 2.0 ** -16
+    assert rel_err(o2, ref2) < tol
+    o3 = torch.empty_like(o)
+    bw.gemm_nt(dyd, K, wd, o3, N, M, N, K)
+    assert torch.equal(o3, o)
+
+
+@pytest.mark.parametrize("name,forced", [("g6_train_16x16_top64", False), ("g13_train_td192_8x8_top16", False), ("g13_train_td64_h2_hi32_8x8_top16", False),
+                                         ("g6_train_16x16_top64", True), ("g13_train_td192_8x8_top16", True)])
+def test_three_adamw_steps_match_reference_g6(dev, monkeypatch, name, forced):
     """Reference train-step semantics (train.py:49-50,59-68): losses of 3 AdamW steps vs the fixtures captured from the
     reference (G6: the shipped geometry; G13: its dataclass-default trans_dim 192 and a small free geometry, on the shape-generic
-    training kernels), dead parameters included in weight decay, unused classifiers left with grad None."""
-    from paths_amd import utils as putils
+    training kernels), dead parameters included in weight decay, unused classifiers left with grad None.
+    ``forced``: the row-count thresholds of the split-bf16 gradient GEMMs lowered to 64 rows, so that the TWO-PLANE kernels of
+    the training default (PATHS_TRAIN_PLANES=4) - which these small fixtures otherwise hardly reach - produce every eligible dX / dW
+    of the three steps; the same 1e-5 loss bar."""
+    from paths_amd import utils as putils, backward as bw, ops
     from tests.conftest import load_golden
+    if forced:
+        assert ops.TRAIN_PLANES == 4 or os.environ.get("PATHS_TRAIN_PLANES") == "3"
+        monkeypatch.setattr(bw, "NT_X6_MIN_M", 64)         # (the fixtures' levels have B x 64 ... B x 257 rows; the 8-row token-0 chain
+        monkeypatch.setattr(bw, "TN_X6_MIN_M", 64)         #  keeps its one-wave-per-column kernel)
+        calls = {"nt": 0, "tn": 0}
+        real_call = bw._lib.call
+
+        def counting_call(fname, *a):
+            if fname == "paths_gemm_nt_x6":
+                calls["nt"] += 1
+            elif fname == "paths_gemm_tn_x6":
+                calls["tn"] += 1
+            return real_call(fname, *a)
+        monkeypatch.setattr(bw._lib, "call", counting_call)
     g, info = load_golden(name)
     cfg, model, params, slides, batch = _train_setup(dev, info["wseed"], info["dseed"], info["top_k"], tuple(info["base_shape"]), info["B"],
                                                      cfg_over=info.get("cfg_over") or None)
@@ -540,6 +591,8 @@ def test_three_adamw_steps_match_reference_g6(dev, name):
     np.testing.assert_allclose(losses, g["losses"], atol=1e-5, rtol=0)      # SURVEY 8(a) row T bar; measured: <= 4e-7
     none = sorted(n for n, p_ in model.named_parameters() if p_.grad is None)
     assert none == sorted(info["grad_none"])
+    if forced:
+        assert calls["nt"] >= 15 and calls["tn"] >= 15, calls      # the split kernels really produced the gradients
 
 
 def test_data_parallel_shards_sum_to_global_batch(dev):

@@ -978,6 +978,42 @@ def test_taped_recursion_replays_bit_identically(dev):
     assert torch.equal(putils.TapedRecursion(model2, fb, cfg2.top_k_patches, 5).run()["logits"], ref3["logits"])
 
 
+def test_replay_paths_raise_on_invalidating_status_bits(dev):
+    """status bit 2 (value 4: a bounded hand-off wait of the token-0 tail gave up) and bit 1 (capacity) must raise in
+    EVERY path that hands back recursion outputs - the replayed tape and the captured graph too, not only recurse().  The tape's
+    own zero fill of the status word is taken out and the word preset: kernels only OR bits into it, so the replay ends with it."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 3, None, top_k_patches=[8] * 4)
+    slides = DeviceSlideBatch([DeviceSlide.synthetic(41, sid, (5, 6), p_bg=0.1, device=dev) for sid in range(2)])
+    t = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5)
+    ok = t.run()
+    assert int(ok["status"].item()) == 0
+    sptr = t.out["status"].data_ptr()
+    fills = [i for i, (_, a, name) in enumerate(t.tape) if name == "paths_memset_zero" and int(getattr(a[0], "value", a[0]) or 0) == sptr]
+    assert len(fills) == 1, "the status word's zero fill is on the tape exactly once"
+    full = list(t.tape)
+    for code in (4, 2, 6):
+        t.tape = [e for i, e in enumerate(full) if i != fills[0]]
+        t.out["status"].fill_(code)
+        torch.cuda.synchronize()
+        with pytest.raises(putils.RecursionError_):
+            t.run()
+    t.tape = full
+    assert torch.equal(t.run()["logits"], ok["logits"])
+    g = putils.GraphedRecursion(model, slides, cfg.top_k_patches, 5)
+    g.replay = lambda: {"status": torch.tensor([4], device=dev, dtype=torch.int32)}
+    with pytest.raises(putils.RecursionError_):
+        g.run()
+    for code, want in ((0, False), (1, True)):
+        assert putils.check_status_word(torch.tensor([code])) is want
+    assert putils.check_status_word(1, fallback_done=True) is False
+    for code in (2, 4, 5, 7):
+        with pytest.raises(putils.RecursionError_):
+            putils.check_status_word(code)
+    t.close()
+
+
 def test_tape_owns_its_buffers(dev):
     """The tape replays raw device addresses: the recorded pass's intermediates must stay the tape's after that pass has returned.
     An eager recursion of ANOTHER batch made afterwards allocates on the same three streams - from the default caching allocator
