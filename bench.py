@@ -44,7 +44,9 @@ CPU_DSEED = 1234
 # slide ids of the cpu_baseline / parity sample: screened here with the oracle so that every level's top-K boundary gap
 # (score[k-1] - score[k]) is >= 1e-5 with the bench weights (seed 0) - the reference's own selection is thread-count
 # dependent below ~1e-6 (hard part 1); id 10001 at K=2048 has a 2.4e-7 gap at level 0 and is left out
-CPU_SLIDE_IDS = {2048: [10003, 10004, 10005, 10002], 1024: [10000, 10001, 10003, 10002], 256: [10000, 10001, 10002, 10003]}
+# (round 4: 10006-10008, 10011, 10014 added so that the parity sample is a FULL 8-slide batch; 10002 (2.1e-6 at level 2), 10009,
+# 10010 and 10012 have gaps < 1e-5)
+CPU_SLIDE_IDS = {2048: [10003, 10004, 10005, 10006, 10007, 10008, 10011, 10014], 1024: [10000, 10001, 10003, 10002], 256: [10000, 10001, 10002, 10003]}
 
 
 def log(msg):
@@ -110,8 +112,8 @@ def cpu_baseline(cfg, sd, K: int, n_slides: int, reps: int):
     log(f"cpu_baseline: {threads} threads (os.cpu_count()={os.cpu_count()}), {n_slides} slides x {reps} reps")
     ocfg = orc.OracleConfig(top_k_patches=list(cfg.top_k_patches))
     params = {k: torch.from_numpy(v) for k, v in sd.items()}
+    n_slides = min(n_slides, len(CPU_SLIDE_IDS[K]))
     ids = CPU_SLIDE_IDS[K][:n_slides]
-    assert len(ids) == n_slides, f"at most {len(CPU_SLIDE_IDS[K])} screened cpu slides"
     grids = [CachedGrids(syn.SyntheticSlide(CPU_DSEED, i, BASE_SHAPES[K])) for i in ids]
     otrace = []
     with torch.no_grad():
@@ -266,6 +268,17 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
         dist.destroy_process_group()
 
 
+def train_dtype(planes: int) -> str:
+    """What the training step multiplies in (paths_amd.ops.TRAIN_PLANES)."""
+    fwd = "forward: f32 operands as 2 fp16 planes (22 bits), 3 MFMAs per product block, fp32 accumulate"
+    if planes == 4:
+        return ("mixed: " + fwd + "; gradient GEMMs (dX, dW): operands as 2 bf16 planes = 16 significant bits at fp32 range, 3 MFMAs per "
+                "block, fp32 accumulate (PATHS_TRAIN_PLANES=4, the default); attention backward: 3 exact bf16 planes; master weights, "
+                "gradients and AdamW state fp32")
+    return ("f32: " + fwd + "; gradient GEMMs and attention backward: operands as 3 exact bf16 planes (hi + mid + lo = the fp32 value), 6 "
+            "MFMAs per block, fp32 accumulate (PATHS_TRAIN_PLANES=3); master weights, gradients and AdamW state fp32")
+
+
 def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unused):
     """Secondary metric (BASELINE.json configs[3]): training slides/s = recursion forward + hand-written HIP backward +
     AdamW, one flat 39.5 MB gradient all-reduce per step over RCCL when world > 1."""
@@ -273,7 +286,8 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
     model.train()
     labels = np.asarray([s.synthetic_spec.label(4) for s in slides.slides], np.int64)
     batch = {"slide": slides, "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    from paths_amd.optim import HipAdamW
+    opt = (torch.optim.AdamW if os.environ.get("PATHS_TORCH_ADAMW", "0") != "0" else HipAdamW)(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
     gb = len(slides) * world
     ar = pdist.allreduce_gradients if world > 1 else None
 
@@ -303,7 +317,8 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
         print(json.dumps({
             "metric": "train_slides_per_sec_5level_K%d_D1024" % K, "value": round(gb * args.steps / elapsed, 2), "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": train_dtype(__import__("paths_amd.ops", fromlist=["ops"]).TRAIN_PLANES),
+            "data": "synthetic", "train_planes": __import__("paths_amd.ops", fromlist=["ops"]).TRAIN_PLANES,
             "config": {"workload": f"train step (reference train.py:59-68 semantics): 5-level recursion K={K}, forward + HIP backward + "
                                    f"AdamW, {len(slides)} slides per GPU, dropout {cfg.model_config.dropout}", "global_batch": gb,
                        "parallelism": f"dp{world}: one flat fp32 gradient all-reduce per step" if world > 1 else "single GPU"},
@@ -354,16 +369,21 @@ def self_launch(n: int) -> int:
     return rc
 
 
-def train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, steps: int, warmup: int):
+def train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, steps: int, warmup: int, planes=None):
     """Short training measurement for the DEFAULT bench line (BASELINE.json configs[3] shape on this rank's resident slides):
     forward + hand-written HIP backward + AdamW (+ the flat gradient all-reduce when a process group exists) on a COPY of the
     model; returns ms_per_step (max over ranks), slides/s of the whole job, peak memory and the all-reduce time per step."""
     import copy
     import numpy as np
+    from paths_amd import ops as pops
+    saved_planes = pops.TRAIN_PLANES
+    if planes is not None:
+        pops.TRAIN_PLANES = int(planes)
     m = copy.deepcopy(model).train()
     labels = np.asarray([s.synthetic_spec.label(4) for s in slides.slides], np.int64)
     batch = {"slide": slides, "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
-    opt = torch.optim.AdamW(m.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+    from paths_amd.optim import HipAdamW
+    opt = (torch.optim.AdamW if os.environ.get("PATHS_TORCH_ADAMW", "0") != "0" else HipAdamW)(m.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
     gb = len(slides) * world
     grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
     ar = pdist.allreduce_gradients if grouped else None
@@ -386,7 +406,10 @@ def train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, steps: int
            "allreduce_ms": round(sum(a.elapsed_time(b) for a, b in ar_ms) / len(ar_ms), 3) if ar_ms else None,
            "allreduce": (f"one flat fp32 bucket per step over {torch.distributed.get_backend()} (world {world})" if grouped else
                          "none (single rank without a process group)"),
+           "train_planes": pops.TRAIN_PLANES, "dtype": train_dtype(pops.TRAIN_PLANES), "optimizer": type(opt).__name__ + (
+               " (torch.optim.AdamW's foreach update in one HIP launch, bit-identical: paths_amd/optim.py)" if type(opt).__name__ == "HipAdamW" else ""),
            "workload": "train step (reference train.py:59-68): 5-level recursion forward + HIP backward + AdamW on the same resident slides"}
+    pops.TRAIN_PLANES = saved_planes
     del m, opt
     torch.cuda.empty_cache()
     return out
@@ -399,8 +422,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--slides-per-gpu", type=int, default=8)
     ap.add_argument("--k", type=int, default=2048, choices=sorted(BASE_SHAPES))
-    ap.add_argument("--cpu-slides", type=int, default=2)
-    ap.add_argument("--cpu-reps", type=int, default=8)
+    ap.add_argument("--cpu-slides", type=int, default=8, help="slides of the cpu_baseline / parity_checked sample (a full batch at K=2048; "
+                    "capped at the number of screened ids of the K)")
+    ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="timed region issues every launch through the Python launch path instead of "
                     "replaying the recorded launch tape (paths_amd.utils.TapedRecursion)")
@@ -408,7 +432,8 @@ def main():
                     "(paths_amd.utils.GraphedRecursion) instead of issuing every launch from Python.  Measured on ROCm 7.2: the host "
                     "share drops from 0.65 to 0.13 of the step but the replay executes the three captured streams with far less "
                     "overlap (3.92 ms per step against 2.43 ms eager), so eager launches stay the default")
-    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the extra DVFS-steady loop (0 = skip)")
+    ap.add_argument("--sustain", type=float, default=6.0, help="seconds of the extra DVFS-steady loop (0 = skip); >= 6 s so that a 5-s "
+                    "utilisation sampler beside the run lands inside GPU work")
     ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
     ap.add_argument("--trans-dim", type=int, default=128, help="stress mode: aggregator width (BASELINE configs[4] reports 128 and 1536; "
@@ -566,6 +591,33 @@ def main():
         live.setdefault(name, []).append((e0.elapsed_time(e1), meta))
     events.clear()
 
+    # ---- launch modes side by side on the SAME rotation of resident batches: replay = one recorded tape per
+    # batch (the headline), rebind = ONE tape re-pointed at the next batch before every step (TapedRecursion.rebind: what a stream of
+    # distinct slides pays), eager = every launch through the Python path, un-instrumented
+    launch_modes = None
+    if replays is not None and not args.graph and nrot > 1 and world == 1:
+        def timed_loop(fn):
+            for i in range(nrot):
+                fn(i)
+            barrier()
+            t1_ = time.perf_counter()
+            for i in range(args.steps):
+                fn(i)
+            barrier()
+            return time.perf_counter() - t1_
+        one = replays[0]
+        el_rb = timed_loop(lambda i: one.rebind(batches[i % nrot]).replay())
+        assert one.tape is not None and one._rec_batch is not None, "rebind dropped the tape on a same-shape batch"
+        one.rebind(batches[0])
+        el_rp = timed_loop(lambda i: replays[i % nrot].replay())
+        el_eg = timed_loop(lambda i: step(batch=batches[i % nrot]))
+        launch_modes = {"steps": args.steps, "batches_rotated": nrot,
+                        "replay_slides_per_s": round(spg * args.steps / el_rp, 2), "rebind_slides_per_s": round(spg * args.steps / el_rb, 2),
+                        "eager_slides_per_s": round(spg * args.steps / el_eg, 2),
+                        "note": "replay: one tape per resident batch; rebind: ONE tape, table tensors re-pointed at the next batch before "
+                                "every step (no re-recording); eager: Python launch path"}
+        log(f"launch modes: replay {launch_modes['replay_slides_per_s']}, rebind {launch_modes['rebind_slides_per_s']}, eager {launch_modes['eager_slides_per_s']} slides/s")
+
     # ---- sustained figure: the same step for >= --sustain seconds (DVFS-steady clocks; the 20-step region above lasts ~50 ms)
     sustained = None
     if args.sustain > 0:
@@ -716,6 +768,11 @@ def main():
         try:
             train = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 3)
             log(f"train probe: {train['ms_per_step']} ms per step, all-reduce {train['allreduce_ms']} ms")
+            # the same step with the OTHER gradient-operand setting (the fp32-accurate three-plane split unless that is the default)
+            other = 3 if train["train_planes"] == 4 else 4
+            t2 = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 2, planes=other)
+            train[f"planes{other}"] = {k: t2[k] for k in ("ms_per_step", "slides_per_s", "train_planes", "dtype")}
+            log(f"train probe (PATHS_TRAIN_PLANES={other}): {t2['ms_per_step']} ms per step")
         except Exception as e:       # the headline (already measured above) must not be lost to a failure of the secondary probe
             train = {"error": f"{type(e).__name__}: {e}"[:400]}
             log(f"train probe FAILED: {train['error']}")
@@ -740,10 +797,13 @@ def main():
                                      "order of an fp32 FMA chain's); everything else fp32") if planes == 2 else
                                     ("x6: operands split exactly into 3 bf16 planes, 6 bf16 MFMAs per product block, fp32 "
                                      "accumulate (error <= an fp32 FMA chain's); everything else fp32") if x6 else "f32 MFMA"},
-            "roofline": roofline,
+            "roofline": dict(roofline, attn_ffn=None if roofline_attn is None else {
+                k: roofline_attn.get(k) for k in ("achieved", "peak", "unit", "frac", "avg_span_us", "serialized_span_us", "serialized_frac",
+                                                   "serialized_frac_of_measured_peak", "algorithmic_gflop_per_level_launch")}),
             "roofline_attn_ffn": roofline_attn,
             "host": {"launch_mode": launch_mode,
                      "t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3), "eager_instrumented_pass": eager,
+                     "launch_modes": launch_modes,
                      "note": "roofline / roofline_attn_ffn event timings come from the eager instrumented pass of the same K steps "
                              "(the replayed launch sequence carries no events)" if graphed is not None else None},
         }

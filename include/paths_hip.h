@@ -154,6 +154,18 @@ int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int 
                      paths_stream_t stream);
 int paths_transpose_f32(const float* in, int64_t ldi, int R, int C, float* out, int64_t ldo, paths_stream_t stream);
 
+/* Multi-tensor AdamW, one launch per step (replaces torch.optim.AdamW's ~12 foreach launches, reference train.py:49-50 /
+ * train.py:66 `opt.step()`; same operation order and fp32 rounding as torch/optim/adam.py:_multi_tensor_adam, so a training
+ * trajectory is torch's own bit for bit).  All arrays live in DEVICE memory: table [n][4] addresses (param, grad, exp_avg,
+ * exp_avg_sq; fp32 contiguous tensors), numel [n], blocks [nblocks][2] = (tensor index, first element) with
+ * paths_adamw_chunk() elements per block, step_size [n] = -lr / (1 - beta1^t), bc2_sqrt [n] = sqrt(1 - beta2^t).
+ * wd_scale = 1 - lr * weight_decay (has_wd = 0: no decay), lerp_w = 1 - beta1 (< 0.5), value = 1 - beta2;
+ * flavor: bit 0 / 1 / 2 = lerp / addcmul / addcdiv evaluated as ONE fused multiply-add (7 = what the installed torch does). */
+int paths_adamw_chunk(void);
+int paths_adamw_multi(const int64_t* table, const int64_t* numel, const int32_t* blocks, int nblocks, const float* step_size,
+                      const float* bc2_sqrt, float wd_scale, int has_wd, float lerp_w, float beta2, float value, float eps, int flavor,
+                      paths_stream_t stream);
+
 /* LSTMCell backward, element-wise parts (reference model/interface.py:52-56 differentiated):
  *   a: dpre_o = dh1 tc o(1-o) -> dG[:, 3Hc:], dpre_h = dh1 o (1-tc^2);  b: packed df|dr|dm -> dG[:, :3Hc], dc0 = dc1 f. */
 int paths_lstm_bwd_a(const float* dh1, int64_t ldd, const float* dh1b, int64_t lddb, const float* o, const float* tc,

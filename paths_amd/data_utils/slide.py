@@ -124,3 +124,13 @@ class DeviceSlideBatch:
 
     def __len__(self):
         return len(self.slides)
+
+    def clone_tables(self) -> "DeviceSlideBatch":
+        """The same batch with PRIVATE copies of the table tensors (a recorded launch tape addresses these, and re-points them at
+        other batches: paths_amd.utils.TapedRecursion.rebind); the slides themselves are shared."""
+        c = object.__new__(DeviceSlideBatch)
+        c.__dict__.update(self.__dict__)
+        for name in ("grid_ptrs", "mask_ptrs", "gx", "gy"):
+            setattr(c, name, [t.clone() for t in getattr(self, name)])
+        c.max_dim = list(self.max_dim)
+        return c

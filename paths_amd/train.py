@@ -104,7 +104,13 @@ def train_loop(model, train_ds, val_ds, test_ds, config, model_dir: str, log=Non
     for key in ["train_loss", f"train_{score_key}", "val_loss", f"val_{score_key}"]:
         train_stats.setdefault(key, {})
     train_eval, val_eval = mk_eval("train"), mk_eval("val")
-    opt = torch.optim.AdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay)
+    # reference train.py:49-50: torch.optim.AdamW.  HipAdamW IS that class (state, state_dict, schedulers) with step() as one HIP
+    # launch that reproduces torch's foreach update bit for bit (paths_amd/optim.py); PATHS_TORCH_ADAMW=1 keeps torch's step
+    if next(model.parameters()).is_cuda and os.environ.get("PATHS_TORCH_ADAMW", "0") == "0":
+        from .optim import HipAdamW
+        opt = HipAdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay)
     sched = config.get_lr_scheduler(opt)
     ar = pdist.allreduce_gradients if world > 1 else None
     best_val = -1

@@ -135,6 +135,7 @@ class TapedRecursion:
         self.model, self.keep, self.levels, self.lane = model, list(keep_patches), int(num_levels), int(lane)
         self.batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
         self.tape, self.out, self.versions, self.stream_handle = None, None, None, None
+        self._rec_batch = None               # private copy of the recorded batch's table TENSORS: what the tape addresses (rebind() re-points them)
         self._events = [[], 0]               # HIP events of the tape's stream joins, re-used when the tape is recorded again
         # The tape holds raw device addresses of every intermediate of the recorded pass.  Those tensors are freed when the pass
         # returns; from the default caching allocator their blocks would be handed to whoever allocates next, and a replay would
@@ -170,7 +171,8 @@ class TapedRecursion:
         saved_lane, STREAM_LANE = STREAM_LANE, self.lane
         try:
             with torch.no_grad():
-                _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)      # warm-up: builds cached images / tables
+                tab = self.batch.clone_tables()                  # the tape's OWN table tensors (rebind() re-points them)
+                _recurse(self.model, tab, self.keep, self.levels, None, careful=False)      # warm-up: builds cached images / tables
                 torch.cuda.synchronize(self.batch.device)
                 assert _lib.TAPE is None, "a launch tape is already being recorded"
                 self.out = None                                   # (a re-recording re-uses the pool's blocks: drop the old outputs first)
@@ -179,7 +181,7 @@ class TapedRecursion:
                 _lib.TAPE_EVENTS = self._events
                 try:
                     with torch.cuda.use_mem_pool(self._pool, device=self.batch.device):
-                        out = _recurse(self.model, self.batch, self.keep, self.levels, None, careful=False)
+                        out = _recurse(self.model, tab, self.keep, self.levels, None, careful=False)
                 finally:
                     _lib.TAPE, _lib.TAPE_EVENTS = None, None
                 torch.cuda.synchronize(self.batch.device)
@@ -189,6 +191,33 @@ class TapedRecursion:
         tape = [(fn, tuple(a if a is None else t(a) for t, a in zip(fn.argtypes, args)), name) for fn, args, name in tape]
         self.tape, self.out, self.versions = tape, out, self._param_versions()
         self.stream_handle = torch.cuda.current_stream(self.batch.device).cuda_stream
+        self._rec_batch = tab
+        return self
+
+    def rebind(self, slides) -> "TapedRecursion":
+        """Point the recorded tape at ANOTHER batch of resident slides without recording again (a stream of distinct slides would
+        otherwise pay record() per batch or run eager).  The tape addresses the recorded batch's per-level TABLE tensors (grid / mask
+        base pointers, grid dims: a private copy made by record()), never the slides themselves, and every capacity in it is static - so a batch
+        with the same slide count, feature width and level count whose level-0 cell count, grid extents and operand range fit the
+        recorded ones is bound by copying its tables into those tensors (a few hundred bytes per level, device to device, enqueued
+        on the current stream: no host sync).  Anything else drops the tape; the next replay records for the new batch."""
+        new = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
+        rec = self._rec_batch
+        fits = (self.tape is not None and rec is not None and len(new) == len(rec) and new.dim == rec.dim and new.device == rec.device
+                and new.num_levels >= self.levels and new.n0 <= rec.n0
+                and all(new.max_dim[l] <= rec.max_dim[l] for l in range(self.levels))
+                and ops.h3_in_range(new.feat_absmax) == ops.h3_in_range(rec.feat_absmax))
+        if not fits:
+            self.tape, self._rec_batch = None, None
+            self.batch = new
+            return self
+        with torch.no_grad():
+            for l in range(self.levels):
+                rec.grid_ptrs[l].copy_(new.grid_ptrs[l], non_blocking=True)
+                rec.mask_ptrs[l].copy_(new.mask_ptrs[l], non_blocking=True)
+                rec.gx[l].copy_(new.gx[l], non_blocking=True)
+                rec.gy[l].copy_(new.gy[l], non_blocking=True)
+        self.batch = new                 # (keeps the bound slides alive; run()'s fallback recurses on them)
         return self
 
     def _play(self, ops_):

@@ -595,6 +595,51 @@ def test_three_adamw_steps_match_reference_g6(dev, monkeypatch, name, forced):
         assert calls["nt"] >= 15 and calls["tn"] >= 15, calls      # the split kernels really produced the gradients
 
 
+def _adamw_pair(dev, shapes, flavor=None, **kw):
+    from paths_amd import optim as popt
+    g = torch.Generator().manual_seed(5)
+    base = [torch.randn(*sh, generator=g) * (10.0 ** float(torch.randint(-4, 2, (1,), generator=g))) for sh in shapes]
+    pa = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    if flavor is not None:
+        popt.FLAVOR = flavor
+    return pa, pb, torch.optim.AdamW(pa, foreach=True, **kw), popt.HipAdamW(pb, **kw), g
+
+
+def test_hip_adamw_is_bitwise_torch_foreach(dev):
+    """paths_amd.optim.HipAdamW (one launch per step, csrc/optim.hip) against torch.optim.AdamW(foreach=True) - the reference's
+    optimizer (train.py:49-50) - BIT FOR BIT over 6 steps: parameters, exp_avg, exp_avg_sq; odd sizes (unaligned tails, scalars),
+    gradients over 12 binades, a parameter whose grad is None on some steps (its step count lags, as the non-final classifiers'),
+    weight decay on and off, lr changed between steps (ExponentialLR), state_dict round trip into torch's class."""
+    from paths_amd import optim as popt
+    shapes = [(1792, 2048), (1024,), (3, 5, 7), (1,), (4097,), (128, 128), (513, 3)]
+    for wd in (0.01, 0.0):
+        pa, pb, oa, ob, g = _adamw_pair(dev, shapes, lr=2e-3, weight_decay=wd, betas=(0.9, 0.999), eps=1e-8)
+        for it in range(6):
+            for i, (a, b) in enumerate(zip(pa, pb)):
+                if i == 2 and it in (1, 4):
+                    a.grad = b.grad = None
+                    continue
+                gr = (torch.randn(a.shape, generator=g) * torch.exp2(torch.randint(-20, 4, (1,), generator=g).float())).to(dev)
+                a.grad, b.grad = gr.clone(), gr.clone()
+            oa.step(); ob.step()
+            if it == 2:
+                for o in (oa, ob):
+                    o.param_groups[0]["lr"] *= 0.93
+            for i, (a, b) in enumerate(zip(pa, pb)):
+                assert torch.equal(a, b), (wd, it, i, float((a - b).abs().max()))
+                assert torch.equal(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) and torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]), (wd, it, i)
+                assert float(oa.state[a]["step"]) == float(ob.state[b]["step"])
+        # torch's class loads our state and continues identically (checkpoint compatibility, reference utils / train.py save + reload)
+        oc = torch.optim.AdamW(pb, foreach=True, lr=oa.param_groups[0]["lr"], weight_decay=wd)
+        oc.load_state_dict(ob.state_dict())
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(dev)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); oc.step()
+        assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+
+
 def test_data_parallel_shards_sum_to_global_batch(dev):
     """Two simulated ranks on one GPU (RCCL refuses two ranks of one communicator on the same device): the sum of the
     shards' gradients (each loss scaled by local/global batch) equals the single-rank global-batch gradient."""

@@ -427,7 +427,8 @@ def test_full_size_properties(dev):
     assert torch.isfinite(out_pair["logits"]).all()
 
 
-@pytest.mark.parametrize("K,base,ids", [(2048, (32, 64), [10003, 10004]), (1024, (32, 32), [10000, 10001])])
+@pytest.mark.parametrize("K,base,ids", [(2048, (32, 64), [10003, 10004, 10005, 10006, 10007, 10008, 10011, 10014]),      # a FULL bench batch (8 slides)
+                                        (1024, (32, 32), [10000, 10001])])
 def test_headline_recursion_vs_oracle(dev, K, base, ids):
     """BASELINE configs[1] / [2] at full size: the 5-level recursion at K patches/level (top_k K/4, 10 % background), bench
     weights (seed 0) and the bench's cpu_baseline slides, against the oracle: per level num_ims, location sets, kept sets and
@@ -446,7 +447,7 @@ def test_headline_recursion_vs_oracle(dev, K, base, ids):
         hz, _ = orc.inference_end2end(params, ocfg, [orc.LazyGrids(s.synthetic_spec) for s in slides], None, otrace)
     res = compare_recursion(trace, otrace, torch.sigmoid(out["logits"]), hz, imp_tol=STATE_TOL, hazard_tol=LOGIT_TOL)
     assert res["index_sets_identical"] and res["parent_pairs_identical"] and res["near_tie_slides"] == []
-    assert res["min_boundary_gap"] >= 1e-5 and res["kept_indices_compared"] == 2 * 4 * (K // 4)
+    assert res["min_boundary_gap"] >= 1e-5 and res["kept_indices_compared"] == len(ids) * 4 * (K // 4)
     np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
 
 
@@ -1011,6 +1012,39 @@ def test_replay_paths_raise_on_invalidating_status_bits(dev):
     for code in (2, 4, 5, 7):
         with pytest.raises(putils.RecursionError_):
             putils.check_status_word(code)
+    t.close()
+
+
+def test_tape_rebinds_to_other_batches(dev):
+    """TapedRecursion.rebind (missing 6): ONE recorded tape pointed at other resident batches by copying their table
+    tensors into the tape's own - same results as the eager recursion of each batch bit for bit, in any order, including a batch of
+    SMALLER grids (static capacities cover it) and back to the recorded one; a batch that does not fit (other slide count) drops
+    the tape and records again."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 3, None, top_k_patches=[24] * 4)
+    mk = lambda seed, shape, n=3, bg=0.15: DeviceSlideBatch([DeviceSlide.synthetic(seed, sid, shape, p_bg=bg, device=dev) for sid in range(n)])
+    a, b, c, small = mk(99, (9, 11)), mk(7, (9, 11)), mk(123, (11, 9), bg=0.3), mk(5, (6, 7))
+    def eager(batch):
+        with torch.no_grad():
+            o = putils.recurse(model, batch, cfg.top_k_patches, 5)
+        return {k: o[k].clone() for k in ("logits", "importance", "ctx_slide")}
+    refs = {id(x): eager(x) for x in (a, b, c, small)}
+    t = putils.TapedRecursion(model, a, cfg.top_k_patches, 5)
+    t.run()
+    tape0 = t.tape
+    for batch in (b, a, c, small, b, a):
+        out = t.rebind(batch).run()
+        ref = refs[id(batch)]
+        assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["ctx_slide"], ref["ctx_slide"]), id(batch)
+        if out["importance"].shape == ref["importance"].shape:      # (the smaller batch's eager pass has smaller capacities)
+            assert torch.equal(out["importance"], ref["importance"])
+    assert t.tape is tape0, "every one of these batches fits the recorded capacities: no re-recording"
+    other = mk(31, (9, 11), n=2)
+    out = t.rebind(other).run()
+    assert torch.equal(out["logits"], eager(other)["logits"]) and out["logits"].shape[0] == 2
+    # the recorded batch's own tables were never touched: its eager recursion still gives the same answer
+    assert torch.equal(eager(a)["logits"], refs[id(a)]["logits"])
     t.close()
 
 

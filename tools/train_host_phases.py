@@ -11,7 +11,8 @@ cfg, model, _ = bench.build_model(2048, dev, None); model.train()
 slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, i, bench.BASE_SHAPES[2048], device=dev) for i in range(8)])
 labels = np.asarray([s.synthetic_spec.label(4) for s in slides.slides], np.int64)
 batch = {"slide": slides, "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
-opt = torch.optim.AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
+from paths_amd.optim import HipAdamW
+opt = (torch.optim.AdamW if os.environ.get("PATHS_TORCH_ADAMW", "0") != "0" else HipAdamW)(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
 for _ in range(4):
     putils.train_step(model, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=8)
 torch.cuda.synchronize()
