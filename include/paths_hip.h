@@ -528,6 +528,11 @@ int64_t paths_attention_bwd_x6_workspace(int B, int T, int H, int head_dim);
 int paths_attention_bwd_x6_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                                    const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
                                    uint64_t drop_key, float drop_p, paths_stream_t stream);
+/* The same with the operand split chosen by the caller: planes 3 = three exact bf16 planes (6 MFMAs per product block), planes 2 =
+ * hi | mid only (16 significant bits at fp32's exponent range, 3 MFMAs: what the training step's gradient GEMMs use by default). */
+int paths_attention_bwd_x6_planes(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                                  const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
+                                  uint64_t drop_key, float drop_p, int planes, paths_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,7 @@ SIGNATURES = {
     "paths_attention_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _u64, _f32, _vp],
     "paths_attention_bwd_f32_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_attention_bwd_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
+    "paths_attention_bwd_x6_planes": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _i32, _vp],
     "paths_stream_wait": [_vp, _vp, _vp],
     "paths_event_destroy": [_vp],
     "paths_memset_zero": [_vp, C.c_size_t, _vp],

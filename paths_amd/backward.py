@@ -92,6 +92,58 @@ def _splits_x6(M: int, N1: int, N2: int, nb0: int) -> int:
     return max(1, min(64, (512 if big else 1024) // tiles, M // 128))
 
 
+# ---- the gradient side stream.  In a level's backward the dX chain is the critical path (each product feeds the next); the weight
+# / bias gradients (dW = dY^T X, column sums) only CONSUME what it produces.  They run on a second HIP stream: the many short
+# launches of the chain (LayerNorm, dropout masks, column sums: 3-10 us each, a few workgroups) then share the chip with the large
+# weight-gradient GEMMs instead of queueing behind them.  Same kernels, same arguments, same order within each stream: results are
+# bit-identical to the single-stream schedule.  MEASURED (round 4, K = 2048, 8 slides) and therefore OFF by default
+# (PATHS_BWD_SIDE=1 enables it): the device side of a step gets shorter (the host no longer waits for it: drain 2.7 -> 0.06 ms), but
+# the ~35 fork points per step (event record + stream wait + record_stream + torch's stream context) cost 3.2 ms of HOST time
+# (backward enqueue 8.2 -> 11.4 ms) and the step becomes host-bound: 15.9 -> 17.0-17.9 ms.  It pays once the backward is replayed
+# from a launch tape (no Python per launch).
+BWD_SIDE = os.environ.get("PATHS_BWD_SIDE", "0") != "0"
+_SIDE_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class side_stream:
+    """``with side_stream(dev, t1, t2, ...):`` - the launches inside go to the device's gradient side stream, ordered after
+    everything enqueued on the current stream so far; the tensors named are read there (their blocks are not re-used before that
+    work is done: ``record_stream``).  :func:`side_join` orders the current stream behind the side stream again - the backward
+    functions call it before they return, i.e. before their raw-pointer operands (saved activations) can be freed."""
+
+    def __init__(self, dev, *reads):
+        self.on = BWD_SIDE and dev.type == "cuda" and _lib.TAPE is None
+        self.dev, self.reads = dev, reads
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        side = _SIDE_STREAMS.get(idx)
+        if side is None:
+            side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        for t in self.reads:
+            if isinstance(t, torch.Tensor):
+                t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def side_join(dev):
+    if BWD_SIDE and dev.type == "cuda":
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        side = _SIDE_STREAMS.get(idx)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+
+
 def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, accumulate=False):
     """out[N1,N2] (+)= a[M,N1]^T [b0 | b1][M,N2]."""
     dev = out.device
@@ -216,16 +268,17 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     else:
         _lib.call("paths_importance_bwd_any", P(d_tokens), P(sv["pproj"]), P(sv["hid"]), P(sv["importance"]), P(lvl_pack["w2"]),
                   P(num_ims), N, M, 1 if mc.importance_mode == "mul" else 0, Hi, d, U, P(du), P(da), P(dah), st)
-    grads["w2"] = colsum(dah, Hi, M, Hi)
-    grads["b2"] = colsum(da, 1, M, 1)
-    grads["b1"] = colsum(du, U, M, Hi)
-    grads["special"] = colsum(d_tokens, T * d, B, d)
-    # proj_in.bias: sum of token gradients over the valid patch rows = colsum of dP / alpha is not usable (alpha may
-    # be 0), so sum d_tokens rows 1..N directly; padded token rows carry exact zeros (masked keys, unused queries)
-    # = (sum over all B*T token rows) - (sum over the B special-token rows): two launches instead of 2 B
-    grads["bp"] = colsum(d_tokens, d, B * T, d) - grads["special"]
-    grads["w_ip"] = torch.empty((Hi + d, D), **f32)
-    gemm_tn(du, U, sv["y"], D, grads["w_ip"], M, Hi + d, D)
+    with side_stream(dev, dah, da, du, d_tokens):
+        grads["w2"] = colsum(dah, Hi, M, Hi)
+        grads["b2"] = colsum(da, 1, M, 1)
+        grads["b1"] = colsum(du, U, M, Hi)
+        grads["special"] = colsum(d_tokens, T * d, B, d)
+        # proj_in.bias: sum of token gradients over the valid patch rows = colsum of dP / alpha is not usable (alpha may
+        # be 0), so sum d_tokens rows 1..N directly; padded token rows carry exact zeros (masked keys, unused queries)
+        # = (sum over all B*T token rows) - (sum over the B special-token rows): two launches instead of 2 B
+        grads["bp"] = colsum(d_tokens, d, B * T, d) - grads["special"]
+        grads["w_ip"] = torch.empty((Hi + d, D), **f32)
+        gemm_tn(du, U, sv["y"], D, grads["w_ip"], M, Hi + d, D)
     dy = torch.empty((M, D), **f32)
     w_ip_t = transpose(lvl_pack["w_ip"], Hi + d, D, pad_to=U)          # [D, U]
     gemm_nt(du, U, w_ip_t, dy, D, M, D, U)
@@ -236,10 +289,11 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     ext_h = d_state_out.data_ptr() if d_state_out is not None else None
     _lib.call("paths_lstm_bwd_a", P(dy), D, ext_h, Dp, P(sv["o"]), P(sv["tc"]), P(num_ims), N, M, D,
               dG.data_ptr() + 4 * 3 * Hc, G, P(dpre_h), st)
-    grads["b_mem"] = colsum(dpre_h, D, M, D)
-    grads["w_mem"] = torch.empty((D, Hc), **f32)
     c1_ptr = sv["state_out"].data_ptr() + 4 * D
-    gemm_tn(dpre_h, D, c1_ptr, Dp, grads["w_mem"], M, D, Hc)
+    with side_stream(dev, dpre_h):
+        grads["b_mem"] = colsum(dpre_h, D, M, D)
+        grads["w_mem"] = torch.empty((D, Hc), **f32)
+        gemm_tn(dpre_h, D, c1_ptr, Dp, grads["w_mem"], M, D, Hc)
     dc1_h = torch.empty((M, Hc), **f32)
     w_mem_t = transpose(lstm_pack["w_mem"], D, Hc)                      # [Hc, D]
     gemm_nt(dpre_h, D, w_mem_t, dc1_h, Hc, M, Hc, D)
@@ -248,16 +302,18 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     c0_ptr = state_prev.data_ptr() + 4 * D if state_prev is not None else None
     _lib.call("paths_lstm_bwd_b", P(dc1_h), ext_c, Dp, P(sv["frm"]), c0_ptr, state_prev.stride(1) if state_prev is not None else 0,
               P(num_ims), N, M, Hc, P(dG), G, d_state_prev.data_ptr() + 4 * D if d_state_prev is not None else None, Dp, st)
-    grads["b_gates"] = colsum(dG, G, M, G)
-    grads["w_gates"] = torch.empty((G, 2 * D), **f32)
-    if state_prev is None:
-        grads["w_gates"][:, D:].zero_()                                      # the h panel is dead at depth 0
+    with side_stream(dev, dG, fts):
+        grads["b_gates"] = colsum(dG, G, M, G)
+        grads["w_gates"] = torch.empty((G, 2 * D), **f32)
+        if state_prev is None:
+            grads["w_gates"][:, D:].zero_()                                      # the h panel is dead at depth 0
+            gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, D, ldo=2 * D)        # only the x panel is live at depth 0
+        else:
+            gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, 2 * D, b1=state_prev.data_ptr(), ldb1=state_prev.stride(1), nb0=D)
     if state_prev is not None:
-        gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, 2 * D, b1=state_prev.data_ptr(), ldb1=state_prev.stride(1), nb0=D)
         wh_t = transpose(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)   # [D, G] = (W_gates[:, D:2D])^T
         gemm_nt(dG, G, wh_t, d_state_prev.data_ptr(), Dp, M, D, G)
-    else:
-        gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, D, ldo=2 * D)        # only the x panel is live at depth 0
+    side_join(dev)                     # (before the saved activations behind the raw pointers above can be freed)
     return grads, d_state_prev
 
 
@@ -511,13 +567,14 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
     gemm_nt(dffo, d, transpose(w["w2"], d, F), dhid, F, M, F, d, mask=hid, ldm=F)
     if drop is not None:
         dropout_rows(dhid, F, M, F, drop.key(layer, Drop.FF_INNER), p, out=dhid, ldo=F)
-    g["w2"] = torch.empty((d, F), **f32)
-    gemm_tn(dffo, d, hd, F, g["w2"], M, d, F)
+    with side_stream(dev, dffo, hd, dhid, n2):
+        g["w2"] = torch.empty((d, F), **f32)
+        gemm_tn(dffo, d, hd, F, g["w2"], M, d, F)
+        g["w1"] = torch.empty((F, d), **f32)
+        gemm_tn(dhid, F, n2, d, g["w1"], M, F, d)
+        g["b1"] = colsum(dhid, F, M, F)
     dn2 = torch.empty((M, d), **f32)
     gemm_nt(dhid, F, transpose(w["w1"], F, d), dn2, d, M, d, F, residual=du3, ldr=d)
-    g["w1"] = torch.empty((F, d), **f32)
-    gemm_tn(dhid, F, n2, d, g["w1"], M, F, d)
-    g["b1"] = colsum(dhid, F, M, F)
     du2, g["ln2g"], g["ln2b"], cs2 = _ln_bwd_sums(dn2, c["xh2"], c["rs2"], w["ln2g"], M, d)
     g["cab"] = cs2 if drop is None else colsum(dropout_rows(du2, d, M, d, drop.key(layer, Drop.CA_OUT), p), d, M, d)
     du1, g["ln1g"], g["ln1b"], cs1 = _ln_bwd_sums(du2, c["xh1"], c["rs1"], w["ln1g"], M, d)
@@ -528,8 +585,9 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
         g["bo"] = colsum(dsa, d, M, d)
     dattn = torch.empty((M, d), **f32)
     gemm_nt(dsa, d, transpose(w["wo"], d, d), dattn, d, M, d, d)
-    g["wo"] = torch.empty((d, d), **f32)
-    gemm_tn(dsa, d, attn_ptr, lda, g["wo"], M, d, d)
+    with side_stream(dev, dsa):
+        g["wo"] = torch.empty((d, d), **f32)
+        gemm_tn(dsa, d, attn_ptr, lda, g["wo"], M, d, d)
     return g, du1, dattn
 
 
@@ -544,12 +602,13 @@ def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: floa
     if fold_qscale:
         wt[:, :d] *= qscale
     gemm_nt(dqkv, 3 * d, wt, dx_accum, d, M, d, 3 * d, accumulate=True)
-    g["wqkv"] = torch.empty((3 * d, d), **f32)
-    gemm_tn(dqkv, 3 * d, x_in, d, g["wqkv"], M, 3 * d, d)
-    g["bqkv"] = colsum(dqkv, 3 * d, M, 3 * d)
-    if fold_qscale:
-        g["wqkv"][:d] *= qscale
-        g["bqkv"][:d] *= qscale
+    with side_stream(x_in.device, dqkv, x_in):
+        g["wqkv"] = torch.empty((3 * d, d), **f32)
+        gemm_tn(dqkv, 3 * d, x_in, d, g["wqkv"], M, 3 * d, d)
+        g["bqkv"] = colsum(dqkv, 3 * d, M, 3 * d)
+        if fold_qscale:
+            g["wqkv"][:d] *= qscale
+            g["bqkv"][:d] *= qscale
     return g
 
 
@@ -818,12 +877,14 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
                       B, T, H, hd, qscale, 0, *dk(l), st)
         elif ATTN_BWD_MODE == "x6q":    # dQ, dK and dV on the split-bf16 kernels (csrc/attn_bwd_x6.hip; PATHS_ATTN_BWD_KV_X6=0 in the C library keeps dK / dV on the f32 MFMA)
             img = torch.empty((int(_lib.load().paths_attention_bwd_x6_workspace(B, T, H, hd)),), device=dqkv.device, dtype=torch.uint8)
-            _lib.call("paths_attention_bwd_x6_dropout", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
-                      P(num_ims), P(dqkv), P(ws), P(img), B, T, H, hd, *dk(l), st)
+            # operand split as the other gradient products of the step (ops.TRAIN_PLANES: 4 = two bf16 planes, 3 = the exact three)
+            _lib.call("paths_attention_bwd_x6_planes", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
+                      P(num_ims), P(dqkv), P(ws), P(img), B, T, H, hd, *dk(l), 2 if ops.TRAIN_PLANES == 4 else 3, st)
         else:
             _lib.call("paths_attention_bwd_f32_dropout", P(lv["q"]), P(lv["k"]), P(lv["v"]), P(lv["attn"]), P(dattn), P(lv["lse"]),
                       P(num_ims), P(dqkv), P(ws), B, T, H, hd, *dk(l), st)
         g.update(qkv_backward(w, lv["x_in"], dqkv, M, qscale, dx_in, fold_qscale=fast))
         grads["layers"][l] = g
         dx = dx_in.view(B, T, d)
+    side_join(dev)                     # the weight / bias gradients issued on the side stream (chain_backward, qkv_backward)
     return grads, dx, d_ctx_prev

@@ -22,7 +22,7 @@
 DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
 int paths_attention_bwd_x6_launch(const float* q, const float* k, const float* v, const float* d_o, const float* lse, const float* dsum,
                                   const int64_t* num_ims, float* dqkv, void* images, int B, int T, int H, DropSite site, int kv_too,
-                                  hipStream_t stream);       // attn_bwd_x6.hip
+                                  int planes, hipStream_t stream);       // attn_bwd_x6.hip
 
 namespace {
 
@@ -255,7 +255,7 @@ extern "C" {
 // dqkv [B,T,384] must be zero-initialised by the caller (rows of padded tokens are never written).
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                               const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, DropSite site,
-                              hipStream_t stream, void* images = nullptr);
+                              hipStream_t stream, void* images = nullptr, int planes = 3);
 
 int paths_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                             const int64_t* num_ims, float* dqkv, float* ws_dsum /*[B*H*T]*/, int B, int T, int H, int head_dim,
@@ -271,7 +271,7 @@ int paths_attention_bwd_f32_dropout(const float* q, const float* k, const float*
   return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(drop_key, drop_p), stream);
 }
 
-// the dQ part on the split-bf16 kernel (paths_attention_bwd_x6_workspace bytes of images), dK / dV on the f32 MFMA
+// the whole backward on the split-bf16 kernels (paths_attention_bwd_x6_workspace bytes of images), three exact planes
 int paths_attention_bwd_x6_dropout(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                                    const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
                                    uint64_t drop_key, float drop_p, hipStream_t stream) {
@@ -279,9 +279,20 @@ int paths_attention_bwd_x6_dropout(const float* q, const float* k, const float* 
   return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(drop_key, drop_p), stream, images);
 }
 
+// the same with the operand split chosen by the caller: planes 3 = hi | mid | lo (exact fp32 products, 6 MFMAs per block), planes 2 =
+// hi | mid (16 significant bits at fp32's exponent range, 3 MFMAs per block: the setting of the training step's other gradient
+// products, PATHS_TRAIN_PLANES=4; relative error of a product ~2e-5)
+int paths_attention_bwd_x6_planes(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                                  const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
+                                  uint64_t drop_key, float drop_p, int planes, hipStream_t stream) {
+  PATHS_REQUIRE(drop_p >= 0.f && drop_p < 1.f && images != nullptr && (uintptr_t)images % 16 == 0, "attention_bwd_x6: p in [0, 1), 16-byte aligned images");
+  PATHS_REQUIRE(planes == 2 || planes == 3, "attention_bwd_x6: planes must be 3 (exact) or 2 (hi | mid)");
+  return attention_bwd_impl(q, k, v, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, head_dim, paths_make_drop_site(drop_key, drop_p), stream, images, planes);
+}
+
 static int attention_bwd_impl(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                               const int64_t* num_ims, float* dqkv, float* ws_dsum, int B, int T, int H, int head_dim, DropSite site,
-                              hipStream_t stream, void* images) {
+                              hipStream_t stream, void* images, int planes) {
   PATHS_REQUIRE(head_dim == HD && H == 4, "attention_bwd: head_dim must be 32 and H 4");
   PATHS_REQUIRE(B > 0 && T > 0 && q && k && v && o && d_o && lse && num_ims && dqkv && ws_dsum, "attention_bwd: bad arguments");
   const int64_t rows = (int64_t)B * T;
@@ -289,10 +300,10 @@ static int attention_bwd_impl(const float* q, const float* k, const float* v, co
   PATHS_LAUNCH_CHECK("attention_bwd(prep)");
   dim3 grid((T + 63) / 64, H, B);
   static const int x6_kv = getenv("PATHS_ATTN_BWD_KV_X6") == nullptr || atoi(getenv("PATHS_ATTN_BWD_KV_X6")) != 0;   // A/B switch
-  if (images != nullptr && x6_kv) return paths_attention_bwd_x6_launch(q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, images, B, T, H, site, 1, stream);
+  if (images != nullptr && x6_kv) return paths_attention_bwd_x6_launch(q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, images, B, T, H, site, 1, planes, stream);
   hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(kv)");
-  if (images != nullptr) return paths_attention_bwd_x6_launch(q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, images, B, T, H, site, 0, stream);
+  if (images != nullptr) return paths_attention_bwd_x6_launch(q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, images, B, T, H, site, 0, planes, stream);
   hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, stream, q, k, v, d_o, lse, ws_dsum, num_ims, dqkv, T, H, site);
   PATHS_LAUNCH_CHECK("attention_bwd(q)");
   return PATHS_OK;

@@ -38,16 +38,21 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-// 8 fp32 -> three planes of 8 bf16 (hi, mid, lo), exact
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&pl)[3]) {
+// 8 fp32 -> PL planes of 8 bf16: PL = 3 hi, mid, lo (exact: 3 x 8 = the 24 bits of fp32); PL = 2 hi, mid only (16 significant bits at
+// fp32's exponent range - the setting of the training step's gradient GEMMs, PATHS_TRAIN_PLANES=4: no scales, nothing overflows)
+template <int PL>
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4 (&pl)[PL]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = x[2 * i], b = x[2 * i + 1];
     const uint32_t h = pk_bf16(a, b);
     const float ra = a - bf_lo(h), rb = b - bf_hi(h);
     const uint32_t m = pk_bf16(ra, rb);
-    const float sa = ra - bf_lo(m), sb = rb - bf_hi(m);
-    pl[0][i] = h; pl[1][i] = m; pl[2][i] = pk_bf16(sa, sb);
+    pl[0][i] = h; pl[1][i] = m;
+    if constexpr (PL == 3) {
+      const float sa = ra - bf_lo(m), sb = rb - bf_hi(m);
+      pl[2][i] = pk_bf16(sa, sb);
+    }
   }
 }
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
@@ -62,7 +67,14 @@ __device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[3], const u32x4 (&b
   c = mfma_bf16(a[0], b[0], c);
   return c;
 }
+__device__ __forceinline__ f32x4 mfma_split(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x4 c) {   // hi, mid: all but mid*mid
+  c = mfma_bf16(a[1], b[0], c);
+  c = mfma_bf16(a[0], b[1], c);
+  c = mfma_bf16(a[0], b[0], c);
+  return c;
+}
 
+template <int PL>
 __global__ void __launch_bounds__(256)
 attn_bwd_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                         const float* __restrict__ d_o /*[B,T,H*32]*/, char* __restrict__ qr, char* __restrict__ kr, char* __restrict__ vr,
@@ -73,7 +85,7 @@ attn_bwd_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k
   const int len = min((int)num_ims[b] + 1, T);
   const int tid = threadIdx.x;
   const int64_t base = ((int64_t)b * H + head) * T * HD;
-  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 6;          // bytes of one (slide, head) image
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * PL;          // bytes of one (slide, head) image
   {
     const int tl = tid >> 2, g = tid & 3, tok = t0 + tl;
     float xq[8], xk[8], xv[8], xg[8];
@@ -85,20 +97,20 @@ attn_bwd_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k
       xq[i] = valid ? q[base + (int64_t)tok * HD + 8 * g + i] : 0.f;
       xg[i] = valid ? d_o[((int64_t)b * T + tok) * (H * HD) + head * HD + 8 * g + i] : 0.f;
     }
-    const int64_t off = ibase + ((int64_t)(tok >> 4) * 3) * FRAG + ((tok & 15) + 16 * g) * 16;
-    u32x4 pl[3];
-    split8(xk, pl);
+    const int64_t off = ibase + ((int64_t)(tok >> 4) * PL) * FRAG + ((tok & 15) + 16 * g) * 16;
+    u32x4 pl[PL];
+    split8<PL>(xk, pl);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(kr + off + p * FRAG) = pl[p];
-    split8(xv, pl);
+    for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x4*>(kr + off + p * FRAG) = pl[p];
+    split8<PL>(xv, pl);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(vr + off + p * FRAG) = pl[p];
-    split8(xq, pl);
+    for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x4*>(vr + off + p * FRAG) = pl[p];
+    split8<PL>(xq, pl);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(qr + off + p * FRAG) = pl[p];
-    split8(xg, pl);
+    for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x4*>(qr + off + p * FRAG) = pl[p];
+    split8<PL>(xg, pl);
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(gr + off + p * FRAG) = pl[p];
+    for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x4*>(gr + off + p * FRAG) = pl[p];
   }
   // K^T, Q^T, dO^T through LDS (coalesced rows in, transposed + token-permuted fragments out)
 #pragma unroll
@@ -112,29 +124,31 @@ attn_bwd_x6_prep_kernel(const float* __restrict__ q, const float* __restrict__ k
   __syncthreads();
   {
     const int kg = tid >> 7, dt = (tid >> 6) & 1, l = tid & 63, dd = l & 15, g = l >> 4;
-    const int64_t off = ibase + ((int64_t)(((t0 >> 5) + kg) * 2 + dt) * 3) * FRAG + l * 16;
+    const int64_t off = ibase + ((int64_t)(((t0 >> 5) + kg) * 2 + dt) * PL) * FRAG + l * 16;
     char* const dst[3] = {kt, qt, gt};
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       float xt[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) xt[j] = sk[a][32 * kg + 4 * g + (j & 3) + 16 * (j >> 2)][16 * dt + dd];
-      u32x4 pl[3];
-      split8(xt, pl);
+      u32x4 pl[PL];
+      split8<PL>(xt, pl);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(dst[a] + off + p * FRAG) = pl[p];
+      for (int p = 0; p < PL; ++p) *reinterpret_cast<u32x4*>(dst[a] + off + p * FRAG) = pl[p];
     }
   }
 }
 
 // LDS per 64-key step: Kr 4 tiles x 3 planes | Vr 4 x 3 | Kt 2 groups x 2 d tiles x 3 = 36 KiB, double-buffered
-constexpr int PART = 12 * FRAG;            // bytes of one of the three parts of a step
-constexpr int STEP = 3 * PART;
+template <int PL> constexpr int part_bytes() { return 4 * PL * FRAG; }      // bytes of one of the three parts of a step
+template <int PL> constexpr int step_bytes() { return 3 * part_bytes<PL>(); }
 
+template <int PL>
 __global__ void __launch_bounds__(256, 2)
 attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, const char* __restrict__ vr, const char* __restrict__ gr,
                      const char* __restrict__ kt, const float* __restrict__ lse, const float* __restrict__ dsum,
                      const int64_t* __restrict__ num_ims, float* __restrict__ dqkv, int T, int Tp, int H, int npairs, int nqb, DropSite drop) {
+  constexpr int PART = part_bytes<PL>(), STEP = step_bytes<PL>();
   extern __shared__ __attribute__((aligned(16))) char smem[];           // [2][STEP]
   // XCD-aware placement as in attn_x6.hip: pair p only ever runs on the XCD group p % 8
   const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
@@ -148,16 +162,16 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 15, g4 = lane >> 4;
-  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 6;
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * PL;
   const int qw = q0 + wave * 16 * QT;
 
-  u32x4 qf[QT][3], gf[QT][3];
+  u32x4 qf[QT][PL], gf[QT][PL];
   float my_lse[QT], my_d[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    const int64_t off = ibase + ((int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * 3) * FRAG + lane * 16;
+    const int64_t off = ibase + ((int64_t)(min(qw + 16 * qt, Tp - 16) >> 4) * PL) * FRAG + lane * 16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < PL; ++p) {
       qf[qt][p] = *reinterpret_cast<const u32x4*>(qr + off + p * FRAG);
       gf[qt][p] = *reinterpret_cast<const u32x4*>(gr + off + p * FRAG);
     }
@@ -173,22 +187,22 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
 
   const int nkt = (len + KSTEP - 1) / KSTEP;
   // staging: a step is three contiguous 12-KiB pieces (Kr, Vr, Kt of 64 keys); 9 x 16 bytes per thread
-  u32x4 st[9];
+  u32x4 st[3 * PL];
   auto gload = [&](int kt_) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < PL; ++i) {
       st[i] = *reinterpret_cast<const u32x4*>(kr + ibase + (int64_t)kt_ * PART + (tid + 256 * i) * 16);
-      st[3 + i] = *reinterpret_cast<const u32x4*>(vr + ibase + (int64_t)kt_ * PART + (tid + 256 * i) * 16);
-      st[6 + i] = *reinterpret_cast<const u32x4*>(kt + ibase + (int64_t)kt_ * PART + (tid + 256 * i) * 16);
+      st[PL + i] = *reinterpret_cast<const u32x4*>(vr + ibase + (int64_t)kt_ * PART + (tid + 256 * i) * 16);
+      st[2 * PL + i] = *reinterpret_cast<const u32x4*>(kt + ibase + (int64_t)kt_ * PART + (tid + 256 * i) * 16);
     }
   };
   auto swrite = [&](int kt_) {
     char* d = smem + (kt_ & 1) * STEP;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < PL; ++i) {
       *reinterpret_cast<u32x4*>(d + (tid + 256 * i) * 16) = st[i];
-      *reinterpret_cast<u32x4*>(d + PART + (tid + 256 * i) * 16) = st[3 + i];
-      *reinterpret_cast<u32x4*>(d + 2 * PART + (tid + 256 * i) * 16) = st[6 + i];
+      *reinterpret_cast<u32x4*>(d + PART + (tid + 256 * i) * 16) = st[PL + i];
+      *reinterpret_cast<u32x4*>(d + 2 * PART + (tid + 256 * i) * 16) = st[2 * PL + i];
     }
   };
   gload(0);
@@ -204,11 +218,11 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
       f32x4 s[QT][2], dp[QT][2];                        // [query tile][key tile of the group]: rows = keys 4 g4 .. +3, col = query ql
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        u32x4 kf[3], vf[3];
+        u32x4 kf[PL], vf[PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          kf[p] = *reinterpret_cast<const u32x4*>(sK + ((2 * kg + t) * 3 + p) * FRAG);
-          vf[p] = *reinterpret_cast<const u32x4*>(sV + ((2 * kg + t) * 3 + p) * FRAG);
+        for (int p = 0; p < PL; ++p) {
+          kf[p] = *reinterpret_cast<const u32x4*>(sK + ((2 * kg + t) * PL + p) * FRAG);
+          vf[p] = *reinterpret_cast<const u32x4*>(sV + ((2 * kg + t) * PL + p) * FRAG);
         }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -216,7 +230,7 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
           dp[qt][t] = mfma_split(vf, gf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
         }
       }
-      u32x4 dsf[QT][3];
+      u32x4 dsf[QT][PL];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float dsv[8];
@@ -228,13 +242,13 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
           const float m = drop.thr ? drop_mult_w(drop, dwin, drow + (uint64_t)min(key, T - 1)) : 1.0f;
           dsv[j] = LN2 * p * (dp[qt][j >> 2][j & 3] * m - my_d[qt]);
         }
-        split8(dsv, dsf[qt]);
+        split8<PL>(dsv, dsf[qt]);
       }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        u32x4 tf[3];
+        u32x4 tf[PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) tf[p] = *reinterpret_cast<const u32x4*>(sT + ((kg * 2 + dt) * 3 + p) * FRAG);
+        for (int p = 0; p < PL; ++p) tf[p] = *reinterpret_cast<const u32x4*>(sT + ((kg * 2 + dt) * PL + p) * FRAG);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) dq[dt][qt] = mfma_split(tf, dsf[qt], dq[dt][qt]);
       }
@@ -262,12 +276,14 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
 //   dV^T[dv][key] += Gt (P m)    2 dv tiles x 2 key tiles x 6
 //   dK^T[d][key]  += Qt dS       2 d tiles x 2 key tiles x 6
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int KV_STEP = 4 * PART;          // Qr | Gr | Qt | Gt of 64 queries: 48 KiB (one buffer; the next step waits in registers)
+template <int PL> constexpr int kv_step_bytes() { return 4 * part_bytes<PL>(); }   // Qr | Gr | Qt | Gt of 64 queries: 48 KiB at three planes (one buffer; the next step waits in registers)
 
+template <int PL>
 __global__ void __launch_bounds__(256, 2)
 attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, const char* __restrict__ vr, const char* __restrict__ gr,
                       const char* __restrict__ qt, const char* __restrict__ gt, const float* __restrict__ lse, const float* __restrict__ dsum,
                       const int64_t* __restrict__ num_ims, float* __restrict__ dqkv, int T, int Tp, int H, int npairs, int nkb, DropSite drop) {
+  constexpr int PART = part_bytes<PL>(), KV_STEP = kv_step_bytes<PL>();
   extern __shared__ __attribute__((aligned(16))) char smem[];           // [KV_STEP] + lse[64] + D[64]
   const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
   const int cnt = (npairs - xg + 7) >> 3;
@@ -280,17 +296,17 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
   if (k0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kl = lane & 15, g4 = lane >> 4;
-  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 6;
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * PL;
   const int kw = k0 + wave * 32;                        // this wave's first key
   float* sL = reinterpret_cast<float*>(smem + KV_STEP);
   float* sD = sL + 64;
 
-  u32x4 kf[2][3], vf[2][3];
+  u32x4 kf[2][PL], vf[2][PL];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int64_t off = ibase + ((int64_t)(min(kw + 16 * t, Tp - 16) >> 4) * 3) * FRAG + lane * 16;
+    const int64_t off = ibase + ((int64_t)(min(kw + 16 * t, Tp - 16) >> 4) * PL) * FRAG + lane * 16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < PL; ++p) {
       kf[t][p] = *reinterpret_cast<const u32x4*>(kr + off + p * FRAG);
       vf[t][p] = *reinterpret_cast<const u32x4*>(vr + off + p * FRAG);
     }
@@ -302,15 +318,15 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
     for (int j = 0; j < 2; ++j) { dk[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int nqs = (len + KSTEP - 1) / KSTEP;            // 64-query steps
-  u32x4 st[12];
+  u32x4 st[4 * PL];
   float st_s = 0.f;
   auto gload = [&](int qs) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < PL; ++i) {
       st[i] = *reinterpret_cast<const u32x4*>(qr + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
-      st[3 + i] = *reinterpret_cast<const u32x4*>(gr + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
-      st[6 + i] = *reinterpret_cast<const u32x4*>(qt + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
-      st[9 + i] = *reinterpret_cast<const u32x4*>(gt + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
+      st[PL + i] = *reinterpret_cast<const u32x4*>(gr + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
+      st[2 * PL + i] = *reinterpret_cast<const u32x4*>(qt + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
+      st[3 * PL + i] = *reinterpret_cast<const u32x4*>(gt + ibase + (int64_t)qs * PART + (tid + 256 * i) * 16);
     }
     if (tid < 128) {
       const int qi = min(qs * KSTEP + (tid & 63), T - 1);
@@ -319,11 +335,11 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
   };
   auto swrite = [&]() {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < PL; ++i) {
       *reinterpret_cast<u32x4*>(smem + (tid + 256 * i) * 16) = st[i];
-      *reinterpret_cast<u32x4*>(smem + PART + (tid + 256 * i) * 16) = st[3 + i];
-      *reinterpret_cast<u32x4*>(smem + 2 * PART + (tid + 256 * i) * 16) = st[6 + i];
-      *reinterpret_cast<u32x4*>(smem + 3 * PART + (tid + 256 * i) * 16) = st[9 + i];
+      *reinterpret_cast<u32x4*>(smem + PART + (tid + 256 * i) * 16) = st[PL + i];
+      *reinterpret_cast<u32x4*>(smem + 2 * PART + (tid + 256 * i) * 16) = st[2 * PL + i];
+      *reinterpret_cast<u32x4*>(smem + 3 * PART + (tid + 256 * i) * 16) = st[3 * PL + i];
     }
     if (tid < 64) sL[tid] = st_s;
     else if (tid < 128) sD[tid - 64] = st_s;
@@ -343,11 +359,11 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
       f32x4 s[2][2], dp[2][2];                          // [query tile of the group][key tile]: rows = queries 4 g4 .. +3, col = key kl
 #pragma unroll
       for (int qt_ = 0; qt_ < 2; ++qt_) {
-        u32x4 qf[3], gf[3];
+        u32x4 qf[PL], gf[PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          qf[p] = *reinterpret_cast<const u32x4*>(sQ + ((2 * qg + qt_) * 3 + p) * FRAG);
-          gf[p] = *reinterpret_cast<const u32x4*>(sG + ((2 * qg + qt_) * 3 + p) * FRAG);
+        for (int p = 0; p < PL; ++p) {
+          qf[p] = *reinterpret_cast<const u32x4*>(sQ + ((2 * qg + qt_) * PL + p) * FRAG);
+          gf[p] = *reinterpret_cast<const u32x4*>(sG + ((2 * qg + qt_) * PL + p) * FRAG);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -355,7 +371,7 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
           dp[qt_][t] = mfma_split(gf, vf[t], f32x4{0.f, 0.f, 0.f, 0.f});
         }
       }
-      u32x4 pf[2][3], dsf[2][3];
+      u32x4 pf[2][PL], dsf[2][PL];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int key = kw + 16 * t + kl;
@@ -370,16 +386,16 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
           dsv[j] = LN2 * pr * (dp[j >> 2][t][j & 3] * m - sD[qloc]);
           pv[j] = pr * m;
         }
-        split8(pv, pf[t]);
-        split8(dsv, dsf[t]);
+        split8<PL>(pv, pf[t]);
+        split8<PL>(dsv, dsf[t]);
       }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        u32x4 qtf[3], gtf[3];
+        u32x4 qtf[PL], gtf[PL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          qtf[p] = *reinterpret_cast<const u32x4*>(sQt + ((qg * 2 + dt) * 3 + p) * FRAG);
-          gtf[p] = *reinterpret_cast<const u32x4*>(sGt + ((qg * 2 + dt) * 3 + p) * FRAG);
+        for (int p = 0; p < PL; ++p) {
+          qtf[p] = *reinterpret_cast<const u32x4*>(sQt + ((qg * 2 + dt) * PL + p) * FRAG);
+          gtf[p] = *reinterpret_cast<const u32x4*>(sGt + ((qg * 2 + dt) * PL + p) * FRAG);
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -411,27 +427,37 @@ extern "C" int64_t paths_attention_bwd_x6_workspace(int B, int T, int H, int hea
 }
 
 // dqkv from the images: dK / dV and dQ (called by attention_bwd_impl in attn_bwd.hip in place of its f32-MFMA kernels)
-int paths_attention_bwd_x6_launch(const float* q, const float* k, const float* v, const float* d_o, const float* lse, const float* dsum,
-                                  const int64_t* num_ims, float* dqkv, void* images, int B, int T, int H, DropSite site, int kv_too,
-                                  hipStream_t stream) {
+template <int PL>
+static int attention_bwd_x6_launch_pl(const float* q, const float* k, const float* v, const float* d_o, const float* lse, const float* dsum,
+                                      const int64_t* num_ims, float* dqkv, void* images, int B, int T, int H, DropSite site, int kv_too,
+                                      hipStream_t stream) {
+  constexpr int STEP = step_bytes<PL>(), KV_STEP = kv_step_bytes<PL>();
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
-  const int64_t img = (int64_t)B * H * Tp * HD * 6;
+  const int64_t img = (int64_t)B * H * Tp * HD * 2 * PL;
   char* qr = reinterpret_cast<char*>(images);
   char* kr = qr + img; char* vr = kr + img; char* gr = vr + img; char* ktp = gr + img; char* qtp = ktp + img; char* gtp = qtp + img;
-  hipLaunchKernelGGL(attn_bwd_x6_prep_kernel, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, d_o, qr, kr, vr, gr, ktp, qtp, gtp, num_ims, T, Tp, H);
+  hipLaunchKernelGGL(attn_bwd_x6_prep_kernel<PL>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, d_o, qr, kr, vr, gr, ktp, qtp, gtp, num_ims, T, Tp, H);
   PATHS_LAUNCH_CHECK("attention_bwd_x6(prep)");
-  PATHS_LDS_OPT_IN(attn_bwd_q_x6_kernel, 2 * STEP, "attention_bwd_x6(dq)");
-  PATHS_LDS_OPT_IN(attn_bwd_kv_x6_kernel, KV_STEP + 512, "attention_bwd_x6(dk, dv)");
+  PATHS_LDS_OPT_IN(attn_bwd_q_x6_kernel<PL>, 2 * STEP, "attention_bwd_x6(dq)");
+  PATHS_LDS_OPT_IN(attn_bwd_kv_x6_kernel<PL>, KV_STEP + 512, "attention_bwd_x6(dk, dv)");
   const int npairs = H * B;
   if (kv_too) {
     const int nkb = (T + 127) / 128;
-    hipLaunchKernelGGL(attn_bwd_kv_x6_kernel, dim3(8 * ((npairs + 7) / 8) * nkb), dim3(256), KV_STEP + 512, stream, qr, kr, vr, gr, qtp, gtp, lse, dsum,
+    hipLaunchKernelGGL(attn_bwd_kv_x6_kernel<PL>, dim3(8 * ((npairs + 7) / 8) * nkb), dim3(256), KV_STEP + 512, stream, qr, kr, vr, gr, qtp, gtp, lse, dsum,
                        num_ims, dqkv, T, Tp, H, npairs, nkb, site);
     PATHS_LAUNCH_CHECK("attention_bwd_x6(kv)");
   }
   const int nqb = (T + 64 * QT - 1) / (64 * QT);
-  hipLaunchKernelGGL(attn_bwd_q_x6_kernel, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 2 * STEP, stream, qr, kr, vr, gr, ktp, lse, dsum,
+  hipLaunchKernelGGL(attn_bwd_q_x6_kernel<PL>, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 2 * STEP, stream, qr, kr, vr, gr, ktp, lse, dsum,
                      num_ims, dqkv, T, Tp, H, npairs, nqb, site);
   PATHS_LAUNCH_CHECK("attention_bwd_x6(q)");
   return PATHS_OK;
+}
+
+// planes: 3 = exact (hi, mid, lo; 6 MFMAs per product block), 2 = hi, mid (16 bits, 3 MFMAs: the training default, PATHS_TRAIN_PLANES=4)
+int paths_attention_bwd_x6_launch(const float* q, const float* k, const float* v, const float* d_o, const float* lse, const float* dsum,
+                                  const int64_t* num_ims, float* dqkv, void* images, int B, int T, int H, DropSite site, int kv_too,
+                                  int planes, hipStream_t stream) {
+  if (planes == 2) return attention_bwd_x6_launch_pl<2>(q, k, v, d_o, lse, dsum, num_ims, dqkv, images, B, T, H, site, kv_too, stream);
+  return attention_bwd_x6_launch_pl<3>(q, k, v, d_o, lse, dsum, num_ims, dqkv, images, B, T, H, site, kv_too, stream);
 }

@@ -442,7 +442,7 @@ def test_training_other_aggregator_geometries_vs_oracle_autograd(dev, over):
         _, loss = putils.forward_backward(model, batch, 5, cfg.top_k_patches, "survival")
     assert "paths_attention_bwd_any" in calls and "paths_attention_any_train" in calls
     assert ("paths_importance_rows_bwd_any" if over.get("lstm") is False else "paths_importance_bwd_any") in calls
-    assert not {"paths_attention_bwd_x6_dropout", "paths_importance_bwd", "paths_importance_rows_bwd", "paths_importance_proj"} & set(calls)
+    assert not {"paths_attention_bwd_x6_dropout", "paths_attention_bwd_x6_planes", "paths_importance_bwd", "paths_importance_rows_bwd", "paths_importance_proj"} & set(calls)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ocfg = H.oracle_config(cfg_over, top_k_patches=[16] * 4)
     labels = {"survival_bin": batch["survival_bin"], "censored": batch["censored"]}
@@ -957,5 +957,7 @@ def test_epoch_loop_matches_reference_g10(dev, tmp_path):
         got = np.asarray([float(v.double().sum()), float(v.double().abs().sum())])
         # (Adam's first steps move every element by ~lr whatever its gradient's size, so elements whose gradient is pure rounding
         # noise - e.g. the key bias of in_proj, whose exact gradient is 0 - step in implementation-dependent directions: a few
-        # times lr = 2e-4 per tensor.  The bar still separates the epoch-1 checkpoint from the epoch-3 weights by orders of magnitude)
-        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * ref[1] + 2e-3, err_msg=k)
+        # times lr = 2e-4 per tensor (measured on in_proj_bias: 2.3e-3 with the attention backward on three bf16 planes, 2.5e-3 on two -
+        # which noise the 128 zero-gradient key-bias elements see depends on the operand split).  The bar still separates the epoch-1
+        # checkpoint from the epoch-3 weights by orders of magnitude)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * ref[1] + 4e-3, err_msg=k)
