@@ -310,13 +310,18 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
         loss = putils.train_step(model, opt, batch, cfg.num_levels, cfg.top_k_patches, global_batch=gb, allreduce=ar)
         if ar is not None and pdist.LAST_ALLREDUCE_EVENTS is not None:
             ar_ev.append(pdist.LAST_ALLREDUCE_EVENTS)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0                 # this rank's own K steps (with a process group every step already ends in the all-reduce)
     sync()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, dev)
+    per_rank = pdist.gather_floats(own / args.steps * 1e3)
     if rank == 0:
         K = args.k
         print(json.dumps({
             "metric": "train_slides_per_sec_5level_K%d_D1024" % K, "value": round(gb * args.steps / elapsed, 2), "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "per_rank_ms_per_step": [round(v, 3) for v in per_rank], "rank_imbalance_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 4),
+            "cores_per_rank": args.cores_per_rank or None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": train_dtype(__import__("paths_amd.ops", fromlist=["ops"]).TRAIN_PLANES),
             "data": "synthetic", "train_planes": __import__("paths_amd.ops", fromlist=["ops"]).TRAIN_PLANES,
             "config": {"workload": f"train step (reference train.py:59-68 semantics): 5-level recursion K={K}, forward + HIP backward + "
@@ -446,6 +451,9 @@ def main():
                     "on different rows than the step before), the single-batch replay figure is reported beside it")
     ap.add_argument("--train-steps", type=int, default=5, help="infer mode: timed steps of the short training measurement added to the "
                     "line as 'train' (0 = skip); 3 warm-up steps")
+    ap.add_argument("--cores-per-rank", type=int, default=0, help="pin this rank to N host cores (cores [rank N, rank N + N) of the "
+                    "process's allowed set) BEFORE anything touches the GPU: what a rank gets when 8 ranks share one host's CPU share "
+                    "(0 = leave the affinity alone)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "stress"],
                     help="infer (default, the BASELINE metric); train: forward + HIP backward + AdamW + gradient all-reduce; "
                          "stress: one level over 8192 patches x 1536 features (BASELINE configs[4] geometry, fp32-accurate path)")
@@ -455,6 +463,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))           # parent of a self-launched job: never touches the GPU
     rank, world, local_rank = pdist.env_rank_world()
+    if args.cores_per_rank > 0 and hasattr(os, "sched_setaffinity"):
+        allowed = sorted(os.sched_getaffinity(0))
+        n = args.cores_per_rank
+        mine = allowed[(local_rank * n) % len(allowed):][:n] or allowed[:n]
+        os.sched_setaffinity(0, mine)              # (threads created later - HIP runtime, torch - inherit it)
+        torch.set_num_threads(max(1, len(mine)))
+        print(f"[bench rank {rank}/{world}] pinned to host cores {mine}", file=sys.stderr, flush=True)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N ranks with torch.distributed.run (or run "
                  f"'python bench.py --gpus N' without RANK / WORLD_SIZE in the environment and it starts them itself)")
@@ -550,12 +565,15 @@ def main():
     for i in range(args.steps):
         out = timed_step(i)
     t_enqueued = time.perf_counter() - t0          # host side done (diagnostic: is the Python launch path ahead of the GPU?)
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0         # this rank's own K steps, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
     log(f"timed region: {args.steps} steps in {elapsed:.4f} s (all launches enqueued after {t_enqueued:.4f} s)")
     status = int(out["status"].item())
     assert status == 0, f"recursion status {status}"
+    per_rank = pdist.gather_floats(own_elapsed / args.steps * 1e3)  # every rank's own ms per step (load imbalance: slides differ)
     elapsed = pdist.max_over_ranks(elapsed, dev_reduce)
     single = None
     if nrot > 1:
@@ -782,6 +800,7 @@ def main():
             "metric": "slides_per_sec_5level_K%d_D1024" % K, "value": round(total_slides / elapsed, 2), "unit": "slides/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "per_rank_ms_per_step": [round(v, 3) for v in per_rank], "rank_imbalance_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 4),
             "vs_baseline": None,
             "dtype": ("f32 (products as 2 fp16 planes per operand = 22 bits, 3 fp16 MFMAs per block, fp32 accumulate)" if planes == 2 else
                       "f32 (products as 3 exact bf16 planes per operand, 6 bf16 MFMAs per block, fp32 accumulate)" if x6 else "f32"),

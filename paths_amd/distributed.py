@@ -54,6 +54,15 @@ def max_over_ranks(value: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(value: float) -> List[float]:
+    """Every rank's ``value`` in rank order, on every rank (per-rank step times: the load imbalance of variable child counts)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, float(value))
+    return [float(v) for v in out]
+
+
 def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """All-gather per-slide rows (e.g. hazards [b_local, nbins]) into global slide order on every rank."""
     if not dist.is_initialized():
@@ -104,8 +113,10 @@ def allreduce_gradients(model, average: bool = False, num_levels: Optional[int] 
         LAST_ALLREDUCE_EVENTS = ev
     if average:
         flat /= dist.get_world_size()
+    # the reduced bucket BECOMES the gradients: every .grad is re-pointed at its slice of the flat buffer (no copy back: round 3
+    # issued one copy_ launch per parameter here, ~150 launches on a host-bound step)
     off = 0
-    for g in grads:
+    for p, g in zip(params, grads):
         n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+        p.grad = flat[off:off + n].view_as(g)
         off += n

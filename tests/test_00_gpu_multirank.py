@@ -65,6 +65,7 @@ def test_bench_two_ranks_one_device(mode):
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and rec["config"]["global_batch"] == 4 and rec["unit"] == "slides/s"
     assert abs(rec["value"] - 4 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 0.01       # whole-job aggregate over both ranks
+    assert len(rec["per_rank_ms_per_step"]) == 2 and rec["rank_imbalance_max_over_min"] >= 1.0    # each rank's own step time (load imbalance)
     ids = []
     for r in range(2):
         tag = [l for l in outs[r][1].splitlines() if l.startswith(f"[bench rank {r}/2] slide ids ")]
@@ -152,6 +153,25 @@ def test_bench_self_launch_without_a_launcher():
     # a WORLD_SIZE that contradicts --gpus is an error message, not a bare assert
     bad = subprocess.run([sys.executable, "bench.py", "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=ROOT, capture_output=True, text=True)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_training_step_on_two_host_cores():
+    """8 ranks share one host's cores in the driver's N = 8 run and the training step's host side (~13.5 ms of launch enqueue) is
+    nearly as long as its device side (~16 ms): a rank pinned to TWO host cores (os.sched_setaffinity at process start, before
+    anything touches the GPU: bench.py --cores-per-rank 2) must not run its step more than 10 % slower than with the box's whole
+    share.  (the 1 -> 8 curve itself needs the node.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PATHS_DIST_BACKEND")}
+    env.update(PATHS_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ms = {}
+    for cores in (0, 2):
+        out = _run_children([([sys.executable, "bench.py", "--mode", "train", "--steps", "8", "--warmup", "3", "--cores-per-rank", str(cores)], env)])[0]
+        rec = json.loads([l for l in out[0].splitlines() if l.startswith("{")][-1])
+        ms[cores] = rec["ms_per_step"]
+        assert rec["per_rank_ms_per_step"] and rec["rank_imbalance_max_over_min"] == 1.0
+        if cores:
+            assert "pinned to host cores" in out[1] and rec["cores_per_rank"] == 2
+    print("training step, whole CPU share vs two cores:", ms)
+    assert ms[2] <= 1.10 * ms[0], ms
 
 
 RCCL_WORKER = r'''
