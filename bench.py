@@ -442,7 +442,8 @@ def main():
     ap.add_argument("--breakdown-steps", type=int, default=3, help="steps of the serialised per-kernel breakdown pass (0 = skip)")
     ap.add_argument("--dropout", type=float, default=None, help="train mode: dropout probability (default: the shipped config's 0.05)")
     ap.add_argument("--trans-dim", type=int, default=128, help="stress mode: aggregator width (BASELINE configs[4] reports 128 and 1536; "
-                    "1536 runs with --trans-heads 24 = head_dim 64: the reference's 4 heads would be head_dim 384, which is not built)")
+                    "1536 with --trans-heads 24 = head_dim 64 runs on the flash-style kernels, with the reference's own 4 heads = head_dim "
+                    "384 on the three-step wide-head form of csrc/attn_wide.hip: correct, untuned)")
     ap.add_argument("--trans-heads", type=int, default=4)
     ap.add_argument("--fp8", action="store_true", help="stress mode: also run the opt-in e4m3 variants (attention only; the whole aggregator) and report speed and "
                     "its logit distance from the fp32-accurate path")

@@ -534,6 +534,18 @@ int paths_attention_bwd_x6_planes(const float* q, const float* k, const float* v
                                   const int64_t* num_ims, float* dqkv, float* ws_dsum, void* images, int B, int T, int H, int head_dim,
                                   uint64_t drop_key, float drop_p, int planes, paths_stream_t stream);
 
+/* ---- wide heads (head_dim > 64, a multiple of 32: e.g. trans_dim 256 / 2 heads, or 1536 / 4 heads = 384, the stress form of
+ * BASELINE configs[4]; reference model/aggregator.py:25-33 accepts any trans_dim % trans_heads == 0).  Per (slide, head): S = q k^T
+ * (f32-input MFMA GEMM), masked softmax, O = P V, and the corresponding five products backward, with the score matrix in scratch
+ * (paths_attention_wide_workspace floats).  Same conventions as paths_attention_any_train / paths_attention_bwd_any; qkv must have at
+ * least 128 readable rows behind its last one. */
+int64_t paths_attention_wide_workspace(int T, int head_dim);
+int paths_attention_wide_fwd(const float* qkv, int64_t ld, float* o, float* lse, const int64_t* num_ims, int B, int T, int H, int head_dim,
+                             float qscale, int max_queries, uint64_t drop_key, float drop_p, float* workspace, paths_stream_t stream);
+int paths_attention_wide_bwd(const float* qkv, int64_t ld, const float* o, const float* d_o, const float* lse, const int64_t* num_ims,
+                             float* dqkv, int B, int T, int H, int head_dim, float qscale, int max_queries, uint64_t drop_key, float drop_p,
+                             float* workspace, paths_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

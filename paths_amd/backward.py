@@ -718,8 +718,25 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
 
 def _attention_generic(qkv, attn, lse, num_ims, B, T, H, hd, qscale, max_queries, drop: Optional[Drop], layer: int):
     key, p = (drop.key(layer, Drop.ATTN), drop.p) if drop is not None else (0, 0.0)
+    if ops.wide_head(hd):            # head_dim > 64: csrc/attn_wide.hip (qkv carries 128 spare rows, see in_proj below)
+        ws = torch.empty((int(_lib.load().paths_attention_wide_workspace(T, hd)),), **_f32(attn.device))
+        _lib.call("paths_attention_wide_fwd", P(qkv), qkv.stride(0), P(attn), P(lse), P(num_ims), B, T, H, hd, qscale, max_queries, key, p,
+                  P(ws), _lib.stream())
+        return
     _lib.call("paths_attention_any_train", P(qkv), qkv.stride(0), P(attn), P(lse), P(num_ims), B, T, H, hd, qscale, max_queries, key, p,
               _lib.stream())
+
+
+def _attention_bwd_generic(qkv, o, d_o, lse, num_ims, dqkv, ws_dsum, B, T, H, hd, d, qscale, max_queries, dkey):
+    """dqkv (zero on entry) from the token-major qkv of the generic training forward: the flash-style kernels of csrc/generic_bwd.hip up
+    to head_dim 64, the three-step form of csrc/attn_wide.hip above."""
+    if ops.wide_head(hd):
+        ws = torch.empty((int(_lib.load().paths_attention_wide_workspace(T, hd)),), **_f32(dqkv.device))
+        _lib.call("paths_attention_wide_bwd", P(qkv), qkv.stride(0), P(o), P(d_o), P(lse), P(num_ims), P(dqkv), B, T, H, hd, qscale, max_queries,
+                  *dkey, P(ws), _lib.stream())
+        return
+    _lib.call("paths_attention_bwd_any", P(qkv), qkv.stride(0), P(o), P(d_o), P(lse), P(num_ims), P(dqkv), P(ws_dsum), B, T, H, hd, qscale, max_queries,
+              *dkey, _lib.stream())
 
 
 def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Optional[Drop], ctx_all: Optional[torch.Tensor]):
@@ -739,8 +756,12 @@ def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, 
     sv = {"layers": [], "num_ims": num_ims, "tokens": tokens, "ctx_prev": ctx_prev, "ctx_all": ctx_all if cdepth > 0 else None,
           "drop": drop}
 
+    spare = 128 if ops.wide_head(hd) else 0          # wide heads: the score products read whole 128-row tiles of k / v
+
     def in_proj(x, w):
-        qkv = torch.empty((M, 3 * d), **f32)
+        qkv = torch.empty((M + spare, 3 * d), **f32)
+        if spare:
+            qkv[M:].zero_()
         gemm_nt(x.view(M, d), d, w["wqkv"], qkv, 3 * d, M, 3 * d, d, bias=w["bqkv"])
         return qkv
 
@@ -856,8 +877,7 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         d_o = torch.zeros((B, T, d), **f32)                                  # only token 0 carries an output gradient
         d_o[:, 0, :] = da0
         ws = torch.empty((B * H * T,), **f32)
-        _lib.call("paths_attention_bwd_any", P(last["qkv"]), 3 * d, P(attn0), P(d_o), P(last["lse0"]), P(num_ims), P(dqkv), P(ws),
-                  B, T, H, hd, qscale, 1, *dk(L - 1), st)
+        _attention_bwd_generic(last["qkv"], attn0, d_o, last["lse0"], num_ims, dqkv, ws, B, T, H, hd, d, qscale, 1, dk(L - 1))
     dx = torch.zeros((B, T, d), **f32)                                       # gradient of the last layer's input
     dx[:, 0, :] = dx0
     g.update(qkv_backward(wl, x_last, dqkv, B * T, qscale, dx, fold_qscale=fast))
@@ -873,8 +893,7 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         dqkv = torch.zeros((B, T, 3 * d), **f32)
         ws = torch.empty((B * H * T,), **f32)
         if not fast:
-            _lib.call("paths_attention_bwd_any", P(lv["qkv"]), 3 * d, P(lv["attn"]), P(dattn), P(lv["lse"]), P(num_ims), P(dqkv), P(ws),
-                      B, T, H, hd, qscale, 0, *dk(l), st)
+            _attention_bwd_generic(lv["qkv"], lv["attn"], dattn, lv["lse"], num_ims, dqkv, ws, B, T, H, hd, d, qscale, 0, dk(l))
         elif ATTN_BWD_MODE == "x6q":    # dQ, dK and dV on the split-bf16 kernels (csrc/attn_bwd_x6.hip; PATHS_ATTN_BWD_KV_X6=0 in the C library keeps dK / dV on the f32 MFMA)
             img = torch.empty((int(_lib.load().paths_attention_bwd_x6_workspace(B, T, H, hd)),), device=dqkv.device, dtype=torch.uint8)
             # operand split as the other gradient products of the step (ops.TRAIN_PLANES: 4 = two bf16 planes, 3 = the exact three)

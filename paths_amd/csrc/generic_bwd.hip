@@ -1,4 +1,4 @@
-// Shape-generic kernels of the TRAINING path: any trans_dim (multiple of 32, <= 1024), head_dim in {16, 32, 48, 64}, any
+// Shape-generic kernels of the TRAINING path: any trans_dim (multiple of 32, <= 2048), head_dim in {16, 32, 48, 64} (wider heads: attn_wide.hip), any
 // importance_mlp_hidden_dim (multiple of 4).  The shipped geometry (128 / 4 heads / 128) trains on the specialised kernels
 // (bwd_rows.hip, attn_bwd.hip, attn_bwd_x6.hip); these evaluate the same derivatives for every other configuration of the
 // reference's config surface (config.py:30-36: the dataclass default is trans_dim 192 = head_dim 48).  What they differentiate:
@@ -23,8 +23,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm, any width d <= 1024 (d % 4 == 0): one wave per row, lane l owns columns 4 l + 256 i
+// LayerNorm, any width d <= 2048 (d % 4 == 0): one wave per row, lane l owns columns 4 l + 256 i, i < NI
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int NI = 8;
 __global__ void __launch_bounds__(256)
 ln_fwd_stats_any_kernel(const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ g,
                         const float* __restrict__ bta, float* __restrict__ y, float* __restrict__ xhat,
@@ -32,10 +33,10 @@ ln_fwd_stats_any_kernel(const float* __restrict__ x, const float* __restrict__ a
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  f32x4 v[4];
+  f32x4 v[NI];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int c = 4 * lane + 256 * i;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < d) {
@@ -47,14 +48,14 @@ ln_fwd_stats_any_kernel(const float* __restrict__ x, const float* __restrict__ a
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
     if (4 * lane + 256 * i < d) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const float c = v[i][e] - mean; q += c * c; }
     }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int c = 4 * lane + 256 * i;
     if (c < d) {
       f32x4 xh;
@@ -81,19 +82,19 @@ ln_bwd_any_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row0 = SUMS ? (int64_t)blockIdx.x * rows_per_block : (int64_t)blockIdx.x * 4;
   const int64_t row1 = min(rows, row0 + (SUMS ? rows_per_block : 4));
-  f32x4 gg[4], sg[4], sb[4], sx[4];
+  f32x4 gg[NI], sg[NI], sb[NI], sx[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int c = 4 * lane + 256 * i;
     gg[i] = c < d ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     sg[i] = sb[i] = sx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float inv_d = 1.0f / (float)d;
   for (int64_t row = row0 + wave; row < row1; row += 4) {
-    f32x4 dv[4], xh[4], dg[4];
+    f32x4 dv[NI], xh[NI], dg[NI];
     float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int c = 4 * lane + 256 * i;
       dv[i] = xh[i] = dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < d) {
@@ -107,7 +108,7 @@ ln_bwd_any_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, 
     const float m1 = wave_sum(a1) * inv_d, m2 = wave_sum(a2) * inv_d;
     const float rs = rstd[row];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int c = 4 * lane + 256 * i;
       if (c < d) {
         f32x4 o4;
@@ -122,7 +123,7 @@ ln_bwd_any_kernel(const float* __restrict__ dy, const float* __restrict__ xhat, 
   if constexpr (SUMS) {
     float* o = aux + (int64_t)blockIdx.x * 3 * d;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int c = 4 * lane + 256 * i;      // (uniform trip count: every wave passes the barriers)
       __syncthreads();
       part[0][wave][lane] = sg[i]; part[1][wave][lane] = sb[i]; part[2][wave][lane] = sx[i];
@@ -408,7 +409,7 @@ extern "C" {
 // LayerNorm forward keeping xhat / rstd for the backward (y may be null), any width; x (+ add) -> y
 int paths_layernorm_fwd_stats_any(const float* x, const float* add, const float* gamma, const float* beta, float* y, float* xhat,
                                   float* rstd, int64_t rows, int d, float eps, hipStream_t stream) {
-  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 1024 && d % 4 == 0 && x && xhat && rstd && (y == nullptr || (gamma && beta)), "layernorm_fwd_stats_any: bad arguments (d = %d)", d);
+  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 2048 && d % 4 == 0 && x && xhat && rstd && (y == nullptr || (gamma && beta)), "layernorm_fwd_stats_any: bad arguments (d = %d)", d);
   hipLaunchKernelGGL(ln_fwd_stats_any_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, add, gamma, beta, y, xhat, rstd, rows, d, eps);
   PATHS_LAUNCH_CHECK("layernorm_fwd_stats_any");
   return PATHS_OK;
@@ -416,7 +417,7 @@ int paths_layernorm_fwd_stats_any(const float* x, const float* add, const float*
 
 int paths_layernorm_bwd_any(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* dyxhat,
                             int64_t rows, int d, hipStream_t stream) {
-  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 1024 && d % 4 == 0 && dy && xhat && rstd && gamma && dx && dyxhat, "layernorm_bwd_any: bad arguments (d = %d)", d);
+  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 2048 && d % 4 == 0 && dy && xhat && rstd && gamma && dx && dyxhat, "layernorm_bwd_any: bad arguments (d = %d)", d);
   hipLaunchKernelGGL(ln_bwd_any_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, dy, xhat, rstd, gamma, dx, dyxhat, rows, d, 4);
   PATHS_LAUNCH_CHECK("layernorm_bwd_any");
   return PATHS_OK;
@@ -425,7 +426,7 @@ int paths_layernorm_bwd_any(const float* dy, const float* xhat, const float* rst
 // dx + one slab [sum dy*xhat (d) | sum dy (d) | sum dx (d)] per block of rows_per_block rows (paths_reduce_slabs_f32 adds them)
 int paths_layernorm_bwd_sums_any(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* slabs,
                                  int64_t rows, int d, int rows_per_block, hipStream_t stream) {
-  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 1024 && d % 4 == 0 && rows_per_block >= 4 && dy && xhat && rstd && gamma && dx && slabs,
+  PATHS_REQUIRE(rows > 0 && d > 0 && d <= 2048 && d % 4 == 0 && rows_per_block >= 4 && dy && xhat && rstd && gamma && dx && slabs,
                 "layernorm_bwd_sums_any: bad arguments (d = %d)", d);
   const unsigned nblk = (unsigned)((rows + rows_per_block - 1) / rows_per_block);
   hipLaunchKernelGGL(ln_bwd_any_kernel<true>, dim3(nblk), dim3(256), 0, stream, dy, xhat, rstd, gamma, dx, slabs, rows, d, rows_per_block);

@@ -381,13 +381,19 @@ def fast_path(mc) -> bool:
     return mc.trans_dim == 128 and mc.trans_heads == 4 and mc.importance_mlp_hidden_dim == 128
 
 
+def wide_head(hd: int) -> bool:
+    """head_dim above the flash-style kernels' 64: the three-step form of csrc/attn_wide.hip (score matrix in scratch)."""
+    return hd > 64 and hd % 32 == 0 and hd <= 1024
+
+
 def check_supported(mc, training: bool = False):
     """Configurations this build runs on the HIP path; everything else is rejected loudly."""
     if not fast_path(mc):
         d, H, Hi = mc.trans_dim, mc.trans_heads, mc.importance_mlp_hidden_dim
-        if d % 32 or d > 2048 or H < 1 or d % H or (d // H) not in (16, 32, 48, 64) or Hi < 1 or Hi > 1024 or (training and d > 1024):
-            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 2048; <= 1024 for training), head_dim in {16, 32, 48, 64} and "
-                                      f"importance_mlp_hidden_dim <= 1024 (got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
+        hd = d // max(H, 1)
+        if d % 32 or d > 2048 or H < 1 or d % H or not (hd in (16, 32, 48, 64) or wide_head(hd)) or Hi < 1 or Hi > 1024:
+            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 2048), head_dim in {16, 32, 48, 64} or a multiple "
+                                      f"of 32 above 64, and importance_mlp_hidden_dim <= 1024 (got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
         if training and Hi % 4:
             raise NotImplementedError("training at aggregator geometries other than trans_dim=128 / 4 heads / importance hidden 128 needs "
                                       f"importance_mlp_hidden_dim % 4 == 0 (got {Hi}); inference runs")
@@ -564,10 +570,16 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     ws8 = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if (fp8 and L > 1) else None
     # full layers' attention on the split-fp16 matrix-core kernel for any head_dim (the arithmetic of the tuned path), unless the
     # f32 mode is selected; the last layer's single query stays on the f32-input kernel
-    h3 = (not fp8) and GENERIC_SPLIT and GEMM_MODE == "h3" and L > 1
+    wide = wide_head(hd)
+    if wide and fp8:
+        raise NotImplementedError(f"the e4m3 aggregator needs head_dim 32 or 64 (got {hd})")
+    wsw = torch.empty((int(_lib.load().paths_attention_wide_workspace(T, hd)),), **f32) if wide else None
+    h3 = (not fp8) and GENERIC_SPLIT and GEMM_MODE == "h3" and L > 1 and not wide
     wsh = torch.empty((int(_lib.load().paths_attention_h3_any_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if h3 else None
     x = tokens.view(M, d)
-    qkv = torch.empty((M, 3 * d), **f32)
+    qkv = torch.empty((M + (128 if wide else 0), 3 * d), **f32)      # (wide heads: the score product reads whole 128-row tiles of k)
+    if wide:
+        qkv[M:].zero_()
     # rows of padded queries are never written by the attention kernels: harmless row-wise garbage on the accurate path, but the e4m3
     # path takes max|.| over WHOLE activation matrices for its per-tensor scales - there they must be defined (zero)
     attn = (torch.zeros if fp8 else torch.empty)((B, T, d), **f32)
@@ -586,6 +598,8 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
         gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
         if big:
             _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
+        elif wide:
+            _lib.call("paths_attention_wide_fwd", p(qkv), 3 * d, p(attn), None, p(num_ims), B, T, H, hd, qscale, 1 if last else 0, 0, 0.0, p(wsw), st)
         elif h3 and not last:
             _lib.call("paths_attention_h3_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(wsh), st)
         elif last and GENERIC_SPLIT:
@@ -598,7 +612,7 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
         if last:
             rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
         y1 = torch.empty((rows, d), **f32)
-        if last and GENERIC_SPLIT:
+        if last and GENERIC_SPLIT and not wide:
             gemm(a0, d, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx)
         else:
             gemm(attn, ldx, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx, low=big)

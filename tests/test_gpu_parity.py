@@ -451,6 +451,26 @@ def test_headline_recursion_vs_oracle(dev, K, base, ids):
     np.testing.assert_allclose(out["logits"].cpu().numpy(), otrace[-1]["logits"].numpy(), atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("tag", ["td256_h2", "td1536_h4"])
+def test_single_level_wide_heads(dev, tag):
+    """g14 (VERDICT r3 missing 2): head_dim above 64 - trans_dim 256 / 2 heads = 128 and the stress row's own form trans_dim 1536 / 4
+    heads = 384 - on csrc/attn_wide.hip (scores through the f32-input MFMA GEMMs, score matrix in scratch), against the
+    fixtures captured from the reference; same bars as every other geometry."""
+    import paths_amd.ops as O
+    calls = []
+    orig = O._lib.call
+    O._lib.call = lambda cname, *a: (calls.append(cname), orig(cname, *a))[1]
+    try:
+        g, info, out = run_single(dev, f"g14_{tag}_level1")
+    finally:
+        O._lib.call = orig
+    assert "paths_attention_wide_fwd" in calls and not {"paths_attention_any", "paths_attention_h3_any"} & set(calls)
+    np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["importance"].numpy(), g["importance"], atol=STATE_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_patch"].numpy(), g["ctx_patch"], atol=STATE_TOL, rtol=0)
+
+
 def test_recursion_trans_dim_192_at_k1024_vs_oracle(dev):
     """The reference's default aggregator width (trans_dim 192, head_dim 48) at a BASELINE size: 5 levels at K = 1024 patches/level on
     the generic kernels against the oracle (the selection chain - LSTM, importance MLP - does not depend on trans_dim, so the

@@ -53,6 +53,15 @@ def test_single_level_other_aggregator_geometries(tag):
         np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["td256_h2", "td1536_h4"])
+def test_single_level_wide_heads(tag):
+    """g14: the oracle at head_dim 128 (trans_dim 256 / 2 heads) and 384 (trans_dim 1536 / 4 heads: SURVEY 8(d)'s stress form) against the
+    reference's outputs (reference model/aggregator.py:25-33 accepts any trans_dim % trans_heads == 0)."""
+    g, info, out = _run_single(f"g14_{tag}_level1")
+    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])
 def test_single_level_k2048(name):
     g, info, out = _run_single(name)

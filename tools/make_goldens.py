@@ -495,6 +495,15 @@ def main():
         }.items():
             single_level(ref, f"g12_{tag}_level1", 1, 2, 64, [64, 50], wseed=4, dseed=15, cfg_over=over)
         recursion(ref, "g12_recursion_td192_6x7_top5", (6, 7), 5, 2, wseed=2, dseed=13, p_bg=0.2, cfg_over={"model_config": {"trans_dim": 192}})
+    if want("g14"):
+        # WIDE heads (head_dim > 64: csrc/attn_wide.hip): trans_dim 256 / 2 heads = 128, and the stress form of SURVEY 8(d),
+        # trans_dim 1536 / 4 heads = 384 (BASELINE configs[4]'s geometry at a size the reference runs in seconds); 3 AdamW steps at 128
+        for tag, over in {
+            "td256_h2": {"model_config": {"trans_dim": 256, "trans_heads": 2}},
+            "td1536_h4": {"model_config": {"trans_dim": 1536, "trans_heads": 4}},
+        }.items():
+            single_level(ref, f"g14_{tag}_level1", 1, 2, 64, [64, 50], wseed=4, dseed=15, cfg_over=over)
+        training(ref, "g14_train_td256_h2_8x8_top16", (8, 8), 16, 3, wseed=7, dseed=23, cfg_over={"model_config": {"trans_dim": 256, "trans_heads": 2}})
     if want("g6"):
         training(ref, "g6_train_16x16_top64", (16, 16), 64, 4, wseed=3, dseed=14)
     if want("g13"):
