@@ -442,6 +442,16 @@ int paths_gather_kept_rows(const float* src, int64_t n_cur, int64_t ld_src, cons
 int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_count, const int* child_pos, const float* d_next,
                           int64_t n_next, int Dp, float* d_cur, int64_t n_cur, int B, paths_stream_t stream);
 
+/* The once-per-parent form of the TRAINING step (siblings share their parent's h, reference data_utils/slide.py:303-331 +
+ * model/interface.py:49-56): paths_sibling_sum adds the rows of the surviving children of every kept parent -
+ * dst[b, row(i), 0:width] = sum_children src[b, child, 0:width], row(i) = keep_idx[b, i] or, with keep_idx NULL, the compact slot i
+ * (the gradient of the once-per-parent partial pre-activations: dHP = sum of the children's dG) - and paths_scatter_kept_rows puts
+ * a compact per-kept-parent table back into the level's rows: dst[b, keep_idx[b, i], 0:width] = src[b, i, 0:width]. */
+int paths_sibling_sum(const int* keep_idx, int64_t ldk, const int* keep_count, const int* child_pos, const float* src, int64_t n_src,
+                      int64_t ld_src, int width, float* dst, int64_t n_dst, int64_t ld_dst, int B, paths_stream_t stream);
+int paths_scatter_kept_rows(const float* src, int64_t ldk, int64_t ld_src, const int* keep_idx, const int* keep_count, float* dst,
+                            int64_t n_dst, int64_t ld_dst, int width, int B, paths_stream_t stream);
+
 /* Level-0 batch: every grid cell in row-major order (reference data_utils/slide.py:257-269,362-381). */
 int paths_level0_batch(const int64_t* grid_ptrs, const int* gx, const int* gy, int B, int D, int patch_size, int64_t n0,
                        float* fts, int64_t* locs, int64_t* parent, int64_t* num_ims, int zero_pad, int64_t* row_ptrs,

@@ -39,6 +39,8 @@ SIGNATURES = {
     "paths_transpose_f32": [_vp, _i64, _i32, _i32, _vp, _i64, _vp],
     "paths_attention_wide_fwd": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _u64, _f32, _vp, _vp],
     "paths_attention_wide_bwd": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _u64, _f32, _vp, _vp],
+    "paths_sibling_sum": [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _i64, _i32, _vp],
+    "paths_scatter_kept_rows": [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "paths_adamw_multi": [_vp, _vp, _vp, _i32, _vp, _vp, _f32, _i32, _f32, _f32, _f32, _f32, _i32, _vp],
     "paths_lstm_bwd_a": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _vp],
     "paths_lstm_bwd_b": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i32, _i64, _i32, _vp, _i64, _vp, _i64, _vp],

@@ -203,21 +203,108 @@ class LevelFn(torch.autograd.Function):
         else:
             tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
         sg, d_state_prev = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
-        lg = bw.unpack_lstm_grads(lstm, sg)
-        grads = [lg[k] for k in LSTM_ORDER]
-        Hi = mc.importance_mlp_hidden_dim
-        imp_live = mc.importance_mode == "mul" and not no_agg
-        grads += [sg["w_ip"][:Hi], sg["b1"], sg["w2"].view(1, -1), sg["b2"]] if imp_live else [None] * 4
-        if no_agg:
-            grads += [None] * (3 + len(LAYER_ORDER) * mc.trans_layers + 4)
-        else:
-            grads += [sg["w_ip"][Hi:], sg["bp"], sg["special"]]
-            for l, g in enumerate(tg["layers"]):
-                grads += [g[key] for _, key in LAYER_ORDER]
-            grads += [tg["lnfg"], tg["lnfb"]]
-            grads += [tg["wcls"], tg["bcls"]] if d_logits is not None else [None, None]     # unused logits: grad stays None
+        grads = _level_grads(mc, lstm, sg, tg, no_agg, d_logits is not None)
         return (None, None, None, None, None, d_state_prev if ctx.has_state else None,
                 d_ctx_prev if ctx.has_ctx else None, *grads)
+
+
+class LevelParentFn(torch.autograd.Function):
+    """:class:`LevelFn` in the device recursion's once-per-parent form: instead of a per-child copy of the parent state the level takes
+    the children's inherited memory cell ``c0`` [B,N,Hc], the kept parents' h rows ``h_kept`` [B*cap, D] and the child -> kept-slot map
+    (paths_amd/backward.py:selection_forward_train ``parent=``); gradients come back for ``c0`` and ``h_kept``."""
+
+    @staticmethod
+    def forward(ctx, proc, lstm, fts, locs, num_ims, c0, h_kept, hp_row, child_pos, keep_count, cap, ctx_prev, *params):
+        mc = proc.config
+        check_dropout_supported(proc)
+        lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
+        sel = bw.selection_forward_train(mc, lp, vp, fts, locs.contiguous(), num_ims.contiguous(), None,
+                                         parent={"c0": c0, "h_kept": h_kept, "hp_row": hp_row, "child_pos": child_pos,
+                                                 "keep_count": keep_count, "cap": int(cap)})
+        res = ctx_prev if (mc.slide_ctx_mode == "residual" and ctx_prev is not None) else None
+        cat = ctx_prev.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_prev is not None and ctx_prev.shape[1] > 0) else None
+        drop = None
+        if proc.training and mc.dropout > 0:
+            drop = bw.Drop(mc.dropout, next_dropout_seed(fts.device), proc.depth)
+        tr = bw.transformer_forward_train(mc, vp, sel["tokens"], sel["num_ims"], res, drop, cat)
+        ctx.proc, ctx.lstm = proc, lstm
+        ctx.sel, ctx.tr = _detached_saves(sel, tr)
+        ctx.has_ctx = res is not None or cat is not None
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(sel["importance"])
+        return tr["logits"], tr["ctx_out"], sel["state_out"], sel["importance"]
+
+    @staticmethod
+    def backward(ctx, d_logits, d_ctx_out, d_state_out, _d_imp):
+        proc, lstm, sel, tr = ctx.proc, ctx.lstm, ctx.sel, ctx.tr
+        ctx.sel = ctx.tr = None
+        mc = proc.config
+        lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
+        cont = lambda t: t.contiguous() if t is not None else None
+        no_agg = d_logits is None and d_ctx_out is None
+        if no_agg:
+            tg, d_ctx_prev = None, None
+            d_tok = torch.zeros_like(tr["tokens"])
+        else:
+            tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+        sg, (d_c0, d_hk) = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
+        grads = _level_grads(mc, lstm, sg, tg, no_agg, d_logits is not None)
+        return (None, None, None, None, None, d_c0, d_hk, None, None, None, None, d_ctx_prev if ctx.has_ctx else None, *grads)
+
+
+def _level_grads(mc, lstm, sg, tg, no_agg: bool, has_logits: bool):
+    """Parameter gradients of one level in the order of lstm_params + level_params (None where there is no path to the loss)."""
+    lg = bw.unpack_lstm_grads(lstm, sg)
+    grads = [lg[k] for k in LSTM_ORDER]
+    Hi = mc.importance_mlp_hidden_dim
+    imp_live = mc.importance_mode == "mul" and not no_agg
+    grads += [sg["w_ip"][:Hi], sg["b1"], sg["w2"].view(1, -1), sg["b2"]] if imp_live else [None] * 4
+    if no_agg:
+        grads += [None] * (3 + len(LAYER_ORDER) * mc.trans_layers + 4)
+    else:
+        grads += [sg["w_ip"][Hi:], sg["bp"], sg["special"]]
+        for l, g in enumerate(tg["layers"]):
+            grads += [g[key] for _, key in LAYER_ORDER]
+        grads += [tg["lnfg"], tg["lnfb"]]
+        grads += [tg["wcls"], tg["bcls"]] if has_logits else [None, None]
+    return grads
+
+
+class GatherParentFn(torch.autograd.Function):
+    """Children of the kept patches in the once-per-parent form: gathered feature rows (not differentiable), the children's inherited
+    memory cell c0 [B,n_next,Hc] and the kept parents' h rows h_kept [B*cap, D].  Backward: the parents' state gradient =
+    (scatter of d_h_kept | sum over the surviving children of d_c0), fixed order."""
+
+    @staticmethod
+    def forward(ctx, state_cur, grid_ptrs, src_cell, src_row, num_next, keep_idx, keep_count, child_pos, D, n_next):
+        B, n_cur, Dp = state_cur.shape
+        Hc = Dp - D
+        cap = keep_idx.shape[1]
+        f32 = dict(device=state_cur.device, dtype=torch.float32)
+        fts_next = torch.empty((B, n_next, D), **f32)
+        c0 = torch.empty((B, n_next, Hc), **f32)
+        h_kept = torch.empty((B * cap, D), **f32)
+        p = _lib.ptr
+        _lib.call("paths_gather_rows", p(grid_ptrs), p(src_cell), D, state_cur.data_ptr() + 4 * D, n_cur, Dp, p(src_row), Hc, p(num_next), B,
+                  n_next, p(fts_next), p(c0), 1, None, None, _lib.stream())
+        _lib.call("paths_gather_kept_rows", p(state_cur), n_cur, Dp, p(keep_idx), cap, p(keep_count), D, B, p(h_kept), _lib.stream())
+        ctx.meta = (keep_idx, keep_count, child_pos, n_cur, n_next, Dp, D, B)
+        ctx.mark_non_differentiable(fts_next)
+        return fts_next, c0, h_kept
+
+    @staticmethod
+    def backward(ctx, _d_fts, d_c0, d_hk):
+        keep_idx, keep_count, child_pos, n_cur, n_next, Dp, D, B = ctx.meta
+        cap = keep_idx.shape[1]
+        dev = (d_c0 if d_c0 is not None else d_hk).device
+        d_cur = torch.zeros((B, n_cur, Dp), device=dev, dtype=torch.float32)
+        p = _lib.ptr
+        if d_c0 is not None:
+            _lib.call("paths_sibling_sum", p(keep_idx), cap, p(keep_count), p(child_pos), p(d_c0.contiguous()), n_next, Dp - D, Dp - D,
+                      d_cur.data_ptr() + 4 * D, n_cur, Dp, B, _lib.stream())
+        if d_hk is not None:
+            _lib.call("paths_scatter_kept_rows", p(d_hk.contiguous()), cap, D, p(keep_idx), p(keep_count), p(d_cur), n_cur, Dp, D, B, _lib.stream())
+        return (d_cur,) + (None,) * 9
 
 
 def level_params_nolstm(proc) -> List[torch.nn.Parameter]:

@@ -179,9 +179,13 @@ def colsum(a, lda, M, N, out=None, accumulate=False):
 # ---------------------------------------------------------------------------------------------------------------
 # selection chain: LSTM cell + importance MLP / projection
 # ---------------------------------------------------------------------------------------------------------------
-def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev) -> Dict[str, torch.Tensor]:
+def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, parent=None) -> Dict[str, torch.Tensor]:
     """Forward of the LSTM + importance/projection part with everything the backward needs kept in HBM.
-    Padded rows are computed too (finite values everywhere: 0 * garbage would poison the reductions)."""
+    Padded rows are computed too (finite values everywhere: 0 * garbage would poison the reductions).
+    ``parent`` (the device recursion's once-per-parent form, ``state_prev`` None then) = {"c0": [B,N,Hc] the children's inherited memory
+    cell, "h_kept": [B*cap, D] the kept parents' h rows, "hp_row": [B,N] int32 child -> kept slot (-1: no parent)}: siblings share
+    their parent's h, so the h half of the gate pre-activations is ONE product over the kept parents (a quarter of the rows) that
+    seeds the children's accumulators (reference model/interface.py:49-56 with cat(x, h) split in two panels)."""
     B, N, D = fts.shape
     d = mc.trans_dim
     Hc = lstm_pack["Hc"]
@@ -195,23 +199,43 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
     sv["o"] = torch.empty((B, N, D), **f32)
     sv["frm"] = torch.empty((B, N, 3 * Hc), **f32)
     sv["tc"] = torch.empty((B, N, D), **f32)
-    if state_prev is not None:
+    G = 3 * Hc + D
+    x6 = ops.use_x6(D, Hc)        # forward GEMMs on the split-bf16 path (weight images are re-packed when the optimizer steps)
+    hp, hp_row = None, None
+    if parent is not None:
+        assert state_prev is None
+        c0t, hk = parent["c0"], parent["h_kept"]
+        assert c0t.shape == (B, N, Hc) and c0t.is_contiguous() and hk.shape[1] == D and hk.is_contiguous()
+        ld, h0, c0 = Hc, None, c0t.data_ptr()
+        M4 = hk.shape[0]
+        sv["parent"] = {"c0": c0t, "h_kept": hk, "hp_row": parent["hp_row"], "child_pos": parent["child_pos"],
+                        "keep_count": parent["keep_count"], "cap": parent["cap"]}
+        hpt = torch.empty((M4, G), **f32)              # HP = h_kept W_gates[:, D:2D]^T (no bias), packed gate-column order
+        if x6 and G % 256 == 0:
+            TP = ops.TRAIN_FWD_PLANES
+            wg, wg_s = ops._x6_of(lstm_pack, "w_gates", TP, lagged=True)
+            _lib.call("paths_gemm_nt_x6", P(hk), D, P(wg), 2 * D, D, None, P(hpt), G, M4, G, G, D, 0, None, 0, None, 0, 0, TP, wg_s,
+                      ops.A_SCALE if TP == 2 else 1.0, st)
+        else:
+            _lib.call("paths_gemm_nt_f32", P(hk), D, lstm_pack["w_gates"].data_ptr() + 4 * D, 2 * D, None, P(hpt), G, M4, G, G, D, 0,
+                      None, 0, None, 0, 0, st)
+        hp, hp_row = P(hpt), P(parent["hp_row"])
+    elif state_prev is not None:
         assert state_prev.shape == (B, N, Dp) and state_prev.stride(2) == 1 and state_prev.stride(0) == N * state_prev.stride(1)
         ld, h0, c0 = state_prev.stride(1), state_prev.data_ptr(), state_prev.data_ptr() + 4 * D
     else:
         ld, h0, c0 = 0, None, None
-    x6 = ops.use_x6(D, Hc)        # forward GEMMs on the split-bf16 path (weight images are re-packed when the optimizer steps)
     if x6:
         TP = ops.TRAIN_FWD_PLANES
         asc = ops.A_SCALE if TP == 2 else 1.0
         (wg, wg_s), (wm, wm_s) = ops._x6_of(lstm_pack, "w_gates", TP, lagged=True), ops._x6_of(lstm_pack, "w_mem", TP, lagged=True)
         _lib.call("paths_lstm_cell_x6", P(fts), D, None, h0, ld, c0, ld, P(wg), P(lstm_pack["b_gates"]), P(wm), P(lstm_pack["b_mem"]),
-                  P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7,
+                  P(sv["state_out"]), Dp, P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), hp, hp_row, M, D, Hc, None, N, 7,
                   TP, wg_s, wm_s, asc, st)
     else:
         _lib.call("paths_lstm_cell", P(fts), D, h0, ld, c0, ld, P(lstm_pack["w_gates"]), P(lstm_pack["b_gates"]),
                   P(lstm_pack["w_mem"]), P(lstm_pack["b_mem"]), P(sv["state_out"]), Dp,
-                  P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), None, None, M, D, Hc, None, N, 7, st)
+                  P(sv["y"]), D, P(sv["o"]), P(sv["frm"]), P(sv["tc"]), hp, hp_row, M, D, Hc, None, N, 7, st)
     sv["importance"] = torch.empty((B, N), **f32)
     sv["tokens"] = torch.empty((B, T, d), **f32)
     Hi = mc.importance_mlp_hidden_dim
@@ -297,11 +321,32 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
     dc1_h = torch.empty((M, Hc), **f32)
     w_mem_t = transpose(lstm_pack["w_mem"], D, Hc)                      # [Hc, D]
     gemm_nt(dpre_h, D, w_mem_t, dc1_h, Hc, M, Hc, D)
+    par = sv.get("parent")
     d_state_prev = torch.empty((B, N, Dp), **f32) if state_prev is not None else None
     ext_c = d_state_out.data_ptr() + 4 * D if d_state_out is not None else None
-    c0_ptr = state_prev.data_ptr() + 4 * D if state_prev is not None else None
-    _lib.call("paths_lstm_bwd_b", P(dc1_h), ext_c, Dp, P(sv["frm"]), c0_ptr, state_prev.stride(1) if state_prev is not None else 0,
-              P(num_ims), N, M, Hc, P(dG), G, d_state_prev.data_ptr() + 4 * D if d_state_prev is not None else None, Dp, st)
+    if par is not None:                 # once-per-parent form: the children inherited c0 [B,N,Hc]; its gradient goes back as such
+        d_c0 = torch.empty((B, N, Hc), **f32)
+        _lib.call("paths_lstm_bwd_b", P(dc1_h), ext_c, Dp, P(sv["frm"]), P(par["c0"]), Hc, P(num_ims), N, M, Hc, P(dG), G, P(d_c0), Hc, st)
+    else:
+        c0_ptr = state_prev.data_ptr() + 4 * D if state_prev is not None else None
+        _lib.call("paths_lstm_bwd_b", P(dc1_h), ext_c, Dp, P(sv["frm"]), c0_ptr, state_prev.stride(1) if state_prev is not None else 0,
+                  P(num_ims), N, M, Hc, P(dG), G, d_state_prev.data_ptr() + 4 * D if d_state_prev is not None else None, Dp, st)
+    if par is not None:
+        # dHP[b, i] = sum of dG over the surviving children of kept parent i (the pre-activations got HP[parent] added): then the h
+        # half of the weight gradient and the parents' h gradient are products over the kept parents - a quarter of the rows
+        cap, hk = par["cap"], par["h_kept"]
+        M4 = hk.shape[0]
+        dhp = torch.zeros((M4, G), **f32)
+        _lib.call("paths_sibling_sum", None, cap, P(par["keep_count"]), P(par["child_pos"]), P(dG), N, G, G, P(dhp), cap, G, B, st)
+        grads["b_gates"] = colsum(dG, G, M, G)
+        grads["w_gates"] = torch.empty((G, 2 * D), **f32)
+        gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, D, ldo=2 * D)                       # x panel: over the children
+        gemm_tn(dhp, G, hk, D, grads["w_gates"][:, D:], M4, G, D, ldo=2 * D)               # h panel: over the kept parents
+        wh_t = transpose(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)                  # [D, G] = (W_gates[:, D:2D])^T
+        d_hk = torch.empty((M4, D), **f32)
+        gemm_nt(dhp, G, wh_t, d_hk, D, M4, D, G)
+        side_join(dev)
+        return grads, (d_c0, d_hk)
     with side_stream(dev, dG, fts):
         grads["b_gates"] = colsum(dG, G, M, G)
         grads["w_gates"] = torch.empty((G, 2 * D), **f32)

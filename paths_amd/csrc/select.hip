@@ -304,6 +304,42 @@ gather_bwd_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __re
   }
 }
 
+// The same sum with separate row strides, an optional compact destination (keep_idx == nullptr: kept slot i -> row i) and a column
+// window: dst[b, row(i), 0:width] (+)= sum over the surviving children of kept parent i of src[b, child, 0:width].  The training
+// step's once-per-parent form: dHP = sum of the children's gate-pre-activation gradients (compact table), dc_parent = sum of dc0.
+__global__ void __launch_bounds__(256)
+sibling_sum_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restrict__ keep_count, const int* __restrict__ child_pos,
+                   const float* __restrict__ src, int64_t n_src, int64_t ld_src, int width, float* __restrict__ dst, int64_t n_dst,
+                   int64_t ld_dst) {
+  const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const int count = keep_count[b];
+  if (i >= count) return;
+  const int row = keep_idx ? keep_idx[(int64_t)b * ldk + i] : i;
+  int pos[4];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) pos[blk] = child_pos[(int64_t)b * 4 * ldk + blk * count + i];
+  f32x4* out = reinterpret_cast<f32x4*>(dst + ((int64_t)b * n_dst + row) * ld_dst);
+  for (int c = tid; c < width / 4; c += 256) {
+    f32x4 s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+      if (pos[blk] >= 0) s += reinterpret_cast<const f32x4*>(src + ((int64_t)b * n_src + pos[blk]) * ld_src)[c];
+    out[c] = s;
+  }
+}
+
+// dst[b, keep_idx[b, i], 0:width] = src[b, i, 0:width] for i < keep_count[b] (the kept parents' h gradient back into the level's state gradient)
+__global__ void __launch_bounds__(256)
+scatter_kept_rows_kernel(const float* __restrict__ src, int64_t ldk, int64_t ld_src, const int* __restrict__ keep_idx,
+                         const int* __restrict__ keep_count, float* __restrict__ dst, int64_t n_dst, int64_t ld_dst, int width) {
+  const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  if (i >= keep_count[b]) return;
+  const int row = keep_idx[(int64_t)b * ldk + i];
+  const f32x4* in = reinterpret_cast<const f32x4*>(src + ((int64_t)b * ldk + i) * ld_src);
+  f32x4* out = reinterpret_cast<f32x4*>(dst + ((int64_t)b * n_dst + row) * ld_dst);
+  for (int c = tid; c < width / 4; c += 256) out[c] = in[c];
+}
+
 // Level 0: every grid cell, row-major, no background filter (slide.py:257-269).
 __global__ void __launch_bounds__(256)
 level0_kernel(const int64_t* __restrict__ grid_ptrs, const int* __restrict__ gx, const int* __restrict__ gy, int D,
@@ -496,6 +532,28 @@ int paths_gather_rows_bwd(const int* keep_idx, int64_t ldk, const int* keep_coun
   PATHS_REQUIRE(B > 0 && ldk > 0 && Dp % 4 == 0 && keep_idx && keep_count && child_pos && d_next && d_cur, "gather_rows_bwd: bad arguments");
   hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)ldk, B), dim3(256), 0, stream, keep_idx, ldk, keep_count, child_pos, d_next, n_next, Dp, d_cur, n_cur);
   PATHS_LAUNCH_CHECK("gather_rows_bwd");
+  return PATHS_OK;
+}
+
+int paths_sibling_sum(const int* keep_idx, int64_t ldk, const int* keep_count, const int* child_pos, const float* src, int64_t n_src,
+                      int64_t ld_src, int width, float* dst, int64_t n_dst, int64_t ld_dst, int B, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && ldk > 0 && width > 0 && width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && keep_count && child_pos && src && dst,
+                "sibling_sum: bad arguments");
+  PATHS_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "sibling_sum: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(sibling_sum_kernel, dim3((unsigned)ldk, B), dim3(256), 0, stream, keep_idx, ldk, keep_count, child_pos, src, n_src, ld_src,
+                     width, dst, n_dst, ld_dst);
+  PATHS_LAUNCH_CHECK("sibling_sum");
+  return PATHS_OK;
+}
+
+int paths_scatter_kept_rows(const float* src, int64_t ldk, int64_t ld_src, const int* keep_idx, const int* keep_count, float* dst,
+                            int64_t n_dst, int64_t ld_dst, int width, int B, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && ldk > 0 && width > 0 && width % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && keep_idx && keep_count && src && dst,
+                "scatter_kept_rows: bad arguments");
+  PATHS_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, "scatter_kept_rows: buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(scatter_kept_rows_kernel, dim3((unsigned)ldk, B), dim3(256), 0, stream, src, ldk, ld_src, keep_idx, keep_count, dst, n_dst,
+                     ld_dst, width);
+  PATHS_LAUNCH_CHECK("scatter_kept_rows");
   return PATHS_OK;
 }
 

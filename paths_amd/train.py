@@ -26,9 +26,15 @@ from .eval import SubtypeClassificationEvaluator, SurvivalEvaluator
 
 def save_state(root_path: str, model, train_stats):
     """reference utils.py:169-178"""
-    torch.save(model.state_dict(), os.path.join(root_path, "model.pt"))
-    with open(os.path.join(root_path, "train_stats.pkl"), "wb") as fh:
+    # written under a temporary name and renamed: a reader (another rank re-loading the early-stopping checkpoint) sees the old
+    # file or the new one, never a half-written one
+    tmp = os.path.join(root_path, "model.pt.tmp")
+    torch.save(model.state_dict(), tmp)
+    os.replace(tmp, os.path.join(root_path, "model.pt"))
+    tmp = os.path.join(root_path, "train_stats.pkl.tmp")
+    with open(tmp, "wb") as fh:
         pickle.dump(train_stats, fh)
+    os.replace(tmp, os.path.join(root_path, "train_stats.pkl"))
 
 
 def load_state(root_path: str, model, map_location=None) -> Dict:
@@ -147,7 +153,8 @@ def train_loop(model, train_ds, val_ds, test_ds, config, model_dir: str, log=Non
             model.train()
     if config.early_stopping:
         load_state(model_dir, model)
-    train_stats["epoch"] = config.num_epochs
+    pdist.barrier()                     # every rank has re-loaded the checkpoint before rank 0 rewrites it (round 4: a rank read
+    train_stats["epoch"] = config.num_epochs     # the file while it was being written - the two-rank rehearsal caught it)
     if rank == 0:
         save_state(model_dir, model, train_stats)
     pdist.barrier()

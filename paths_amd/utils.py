@@ -268,6 +268,7 @@ class _Range:
             torch.cuda.nvtx.range_pop()
         return False
 ROWS_IN_PLACE = os.environ.get("PATHS_ROWS_IN_PLACE", "1") != "0"
+TRAIN_PARENT = os.environ.get("PATHS_TRAIN_PARENT", "1") != "0"      # training: h half of the LSTM gates once per kept parent
 _STREAMS: Dict[int, tuple] = {}
 
 
@@ -525,11 +526,22 @@ def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
               p(fts), p(locs), p(parent), p(num_ims), 1, None, None, st)
     state_prev, ctx_prev, ctx_hist = None, None, []
     logits = None
+    # Once-per-parent form (LSTM, optimistic pass): siblings share their parent's h, so the h half of the gate pre-activations is one
+    # product over the kept parents and its gradients are products over a quarter of the rows (autograd.LevelParentFn /
+    # GatherParentFn).  The careful re-run (rare: a slide whose kept patches have no tissue children) keeps the per-child form,
+    # whose fallback rows carry no parent.  PATHS_TRAIN_PARENT=0 keeps the per-child form everywhere.
+    parent_form = TRAIN_PARENT and model.use_lstm and not careful
+    par = None
     for i in range(num_levels):
         if mc.slide_ctx_mode == "concat":          # the classifier reads every previous level's slide context (model/paths.py:134-137)
             ctx_prev = torch.stack(ctx_hist, dim=1) if ctx_hist else None
-        logits, ctx_slide, state_out, importance = pag.level_apply(model.procs[i], model.lstm if model.use_lstm else None, fts, locs,
-                                                                   num_ims, state_prev, ctx_prev)
+        if par is not None:
+            logits, ctx_slide, state_out, importance = pag.LevelParentFn.apply(
+                model.procs[i], model.lstm, fts, locs, num_ims, par["c0"], par["h_kept"], par["hp_row"], par["child_pos"], par["keep_count"],
+                par["cap"], ctx_prev, *pag.lstm_params(model.lstm), *pag.level_params(model.procs[i]))
+        else:
+            logits, ctx_slide, state_out, importance = pag.level_apply(model.procs[i], model.lstm if model.use_lstm else None, fts, locs,
+                                                                       num_ims, state_prev, ctx_prev)
         ctx_prev = ctx_slide
         ctx_hist.append(ctx_slide)
         if i == num_levels - 1:
@@ -546,11 +558,12 @@ def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
         src_row = torch.empty((B, Nn), **i32)
         src_cell = torch.empty((B, Nn), **i32)
         child_pos = torch.empty((B, 4 * cap_keep), **i32)
+        hp_row = torch.empty((B, Nn), **i32) if parent_form else None
 
         def expand():
             _lib.call("paths_expand_children", p(keep_idx), cap_keep, p(keep_count), p(locs), N, mc.patch_size,
                       p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), B, Nn, p(num_next), p(locs_next),
-                      p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), None, st)
+                      p(parent_next), p(src_row), p(src_cell), p(status), p(child_pos), p(hp_row), st)
 
         expand()
         if careful:
@@ -571,8 +584,14 @@ def _recurse_train_body(model, batch, keep_patches, num_levels, careful):
                 # fallback rows: src_row = -1 (zero parent state, no gradient to any parent: child_pos of that slide is all -1)
                 _lib.call("paths_fallback_all_cells", p(batch.gx[i + 1]), p(batch.gy[i + 1]), p(batch.mask_ptrs[i + 1]), mc.patch_size,
                           B, Nn, p(num_next), p(locs_next), p(parent_next), p(src_row), p(src_cell), p(status), None, st)
-        fts, state_prev = pag.GatherFn.apply(state_out, batch.grid_ptrs[i + 1], src_cell, src_row, num_next, keep_idx,
-                                             keep_count, child_pos, D, Nn)
+        if parent_form:
+            fts, c0, h_kept = pag.GatherParentFn.apply(state_out, batch.grid_ptrs[i + 1], src_cell, src_row, num_next, keep_idx, keep_count,
+                                                       child_pos, D, Nn)
+            par = {"c0": c0, "h_kept": h_kept, "hp_row": hp_row, "child_pos": child_pos, "keep_count": keep_count, "cap": cap_keep}
+            state_prev = None
+        else:
+            fts, state_prev = pag.GatherFn.apply(state_out, batch.grid_ptrs[i + 1], src_cell, src_row, num_next, keep_idx,
+                                                 keep_count, child_pos, D, Nn)
         locs, parent, num_ims, N = locs_next, parent_next, num_next, Nn
     return {"logits": logits, "status": status}
 
