@@ -536,7 +536,7 @@ int64_t paths_tlayer_ws_image_bytes(int part, int d) {
 // Pack one part: part 0 = (wo [d,d], w1 [4d,d], w2 [d,4d]) scaled by the powers of two s_a, s_b, s_c; part 1 = wqkv [3d,d] by s_a.
 int paths_tlayer_pack_ws(int part, const float* wa, const float* wb, const float* wc, float s_a, float s_b, float s_c, void* out, int d,
                          hipStream_t stream) {
-  PATHS_REQUIRE(d == 128, "tlayer_pack_ws: trans_dim must be 128 (got %d)", d);
+  PATHS_REQUIRE(d == 128 || (d == 192 && part == 0), "tlayer_pack_ws: trans_dim 128, or 192 (part 0: the post-attention chain) (got %d, part %d)", d, part);
   PATHS_REQUIRE((part == 0 && wa && wb && wc) || (part == 1 && wa), "tlayer_pack_ws: bad arguments");
   PATHS_REQUIRE(out != nullptr && (uintptr_t)out % 16 == 0, "tlayer_pack_ws: out must be 16-byte aligned");
   WsPackJobs jobs;
@@ -550,7 +550,8 @@ int paths_tlayer_pack_ws(int part, const float* wa, const float* wb, const float
   } else {
     for (int c = 0; c < 3; ++c) jobs.j[n++] = WsPackJob{wa, d, d * c, 0, s_a};
   }
-  hipLaunchKernelGGL(tlayer_pack_ws_kernel<128>, dim3(n), dim3(256), 0, stream, jobs, reinterpret_cast<char*>(out));
+  if (d == 192) hipLaunchKernelGGL(tlayer_pack_ws_kernel<192>, dim3(n), dim3(256), 0, stream, jobs, reinterpret_cast<char*>(out));
+  else hipLaunchKernelGGL(tlayer_pack_ws_kernel<128>, dim3(n), dim3(256), 0, stream, jobs, reinterpret_cast<char*>(out));
   PATHS_LAUNCH_CHECK("tlayer_pack_ws");
   return PATHS_OK;
 }
@@ -566,7 +567,10 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
                          float s_wo, float s_w1, float s_w2, float s_wqkv, void* qkv_images, const int64_t* num_ims,
                          int B, int T, int d, int H, int do_post, int do_qkv, int skip_padding, float qscale, float eps,
                          int* zero_words, int n_zero, hipStream_t stream) {
-  PATHS_REQUIRE(d == 128 && H == 4, "token_layer_ws: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
+  // trans_dim 192 (the reference's dataclass default, config.py:30): the post-attention chain only, attention output as fp32 rows (its
+  // in_proj and attention run on the shape-generic kernels, whose operands are token-major fp32)
+  PATHS_REQUIRE((d == 128 && H == 4) || (d == 192 && do_post && !do_qkv && attn != nullptr && attn_img == nullptr),
+                "token_layer_ws: trans_dim 128 / 4 heads, or trans_dim 192 with do_post only and fp32 attention rows (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer_ws: nothing to do");
   PATHS_REQUIRE(!skip_padding || num_ims, "token_layer_ws: skip_padding needs num_ims");
   PATHS_REQUIRE(x_in && (!do_post || ((attn || attn_img) && x_out && w_post && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b)),
@@ -583,6 +587,7 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
              , g_ws_stamps
 #endif
   };
+  if (d == 192) return launch_ws<192, true, false>(p, stream);
   if (do_post && do_qkv) return launch_ws<128, true, true>(p, stream);
   if (do_post) return launch_ws<128, true, false>(p, stream);
   return launch_ws<128, false, true>(p, stream);

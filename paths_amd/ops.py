@@ -381,6 +381,9 @@ def fast_path(mc) -> bool:
     return mc.trans_dim == 128 and mc.trans_heads == 4 and mc.importance_mlp_hidden_dim == 128
 
 
+WS_CHAIN_192 = os.environ.get("PATHS_WS_CHAIN_192", "1") != "0"     # trans_dim 192: full layers' row chain on tlayer_ws_kernel<192>
+
+
 def wide_head(hd: int) -> bool:
     """head_dim above the flash-style kernels' 64: the three-step form of csrc/attn_wide.hip (score matrix in scratch)."""
     return hd > 64 and hd % 32 == 0 and hd <= 1024
@@ -609,6 +612,17 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             _lib.call("paths_attention_token0_any", p(qkv), 3 * d, p(num_ims), p(a0), p(ws0), B, T, H, hd, qscale, st)
         else:
             _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
+        if WS_CHAIN_192 and d == 192 and not last and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and ldx == d:
+            # the reference's dataclass-default width (config.py:30): out_proj + norm1 + cross-attention bias + norm2 + feed-forward +
+            # norm3 of a full layer in ONE launch of the weight-stationary chain kernel (csrc/tlayer_ws.hip, instantiated at 192;
+            # the attention output enters as fp32 rows) instead of three GEMMs and two LayerNorm launches
+            ip, sp = tlayer_ws_images(lay, 0)
+            x3 = torch.empty((M, d), **f32)
+            _lib.call("paths_token_layer_ws", p(x), p(attn), None, p(x3), p(ip), None, p(lay["bo"]), p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]),
+                      p(lay["ln2g"]), p(lay["ln2b"]), p(lay["b1"]), p(lay["b2"]), p(lay["ln3g"]), p(lay["ln3b"]), None, sp[0], sp[1], sp[2], 1.0,
+                      None, p(num_ims), B, T, d, H, 1, 0, 1, qscale, lay["eps"], None, 0, st)
+            x, ldx = x3, d
+            continue
         if last:
             rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
         y1 = torch.empty((rows, d), **f32)

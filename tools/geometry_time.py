@@ -40,6 +40,9 @@ for geo in ((128, 4, 128), (td, heads, hid)):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     line = f"trans_dim {geo[0]} / {geo[1]} heads / hidden {geo[2]}: inference {el / n * 1e3:.3f} ms per 8-slide step = {spg * n / el:.0f} slides/s (eager launches)"
+    if os.environ.get("GEO_NO_TRAIN"):
+        print(line, flush=True)
+        continue
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
     for _ in range(3):
