@@ -28,6 +28,9 @@
 // 86 % MFMA-busy in the loop at the 1.7-1.9 GHz the chip holds under this load) vs 281 us on the f32 MFMA.
 #include "common.h"
 #include "gemm_epi.h"
+#ifndef PATHS_X6_MIX16
+#define PATHS_X6_MIX16 1
+#endif
 
 namespace {
 using namespace paths_epi;
@@ -202,8 +205,8 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   // Split of one staged A chunk in NS micro-steps of at most 2 VALU instructions (the last one: the three LDS writes).  A gap
   // between two 32-cycle MFMAs hides about 24 cycles of other issue; the first version used 7 steps of 4 VALU + waits, every
   // such gap overflowed by ~15 cycles and idle gaps cannot win that back: ~500 cycles per stage (tools/x6_stages.py).
-  //   NP == 3 (bf16): 12 micro-steps (+1 for the ADD sum);  NP == 2 (fp16): scale, hi, 2 x residuals (v_fma_mix), lo, writes = 6 (+1).
-  constexpr int NS = (NP == 3 ? 12 : NP == 4 ? 7 : 6) + (ADD ? 1 : 0);
+  //   NP == 3 (bf16): 12 micro-steps (+1 for the ADD sum);  NP == 2 (fp16): scale, hi, lo low halves, lo high halves, writes = 5 (+1).
+  constexpr int NS = (NP == 3 ? 12 : NP == 4 ? 7 : (PATHS_X6_MIX16 ? 5 : 6)) + (ADD ? 1 : 0);
   float tf[NA][2];
   auto a_step = [&](int set, int q, int st0, int buf) __attribute__((always_inline)) {
     f32x4& v = sa[set][q];
@@ -242,12 +245,32 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
         *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{mid[q][0], mid[q][1]};
       }
     } else {
+#ifndef PATHS_X6_WHATIF_NOSPLIT
       if (st == 0) v *= g.a_scale;                      // power of two: exact
+#endif
       if (st == 1) { hi[q][0] = pk_f16(v[0], v[1]); hi[q][1] = pk_f16(v[2], v[3]); }
-      if (st == 2) f16_pair_residuals(hi[q][0], v[0], v[1], tf[q][0], tf[q][1]);   // 2 x v_fma_mix_f32 (was cvt, cvt | sub, sub)
+      // lo plane: residual AND its rounding to fp16 in one instruction per value (v_fma_mixlo_f16 / v_fma_mixhi_f16 write one half
+      // of the packed register each; round 4: was 2 x v_fma_mix_f32 + v_cvt_pk per pair).  The two halves of a register go to
+      // different micro-steps: a half-register write directly in front of the other half's costs a wait state.
+#if defined(PATHS_X6_WHATIF_NOSPLIT)   // diagnostic build, WRONG results: what a pre-split resident image could save at most (no scale, no lo plane work)
+      if (st == 2) { lo[q][0] = hi[q][0]; lo[q][1] = hi[q][1]; }
+      if (st == 4) {
+#elif PATHS_X6_MIX16
+      if (st == 2) {
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[q][0]) : "v"(hi[q][0]), "v"(v[0]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[q][1]) : "v"(hi[q][1]), "v"(v[2]));
+      }
+      if (st == 3) {
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo[q][0]) : "v"(hi[q][0]), "v"(v[1]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo[q][1]) : "v"(hi[q][1]), "v"(v[3]));
+      }
+      if (st == 4) {
+#else   // (round-3 form, kept for A/B builds: -DPATHS_X6_MIX16=0)
+      if (st == 2) f16_pair_residuals(hi[q][0], v[0], v[1], tf[q][0], tf[q][1]);
       if (st == 3) { float r2, r3; f16_pair_residuals(hi[q][1], v[2], v[3], r2, r3); v[2] = r2; v[3] = r3; }
       if (st == 4) { lo[q][0] = pk_f16(tf[q][0], tf[q][1]); lo[q][1] = pk_f16(v[2], v[3]); }
       if (st == 5) {
+#endif
         char* d = smem + buf * STAGE + awr[q];
         *reinterpret_cast<u32x2*>(d) = u32x2{hi[q][0], hi[q][1]};
         *reinterpret_cast<u32x2*>(d + FRAG) = u32x2{lo[q][0], lo[q][1]};
