@@ -125,12 +125,32 @@ class DeviceSlideBatch:
     def __len__(self):
         return len(self.slides)
 
+    def flat_tables(self) -> torch.Tensor:
+        """Every per-level table in ONE byte buffer, level by level (grid pointers, mask pointers, gx, gy), built once per batch:
+        binding a recorded launch tape to this batch is then a single small device-to-device copy."""
+        flat = getattr(self, "_flat_tables", None)
+        if flat is None:
+            parts = []
+            for l in range(self.num_levels):
+                parts += [self.grid_ptrs[l].view(torch.uint8), self.mask_ptrs[l].view(torch.uint8), self.gx[l].view(torch.uint8), self.gy[l].view(torch.uint8)]
+            flat = self._flat_tables = torch.cat(parts)
+        return flat
+
     def clone_tables(self) -> "DeviceSlideBatch":
         """The same batch with PRIVATE copies of the table tensors (a recorded launch tape addresses these, and re-points them at
-        other batches: paths_amd.utils.TapedRecursion.rebind); the slides themselves are shared."""
+        other batches: paths_amd.utils.TapedRecursion.rebind); the slides themselves are shared.  The copies are views of one flat
+        buffer laid out like :meth:`flat_tables`."""
         c = object.__new__(DeviceSlideBatch)
         c.__dict__.update(self.__dict__)
-        for name in ("grid_ptrs", "mask_ptrs", "gx", "gy"):
-            setattr(c, name, [t.clone() for t in getattr(self, name)])
+        flat = self.flat_tables().clone()
+        B = len(self.slides)
+        c._flat_tables = flat
+        c.grid_ptrs, c.mask_ptrs, c.gx, c.gy = [], [], [], []
+        off = 0
+        for l in range(self.num_levels):
+            c.grid_ptrs.append(flat[off:off + 8 * B].view(torch.int64)); off += 8 * B
+            c.mask_ptrs.append(flat[off:off + 8 * B].view(torch.int64)); off += 8 * B
+            c.gx.append(flat[off:off + 4 * B].view(torch.int32)); off += 4 * B
+            c.gy.append(flat[off:off + 4 * B].view(torch.int32)); off += 4 * B
         c.max_dim = list(self.max_dim)
         return c

@@ -212,11 +212,15 @@ class TapedRecursion:
             self.batch = new
             return self
         with torch.no_grad():
-            for l in range(self.levels):
-                rec.grid_ptrs[l].copy_(new.grid_ptrs[l], non_blocking=True)
-                rec.mask_ptrs[l].copy_(new.mask_ptrs[l], non_blocking=True)
-                rec.gx[l].copy_(new.gx[l], non_blocking=True)
-                rec.gy[l].copy_(new.gy[l], non_blocking=True)
+            src, dst = new.flat_tables(), rec.flat_tables()
+            if src.numel() == dst.numel():                 # same level count: ONE copy of all tables (a few hundred bytes)
+                dst.copy_(src, non_blocking=True)
+            else:
+                for l in range(self.levels):
+                    rec.grid_ptrs[l].copy_(new.grid_ptrs[l], non_blocking=True)
+                    rec.mask_ptrs[l].copy_(new.mask_ptrs[l], non_blocking=True)
+                    rec.gx[l].copy_(new.gx[l], non_blocking=True)
+                    rec.gy[l].copy_(new.gy[l], non_blocking=True)
         self.batch = new                 # (keeps the bound slides alive; run()'s fallback recurses on them)
         return self
 
