@@ -128,6 +128,11 @@ int64_t paths_importance_proj_x6_workspace(int M);
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                      int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, paths_stream_t stream);
+/* out = act((A + A_add) W^T + b), planes = 2: the GEMM input is summed in fp32 while staged (Y = X + h1, reference model/paths.py:89-91,
+ * never materialised); A as a matrix or as row addresses (exactly one of a / a_rows); num_ims (optional) skips whole tiles of padding. */
+int paths_gemm_add_nt_x6(const float* a, int64_t lda, const int64_t* a_rows, const float* a_add, int64_t ld_add, const void* w_x6, int Kpacked,
+                         const float* b, float* out, int64_t ldo, int M, int N, int Npad, int K, int act, const int64_t* num_ims,
+                         int rows_per_slide, float w_scale, float a_scale, paths_stream_t stream);
 /* The same product without bias / activation, A given as row ADDRESSES (planes = 2 only): row m = the K floats at a_rows[m]. */
 int paths_gemm_rows_nt_x6(const int64_t* a_rows, const void* w_x6, int Kpacked, int k0, float* out, int64_t ldo,
                           int M, int Npad, int K, int planes, float w_scale, float a_scale, paths_stream_t stream);
@@ -281,6 +286,14 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
                          float s_wo, float s_w1, float s_w2, float s_wqkv, void* qkv_images, const int64_t* num_ims,
                          int B, int T, int d, int H, int do_post, int do_qkv, int skip_padding, float qscale, float eps,
                          int* zero_words, int n_zero, paths_stream_t stream);
+/* The same kernel instantiated at trans_dim 192 (the reference's dataclass default, config.py:30; any head count) with the in_proj result
+ * as fp32 token-major rows qkv_rows [B*T][ld_qkv] = [q | k | v] (q UNscaled: the operand of the shape-generic attention kernels)
+ * instead of the head_dim-32 fragment images; the attention output enters as fp32 rows.  do_post and / or do_qkv as above. */
+int paths_token_layer_ws_rows(const float* x_in, const float* attn, float* x_out, const void* w_post, const void* w_qkv,
+                              const float* bo, const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                              const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
+                              float s_wo, float s_w1, float s_w2, float s_wqkv, float* qkv_rows, int64_t ld_qkv, const int64_t* num_ims,
+                              int B, int T, int d, int do_post, int do_qkv, int skip_padding, float eps, paths_stream_t stream);
 /* paths_attention_x6 (planes = 2, operand images already in `workspace`) with the output written as the out_proj operand image of
  * paths_token_layer_ws: B * ceil(T/64) * 64 * H * 32 * 4 bytes, [slide][64-token group][head][16-token tile][plane][64 lanes][16 B]. */
 int paths_attention_h3_img(void* o_img, const int64_t* num_ims, int B, int T, int H, int head_dim, void* workspace, paths_stream_t stream);

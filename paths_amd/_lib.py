@@ -32,6 +32,7 @@ SIGNATURES = {
                                  _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp],
     "paths_gemm_nt_x6": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32,
                          _i32, _f32, _f32, _vp],
+    "paths_gemm_add_nt_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _f32, _vp],
     "paths_gemm_tn_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "paths_attention_fp8": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "paths_gemm_tn_x6": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
@@ -60,6 +61,7 @@ SIGNATURES = {
     "paths_token_layer_h3": [_vp] * 16 + [_f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp],
     "paths_tlayer_pack_ws": [_i32, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _i32, _vp],
     "paths_token_layer_ws": [_vp] * 17 + [_f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp],
+    "paths_token_layer_ws_rows": [_vp] * 16 + [_f32, _f32, _f32, _f32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "paths_token0_pack_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp],
     "paths_token0_tail_ws": [_vp] * 16 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp],
     "paths_attention_any": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],

@@ -774,4 +774,20 @@ int paths_gemm_rows_nt_x6(const int64_t* a_rows, const void* w_x6, int Kpacked, 
   return launch_x6<2, 4, 2, false>(planes, g, Npad, e, stream, "gemm_rows_nt_x6");
 }
 
+// out[M, N] = act((A + A_add) W^T + b): paths_gemm_nt_x6 (planes = 2) with the GEMM input summed in fp32 while it is staged (the
+// reference's Y = X + h1, model/paths.py:89-91, never materialised) and A given either as a matrix (a, lda) or as row ADDRESSES
+// (a_rows: feature rows read in place in the resident grids); num_ims (optional): whole 128-row tiles of padding are skipped.
+// The importance / projection products of aggregator geometries other than the fused 128 / 128 one (ops.importance_proj_generic_add).
+int paths_gemm_add_nt_x6(const float* a, int64_t lda, const int64_t* a_rows, const float* a_add, int64_t ld_add, const void* w_x6, int Kpacked,
+                         const float* b, float* out, int64_t ldo, int M, int N, int Npad, int K, int act, const int64_t* num_ims,
+                         int rows_per_slide, float w_scale, float a_scale, hipStream_t stream) {
+  PATHS_REQUIRE((a != nullptr) != (a_rows != nullptr), "gemm_add_nt_x6: exactly one of a / a_rows");
+  PATHS_REQUIRE(a_add != nullptr && ld_add % 4 == 0 && (uintptr_t)a_add % 16 == 0, "gemm_add_nt_x6: a_add must be 16-byte aligned with ld_add %% 4 == 0");
+  PATHS_REQUIRE(pow2(w_scale) && pow2(a_scale) && K == Kpacked && Npad % 256 == 0, "gemm_add_nt_x6: power-of-two scales, whole-K image, Npad %% 256 == 0");
+  X6Operands g{a, lda, K, a_rows, nullptr, 0, 0, a_add, ld_add, reinterpret_cast<const char*>(w_x6), group_stride(2, Kpacked), M, num_ims, rows_per_slide, a_scale};
+  EpiBias e{b, out, ldo, N, act, nullptr, 0, nullptr, 0, 0, 1.0f / (w_scale * a_scale)};
+  return a_rows ? launch_x6_np<2, 2, 4, 2, true, true>(g, Npad, e, stream, "gemm_add_nt_x6(rows)")
+                : launch_x6_np<2, 2, 4, 2, true, false>(g, Npad, e, stream, "gemm_add_nt_x6");
+}
+
 }  // extern "C"

@@ -120,6 +120,7 @@ struct WsParams {
   const float *bo, *ln1g, *ln1b, *cab, *ln2g, *ln2b, *b1, *b2, *ln3g, *ln3b, *bqkv;
   float inv_wo, inv_w1, inv_w2, inv_wqkv;      // 1 / (power-of-two scale of the packed tensor)
   char* qkv_img;                // QKV: the two-plane operand images of attn_x6_kernel<2>, Q | K | V
+  float* qkv_rows; int64_t ld_qkv;   // QKV, ROWS form: q | k | v as fp32 token-major rows [B*T][ld_qkv] (q unscaled: the shape-generic attention kernels)
   const int64_t* num_ims;
   int T, Tp, B, skip_padding;
   float qscale, eps;
@@ -132,7 +133,7 @@ struct WsParams {
 // One workgroup = 64 tokens of one slide.  Lane (ql = lane & 15, g = lane >> 4) of wave w holds, for token tile tt and output
 // tile ot, the features 16 (OT w + ot) + 4 g + r (r = 0..3) of token 16 tt + ql  -  the C layout of v_mfma_f32_16x16x32_f16 with the
 // weights as A (rows = output features) and the activations as B (columns = tokens).
-template <int DM, bool POST, bool QKV>
+template <int DM, bool POST, bool QKV, bool ROWS = false>
 __global__ void __launch_bounds__(64 * NW, 1)
 tlayer_ws_kernel(WsParams p) {
   using G = Geo<DM>;
@@ -419,7 +420,30 @@ tlayer_ws_kernel(WsParams p) {
     WS_STAMP(10);
   }
 
-  if constexpr (QKV) {
+  if constexpr (QKV && ROWS) {
+    // ---- in_proj as fp32 rows (any DM % 64 == 0, any head count): q | k | v = x W^T + b, token-major, unscaled - what the
+    // shape-generic attention kernels read (csrc/generic.hip, attn_h3_any.hip); three units, features on the accumulator rows
+    static_for<0, 3>([&](auto which_) {
+      constexpr int which = decltype(which_)::value;
+      f32x4 acc[OT][TT];
+      zero(acc);
+      if constexpr (which == 0) unit(std::integral_constant<int, POST_STEPS>{}, NO, NO, acc, sAct, sAct);
+      else if constexpr (which == 1) unit(std::integral_constant<int, POST_STEPS + KB>{}, NO, YES, acc, sAct, sAct);
+      else unit(std::integral_constant<int, POST_STEPS + 2 * KB>{}, NO, YES, acc, sAct, nullptr);
+      f32x4 bb[OT];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) bb[ot] = *reinterpret_cast<const f32x4*>(sBqkv + which * DM + fbase + 16 * ot);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int tok = t0 + 16 * tt + ql;
+        if (tok < p.T) {
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot)
+            *reinterpret_cast<f32x4*>(p.qkv_rows + ((int64_t)b * p.T + tok) * p.ld_qkv + which * DM + fbase + 16 * ot) = acc[ot][tt] * p.inv_wqkv + bb[ot];
+        }
+      }
+    });
+  } else if constexpr (QKV) {
     static_assert(OT == 2, "in_proj images: head_dim 32 (one k32 block per head)");
     // ---- in_proj: wave w = head w.  q, k: features on the accumulator rows; v: operands swapped, tokens on the rows
     const int64_t img = (int64_t)p.B * NW * p.Tp * 128;          // bytes of one of the three images (32 dims x 2 planes x 2 B)
@@ -508,13 +532,13 @@ size_t ws_lds_bytes(bool post, bool qkv) {
   return Geo<DM>::ACT + (post ? 2 * Geo<DM>::ACT : 0) + 2 * NW * TOK * 2 * sizeof(float) + ((post ? 13 * DM : 0) + (qkv ? 3 * DM : 0)) * sizeof(float);
 }
 
-template <int DM, bool POST, bool QKV>
+template <int DM, bool POST, bool QKV, bool ROWS = false>
 int launch_ws(const WsParams& p, hipStream_t stream) {
   const size_t lds = ws_lds_bytes<DM>(POST, QKV);
-  PATHS_LDS_OPT_IN((tlayer_ws_kernel<DM, POST, QKV>), 160 * 1024, "token_layer_ws");
+  PATHS_LDS_OPT_IN((tlayer_ws_kernel<DM, POST, QKV, ROWS>), 160 * 1024, "token_layer_ws");
   // (> 80 KiB per workgroup: one workgroup per CU, so a grid of ~one workgroup per CU spreads over the whole chip)
   const size_t ask = lds > 84 * 1024 ? lds : 84 * 1024;
-  hipLaunchKernelGGL((tlayer_ws_kernel<DM, POST, QKV>), dim3((p.T + TOK - 1) / TOK, p.B), dim3(64 * NW), ask, stream, p);
+  hipLaunchKernelGGL((tlayer_ws_kernel<DM, POST, QKV, ROWS>), dim3((p.T + TOK - 1) / TOK, p.B), dim3(64 * NW), ask, stream, p);
   PATHS_LAUNCH_CHECK("token_layer_ws");
   return PATHS_OK;
 }
@@ -536,7 +560,7 @@ int64_t paths_tlayer_ws_image_bytes(int part, int d) {
 // Pack one part: part 0 = (wo [d,d], w1 [4d,d], w2 [d,4d]) scaled by the powers of two s_a, s_b, s_c; part 1 = wqkv [3d,d] by s_a.
 int paths_tlayer_pack_ws(int part, const float* wa, const float* wb, const float* wc, float s_a, float s_b, float s_c, void* out, int d,
                          hipStream_t stream) {
-  PATHS_REQUIRE(d == 128 || (d == 192 && part == 0), "tlayer_pack_ws: trans_dim 128, or 192 (part 0: the post-attention chain) (got %d, part %d)", d, part);
+  PATHS_REQUIRE(d == 128 || d == 192, "tlayer_pack_ws: trans_dim 128 or 192 (got %d)", d);
   PATHS_REQUIRE((part == 0 && wa && wb && wc) || (part == 1 && wa), "tlayer_pack_ws: bad arguments");
   PATHS_REQUIRE(out != nullptr && (uintptr_t)out % 16 == 0, "tlayer_pack_ws: out must be 16-byte aligned");
   WsPackJobs jobs;
@@ -582,7 +606,7 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
   WsParams p{x_in, attn, reinterpret_cast<const char*>(attn_img), x_out, reinterpret_cast<const char*>(w_post), reinterpret_cast<const char*>(w_qkv),
              bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, bqkv,
              do_post ? 1.0f / s_wo : 1.0f, do_post ? 1.0f / s_w1 : 1.0f, do_post ? 1.0f / s_w2 : 1.0f, do_qkv ? 1.0f / s_wqkv : 1.0f,
-             reinterpret_cast<char*>(qkv_images), num_ims, T, (T + 63) / 64 * 64, B, skip_padding, qscale, eps, zero_words, n_zero
+             reinterpret_cast<char*>(qkv_images), nullptr, 0, num_ims, T, (T + 63) / 64 * 64, B, skip_padding, qscale, eps, zero_words, n_zero
 #ifdef PATHS_WS_STAMPS
              , g_ws_stamps
 #endif
@@ -591,6 +615,35 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
   if (do_post && do_qkv) return launch_ws<128, true, true>(p, stream);
   if (do_post) return launch_ws<128, true, false>(p, stream);
   return launch_ws<128, false, true>(p, stream);
+}
+
+// The same kernel for trans_dim 192 (the reference's dataclass default, config.py:30; any head count) with the in_proj result written
+// as fp32 token-major rows qkv_rows [B*T][ld_qkv] = [q | k | v] (q UNscaled) - the operand of the shape-generic attention kernels -
+// instead of the head_dim-32 fragment images: do_post and / or do_qkv as above, attention output as fp32 rows.
+int paths_token_layer_ws_rows(const float* x_in, const float* attn, float* x_out, const void* w_post, const void* w_qkv,
+                              const float* bo, const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
+                              const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* bqkv,
+                              float s_wo, float s_w1, float s_w2, float s_wqkv, float* qkv_rows, int64_t ld_qkv, const int64_t* num_ims,
+                              int B, int T, int d, int do_post, int do_qkv, int skip_padding, float eps, hipStream_t stream) {
+  PATHS_REQUIRE(d == 192, "token_layer_ws_rows: this build instantiates trans_dim 192 (got %d)", d);
+  PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer_ws_rows: nothing to do");
+  PATHS_REQUIRE(!skip_padding || num_ims, "token_layer_ws_rows: skip_padding needs num_ims");
+  PATHS_REQUIRE(x_in && (!do_post || (attn && x_out && w_post && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b)),
+                "token_layer_ws_rows: null operand (post)");
+  PATHS_REQUIRE(!do_qkv || (w_qkv && bqkv && qkv_rows && ld_qkv >= 3 * d && ld_qkv % 4 == 0), "token_layer_ws_rows: null operand / bad ld (in_proj)");
+  PATHS_REQUIRE(((uintptr_t)x_in | (uintptr_t)attn | (uintptr_t)x_out | (uintptr_t)w_post | (uintptr_t)w_qkv | (uintptr_t)qkv_rows) % 16 == 0,
+                "token_layer_ws_rows: buffers must be 16-byte aligned");
+  WsParams p{x_in, attn, nullptr, x_out, reinterpret_cast<const char*>(w_post), reinterpret_cast<const char*>(w_qkv),
+             bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, bqkv,
+             do_post ? 1.0f / s_wo : 1.0f, do_post ? 1.0f / s_w1 : 1.0f, do_post ? 1.0f / s_w2 : 1.0f, do_qkv ? 1.0f / s_wqkv : 1.0f,
+             nullptr, qkv_rows, ld_qkv, num_ims, T, (T + 63) / 64 * 64, B, skip_padding, 1.0f, eps, nullptr, 0
+#ifdef PATHS_WS_STAMPS
+             , g_ws_stamps
+#endif
+  };
+  if (do_post && do_qkv) return launch_ws<192, true, true, true>(p, stream);
+  if (do_post) return launch_ws<192, true, false>(p, stream);
+  return launch_ws<192, false, true, true>(p, stream);
 }
 
 }  // extern "C"

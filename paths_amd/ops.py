@@ -381,6 +381,7 @@ def fast_path(mc) -> bool:
     return mc.trans_dim == 128 and mc.trans_heads == 4 and mc.importance_mlp_hidden_dim == 128
 
 
+GENERIC_ADD = os.environ.get("PATHS_GENERIC_ADD", "1") != "0"       # other geometries: tuned LSTM kernels, importance / proj on x + h1 in flight
 WS_CHAIN_192 = os.environ.get("PATHS_WS_CHAIN_192", "1") != "0"     # trans_dim 192: full layers' row chain on tlayer_ws_kernel<192>
 
 
@@ -467,6 +468,36 @@ def importance_proj_generic(mc, lvl_pack, src, ld_src: int, locs, num_ims, B: in
     _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), st)
     proj = torch.empty((M, d), device=dev, dtype=torch.float32)
     gemm_f32(src, ld_src, gp["wp"], None, proj, d, M, d, D, split=(gp, "wp"))
+    pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+    _lib.call("paths_tokens_assemble", p(proj), d, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
+              p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
+
+
+def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B: int, N: int, D: int, imp_mul: int, imp_out, tokens, skip_padding: bool):
+    """:func:`importance_proj_generic` on the split-operand kernel with the GEMM input ``src + add`` summed while it is staged (the
+    Y = X + h1 form of the tuned path: Y is never stored, ``src`` may be row addresses into the resident grids): the LSTM part of the
+    selection chain does not depend on the aggregator's geometry, so every geometry gets the tuned gate kernels."""
+    gp = generic_pack(lvl_pack, mc)
+    d, Hi, M = mc.trans_dim, mc.importance_mlp_hidden_dim, B * N
+    dev = locs.device
+    st = _lib.stream()
+    p = _lib.ptr
+    nim = p(num_ims) if skip_padding else None
+
+    def gemm(key, n, bias, out, act):
+        k6 = f"{key}_x6_{split_planes()}"
+        if k6 not in gp:
+            gp[k6] = x6_pack(gp[key][:n].contiguous(), n_pad=(n + 255) // 256 * 256)
+        img, ws = gp[k6]
+        _lib.call("paths_gemm_add_nt_x6", p(src) if x_rows is None else None, D, p(x_rows), p(add), add.stride(1), img.data_ptr(), D, p(bias), p(out), n,
+                  M, n, (n + 255) // 256 * 256, D, act, nim, N, ws, a_scale(), st)
+
+    # (skipped tiles of padding stay defined; _lib.zeros: the fill is repeated when a recorded launch tape is replayed)
+    hid = (_lib.zeros if skip_padding else torch.empty)((M, Hi), device=dev, dtype=torch.float32)
+    gemm("w1", Hi, lvl_pack["b1"], hid, 1)
+    _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), st)
+    proj = (_lib.zeros if skip_padding else torch.empty)((M, d), device=dev, dtype=torch.float32)
+    gemm("wp", d, None, proj, 0)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
     _lib.call("paths_tokens_assemble", p(proj), d, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
               p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
@@ -587,6 +618,8 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     # path takes max|.| over WHOLE activation matrices for its per-tensor scales - there they must be defined (zero)
     attn = (torch.zeros if fp8 else torch.empty)((B, T, d), **f32)
     rows, ldx = M, d                      # the current activation: `rows` rows, row stride ldx (the last layer keeps token 0 of every slide)
+    ws192 = WS_CHAIN_192 and d == 192 and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and not wide
+    qkv_ready = False
     for l in range(L):
         lay, gl = lvl_pack["layers"][l], gp["layers"][l]
         last = l == L - 1
@@ -598,7 +631,14 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             else:
                 gemm_f32(a, lda, gl[key], bias, out, ldo, m, n, kdim, act, residual, ldr, split=(gl, key))
 
-        gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
+        if qkv_ready:                         # the previous layer's chain launch already projected this layer's q | k | v
+            qkv_ready = False
+        elif ws192:
+            iq, sq = tlayer_ws_images(lay, 1)
+            _lib.call("paths_token_layer_ws_rows", p(x), None, None, None, p(iq), None, None, None, None, None, None, None, None, None, None,
+                      p(lay["bqkv"]), 1.0, 1.0, 1.0, sq[0], p(qkv), 3 * d, p(num_ims), B, T, d, 0, 1, 1, lay["eps"], st)
+        else:
+            gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
         if big:
             _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
         elif wide:
@@ -612,16 +652,19 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             _lib.call("paths_attention_token0_any", p(qkv), 3 * d, p(num_ims), p(a0), p(ws0), B, T, H, hd, qscale, st)
         else:
             _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
-        if WS_CHAIN_192 and d == 192 and not last and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and ldx == d:
+        if ws192 and not last:
             # the reference's dataclass-default width (config.py:30): out_proj + norm1 + cross-attention bias + norm2 + feed-forward +
-            # norm3 of a full layer in ONE launch of the weight-stationary chain kernel (csrc/tlayer_ws.hip, instantiated at 192;
-            # the attention output enters as fp32 rows) instead of three GEMMs and two LayerNorm launches
+            # norm3 of a full layer AND the next layer's in_proj in ONE launch of the weight-stationary chain kernel (csrc/tlayer_ws.hip
+            # instantiated at 192; attention output in, q | k | v out as fp32 rows) instead of four GEMMs and two LayerNorm launches
+            nxt = lvl_pack["layers"][l + 1]
             ip, sp = tlayer_ws_images(lay, 0)
+            iq, sq = tlayer_ws_images(nxt, 1)
             x3 = torch.empty((M, d), **f32)
-            _lib.call("paths_token_layer_ws", p(x), p(attn), None, p(x3), p(ip), None, p(lay["bo"]), p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]),
-                      p(lay["ln2g"]), p(lay["ln2b"]), p(lay["b1"]), p(lay["b2"]), p(lay["ln3g"]), p(lay["ln3b"]), None, sp[0], sp[1], sp[2], 1.0,
-                      None, p(num_ims), B, T, d, H, 1, 0, 1, qscale, lay["eps"], None, 0, st)
-            x, ldx = x3, d
+            qkv_next = torch.empty((M, 3 * d), **f32)
+            _lib.call("paths_token_layer_ws_rows", p(x), p(attn), p(x3), p(ip), p(iq), p(lay["bo"]), p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]),
+                      p(lay["ln2g"]), p(lay["ln2b"]), p(lay["b1"]), p(lay["b2"]), p(lay["ln3g"]), p(lay["ln3b"]), p(nxt["bqkv"]), sp[0], sp[1], sp[2],
+                      sq[0], p(qkv_next), 3 * d, p(num_ims), B, T, d, 1, 1, 1, lay["eps"], st)
+            x, ldx, qkv, qkv_ready = x3, d, qkv_next, True
             continue
         if last:
             rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
@@ -712,11 +755,13 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     tokens = torch.empty((B, T, d), **f32)
 
     x6 = use_x6(D, lstm_pack["Hc"] if mc.lstm else 64)
-    assert x_rows is None or (x6 and split_planes() == 2 and mc.lstm and fast_path(mc)), "row pointers need the default split mode, lstm=true and the 128-wide aggregator"
+    assert x_rows is None or (x6 and split_planes() == 2 and mc.lstm), "row pointers need the default split mode and lstm=true"
     pe_rows = N if pe_mode == 1 else int(max_pos)
     pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
 
     generic = not fast_path(mc)
+    # any aggregator geometry on the tuned LSTM kernels: the importance / projection products take x + h1 summed while staged
+    generic_add = generic and x6 and split_planes() == 2 and mc.lstm and GENERIC_ADD and GENERIC_SPLIT and D % 128 == 0
 
     def importance_proj(src, imp_mul, imp_out, add=None):
         """tokens / importance from ``src`` (+ ``add``: x6 only, the GEMM input is src + add, row stride of add arbitrary)."""
@@ -751,7 +796,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         Dp = D + Hc
         state_out = torch.empty((B, N, Dp), **f32)
         # x6: Y = X + h1 is summed inside the importance/proj GEMM's staging (the generic importance / projection GEMMs read a stored Y)
-        y = None if (x6 and not generic) else torch.empty((B, N, D), **f32)
+        y = None if (x6 and (not generic or generic_add)) else torch.empty((B, N, D), **f32)
         ws_o = torch.empty(((M + 255) // 256 * 256, D), **f32)       # gate scratch: whole 256-row tiles (raw accumulator layout)
         hp, hp_row = None, None
         if parent is not None:
@@ -786,7 +831,10 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             timed("lstm_gate_o", lambda: lstm(2), {"rows": N, "B": B, "K": D if h0 is None else 2 * D, "Ncols": D, "parent_partials": parent is not None,
                                                    "x6": x6, "planes": split_planes() if x6 else 0}, detail=False)
             timed("lstm_mem_to_out", lambda: lstm(4))
-        if x6 and not generic:
+        if generic_add:
+            timed("importance_proj", lambda: importance_proj_generic_add(mc, lvl_pack, fts, x_rows, state_out, locs, num_ims, B, N, D,
+                                                                         1 if mc.importance_mode == "mul" else 0, importance, tokens, skip_padding))
+        elif x6 and not generic:
             timed("importance_proj", lambda: importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out))
         else:
             timed("importance_proj", lambda: importance_proj(y, 1 if mc.importance_mode == "mul" else 0, importance))

@@ -351,7 +351,8 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
     # default split mode: feature rows are read in place in the resident grids (row-pointer GEMM operands) instead of being
     # copied (level 0) or gathered (children)
-    rows_in_place = share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE and ops.fast_path(mc)
+    rows_in_place = (share_parent and ops.use_x6(D, Dp - D) and ops.split_planes() == 2 and ROWS_IN_PLACE
+                     and (ops.fast_path(mc) or (ops.GENERIC_ADD and ops.GENERIC_SPLIT and D % 128 == 0)))
     zero_row = torch.zeros((D,), **f32) if rows_in_place else None
     fts = None if rows_in_place else torch.empty((B, N, D), **f32)
     x_rows = torch.empty((B, N), **i64) if rows_in_place else None

@@ -39,7 +39,19 @@ for geo in ((128, 4, 128), (td, heads, hid)):
             putils.recurse(model, slides, cfg.top_k_patches, cfg.num_levels, check_status=False)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    line = f"trans_dim {geo[0]} / {geo[1]} heads / hidden {geo[2]}: inference {el / n * 1e3:.3f} ms per 8-slide step = {spg * n / el:.0f} slides/s (eager launches)"
+    with torch.no_grad():
+        tp = putils.TapedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).record()
+        for _ in range(3):
+            tp.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            tp.replay()
+        torch.cuda.synchronize()
+        el_t = time.perf_counter() - t0
+        tp.close()
+    line = (f"trans_dim {geo[0]} / {geo[1]} heads / hidden {geo[2]}: inference {el / n * 1e3:.3f} ms per 8-slide step = {spg * n / el:.0f} slides/s (eager launches), "
+            f"{spg * n / el_t:.0f} slides/s (launch tape)")
     if os.environ.get("GEO_NO_TRAIN"):
         print(line, flush=True)
         continue
