@@ -211,6 +211,17 @@ constexpr float ATTN_DEFER = (float)(PATHS_ATTN_DEFER);   // deferred-rescale th
 // PATHS_ATTN_WHATIF (diagnostic builds, WRONG results, tools/attn_time.py): 1 no exp2, 2 no lo plane of P, 4 one MFMA per product
 // block, 8 no PV products, 16 no score products, 32 no LDS fragment reads (one fragment set re-used), 64 no staging (loads, LDS writes)
 constexpr int WHATIF = PATHS_ATTN_WHATIF;
+#ifndef PATHS_ATTN_DELAY_PV
+#define PATHS_ATTN_DELAY_PV 0
+#endif
+// DELAY_PV (FAST path): the PV product of key step k is issued in step k+1, in the same basic block as the score product of step k+2
+// and the exp2 / split work of step k+1 - every MFMA of the loop then has vector work to hide behind (before, the 24 PV MFMAs of a
+// step ran bare, after the step's vector work: the probabilities they multiply did not exist earlier).  V^T tiles live one step
+// longer (ring of three LDS buffers instead of two); a revision of the running maximum in step k+1 happens AFTER the pending product
+// was added, so one rescale covers it.  MEASURED (round 4) and OFF: hipcc does interleave the 48 MFMAs with ~100 vector instructions
+// then, results are bit-identical, and the kernel takes 57.6 us against 56.6 (A/B/A/B on one box) - the SIMD's aggregate issue
+// capacity, not the order inside one wave, is what bounds the step (tools/simd_probe.hip).
+constexpr bool ATTN_DELAY_PV = PATHS_ATTN_DELAY_PV != 0;
 #ifndef PATHS_ATTN_FAST
 #define PATHS_ATTN_FAST 1
 #endif
@@ -278,8 +289,12 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   // them).  K therefore runs one step ahead of V in LDS: K(k+1), K(k+2 being written) | V(k), V(k+1 being written).
   const int nkt = (len + KSTEP - 1) / KSTEP;
   constexpr int HALF = 4 * NP * FRAG;                   // bytes of the K (or V) fragments of one step
+  constexpr bool FASTC = ATTN_FAST && NP == 2 && !DROP;
+  constexpr bool DELAY = FASTC && ATTN_DELAY_PV && ATTN_OCC < 3;
+  constexpr int NVB = DELAY ? 3 : 2;                    // V^T buffers (DELAY: a tile is read one step after its scores)
+  auto vbuf = [&](int kt) { return DELAY ? kt % 3 : (kt & 1); };
   char* const sKb = smem_raw;                           // [2][HALF]
-  char* const sVb = smem_raw + 2 * HALF;                // [2][HALF]
+  char* const sVb = smem_raw + 2 * HALF;                // [NVB][HALF]
   u32x4 st[2 * NP];
   auto gload_k = [&](int kt) {
 #pragma unroll
@@ -295,7 +310,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   };
   auto swrite_v = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sVb + (kt & 1) * HALF + (tid + 256 * i) * 16) = st[NP + i];
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sVb + vbuf(kt) * HALF + (tid + 256 * i) * 16) = st[NP + i];
   };
   auto qk = [&](int kt, f32x4 (&s)[QT][4]) __attribute__((always_inline)) {      // S^T = K Q^T for the 4 key tiles of step kt
     const char* sK = sKb + (kt & 1) * HALF + lane * 16;
@@ -438,8 +453,24 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   unsigned st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
-  auto step_fast = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], auto lastc) __attribute__((always_inline)) {
-    constexpr bool LAST = decltype(lastc)::value;
+  auto pv_product = [&](const char* sV, u32x4 (&pfr)[QT][2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int dvt = 0; dvt < 2; ++dvt) {
+        u32x4 vf[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + (((WHATIF & 32) ? 0 : (kg * 2 + dvt)) * NP + p) * FRAG);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          if constexpr ((WHATIF & 8) != 0) { oacc[dvt][qt] += __builtin_bit_cast(f32x4, pfr[qt][kg][0]) + __builtin_bit_cast(f32x4, pfr[qt][kg][1]) + __builtin_bit_cast(f32x4, vf[0]); }
+          else oacc[dvt][qt] = mfma_split(vf, pfr[qt][kg], oacc[dvt][qt]);
+        }
+      }
+  };
+  // pf: receives this step's probability fragments; pfp (DELAY): the previous step's, whose PV product is issued here (pendc: there is one)
+  auto step_fast = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], u32x4 (&pf)[QT][2][2], u32x4 (&pfp)[QT][2][2], auto lastc, auto pendc) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(lastc)::value, PEND = decltype(pendc)::value;
     if constexpr (PATHS_ATTN_PRIO_SHIFT >= 0) {
       if ((((kt >> PATHS_ATTN_PRIO_SHIFT) ^ prio_parity) & 1) != 0) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
@@ -450,7 +481,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     if (kt + 1 < nkt) gload_v(kt + 1);
     }
     if constexpr (ATTN_OCC >= 3) qk(kt, s);
-    const char* sV = sVb + (kt & 1) * HALF + lane * 16;
+    const char* sV = sVb + vbuf(DELAY ? kt - 1 : kt) * HALF + lane * 16;      // (DELAY: the tile of the pending product)
     if constexpr (LAST) {
       const int kbase = kt * KSTEP + 4 * g4;
 #pragma unroll
@@ -462,8 +493,8 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
             if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
     }
     if constexpr (ATTN_OCC < 3) qk(kt + 1, sn);
+    if constexpr (DELAY && PEND) pv_product(sV, pfp);   // O^T += V^T(kt-1) P^T(kt-1): same basic block as the score product above and exp2 / split below
     ATTN_STAMP(1, 2);
-    u32x4 pf[QT][2][2];
     float psum[QT];
     auto probs = [&](int qt) __attribute__((always_inline)) {
       // four independent partial sums (a 16-deep dependent chain sat on the step's critical path: hipcc packed the two query tiles'
@@ -519,19 +550,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     ATTN_STAMP(3, 2);
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) l_run[qt] += psum[qt];
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-      for (int dvt = 0; dvt < 2; ++dvt) {
-        u32x4 vf[2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) vf[p] = *reinterpret_cast<const u32x4*>(sV + (((WHATIF & 32) ? 0 : (kg * 2 + dvt)) * NP + p) * FRAG);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          if constexpr ((WHATIF & 8) != 0) { oacc[dvt][qt] += __builtin_bit_cast(f32x4, pf[qt][kg][0]) + __builtin_bit_cast(f32x4, pf[qt][kg][1]) + __builtin_bit_cast(f32x4, vf[0]); }
-          else oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
-        }
-      }
+    if constexpr (!DELAY) pv_product(sV, pf);
     ATTN_STAMP(4, 2);
     if constexpr ((WHATIF & 64) == 0) {
     if (kt + 2 < nkt) swrite_k(kt + 2);
@@ -541,24 +560,42 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
     __syncthreads();
     ATTN_STAMP(6, 1);
   };
-  auto stepx = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], auto lastc) __attribute__((always_inline)) {
-    if constexpr (FAST) step_fast(kt, s, sn, lastc);
+  u32x4 pfA[QT][2][2], pfB[QT][2][2];                  // probability fragments of two consecutive steps (DELAY keeps one pending)
+  auto stepx = [&](int kt, f32x4 (&s)[QT][4], f32x4 (&sn)[QT][4], u32x4 (&pf)[QT][2][2], u32x4 (&pfp)[QT][2][2], auto lastc, auto pendc) __attribute__((always_inline)) {
+    if constexpr (FAST) step_fast(kt, s, sn, pf, pfp, lastc, pendc);
     else step(kt, s, sn, lastc);
   };
   {
     constexpr std::false_type MID{};
     constexpr std::true_type END{};
+    constexpr std::false_type NOPEND{};
+    constexpr std::true_type PEND{};
     int kt = 0;
     if constexpr (ATTN_OCC >= 3) {
-      for (; kt + 1 < nkt; ++kt) stepx(kt, sA, sA, MID);
-      stepx(kt, sA, sA, END);
+      for (; kt + 1 < nkt; ++kt) stepx(kt, sA, sA, pfA, pfA, MID, NOPEND);
+      stepx(kt, sA, sA, pfA, pfA, END, NOPEND);
     } else {
-      for (; kt + 2 < nkt; kt += 2) {
-        stepx(kt, sA, sB, MID);
-        stepx(kt + 1, sB, sA, MID);
+      // steps alternate the score buffers (sA, sB) and the fragment buffers (pfA, pfB); the first step has no pending product
+      if (nkt == 1) {
+        stepx(0, sA, sB, pfA, pfB, END, NOPEND);
+        if constexpr (DELAY) pv_product(sVb + vbuf(0) * HALF + lane * 16, pfA);
+      } else {
+        stepx(0, sA, sB, pfA, pfB, MID, NOPEND);
+        kt = 1;
+        for (; kt + 2 < nkt; kt += 2) {
+          stepx(kt, sB, sA, pfB, pfA, MID, PEND);
+          stepx(kt + 1, sA, sB, pfA, pfB, MID, PEND);
+        }
+        // kt = first step not yet done (odd); one or two steps left
+        if (kt + 1 < nkt) {
+          stepx(kt, sB, sA, pfB, pfA, MID, PEND);
+          stepx(kt + 1, sA, sB, pfA, pfB, END, PEND);
+          if constexpr (DELAY) pv_product(sVb + vbuf(kt + 1) * HALF + lane * 16, pfA);
+        } else {
+          stepx(kt, sB, sA, pfB, pfA, END, PEND);
+          if constexpr (DELAY) pv_product(sVb + vbuf(kt) * HALF + lane * 16, pfB);
+        }
       }
-      if (kt + 1 < nkt) { stepx(kt, sA, sB, MID); stepx(kt + 1, sB, sA, END); }
-      else stepx(kt, sA, sB, END);
     }
   }
 #pragma unroll
@@ -631,7 +668,7 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
   const int nblk = ((nq + 64 * QT - 1) / (64 * QT)) * H * B;
   static const int depth_env = getenv("PATHS_ATTN_DEPTH") ? atoi(getenv("PATHS_ATTN_DEPTH")) : 0;   // experiment
   const int depth = depth_env ? depth_env : ATTN_OCC >= 3 ? (nblk <= 256 ? 1 : nblk <= 512 ? 2 : 3) : nblk <= 256 ? 1 : nblk <= 640 ? 2 : 3;    // (544 workgroups at K = 2048 x 8 slides: 2 per CU on every CU beat 3 per CU on 2/3 of them by 2 %)
-  const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : 2 * step_bytes<NP>();
+  const int lds = depth == 1 ? 96 * 1024 : depth == 2 ? 64 * 1024 : (5 * step_bytes<NP>()) / 2;     // (K ring of two + V^T ring of up to three half-step buffers)
   PATHS_LDS_OPT_IN((attn_x6_kernel<NP, false>), 96 * 1024, "attention_x6");
   PATHS_LDS_OPT_IN((attn_x6_kernel<NP, true>), 96 * 1024, "attention_x6(dropout)");
   const int nqb = (nq + 64 * QT - 1) / (64 * QT), npairs = H * B;
