@@ -924,8 +924,9 @@ def test_graphed_recursion_replays_bit_identically(dev):
     assert torch.equal(out3["logits"], ref3["logits"])
 
 
-@pytest.mark.parametrize("over", [{"trans_dim": 192}, {"trans_dim": 64, "trans_heads": 2, "importance_mlp_hidden_dim": 32, "lstm": False}],
-                         ids=["td192", "td64_h2_hi32_nolstm"])
+@pytest.mark.parametrize("over", [{"trans_dim": 192}, {"trans_dim": 64, "trans_heads": 2, "importance_mlp_hidden_dim": 32, "lstm": False},
+                                  {"trans_dim": 256, "trans_heads": 2}],
+                         ids=["td192", "td64_h2_hi32_nolstm", "td256_h2_wide"])
 def test_taped_recursion_other_geometries(dev, over):
     """The launch tape on the shape-generic path (no torch-side kernel may hide in it): replays equal the eager pass bit for bit, also
     after the tape's outputs were poisoned."""
@@ -1285,7 +1286,12 @@ def test_random_small_recursions_vs_oracle(dev, case):
 
 VARIANT_OVERS = [{"lstm": False}, {"slide_ctx_mode": "concat"}, {"pos_encoding_mode": "1d"}, {"importance_mode": "none"},
                  {"slide_ctx_mode": "none"}, {"lstm": False, "slide_ctx_mode": "concat"}, {"lstm": False, "pos_encoding_mode": "1d"},
-                 {"slide_ctx_mode": "concat", "importance_mode": "none"}]
+                 {"slide_ctx_mode": "concat", "importance_mode": "none"},
+                 # round 4: other aggregator geometries through the DEVICE recursion (tuned gate kernels with rows read in place,
+                 # importance / projection on x + h1 in flight, the chain kernel at 192, wide heads)
+                 {"trans_dim": 192}, {"trans_dim": 192, "slide_ctx_mode": "concat", "pos_encoding_mode": "1d"},
+                 {"trans_dim": 256, "trans_heads": 2}, {"trans_dim": 96, "trans_heads": 2, "importance_mlp_hidden_dim": 64},
+                 {"trans_dim": 384, "trans_heads": 1, "trans_layers": 3}]
 
 
 @pytest.mark.parametrize("case", range(len(VARIANT_OVERS)))
