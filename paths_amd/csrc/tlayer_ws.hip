@@ -30,7 +30,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FRAG = 1024;         // bytes of one 16-row x 32-k fragment of one plane
 constexpr int NW = 4;              // waves per workgroup
-constexpr int TT = 4;              // 16-token tiles per workgroup
+#ifndef PATHS_WS_TT
+#define PATHS_WS_TT 4
+#endif
+constexpr int TT = PATHS_WS_TT;    // 16-token tiles per workgroup (4: 64 tokens, one workgroup per CU; 2: 32 tokens, two per CU)
 constexpr int TOK = 16 * TT;
 constexpr int NFF = 4;             // feed-forward hidden chunks of DM features (dim_feedforward = 4 DM, reference aggregator.py:29)
 #ifndef PATHS_WS_NPF
@@ -134,7 +137,7 @@ struct WsParams {
 // tile ot, the features 16 (OT w + ot) + 4 g + r (r = 0..3) of token 16 tt + ql  -  the C layout of v_mfma_f32_16x16x32_f16 with the
 // weights as A (rows = output features) and the activations as B (columns = tokens).
 template <int DM, bool POST, bool QKV, bool ROWS = false>
-__global__ void __launch_bounds__(64 * NW, 1)
+__global__ void __launch_bounds__(64 * NW, TT == 2 ? 2 : 1)
 tlayer_ws_kernel(WsParams p) {
   using G = Geo<DM>;
   constexpr int KB = G::KB, OT = G::OT;
@@ -194,10 +197,14 @@ tlayer_ws_kernel(WsParams p) {
 
   // first B-operand image: the attention output (POST) or the input rows themselves (QKV only)
   if (POST && p.attn_img != nullptr) {
-    const char* src = p.attn_img + ((int64_t)b * (p.Tp / TOK) + (t0 / TOK)) * G::ACT;
+    // the attention kernel writes one image per 64-TOKEN GROUP, [kb][4 tiles][plane]; this workgroup takes tiles tt0 .. tt0 + TT - 1
+    constexpr int ACT64 = KB * 4 * 2 * FRAG, ROWB = TT * 2 * FRAG;                 // bytes per group / per k32 block of this workgroup
+    const char* src = p.attn_img + ((int64_t)b * (p.Tp / 64) + (t0 / 64)) * ACT64 + ((t0 >> 4) & 3) * 2 * FRAG;
 #pragma unroll
-    for (int i = 0; i < G::ACT / (16 * 64 * NW); ++i)
-      *reinterpret_cast<u32x4*>(sAct + (tid + i * 64 * NW) * 16) = ldg_u32x4(src + (tid + i * 64 * NW) * 16);
+    for (int i = 0; i < G::ACT / (16 * 64 * NW); ++i) {
+      const int piece = tid + i * 64 * NW, kb = piece / (ROWB / 16), r = piece % (ROWB / 16);
+      *reinterpret_cast<u32x4*>(sAct + piece * 16) = ldg_u32x4(src + (int64_t)kb * (4 * 2 * FRAG) + r * 16);
+    }
   } else {
     const float* src = POST ? p.attn : p.x_in;
     for (int kb = wave; kb < KB; kb += NW) {
@@ -537,7 +544,7 @@ int launch_ws(const WsParams& p, hipStream_t stream) {
   const size_t lds = ws_lds_bytes<DM>(POST, QKV);
   PATHS_LDS_OPT_IN((tlayer_ws_kernel<DM, POST, QKV, ROWS>), 160 * 1024, "token_layer_ws");
   // (> 80 KiB per workgroup: one workgroup per CU, so a grid of ~one workgroup per CU spreads over the whole chip)
-  const size_t ask = lds > 84 * 1024 ? lds : 84 * 1024;
+  const size_t ask = TT == 2 ? lds : (lds > 84 * 1024 ? lds : 84 * 1024);
   hipLaunchKernelGGL((tlayer_ws_kernel<DM, POST, QKV, ROWS>), dim3((p.T + TOK - 1) / TOK, p.B), dim3(64 * NW), ask, stream, p);
   PATHS_LAUNCH_CHECK("token_layer_ws");
   return PATHS_OK;
