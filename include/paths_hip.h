@@ -42,6 +42,8 @@ int paths_abi_version(void);
  * no reference equivalent).  paths_event_create / paths_event_destroy: a timing-less event handle (host object) for paths_stream_wait, which makes `dst`
  * wait for everything enqueued on `src` so far; paths_memset_zero: hipMemsetAsync(0).  None of them synchronises the host. */
 void* paths_event_create(void);
+/* a HIP stream restricted to the compute units set in cu_mask (words x 32 bits): measurement aid (CU-partitioned streams) */
+void* paths_stream_create_masked(const uint32_t* cu_mask, int words);
 int paths_event_destroy(void* event);
 int paths_stream_wait(paths_stream_t dst, paths_stream_t src, void* event);
 int paths_memset_zero(void* p, size_t bytes, paths_stream_t stream);

@@ -286,8 +286,24 @@ def _streams(dev, lane: Optional[int] = None):
     key = (idx, STREAM_LANE if lane is None else lane)
     if key not in _STREAMS:
         hi = -1 if os.environ.get("PATHS_STREAM_PRIORITIES", "1") != "0" else 0
-        _STREAMS[key] = (torch.cuda.Stream(device=idx, priority=hi), torch.cuda.Stream(device=idx, priority=0),
-                         torch.cuda.Stream(device=idx, priority=hi))
+        agg = torch.cuda.Stream(device=idx, priority=0)
+        ncu = int(os.environ.get("PATHS_AGG_CU_MASK", "0"))
+        if ncu > 0:
+            # measurement aid: the aggregator stream confined to `ncu` of the chip's compute units, spread evenly over the
+            # mask's bit positions (which interleave the XCDs); the selection streams keep the whole chip
+            import ctypes
+            total = torch.cuda.get_device_properties(idx).multi_processor_count
+            words = (total + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for j in range(ncu):
+                bit = (j * total) // ncu
+                mask[bit // 32] |= 1 << (bit % 32)
+            with torch.cuda.device(idx):
+                h = _lib.load().paths_stream_create_masked(mask, words)
+            if not h:
+                raise _lib.PathsHipError("paths_stream_create_masked failed: " + _lib.load().paths_last_error().decode())
+            agg = torch.cuda.ExternalStream(h, device=idx)
+        _STREAMS[key] = (torch.cuda.Stream(device=idx, priority=hi), agg, torch.cuda.Stream(device=idx, priority=hi))
     return _STREAMS[key]
 
 
