@@ -25,6 +25,12 @@ DropSite paths_make_drop_site(uint64_t key, float p);      // dropout.hip
 #if defined(PATHS_ATTN_STAMPS) && !defined(PATHS_ATTN_DEBUG)
 #define PATHS_ATTN_DEBUG 1
 #endif
+#ifdef PATHS_M32P_STAMPS
+unsigned long long* g_m32p_dbg = nullptr;     // diagnostic builds only (tools/attn_pair_stamps.py): segment / barrier cycles per wave
+#define M32P_T(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define M32P_T(i) do { } while (0)
+#endif
 #ifdef PATHS_ATTN_DEBUG
 unsigned long long* g_attn_dbg = nullptr;
 #endif
@@ -43,6 +49,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -645,6 +652,601 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same attention on v_mfma_f32_32x32x16_f16 (two fp16 planes, no dropout; round 4).  Why: a 16x16x32 MFMA holds the SIMD's
+// vector issue for 8 of its 16 cycles, a 32x32x16 for 8 of its 32 - at equal matrix-pipe time the softmax's vector work (exp2, sums,
+// operand split) finds three times the issue slots under the MFMAs (tools/simd_probe.hip: "12 x (32x32x16 + 6 fma)" 404 cycles per
+// SIMD against "24 x (16x16x32 + 3 fma)" 499).  NOTHING changes for the producers and the consumer: the operand images are the
+// 16x16x32 fragment images of the kernel above, read with a permuted lane address -
+//   K / Q (32 tokens x 16 dims of k-step ks): lane (r = l & 31, h = l >> 5) takes the 16 bytes of old lane (r & 15) + 16 (2 ks + h) of
+//         16-token tile r >> 4  (its dims 16 ks + 8 h .. + 7);
+//   V^T   (32 dims x 16 keys of step u of a 32-key group): lane (dv = l & 31, h) takes the 16 bytes of old lane (dv & 15) + 16 (h + 2 u)
+//         of dv tile dv >> 4: keys 4 h + 8 u + (j & 3) + 16 (j >> 2), j = 0..7 - the S^T accumulators 4 u + (j & 3) + 8 (j >> 2) of the
+//         lane (accumulator i of a 32 x 32 tile = row (i & 3) + 8 (i >> 2) + 4 h): the contraction order is free, only P and V^T must
+//         agree on it (two 8-byte reads per fragment in "natural" order cost a 4-way bank conflict: 58 us against 55);
+//   O     lane (q, h) holds dims 4 h + r + 8 m (m = 0..3) of query q = the contents of old lanes (q & 15) + 16 h and + 16 (h + 2) of
+//         the chain kernel's out_proj image: two 16-byte stores per plane, no shuffle.
+// One wave = 32 queries (one accumulator column per lane: the softmax state is one scalar per lane, the two lane halves hold
+// different keys of the same query); per 64-key step 12 + 12 MFMAs of 32 cycles.  Same FAST softmax as above (running maximum
+// subtracted inside the score product, optimistic probabilities, revision path).
+__device__ __forceinline__ f32x16 mfma32_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32_split(const u32x4 (&a)[2], const u32x4 (&b)[2], f32x16 c) {   // hi, lo: all but lo*lo, smallest first
+  c = mfma32_f16(a[1], b[0], c);
+  c = mfma32_f16(a[0], b[1], c);
+  return mfma32_f16(a[0], b[0], c);
+}
+
+__global__ void __launch_bounds__(256, 2)
+attn_m32_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6, float* __restrict__ o,
+                float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H, int npairs_arg, int nqb_arg,
+                char* __restrict__ o_img) {
+  constexpr int NP = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int npairs = npairs_arg, nqb = nqb_arg;
+  const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
+  const int cnt = (npairs - xg + 7) >> 3;
+  if (cnt <= 0) return;
+  const int pair = xg + 8 * (jx % cnt), qb = jx / cnt;
+  if (qb >= nqb) return;
+  const int b = pair / H, head = pair - b * H, q0 = qb * 128;
+  const int len = min((int)num_ims[b] + 1, T);
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qc = lane & 31, h = lane >> 5, l15 = lane & 15, sub = (lane >> 4) & 1;      // sub: which 16-token / 16-dim tile of the 32
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * NP;
+  const int qw = q0 + wave * 32;
+
+  // Q fragments [k-step][plane] (B operand: 16 dims x 32 queries)
+  u32x4 qf[2][NP];
+  {
+    const int64_t tq = min(qw + 16 * sub, Tp - 16) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        qf[ks][p] = *reinterpret_cast<const u32x4*>(q6 + ibase + (tq * NP + p) * FRAG + (l15 + 16 * (2 * ks + h)) * 16);
+  }
+  f32x16 oacc, negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[i] = 0.f; negm[i] = 0.f; }
+  float m_run = 0.f, l_run = 0.f;
+
+  const int nkt = (len + KSTEP - 1) / KSTEP;
+  constexpr int HALF = 4 * NP * FRAG;
+  char* const sKb = smem_raw;                           // [2][HALF]
+  char* const sVb = smem_raw + 2 * HALF;                // [2][HALF]
+  u32x4 st[2 * NP];
+  auto gload_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st[i] = *reinterpret_cast<const u32x4*>(k6 + ibase + (int64_t)kt * HALF + (tid + 256 * i) * 16);
+  };
+  auto gload_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) st[NP + i] = *reinterpret_cast<const u32x4*>(v6 + ibase + (int64_t)kt * HALF + (tid + 256 * i) * 16);
+  };
+  auto swrite_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sKb + (kt & 1) * HALF + (tid + 256 * i) * 16) = st[i];
+  };
+  auto swrite_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *reinterpret_cast<u32x4*>(sVb + (kt & 1) * HALF + (tid + 256 * i) * 16) = st[NP + i];
+  };
+  // S^T of the two 32-key tiles of step kt: s[t] = K_t Q^T - m_run
+  auto qk = [&](int kt, f32x16 (&s)[2]) __attribute__((always_inline)) {
+    const char* sK = sKb + (kt & 1) * HALF;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 kf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          kf[p] = *reinterpret_cast<const u32x4*>(sK + ((2 * t + sub) * NP + p) * FRAG + (l15 + 16 * (2 * ks + h)) * 16);
+        s[t] = mfma32_split(kf, qf[ks], ks == 0 ? negm : s[t]);
+      }
+  };
+  gload_k(0); gload_v(0);
+  swrite_k(0); swrite_v(0);
+  if (nkt > 1) { gload_k(1); swrite_k(1); }
+  __syncthreads();
+  f32x16 sA[2], sB[2];
+  qk(0, sA);
+  auto step = [&](int kt, f32x16 (&s)[2], f32x16 (&sn)[2], auto lastc) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(lastc)::value;
+    if (kt + 2 < nkt) gload_k(kt + 2);
+    if (kt + 1 < nkt) gload_v(kt + 1);
+    const char* sV = sVb + (kt & 1) * HALF;
+    if constexpr (LAST) {
+      const int kbase = kt * KSTEP + 4 * h;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kbase + 32 * t + (i & 3) + 8 * (i >> 2) >= len) s[t][i] = -INFINITY;
+    }
+    qk(kt + 1, sn);                                     // (past the end: stale K fragments, finite garbage nobody reads)
+    u32x4 pf[2][2][NP];                                 // [key tile][16-key step][plane]
+    float psum;
+    auto probs = [&]() __attribute__((always_inline)) {
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {                 // k-slot (h, j) of PV step u = key 4 h + 8 u + (j & 3) + 16 (j >> 2) of the tile
+            pv[j] = __builtin_amdgcn_exp2f(s[t][4 * u + (j & 3) + 8 * (j >> 2)]);
+            ps[j & 3] += pv[j];
+            asm("" : "+v"(ps[j & 3]));
+          }
+          split8h(pv, pf[t][u][0], pf[t][u][1]);
+        }
+      psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+    probs();
+    if (kt == 0 || __any(!(psum <= 256.0f))) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[t][i]), s[t][i + 1]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));               // the other half of the query's keys; finite: key 0 is valid for every query
+      const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+      const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+      l_run *= alpha;
+      m_run += d;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oacc[i] *= alpha; negm[i] = -m_run; }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[t][i] -= d; sn[t][i] -= d; }
+      probs();
+    }
+    l_run += psum;
+    // O^T += V^T P^T: four 16-key steps
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        u32x4 vf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          vf[p] = *reinterpret_cast<const u32x4*>(sV + ((t * 2 + sub) * NP + p) * FRAG + (l15 + 16 * (h + 2 * u)) * 16);
+        oacc = mfma32_split(vf, pf[t][u], oacc);
+      }
+    if (kt + 2 < nkt) swrite_k(kt + 2);
+    if (kt + 1 < nkt) swrite_v(kt + 1);
+    __syncthreads();
+  };
+  {
+    constexpr std::false_type MID{};
+    constexpr std::true_type END{};
+    int kt = 0;
+    for (; kt + 2 < nkt; kt += 2) {
+      step(kt, sA, sB, MID);
+      step(kt + 1, sB, sA, MID);
+    }
+    if (kt + 1 < nkt) { step(kt, sA, sB, MID); step(kt + 1, sB, sA, END); }
+    else step(kt, sA, sB, END);
+  }
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l;
+  if (o_img != nullptr) {
+    const int tq = qw + 16 * sub;
+    if (tq < Tp) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {                  // old lanes (q & 15) + 16 g4, g4 = h + 2 gg: dims 4 g4 + r and 16 + 4 g4 + r
+        const int i0 = 4 * gg, i1 = 8 + 4 * gg;
+        const float v[8] = {oacc[i0] * inv, oacc[i0 + 1] * inv, oacc[i0 + 2] * inv, oacc[i0 + 3] * inv,
+                            oacc[i1] * inv, oacc[i1 + 1] * inv, oacc[i1 + 2] * inv, oacc[i1 + 3] * inv};
+        u32x4 hi, lo;
+        split8h(v, hi, lo);
+        char* dst = o_img + ((((int64_t)b * (Tp >> 6) + (tq >> 6)) * H + head) * 4 + ((tq >> 4) & 3)) * (2 * FRAG) + (l15 + 16 * (h + 2 * gg)) * 16;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+      }
+    }
+    return;
+  }
+  const int qi = qw + qc;
+  if (qi < T) {
+    float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * h;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      *reinterpret_cast<f32x4*>(op + 8 * m) = f32x4{oacc[4 * m] * inv, oacc[4 * m + 1] * inv, oacc[4 * m + 2] * inv, oacc[4 * m + 3] * inv};
+    if (lse && h == 0) lse[((int64_t)b * H + head) * T + qi] = m_run + log2f(l);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The 32x32x16 kernel as a PHASE-LOCKED WAVE PAIR (round 4): 512 threads = 8 waves of 32 queries, waves w and w + 4 share a SIMD.
+// A wave's key step is two segments - V: the softmax of S(kt) (vector unit only: 32 exp2, sums, the fp16 split) and M: O += V^T P(kt),
+// S(kt+1) = K Q^T (matrix unit only, 24 MFMAs of 32 cycles) - with a workgroup barrier after each, and waves 4-7 run one segment
+// behind waves 0-3: on every SIMD one wave is in its M segment while the other is in its V segment, all the time.  Why: two
+// free-running waves that each interleave MFMAs and vector work do not overlap them - an in-order wave whose next MFMA waits for the
+// partner's MFMA cannot issue the vector instructions behind it, and the measured step was the SUM of both pipes' time
+// (profiles/r04_experiments.md: 3056 cycles per SIMD and pair of wave-steps = 1536 MFMA + ~1400 vector); tools/simd_probe.hip's
+// LOCKED rows give 1806 for the pair in complementary segments.  S needs one buffer only (S(kt+1) is produced after P(kt) was taken).
+//   slot (barrier interval):   2kt                          2kt+1                        2kt+2
+//   waves 0-3                  V(kt)                        M(kt)                        V(kt+1)
+//   waves 4-7                  M(kt-1)                      V(kt)                        M(kt)
+//   waves 8-11 (loaders)       -                            DMA of bundle kt+3, wait for bundle kt+1
+// Staging is LDS-DMA (global_load_lds_dwordx4: the fragment images are copied verbatim, 1 KiB per wave instruction) by four loader
+// waves, one per SIMD, that do nothing else (768 threads; 159 VGPRs x 3 waves fit a SIMD).  Bundle j = {V^T(j), K(j+1)} (what M(j)
+// reads) is issued in slot 2j-5, waited for (counted vmcnt: the next two bundles stay in flight) at the end of slot 2j-1 and published
+// by that slot's barrier, so BOTH groups may issue the first fragment reads of M(j) before the barrier that opens it (end of slot 2j
+// / 2j+1); read until slot 2j+2, bundle j+4 takes its place from slot 2j+3: rings of four steps (64 KiB).
+// (Measured on the way, profiles/r04_experiments.md: issued by waves 4-7 themselves, the four DMAs of a step took 650-1000 cycles to
+// ISSUE - in front of their vector segment or of their MFMAs alike, with or without s_setprio - whenever the SIMD partner was in its
+// dense vector segment; through registers (global_load + ds_write) ~300.)
+// Barriers are raw s_barrier (a __syncthreads would drain the DMA in flight); nothing in the loop writes LDS by ds_write.
+__device__ __forceinline__ void glds16(const char* sbase, uint32_t voff, uint32_t lds_dst) {
+  // sbase + voff: wave-uniform base (SGPR pair) + per-lane byte offset - no vector instruction at the issue: a 64-bit VALU add per DMA
+  // in front of the M segment waited for issue slots behind the partner's dense vector stream (~250 cycles per DMA);
+  // lds_dst: wave-uniform byte address, lane l lands at + 16 l
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void pair_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+#ifndef PATHS_M32P_PKADD
+#define PATHS_M32P_PKADD 0
+#endif
+#ifndef PATHS_M32P_EARLYPRE
+#define PATHS_M32P_EARLYPRE 1
+#endif
+#ifndef PATHS_M32P_PIPE
+#define PATHS_M32P_PIPE 0                 // explicit two-chunks-ahead fragment reads in M: over the 168-VGPR cap of three waves per SIMD (spills, 65 us)
+#endif
+__global__ void __launch_bounds__(768)
+attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6, float* __restrict__ o,
+                 float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H, int npairs_arg, int nqb_arg,
+                 char* __restrict__ o_img
+#ifdef PATHS_M32P_STAMPS
+                 , unsigned long long* __restrict__ dbg
+#endif
+                 ) {
+  constexpr int NP = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifdef PATHS_M32P_STAMPS
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+  const int npairs = npairs_arg, nqb = nqb_arg;
+  const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
+  const int cnt = (npairs - xg + 7) >> 3;
+  if (cnt <= 0) return;
+  const int pair = xg + 8 * (jx % cnt), qb = jx / cnt;
+  if (qb >= nqb) return;
+  const int b = pair / H, head = pair - b * H, q0 = qb * 256;
+  const int len = min((int)num_ims[b] + 1, T);
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                            // 1 = the half that runs one segment behind; 2 = the four loader waves
+  const int qc = lane & 31, h = lane >> 5, l15 = lane & 15, sub = (lane >> 4) & 1;
+  const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * NP;
+  const int qw = q0 + wave * 32;
+  const bool active = qw < len && grp < 2;              // (a wave without queries still meets every barrier)
+
+  u32x4 qf[2][NP];
+  {
+    const int64_t tq = min(qw + 16 * sub, Tp - 16) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        qf[ks][p] = *reinterpret_cast<const u32x4*>(q6 + ibase + (tq * NP + p) * FRAG + (l15 + 16 * (2 * ks + h)) * 16);
+  }
+  f32x16 oacc, negm, s[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[i] = 0.f; negm[i] = 0.f; }
+  float m_run = 0.f, l_run = 0.f;
+  u32x4 pf[2][2][NP];                                   // P^T fragments [key tile][16-key step][plane]
+#if PATHS_M32P_PIPE
+  u32x4 fr[3][NP];                                      // operand fragments of M in flight (chunk c in fr[c % 3]); fr[0], fr[1] = V^T of key tile 0, read ahead of the barrier
+  auto& vpre = fr;
+#else
+  u32x4 vpre[2][NP];                                    // V^T fragments of key tile 0, read ahead of the barrier that opens M
+#endif
+
+  const int nkt = (len + KSTEP - 1) / KSTEP;
+  constexpr int HALF = 4 * NP * FRAG;                   // one 64-key step of K or of V^T
+  char* const sKb = smem_raw;                           // [4][HALF]
+  char* const sVb = smem_raw + 4 * HALF;                // [4][HALF]
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
+  // prologue: K(0) and bundle 0 = {V^T(0), K(1)} by all 512 threads through registers
+  {
+    const int t5 = tid & 511;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(k6 + ibase + t5 * 16);
+    const u32x4 c = *reinterpret_cast<const u32x4*>(v6 + ibase + t5 * 16);
+    u32x4 d = a;
+    if (nkt > 1) d = *reinterpret_cast<const u32x4*>(k6 + ibase + HALF + t5 * 16);
+    if (grp < 2) {
+      *reinterpret_cast<u32x4*>(sKb + t5 * 16) = a;
+      *reinterpret_cast<u32x4*>(sVb + t5 * 16) = c;
+      *reinterpret_cast<u32x4*>(sKb + HALF + t5 * 16) = d;
+    }
+  }
+  // bundle j by waves 4-7: V^T(j) -> V ring position j & 3, K(j + 1) -> K ring position (j + 1) & 3; each wave 2 + 2 KiB
+  const int wq = wave & 3;
+  const uint32_t voff = wq * 1024 + lane * 16;
+  auto dma_bundle = [&](int j) {
+#ifndef PATHS_M32P_NOSTAGE
+    if (j >= nkt) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16(v6 + ibase + (int64_t)j * HALF + 4096 * i, voff, lds0 + (4 + (j & 3)) * HALF + (wq + 4 * i) * 1024);
+    if (j + 1 < nkt) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        glds16(k6 + ibase + (int64_t)(j + 1) * HALF + 4096 * i, voff, lds0 + ((j + 1) & 3) * HALF + (wq + 4 * i) * 1024);
+    }
+#endif
+  };
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (grp == 2) {
+    // The loader waves (one per SIMD, at priority 3: they issue ~30 instructions per key step).  Issued by waves 4-7 themselves the
+    // four DMAs of a step took 650-1000 cycles to ISSUE behind the partner's dense vector stream, in front of the wave's MFMAs.
+    // Slot s ends with barrier s + 1; in slot 2kt+1: issue bundle kt+3 (its ring position was last read in slot 2kt), then wait until
+    // bundle kt+1 has landed (bundles kt+2 and kt+3 may fly).
+    __builtin_amdgcn_s_setprio(3);
+    dma_bundle(1); dma_bundle(2);
+    auto count = [&](int j) { return j >= nkt ? 0 : j + 1 < nkt ? 4 : 2; };
+    pair_barrier();                                     // (the prologue's)
+    pair_barrier();                                     // slot -1
+    pair_barrier();                                     // slot 0
+    for (int kt = 0; kt < nkt; ++kt) {
+      dma_bundle(kt + 3);
+      const int fly = count(kt + 2) + count(kt + 3);
+      if (fly == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (fly == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (fly == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (fly == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pair_barrier();                                   // slot 2kt+1
+      pair_barrier();                                   // slot 2kt+2
+    }
+    return;
+  }
+  pair_barrier();
+
+  auto qk = [&](const char* sK) __attribute__((always_inline)) {   // s[t] = K_t Q^T - m_run
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 kf[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          kf[p] = *reinterpret_cast<const u32x4*>(sK + ((2 * t + sub) * NP + p) * FRAG + (l15 + 16 * (2 * ks + h)) * 16);
+        if (ks == 0)                                    // (C = -m_run read in place: hipcc would copy the 16 registers into s[t] first)
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[t]) : "v"(kf[1]), "v"(qf[0][0]), "v"(negm));
+        else
+          s[t] = mfma32_f16(kf[1], qf[ks][0], s[t]);
+        s[t] = mfma32_f16(kf[0], qf[ks][1], s[t]);
+        s[t] = mfma32_f16(kf[0], qf[ks][0], s[t]);
+      }
+  };
+  auto vfrag = [&](const char* sV, int t, int u, int p) __attribute__((always_inline)) {
+    return *reinterpret_cast<const u32x4*>(sV + ((t * 2 + sub) * NP + p) * FRAG + (l15 + 16 * (h + 2 * u)) * 16);
+  };
+  // V segment: (waves 4-7: DMA issue), softmax of s -> pf, l_run (and, rarely, a new running maximum), first V^T fragments of M(kt)
+  auto vseg = [&](int kt) __attribute__((always_inline)) {
+    M32P_T(5);
+#ifdef PATHS_M32P_WHATIF
+    if (active && !((PATHS_M32P_WHATIF & 1) && grp == 0) && !((PATHS_M32P_WHATIF & 8) && grp == 1)) {
+#else
+    if (active) {
+#endif
+      if (kt == nkt - 1) {
+        const int kbase = kt * KSTEP + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kbase + 32 * t + (i & 3) + 8 * (i >> 2) >= len) s[t][i] = -INFINITY;
+      }
+#if PATHS_M32P_EARLYPRE
+      {                                                 // first V^T fragments of M(kt): published one slot ago, read under the softmax
+        const char* sV = sVb + (kt & 3) * HALF;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) vpre[u][p] = vfrag(sV, 0, u, p);
+      }
+#endif
+      float psum;
+      auto probs = [&]() __attribute__((always_inline)) {
+#if PATHS_M32P_PKADD
+        f32x2 ps[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // four independent v_pk_add_f32 chains
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(s[t][4 * u + (j & 3) + 8 * (j >> 2)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps[j] += f32x2{pv[2 * j], pv[2 * j + 1]};
+            split8h(pv, pf[t][u][0], pf[t][u][1]);
+          }
+        const f32x2 q = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        psum = q[0] + q[1];
+#else
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              pv[j] = __builtin_amdgcn_exp2f(s[t][4 * u + (j & 3) + 8 * (j >> 2)]);
+              ps[j & 3] += pv[j];
+              asm("" : "+v"(ps[j & 3]));
+            }
+            split8h(pv, pf[t][u][0], pf[t][u][1]);
+          }
+        psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#endif
+      };
+      probs();
+      M32P_T(6);
+      if (kt == 0 || __any(!(psum <= 256.0f))) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[t][i]), s[t][i + 1]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha = kt == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+        m_run += d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[i] *= alpha; negm[i] -= d; }     // (in place: = -m_run, bit for bit - m_run is the sum of the d's)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[t][i] -= d;
+        probs();
+      }
+      l_run += psum;
+#if !PATHS_M32P_EARLYPRE
+      const char* sV = sVb + (kt & 3) * HALF;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) vpre[u][p] = vfrag(sV, 0, u, p);
+#endif
+    }
+  };
+  // M segment: O^T += V^T(kt) P^T(kt), then S(kt+1)
+  auto mseg = [&](int kt, auto morec) __attribute__((always_inline)) {
+    constexpr bool more = decltype(morec)::value;       // S(kt+1) wanted: all but the last step
+    M32P_T(7);
+    if (!active) return;
+#ifdef PATHS_M32P_WHATIF
+    if ((PATHS_M32P_WHATIF & 4) && grp == 0) return;
+    if ((PATHS_M32P_WHATIF & 16) && grp == 1) return;
+#endif
+    const char* sV = sVb + (kt & 3) * HALF;
+#if PATHS_M32P_PIPE
+    // 12 chunks of 3 MFMAs: 0-3 = V^T (tile, step), 4-11 = K (tile, k-step); chunk c + 2 is read while chunk c multiplies (chunks 0, 1
+    // came in before the barrier): the fragment reads run two chunks = 192+ matrix cycles ahead of their use
+    const char* sK = sKb + ((kt + 1) & 3) * HALF;
+    auto rd = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (c < 4) fr[c % 3][p] = vfrag(sV, c >> 1, c & 1, p);
+        else { const int t = (c - 4) >> 1, ks = (c - 4) & 1;
+               fr[c % 3][p] = *reinterpret_cast<const u32x4*>(sK + ((2 * t + sub) * NP + p) * FRAG + (l15 + 16 * (2 * ks + h)) * 16); }
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      if (c + 2 < 4 || (c + 2 < 12 && more)) rd(c + 2);
+      if (c < 4) oacc = mfma32_split(fr[c % 3], pf[c >> 1][c & 1], oacc);
+      else if (more) {
+        const int t = (c - 4) >> 1, ks = (c - 4) & 1;
+        if (ks == 0)
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[t]) : "v"(fr[c % 3][1]), "v"(qf[0][0]), "v"(negm));
+        else
+          s[t] = mfma32_f16(fr[c % 3][1], qf[ks][0], s[t]);
+        s[t] = mfma32_f16(fr[c % 3][0], qf[ks][1], s[t]);
+        s[t] = mfma32_f16(fr[c % 3][0], qf[ks][0], s[t]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+#pragma unroll
+    for (int u = 0; u < 2; ++u) oacc = mfma32_split(vpre[u], pf[0][u], oacc);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      u32x4 vf[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) vf[p] = vfrag(sV, 1, u, p);
+      oacc = mfma32_split(vf, pf[1][u], oacc);
+    }
+    if (more) qk(sKb + ((kt + 1) & 3) * HALF);
+#endif
+  };
+  if (grp) pair_barrier();                              // (slot -1: waves 0-3 compute S(0))
+  if (active) qk(sKb);
+  pair_barrier();
+  M32P_T(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    vseg(kt);
+    M32P_T(1);
+    pair_barrier();
+    M32P_T(2);
+    if (kt + 1 < nkt) mseg(kt, std::true_type{}); else mseg(kt, std::false_type{});
+    M32P_T(3);
+    pair_barrier();
+    M32P_T(4);
+  }
+  if (!grp) pair_barrier();                             // (the last slot belongs to waves 4-7)
+#ifdef PATHS_M32P_STAMPS
+  if (dbg != nullptr && lane == 0) {
+    unsigned long long* d = dbg + ((int64_t)blockIdx.x * 8 + wave) * 8;
+    for (int i = 0; i < 5; ++i) d[i] = tacc[i];
+    d[5] = tacc[5]; d[6] = nkt; d[7] = tacc[6]; d[4] = tacc[7];
+  }
+#endif
+  if (!active) return;
+  const float l = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l;
+  if (o_img != nullptr) {
+    const int tq = qw + 16 * sub;
+    if (tq < Tp) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int i0 = 4 * gg, i1 = 8 + 4 * gg;
+        const float v[8] = {oacc[i0] * inv, oacc[i0 + 1] * inv, oacc[i0 + 2] * inv, oacc[i0 + 3] * inv,
+                            oacc[i1] * inv, oacc[i1 + 1] * inv, oacc[i1 + 2] * inv, oacc[i1 + 3] * inv};
+        u32x4 hi, lo;
+        split8h(v, hi, lo);
+        char* dst = o_img + ((((int64_t)b * (Tp >> 6) + (tq >> 6)) * H + head) * 4 + ((tq >> 4) & 3)) * (2 * FRAG) + (l15 + 16 * (h + 2 * gg)) * 16;
+        *reinterpret_cast<u32x4*>(dst) = hi;
+        *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+      }
+    }
+    return;
+  }
+  const int qi = qw + qc;
+  if (qi < T) {
+    float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * h;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      *reinterpret_cast<f32x4*>(op + 8 * m) = f32x4{oacc[4 * m] * inv, oacc[4 * m + 1] * inv, oacc[4 * m + 2] * inv, oacc[4 * m + 3] * inv};
+    if (lse && h == 0) lse[((int64_t)b * H + head) * T + qi] = m_run + log2f(l);
+  }
+}
+
+#ifndef PATHS_ATTN_M32
+#define PATHS_ATTN_M32 2
+#endif
+static int attn_num_cus() {                 // CUs of the current device (asked once per device)
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = cus;
+  }
+  return cached[dev];
+}
 template <int NP>
 int attention_split(const float* q, const float* k, const float* v, float* o, float* lse, const int64_t* num_ims, int B, int T,
                            int H, int max_queries, void* workspace, int images_ready, hipStream_t stream, uint64_t drop_key = 0, float drop_p = 0.f,
@@ -677,9 +1279,27 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
 #ifdef PATHS_ATTN_DEBUG
   hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, o_img, g_attn_dbg);
 #else
+  const char* m32_env = getenv("PATHS_ATTN_M32");       // (read per call: the tests switch kernels inside one process)
+  const int m32 = m32_env ? atoi(m32_env) : PATHS_ATTN_M32;     // 0: 16x16x32 kernel, 1: 32x32x16, 2: 32x32x16 wave pairs, 3: wave pairs on any grid
+  // The wave-pair kernel puts 256 queries on one CU: it wins where its grid covers most of the chip (K = 2048 x 8 slides: 256
+  // workgroups, 50.9 us against 55.3; 1024 x 8: 160, 28.4 against 29.9) and loses on small grids, which the 128-query kernel spreads
+  // over twice as many CUs (2048 x 4 slides: 43.6 against 36.3; 512 x 8: 17.3 against 13.2).
+  const int nqb2 = (nq + 255) / 256;
+  const int pair_min = attn_num_cus() * 5 / 8;
   if (drop_p > 0.f)
     hipLaunchKernelGGL((attn_x6_kernel<NP, true>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, o_img);
-  else
+  else if (NP == 2 && (m32 == 3 || (m32 == 2 && npairs * nqb2 >= pair_min))) {
+    // one workgroup of 12 waves per CU (168 VGPRs a wave): 84 KiB of LDS asked for, 64 KiB used
+    PATHS_LDS_OPT_IN(attn_m32p_kernel, 96 * 1024, "attention_x6(32x32x16, wave pairs)");
+#ifdef PATHS_M32P_STAMPS
+    hipLaunchKernelGGL(attn_m32p_kernel, dim3(8 * ((npairs + 7) / 8) * nqb2, 1, 1), dim3(768), 84 * 1024, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb2, o_img, g_m32p_dbg);
+#else
+    hipLaunchKernelGGL(attn_m32p_kernel, dim3(8 * ((npairs + 7) / 8) * nqb2, 1, 1), dim3(768), 84 * 1024, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb2, o_img);
+#endif
+  } else if (NP == 2 && QT == 2 && m32 == 1) {
+    PATHS_LDS_OPT_IN(attn_m32_kernel, 96 * 1024, "attention_x6(32x32x16)");
+    hipLaunchKernelGGL(attn_m32_kernel, dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, o_img);
+  } else
     hipLaunchKernelGGL((attn_x6_kernel<NP, false>), dim3(8 * ((npairs + 7) / 8) * nqb, 1, 1), dim3(256), lds, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb, site, o_img);
 #endif
   PATHS_LAUNCH_CHECK("attention_x6");
@@ -689,6 +1309,9 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
 
 }  // namespace
 
+#ifdef PATHS_M32P_STAMPS
+extern "C" void paths_attn_pair_debug_buffer(unsigned long long* p) { g_m32p_dbg = p; }
+#endif
 #ifdef PATHS_ATTN_DEBUG
 extern "C" void paths_attn_debug_buffer(unsigned long long* p) { g_attn_dbg = p; }     // development hook (tools/attn_wg_times.py)
 #endif

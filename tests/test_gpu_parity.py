@@ -731,6 +731,52 @@ def test_attention_x6_matches_fp64(dev, T, lens, planes):
         assert (lse6[b, :, :n].double() - lse_ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("kernel", ["1", "3"])
+@pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37]), (65, [64, 65]), (129, [128, 129, 1]),
+                                    (513, [257, 256, 511, 513]), (1100, [1100, 1025, 960, 33])])
+def test_attention_32x32_kernels_match_fp64(dev, T, lens, kernel, monkeypatch):
+    """The 32x32x16 forms of the h3 attention (csrc/attn_x6.hip: PATHS_ATTN_M32 = 1 one wave per 32 queries, = 3 the phase-locked wave
+    pair with loader waves, forced onto grids the dispatcher would give to the 16x16x32 kernel): same bar as the kernel they replace,
+    on ragged batches whose lengths put the end of a slide in every position of a 256-query workgroup and of a 64-key step (one to
+    33 key steps: prologue-only, ring wrap-around, waves without queries, DMA bundles without a K half)."""
+    from paths_amd import _lib
+    monkeypatch.setenv("PATHS_ATTN_M32", kernel)
+    B, H, hd, planes = len(lens), 4, 32, 2
+    g = torch.Generator(device=dev); g.manual_seed(T)
+    q = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1) * 1.5
+    k = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1) * 1.5
+    v = (torch.rand(B, H, T, hd, device=dev, generator=g) * 2 - 1)
+    num_ims = torch.tensor([n - 1 for n in lens], device=dev, dtype=torch.int64)
+    p, st = _lib.ptr, _lib.stream()
+    ws = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, planes)),), device=dev, dtype=torch.uint8)
+    o6 = torch.full((B, T, H * hd), float("nan"), device=dev)
+    lse6 = torch.empty((B, H, T), device=dev)
+    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o6), p(lse6), p(num_ims), B, T, H, hd, 0, p(ws), planes, 0, st)
+    monkeypatch.setenv("PATHS_ATTN_M32", "0")
+    o0 = torch.full((B, T, H * hd), float("nan"), device=dev)
+    _lib.call("paths_attention_x6", p(q), p(k), p(v), p(o0), None, p(num_ims), B, T, H, hd, 0, p(ws), planes, 1, st)
+    for b, n in enumerate(lens):
+        s = (q[b, :, :n].double() @ k[b, :, :n].double().transpose(1, 2)) * np.log(2.0)
+        ref = (torch.softmax(s, dim=-1) @ v[b, :, :n].double()).permute(1, 0, 2).reshape(n, H * hd)
+        assert torch.isfinite(o6[b, :n]).all()
+        assert (o6[b, :n].double() - ref).abs().max().item() < 2e-6, b
+        assert (o6[b, :n] - o0[b, :n]).abs().max().item() < 3e-6, b          # the 16x16x32 kernel on the same images (each within 2e-6 of float64)
+        lse_ref = torch.logsumexp(s, dim=-1) / np.log(2.0)
+        assert (lse6[b, :, :n].double() - lse_ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("name", ["g9_level1_b2_k2048", "g1_level0_b2_k256"])
+def test_wave_pair_attention_in_the_chain(dev, name, monkeypatch):
+    """The wave-pair kernel's fragment-image epilogue (what the chain kernel's out_proj reads) on golden levels whose grids are far
+    below its dispatch threshold: logits at the parity bar, and equal to the default kernels' to accumulation order."""
+    gold, info, out_def = run_single(dev, name)
+    monkeypatch.setenv("PATHS_ATTN_M32", "3")
+    _, _, out_pair = run_single(dev, name)
+    np.testing.assert_allclose(out_pair["logits"].numpy(), gold["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out_pair["logits"].numpy(), out_def["logits"].numpy(), atol=2e-5, rtol=0)
+    assert torch.equal(out_pair["importance"], out_def["importance"])
+
+
 def _spy_calls(dev, name, **flags):
     """Run one golden level and return (golden, outputs, names of the C entry points it went through)."""
     import paths_amd.ops as O
