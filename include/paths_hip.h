@@ -196,6 +196,14 @@ int paths_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, c
 int paths_layernorm_bwd_sums(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx, float* slabs,
                              int64_t rows, int d, int rows_per_block, paths_stream_t stream);
 int paths_reduce_slabs_f32(const float* slabs, int splits, int n, float* out, int accumulate, paths_stream_t stream);
+/* Deferred slab reductions (csrc/reduce_multi.hip): between paths_defer_reductions(1) and paths_flush_reductions() the final
+ * "out (+)= sum of slabs" pass of paths_gemm_tn_f32 / paths_gemm_tn_x6 / paths_colsum_f32 / paths_reduce_slabs_f32 is registered instead
+ * of launched; the flush runs all registered reductions in one launch per 32 entries, each in the summation order of the launch it
+ * replaces (bit-identical outputs).  The caller keeps the slab workspaces alive until the flush and flushes before anything reads an
+ * output; an entry whose output overlaps a pending output or pending slabs flushes first.  Per host thread.  paths_defer_reductions
+ * returns the previous setting and does not flush. */
+int paths_defer_reductions(int on);
+int paths_flush_reductions(int* n_entries, paths_stream_t stream);
 
 /* Self-attention backward, flash style (recompute from q, k, lse; reference: autograd through the attention of
  * model/aggregator.py:70-72).  q is the stored pre-scaled query; gradients land token-major in dqkv [B,T,384] =

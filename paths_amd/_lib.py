@@ -54,6 +54,8 @@ SIGNATURES = {
     "paths_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp],
     "paths_layernorm_bwd_sums": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "paths_reduce_slabs_f32": [_vp, _i32, _i32, _vp, _i32, _vp],
+    "paths_defer_reductions": [_i32],
+    "paths_flush_reductions": [_vp, _vp],
     "paths_linear_f32": [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_attention_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_attention_x6": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp],

@@ -197,12 +197,13 @@ class LevelFn(torch.autograd.Function):
         # under slide_ctx_mode "none"): the whole aggregator, proj_in and - its only consumer being the tokens - the
         # importance MLP are cut off; importance_mode != "mul": the importance only drives the (non-differentiable) top-K.
         no_agg = d_logits is None and d_ctx_out is None
-        if no_agg:
-            tg, d_ctx_prev = None, None
-            d_tok = torch.zeros_like(tr["tokens"])
-        else:
-            tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
-        sg, d_state_prev = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
+        with bw.deferred_reductions():               # the ~35 slab reductions of this level's parameter gradients: one launch
+            if no_agg:
+                tg, d_ctx_prev = None, None
+                d_tok = torch.zeros_like(tr["tokens"])
+            else:
+                tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+            sg, d_state_prev = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
         grads = _level_grads(mc, lstm, sg, tg, no_agg, d_logits is not None)
         return (None, None, None, None, None, d_state_prev if ctx.has_state else None,
                 d_ctx_prev if ctx.has_ctx else None, *grads)
@@ -242,12 +243,13 @@ class LevelParentFn(torch.autograd.Function):
         lp, vp = ops.pack_lstm(lstm), ops.pack_level(proc)
         cont = lambda t: t.contiguous() if t is not None else None
         no_agg = d_logits is None and d_ctx_out is None
-        if no_agg:
-            tg, d_ctx_prev = None, None
-            d_tok = torch.zeros_like(tr["tokens"])
-        else:
-            tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
-        sg, (d_c0, d_hk) = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
+        with bw.deferred_reductions():
+            if no_agg:
+                tg, d_ctx_prev = None, None
+                d_tok = torch.zeros_like(tr["tokens"])
+            else:
+                tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+            sg, (d_c0, d_hk) = bw.selection_backward(mc, lp, vp, sel, d_tok, cont(d_state_out))
         grads = _level_grads(mc, lstm, sg, tg, no_agg, d_logits is not None)
         return (None, None, None, None, None, d_c0, d_hk, None, None, None, None, d_ctx_prev if ctx.has_ctx else None, *grads)
 
@@ -346,12 +348,13 @@ class LevelFnNoLstm(torch.autograd.Function):
         vp = ops.pack_level(proc)
         cont = lambda t: t.contiguous() if t is not None else None
         no_agg = d_logits is None and d_ctx_out is None          # (see LevelFn.backward; here Z = alpha X + hctx still reaches the next level)
-        if no_agg:
-            tg, d_ctx_prev = None, None
-            d_tok = torch.zeros_like(tr["tokens"])
-        else:
-            tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
-        sg, d_state_prev = bw.selection_backward_nolstm(mc, vp, sel, d_tok, cont(d_state_out))
+        with bw.deferred_reductions():
+            if no_agg:
+                tg, d_ctx_prev = None, None
+                d_tok = torch.zeros_like(tr["tokens"])
+            else:
+                tg, d_tok, d_ctx_prev = bw.transformer_backward(mc, vp, tr, cont(d_logits), cont(d_ctx_out))
+            sg, d_state_prev = bw.selection_backward_nolstm(mc, vp, sel, d_tok, cont(d_state_out))
         v = lambda t, shape: t.view(shape) if t is not None else None
         grads = [sg["w1"], sg["b1"], v(sg["w2"], (1, -1)), sg["b2"], sg["wh1"], sg["bh1"], sg["wh2"], sg["bh2"]]
         if no_agg:

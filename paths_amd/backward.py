@@ -144,6 +144,60 @@ def side_join(dev):
             torch.cuda.current_stream(dev).wait_stream(side)
 
 
+# Deferred slab reductions (csrc/reduce_multi.hip): inside ``with deferred_reductions():`` the "out (+)= sum of slabs" pass that ends
+# every weight / bias / LayerNorm-affine gradient is registered instead of launched and all of them run in one launch per 32 at the
+# exit (~170 launches of 4-10 us per training step -> ~10).  Outputs are bit-identical.  Rules inside the block: nothing may read or
+# modify a gradient produced by gemm_tn / colsum / _ln_bwd_sums with a torch op (use after_reductions(fn) for a touch-up such as a
+# scale, or flush_reductions() first); the slab workspaces are kept alive here until the flush.
+DEFER_REDUCTIONS = os.environ.get("PATHS_DEFER_REDUCTIONS", "1") != "0"
+_DEFER = {"depth": 0, "keep": [], "post": []}
+
+
+def flush_reductions():
+    if _DEFER["depth"] > 0:
+        _lib.call("paths_flush_reductions", None, _lib.stream())
+        _DEFER["keep"].clear()
+        post, _DEFER["post"] = _DEFER["post"], []
+        for fn in post:
+            fn()
+
+
+def after_reductions(fn):
+    """Run ``fn()`` (a torch op on gradients still waiting for their reduction) once they have been reduced: now when nothing is deferred."""
+    if _DEFER["depth"] > 0:
+        _DEFER["post"].append(fn)
+    else:
+        fn()
+
+
+def _keep_slabs(ws):
+    if _DEFER["depth"] > 0:
+        _DEFER["keep"].append(ws)
+
+
+class deferred_reductions:
+    def __enter__(self):
+        self.on = DEFER_REDUCTIONS and not BWD_SIDE and _lib.TAPE is None
+        if self.on:
+            if _DEFER["depth"] == 0:
+                _lib.load().paths_defer_reductions(1)
+            _DEFER["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            try:
+                if _DEFER["depth"] == 1:
+                    flush_reductions()                  # (also on an exception: the registered entries point into workspaces freed below)
+            finally:
+                _DEFER["depth"] -= 1
+                if _DEFER["depth"] == 0:
+                    _lib.load().paths_defer_reductions(0)
+                    _DEFER["keep"].clear()
+                    _DEFER["post"].clear()
+        return False
+
+
 def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, accumulate=False):
     """out[N1,N2] (+)= a[M,N1]^T [b0 | b1][M,N2]."""
     dev = out.device
@@ -155,6 +209,7 @@ def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, 
         b1p = None if b1 is None else (b1 if isinstance(b1, int) else b1.data_ptr())
         _lib.call("paths_gemm_tn_x6", ap, lda, b0p, ldb0, nb0, b1p, ldb1, P(out), ldo if ldo is not None else N2, M, N1, N2,
                   splits, 1 if accumulate else 0, P(ws), 2 if ops.TRAIN_PLANES == 4 else 3, _lib.stream())
+        _keep_slabs(ws)
         return
     splits = _splits(M, ((N1 + 127) // 128) * ((N2 + 127) // 128))
     ws = torch.empty((splits * N1 * N2,), **_f32(dev))
@@ -163,6 +218,7 @@ def gemm_tn(a, lda, b0, ldb0, out, M, N1, N2, b1=None, ldb1=0, nb0=0, ldo=None, 
     b1p = None if b1 is None else (b1 if isinstance(b1, int) else b1.data_ptr())
     _lib.call("paths_gemm_tn_f32", ap, lda, b0p, ldb0, nb0, b1p, ldb1, P(out), ldo if ldo is not None else N2, M, N1, N2,
               splits, 1 if accumulate else 0, P(ws), _lib.stream())
+    _keep_slabs(ws)
 
 
 def colsum(a, lda, M, N, out=None, accumulate=False):
@@ -173,6 +229,7 @@ def colsum(a, lda, M, N, out=None, accumulate=False):
     ws = torch.empty((splits * N,), **_f32(dev))
     ap = a if isinstance(a, int) else a.data_ptr()
     _lib.call("paths_colsum_f32", ap, lda, M, N, P(out), splits, 1 if accumulate else 0, P(ws), _lib.stream())
+    _keep_slabs(ws)
     return out
 
 
@@ -300,7 +357,8 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
         # proj_in.bias: sum of token gradients over the valid patch rows = colsum of dP / alpha is not usable (alpha may
         # be 0), so sum d_tokens rows 1..N directly; padded token rows carry exact zeros (masked keys, unused queries)
         # = (sum over all B*T token rows) - (sum over the B special-token rows): two launches instead of 2 B
-        grads["bp"] = colsum(d_tokens, d, B * T, d) - grads["special"]
+        grads["bp"] = bp_all = colsum(d_tokens, d, B * T, d)
+        after_reductions(lambda a=bp_all, b=grads["special"]: a.sub_(b))
         grads["w_ip"] = torch.empty((Hi + d, D), **f32)
         gemm_tn(du, U, sv["y"], D, grads["w_ip"], M, Hi + d, D)
     dy = torch.empty((M, D), **f32)
@@ -544,6 +602,7 @@ def _ln_bwd_sums(dy, xh, rs, g, rows, d=128):
               _lib.stream())
     gb = torch.empty((3 * d,), **f32)
     _lib.call("paths_reduce_slabs_f32", P(slabs), nblk, 3 * d, P(gb), 0, _lib.stream())
+    _keep_slabs(slabs)
     return dx, gb[:d], gb[d:2 * d], gb[2 * d:]
 
 
@@ -652,8 +711,7 @@ def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: floa
         gemm_tn(dqkv, 3 * d, x_in, d, g["wqkv"], M, 3 * d, d)
         g["bqkv"] = colsum(dqkv, 3 * d, M, 3 * d)
         if fold_qscale:
-            g["wqkv"][:d] *= qscale
-            g["bqkv"][:d] *= qscale
+            after_reductions(lambda w_=g["wqkv"], b_=g["bqkv"]: (w_[:d].mul_(qscale), b_[:d].mul_(qscale)))
     return g
 
 

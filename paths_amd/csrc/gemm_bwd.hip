@@ -14,6 +14,7 @@
 // split across gridDim.z; every split writes its own fp32 slab and a second kernel adds the slabs in a fixed order
 // (deterministic: needed for N-rank == 1-rank gradient parity, no float atomics).
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -282,6 +283,7 @@ int paths_gemm_tn_f32(const float* a, int64_t lda, const float* b0, int64_t ldb0
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((N2 + 127) / 128, (N1 + 127) / 128, splits), dim3(256), 0, stream, g);
   PATHS_LAUNCH_CHECK("gemm_tn");
   const int64_t n = (int64_t)N1 * N2;
+  if (const int rd = paths_reduce_try_defer(workspace, splits, n, out, ldo, N2, accumulate, 0, stream)) return rd == PATHS_DEFERRED ? PATHS_OK : rd;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, splits, n, out, ldo, N2, accumulate);
   PATHS_LAUNCH_CHECK("gemm_tn(reduce)");
   return PATHS_OK;
@@ -298,6 +300,7 @@ int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int 
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, stream, a, lda, M, N, rps, workspace);
   }
   PATHS_LAUNCH_CHECK("colsum");
+  if (const int rd = paths_reduce_try_defer(workspace, splits, N, out, N, N, accumulate, 1, stream)) return rd == PATHS_DEFERRED ? PATHS_OK : rd;
   hipLaunchKernelGGL(reduce_slabs_small_kernel, dim3((N + 63) / 64), dim3(256), 0, stream, workspace, splits, N, out, accumulate);
   PATHS_LAUNCH_CHECK("colsum(reduce)");
   return PATHS_OK;
@@ -307,6 +310,7 @@ int paths_colsum_f32(const float* a, int64_t lda, int M, int N, float* out, int 
 // their own slabs: paths_layernorm_bwd_sums)
 int paths_reduce_slabs_f32(const float* slabs, int splits, int n, float* out, int accumulate, hipStream_t stream) {
   PATHS_REQUIRE(slabs && out && splits > 0 && n > 0, "reduce_slabs: bad arguments");
+  if (const int rd = paths_reduce_try_defer(slabs, splits, n, out, n, n, accumulate, 1, stream)) return rd == PATHS_DEFERRED ? PATHS_OK : rd;
   hipLaunchKernelGGL(reduce_slabs_small_kernel, dim3((n + 63) / 64), dim3(256), 0, stream, slabs, splits, n, out, accumulate);
   PATHS_LAUNCH_CHECK("reduce_slabs");
   return PATHS_OK;

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "reduce.h"
 
 namespace {
 
@@ -348,6 +349,7 @@ int paths_gemm_tn_x6(const float* a, int64_t lda, const float* b0, int64_t ldb0,
   PATHS_LAUNCH_CHECK("gemm_tn_x6");
   if (!direct) {
     const int64_t n = (int64_t)N1 * N2;
+    if (const int rd = paths_reduce_try_defer(workspace, nsplit, n, out, ldo, N2, accumulate, 0, stream)) return rd == PATHS_DEFERRED ? PATHS_OK : rd;
     hipLaunchKernelGGL(reduce_slabs_x6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, workspace, nsplit, n, out, ldo, N2, accumulate);
     PATHS_LAUNCH_CHECK("gemm_tn_x6(reduce)");
   }
