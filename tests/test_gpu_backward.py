@@ -290,6 +290,33 @@ def test_recursion_gradients_vs_oracle_autograd(dev):
     assert live > 100
 
 
+@pytest.mark.parametrize("over", [{}, {"model_config": {"trans_dim": 192}}, {"model_config": {"lstm": False}}], ids=["default", "td192", "nolstm"])
+def test_deferred_slab_reductions_are_bitwise_the_single_launches(dev, monkeypatch, over):
+    """csrc/reduce_multi.hip: with the slab reductions of a level's parameter gradients deferred into one launch (the default) every
+    gradient equals, bit for bit, the one from a launch per reduction (PATHS_DEFER_REDUCTIONS=0) - same per-element summation order -
+    incl. the touch-ups that wait for the flush (proj_in.bias = all rows - special rows, the folded q scale), dropout on."""
+    from paths_amd import utils as putils, backward as bw
+
+    def grads(defer):
+        monkeypatch.setattr(bw, "DEFER_REDUCTIONS", defer)
+        cfg, model, params, slides, batch = _train_setup(dev, top_k=16, base=(6, 7), n_slides=3, cfg_over=dict(over))
+        for proc in model.procs:
+            proc.config.dropout = 0.05
+        model.train()
+        torch.manual_seed(5)                         # (restarts the dropout seed sequence: autograd.next_dropout_seed)
+        out = putils.recurse_train(model, batch["slide"], cfg.top_k_patches, 5)
+        _, loss = putils.loss_from_logits(out["logits"], batch, "survival")
+        loss.backward()
+        torch.cuda.synchronize()
+        assert bw._DEFER["depth"] == 0 and not bw._DEFER["keep"] and not bw._DEFER["post"]
+        return {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}, float(loss)
+
+    (g1, l1), (g0, l0) = grads(True), grads(False)
+    assert l1 == l0 and g1.keys() == g0.keys() and len(g1) > 50
+    for k in g1:
+        assert torch.equal(g1[k], g0[k]), k
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_random_small_training_steps_vs_oracle_autograd(dev, case):
     """A seeded sweep over shapes for the differentiable path (grid shape, background rate incl. fallback slides, batch size, level
