@@ -909,7 +909,10 @@ __device__ __forceinline__ void pair_barrier() {
 #ifndef PATHS_M32P_PIPE
 #define PATHS_M32P_PIPE 0                 // explicit two-chunks-ahead fragment reads in M: over the 168-VGPR cap of three waves per SIMD (spills, 65 us)
 #endif
-__global__ void __launch_bounds__(768)
+#ifndef PATHS_M32P_LOADERS
+#define PATHS_M32P_LOADERS 1              // 1: four loader waves (768 threads); 0: waves 0-3 issue the DMAs at the head of their M segment (512 threads)
+#endif
+__global__ void __launch_bounds__(PATHS_M32P_LOADERS ? 768 : 512)
 attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const char* __restrict__ v6, float* __restrict__ o,
                  float* __restrict__ lse, const int64_t* __restrict__ num_ims, int T, int Tp, int H, int npairs_arg, int nqb_arg,
                  char* __restrict__ o_img
@@ -994,6 +997,18 @@ attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const
 #endif
   };
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  auto fly_wait = [&](int kt) {                         // bundle kt + 1 has landed; kt + 2 and kt + 3 may fly
+    auto count = [&](int j) { return j >= nkt ? 0 : j + 1 < nkt ? 4 : 2; };
+    const int fly = count(kt + 2) + count(kt + 3);
+    if (fly == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (fly == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (fly == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (fly == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+#if !PATHS_M32P_LOADERS
+  if (grp == 0) { dma_bundle(1); dma_bundle(2); }
+#endif
   if (grp == 2) {
     // The loader waves (one per SIMD, at priority 3: they issue ~30 instructions per key step).  Issued by waves 4-7 themselves the
     // four DMAs of a step took 650-1000 cycles to ISSUE behind the partner's dense vector stream, in front of the wave's MFMAs.
@@ -1190,7 +1205,13 @@ attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const
     M32P_T(1);
     pair_barrier();
     M32P_T(2);
+#if !PATHS_M32P_LOADERS
+    if (grp == 0) dma_bundle(kt + 3);                   // (slot 2kt+1, like the loader waves)
+#endif
     if (kt + 1 < nkt) mseg(kt, std::true_type{}); else mseg(kt, std::false_type{});
+#if !PATHS_M32P_LOADERS
+    if (grp == 0) fly_wait(kt);
+#endif
     M32P_T(3);
     pair_barrier();
     M32P_T(4);
@@ -1292,9 +1313,9 @@ int attention_split(const float* q, const float* k, const float* v, float* o, fl
     // one workgroup of 12 waves per CU (168 VGPRs a wave): 84 KiB of LDS asked for, 64 KiB used
     PATHS_LDS_OPT_IN(attn_m32p_kernel, 96 * 1024, "attention_x6(32x32x16, wave pairs)");
 #ifdef PATHS_M32P_STAMPS
-    hipLaunchKernelGGL(attn_m32p_kernel, dim3(8 * ((npairs + 7) / 8) * nqb2, 1, 1), dim3(768), 84 * 1024, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb2, o_img, g_m32p_dbg);
+    hipLaunchKernelGGL(attn_m32p_kernel, dim3(8 * ((npairs + 7) / 8) * nqb2, 1, 1), dim3(PATHS_M32P_LOADERS ? 768 : 512), 84 * 1024, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb2, o_img, g_m32p_dbg);
 #else
-    hipLaunchKernelGGL(attn_m32p_kernel, dim3(8 * ((npairs + 7) / 8) * nqb2, 1, 1), dim3(768), 84 * 1024, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb2, o_img);
+    hipLaunchKernelGGL(attn_m32p_kernel, dim3(8 * ((npairs + 7) / 8) * nqb2, 1, 1), dim3(PATHS_M32P_LOADERS ? 768 : 512), 84 * 1024, stream, q6, k6, v6, o, lse, num_ims, T, Tp, H, npairs, nqb2, o_img);
 #endif
   } else if (NP == 2 && QT == 2 && m32 == 1) {
     PATHS_LDS_OPT_IN(attn_m32_kernel, 96 * 1024, "attention_x6(32x32x16)");
