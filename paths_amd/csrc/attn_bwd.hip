@@ -64,7 +64,7 @@ attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
   __shared__ float sLse[16], sD[16];
   const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 64;
   const int len = (int)num_ims[b] + 1;
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   if (k0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane & 15, g4 = lane >> 4;
   const int64_t base = ((int64_t)b * H + head) * T * HD;
@@ -136,7 +136,7 @@ attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k, con
       const int ql = 4 * g4 + r;
       const bool ok = key_ok && (q0 + ql < len);
       const float pr = ok ? __builtin_amdgcn_exp2f(s[r] - sLse[ql]) : 0.f;
-      const float m = drop.thr ? drop_mult_w(drop, dwin, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)min(q0 + ql, T - 1)) * (uint64_t)T + (uint64_t)keyc) : 1.0f;
+      const float m = drop.thr ? drop_mult_w(drop, dwin, drop_attn_row((uint64_t)b * H + head, T, min(q0 + ql, T - 1)) + (uint64_t)keyc) : 1.0f;
       ds[r] = LN2 * pr * (dp[r] * m - sD[ql]);
       p[r] = pr * m;
     }
@@ -170,7 +170,7 @@ attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, cons
   __shared__ __attribute__((aligned(16))) float sK40[64 * LD40], sK36[64 * LD36], sV40[64 * LD40];
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
   const int len = (int)num_ims[b] + 1;
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
   const int64_t base = ((int64_t)b * H + head) * T * HD;
@@ -230,7 +230,7 @@ attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k, cons
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 64 + 16 * t + 4 * g4 + r;
         const float p = key < len ? __builtin_amdgcn_exp2f(s[r] - my_lse) : 0.f;
-        const float m = drop.thr ? drop_mult_w(drop, dwin, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)qc) * (uint64_t)T + (uint64_t)min(key, T - 1)) : 1.0f;
+        const float m = drop.thr ? drop_mult_w(drop, dwin, drop_attn_row((uint64_t)b * H + head, T, qc) + (uint64_t)min(key, T - 1)) : 1.0f;
         ds[r] = LN2 * p * (dp[r] * m - my_d);
       }
       const float* kp = &sK36[(16 * t + 4 * g4) * LD36 + ql];     // dQ_s^T[d][q] += K^T[d][key] ds^T[key][q]

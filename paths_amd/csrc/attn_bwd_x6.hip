@@ -158,7 +158,7 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
   if (qb >= nqb) return;
   const int b = pair / H, head = pair - b * H, q0 = qb * 64 * QT;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 15, g4 = lane >> 4;
@@ -234,13 +234,19 @@ attn_bwd_q_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, c
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         float dsv[8];
-        const uint64_t drow = (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)min(qw + 16 * qt + ql, T - 1)) * (uint64_t)T;
+        const uint64_t drow = drop_attn_row((uint64_t)b * H + head, T, min(qw + 16 * qt + ql, T - 1));
+        float mk[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {                // keys 4 g4 + (j & 3), + 1 of a query: one hash per pair (dropout.h)
+          const int key = kt_ * KSTEP + 32 * kg + 16 * (j >> 2) + 4 * g4 + (j & 3);
+          mk[j] = mk[j + 1] = 1.0f;
+          if (drop.thr) drop_mult2_w(drop, dwin, drow + (uint64_t)min(key, (int)drop_attn_stride(T) - 2), mk[j], mk[j + 1]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) = key 4 g4 + (j & 3) + 16 (j >> 2) of the group
           const int key = kt_ * KSTEP + 32 * kg + 16 * (j >> 2) + 4 * g4 + (j & 3);
           const float p = key < len ? __builtin_amdgcn_exp2f(s[qt][j >> 2][j & 3] - my_lse[qt]) : 0.f;
-          const float m = drop.thr ? drop_mult_w(drop, dwin, drow + (uint64_t)min(key, T - 1)) : 1.0f;
-          dsv[j] = LN2 * p * (dp[qt][j >> 2][j & 3] * m - my_d[qt]);
+          dsv[j] = LN2 * p * (dp[qt][j >> 2][j & 3] * mk[j] - my_d[qt]);
         }
         split8<PL>(dsv, dsf[qt]);
       }
@@ -292,7 +298,7 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
   if (kb >= nkb) return;
   const int b = pair / H, head = pair - b * H, k0 = kb * 128;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   if (k0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kl = lane & 15, g4 = lane >> 4;
@@ -376,15 +382,35 @@ attn_bwd_kv_x6_kernel(const char* __restrict__ qr, const char* __restrict__ kr, 
       for (int t = 0; t < 2; ++t) {
         const int key = kw + 16 * t + kl;
         const bool key_ok = key < len;
-        float pv[8], dsv[8];
+        float pv[8], dsv[8], mk[8];
+        if (drop.thr) {
+          // A lane owns ONE key and eight queries, its neighbour (lane ^ 1) the other key of the pair and the same queries: each
+          // of the two hashes four of the eight (query, key pair) elements and they swap through DPP (one hash per pair: dropout.h)
+          const int odd = kl & 1;                       // = key & 1 (kw + 16 t is even)
+          const uint64_t kev = (uint64_t)(min(key, T - 1) & ~1);
+          uint32_t hm[4], ho[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int qi = qs * KSTEP + 32 * qg + 16 * odd + 4 * g4 + jj;
+            hm[jj] = drop_hash_w(drop, dwin, drop_attn_row((uint64_t)b * H + head, T, min(qi, T - 1)) + kev);
+            ho[jj] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hm[jj], 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t hsh = ((j >> 2) == odd) ? hm[j & 3] : ho[j & 3];
+            mk[j] = (odd ? hsh >> 16 : hsh & 0xFFFFu) >= drop.thr ? drop.scale : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mk[j] = 1.0f;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                   // k-slot (g4, j) = query 4 g4 + (j & 3) + 16 (j >> 2) of the group
           const int qloc = 32 * qg + 16 * (j >> 2) + 4 * g4 + (j & 3), qi = qs * KSTEP + qloc;
           const bool ok = key_ok && qi < len;
           const float pr = ok ? __builtin_amdgcn_exp2f(s[j >> 2][t][j & 3] - sL[qloc]) : 0.f;
-          const float m = drop.thr ? drop_mult_w(drop, dwin, (((uint64_t)b * H + head) * (uint64_t)T + (uint64_t)min(qi, T - 1)) * (uint64_t)T + (uint64_t)min(key, T - 1)) : 1.0f;
-          dsv[j] = LN2 * pr * (dp[j >> 2][t][j & 3] * m - sD[qloc]);
-          pv[j] = pr * m;
+          dsv[j] = LN2 * pr * (dp[j >> 2][t][j & 3] * mk[j] - sD[qloc]);
+          pv[j] = pr * mk[j];
         }
         split8<PL>(pv, pf[t]);
         split8<PL>(dsv, dsf[t]);

@@ -45,7 +45,7 @@ token0_fwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
   __shared__ float sred[4];
   const int part = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   int k0, k1;
   split_range(len, S, part, k0, k1);
   const int64_t base = ((int64_t)b * H + head) * T * HD;
@@ -81,7 +81,7 @@ token0_fwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
   m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
   __syncthreads();
   float l = 0.f;
-  const uint64_t row = (((uint64_t)b * H + head) * T) * T;          // query 0
+  const uint64_t row = drop_attn_row((uint64_t)b * H + head, T, 0);          // query 0
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int key = k0 + tid + 256 * j;
@@ -138,7 +138,7 @@ token0_bwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
   __shared__ float red[4][HD];
   const int part = blockIdx.x, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   int k0, k1;
   split_range(len, S, part, k0, k1);
   const int64_t base = ((int64_t)b * H + head) * T * HD;
@@ -152,7 +152,7 @@ token0_bwd_partial_kernel(const float* __restrict__ q, const float* __restrict__
     dsum += (gv[i][0] * av[0] + gv[i][1] * av[1]) + (gv[i][2] * av[2] + gv[i][3] * av[3]);
   }
   const float L = lse0[(int64_t)b * H + head];
-  const uint64_t row = (((uint64_t)b * H + head) * T) * T;
+  const uint64_t row = drop_attn_row((uint64_t)b * H + head, T, 0);
   f32x4 dq[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};

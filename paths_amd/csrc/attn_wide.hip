@@ -67,7 +67,7 @@ wide_softmax_kernel(float* __restrict__ S, int Tp, int nq, const int64_t* __rest
     L = m + __builtin_amdgcn_logf(l);                  // v_log_f32 = log2
     if (lse_out != nullptr && lane == 0) lse_out[r] = L;
   }
-  const uint64_t mrow = (site_base + (uint64_t)r) * (uint64_t)T;
+  const uint64_t mrow = (site_base + (uint64_t)r) * drop_attn_stride(T);
   float* drow = dropped != nullptr ? dropped + (int64_t)r * Tp : nullptr;
   for (int c = lane; c < Tp; c += 64) {
     const float p = c < len ? __builtin_amdgcn_exp2f(row[c] * qscale - L) : 0.f;
@@ -95,7 +95,7 @@ wide_ds_kernel(float* __restrict__ P, float* __restrict__ dP, int Tp, int nq, co
   float D = 0.f;
   for (int c = lane; c < hd; c += 64) D = fmaf(d_o[(int64_t)r * ldo + c], o[(int64_t)r * ldo + c], D);
   D = wave_sum(D);
-  const uint64_t mrow = (site_base + (uint64_t)r) * (uint64_t)T;
+  const uint64_t mrow = (site_base + (uint64_t)r) * drop_attn_stride(T);
   float* prow = P + (int64_t)r * Tp;
   float* drow = dP + (int64_t)r * Tp;
   for (int c = lane; c < Tp; c += 64) {

@@ -264,7 +264,7 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
   if (qb >= nqb) return;
   const int b = pair / H, head = pair - b * H, q0 = qb * 64 * QT;
   const int len = min((int)num_ims[b] + 1, T);          // valid keys = special token + patches
-  const DropWin dwin = drop_window(drop, (uint64_t)pair * (uint64_t)T * (uint64_t)T);      // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)pair, T, 0));      // (this pair's T x T' mask elements: csrc/dropout.h)
   if (q0 >= len) return;                                // every query of this block is padding
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 15, g4 = lane >> 4;
@@ -411,9 +411,13 @@ attn_x6_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const c
           if constexpr (!P1) psum += pv[j] + pv[j + 1];
         }
         if constexpr (DROP) {
-          const uint64_t row = ((uint64_t)pair * (uint64_t)T + (uint64_t)min(qw + 16 * qt + ql, T - 1)) * (uint64_t)T;
+          const uint64_t row = drop_attn_row((uint64_t)pair, T, min(qw + 16 * qt + ql, T - 1));
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pv[j] *= drop_mult_w(drop, dwin, row + (uint64_t)(kt * KSTEP + 16 * (2 * kg + (j >> 2)) + 4 * g4 + (j & 3)));
+          for (int j = 0; j < 8; j += 2) {              // keys 4 g4 + (j & 3), + 1: one hash per pair
+            float m0, m1;
+            drop_mult2_w(drop, dwin, row + (uint64_t)(kt * KSTEP + 16 * (2 * kg + (j >> 2)) + 4 * g4 + (j & 3)), m0, m1);
+            pv[j] *= m0; pv[j + 1] *= m1;
+          }
         }
         if constexpr (P1) {
 #pragma unroll

@@ -17,8 +17,11 @@ dropout_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __res
     const f32x4 v = vec ? *reinterpret_cast<const f32x4*>(vec + c) : *reinterpret_cast<const f32x4*>(x + r * ldx + c);
     f32x4 o = resid ? *reinterpret_cast<const f32x4*>(resid + r * ldr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     const uint64_t idx = (uint64_t)r * (uint64_t)N + (uint64_t)c;
+    float m[4];                                           // (N % 4 == 0: idx is even, two hashes for the four elements)
+    drop_mult2(site, idx, m[0], m[1]);
+    drop_mult2(site, idx + 2, m[2], m[3]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] += v[e] * drop_mult(site, idx + e);
+    for (int e = 0; e < 4; ++e) o[e] += v[e] * m[e];
     *reinterpret_cast<f32x4*>(out + r * ldo + c) = o;
   }
 }
@@ -27,7 +30,7 @@ dropout_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __res
 __global__ void __launch_bounds__(256)
 dropout_mask_kernel(float* __restrict__ mask, int64_t n, DropSite site) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    mask[i] = drop_hash((uint64_t)i, site.key_lo, site.key_hi) >= site.thr ? 1.f : 0.f;
+    mask[i] = drop_mult(site, (uint64_t)i) != 0.f ? 1.f : 0.f;
 }
 
 }  // namespace
@@ -35,9 +38,9 @@ dropout_mask_kernel(float* __restrict__ mask, int64_t n, DropSite site) {
 DropSite paths_make_drop_site(uint64_t key, float p) {
   DropSite s;
   s.key_lo = (uint32_t)key; s.key_hi = (uint32_t)(key >> 32);
-  const double t = (double)p * 4294967296.0;
-  s.thr = p <= 0.f ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)(t + 0.5));
-  s.scale = p <= 0.f ? 1.0f : 1.0f / (1.0f - p);
+  const double t = (double)p * 65536.0;                     // 16-bit threshold: one 32-bit hash serves two elements (dropout.h)
+  s.thr = p <= 0.f ? 0u : (t >= 65535.0 ? 65535u : (t < 1.0 ? 1u : (uint32_t)(t + 0.5)));
+  s.scale = s.thr == 0u ? 1.0f : (float)(1.0 / (1.0 - (double)s.thr / 65536.0));
   return s;
 }
 

@@ -32,7 +32,7 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
   __shared__ __attribute__((aligned(16))) float sV[2][KT * LDVs];
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 15, g4 = lane >> 4;
   const float* qb = qkv + (int64_t)b * T * ld + head * HD;
@@ -119,11 +119,15 @@ attn_any_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qscale, 
     m_run = m_new;
     if constexpr (TRAIN) {
       if (drop.thr != 0u) {
-        const uint64_t rowi = (((uint64_t)b * H + head) * T + (uint64_t)min(q0 + wave * 16 + ql, T - 1)) * T + (uint64_t)(kt * KT + 4 * g4);
+        const uint64_t rowi = drop_attn_row((uint64_t)b * H + head, T, min(q0 + wave * 16 + ql, T - 1)) + (uint64_t)(kt * KT + 4 * g4);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[t][r] *= drop_mult_w(drop, dwin, rowi + (uint64_t)(16 * t + r));
+          for (int r = 0; r < 4; r += 2) {              // keys 4 g4 + r, + 1: one hash per pair (dropout.h)
+            float m0, m1;
+            drop_mult2_w(drop, dwin, rowi + (uint64_t)(16 * t + r), m0, m1);
+            s[t][r] *= m0; s[t][r + 1] *= m1;
+          }
       }
     }
 #pragma unroll

@@ -241,7 +241,7 @@ attn_bwd_any_kv_kernel(const float* __restrict__ qkv, int64_t ld, int d, float q
   __shared__ float red[64 * (HD + 1)];
   const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 64;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   if (k0 >= len) return;
   const int nq = max_q > 0 ? min(len, max_q) : len;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,7 +284,7 @@ attn_bwd_any_kv_kernel(const float* __restrict__ qkv, int64_t ld, int d, float q
 #pragma unroll
       for (int c = 0; c < HD; ++c) { s = fmaf(qrow[c], kr[c], s); dp = fmaf(grow[c], vr[c], dp); }
       const float p = key_ok ? __builtin_amdgcn_exp2f(s - sL[r]) : 0.f;
-      const float m = drop.thr != 0u ? drop_mult_w(drop, dwin, (site_row + (uint64_t)(q0 + r)) * T + (uint64_t)key) : 1.f;
+      const float m = drop.thr != 0u ? drop_mult_w(drop, dwin, (site_row + (uint64_t)(q0 + r)) * drop_attn_stride(T) + (uint64_t)key) : 1.f;
       const float pd = p * m;
       const float ds = LN2 * p * (dp * m - sD[r]);
 #pragma unroll
@@ -326,7 +326,7 @@ attn_bwd_any_q_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qs
   __shared__ float red[64 * (HD + 1)];
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 64;
   const int len = min((int)num_ims[b] + 1, T);
-  const DropWin dwin = drop_window(drop, ((uint64_t)b * H + head) * (uint64_t)T * (uint64_t)T);       // (this pair's T^2 mask elements: csrc/dropout.h)
+  const DropWin dwin = drop_window(drop, drop_attn_row((uint64_t)b * H + head, T, 0));       // (this pair's T x T' mask elements: csrc/dropout.h)
   const int nq = max_q > 0 ? min(len, max_q) : len;
   if (q0 >= nq) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -346,7 +346,7 @@ attn_bwd_any_q_kernel(const float* __restrict__ qkv, int64_t ld, int d, float qs
     }
   }
   const float L = lse[((int64_t)b * H + head) * T + qi], Dv = dsum[((int64_t)b * H + head) * T + qi];
-  const uint64_t site_row = (((uint64_t)b * H + head) * T + (uint64_t)qi) * T;
+  const uint64_t site_row = drop_attn_row((uint64_t)b * H + head, T, qi);
   for (int k0 = 0; k0 < len; k0 += BT) {
     __syncthreads();
     for (int i = tid; i < BT * HD / 4; i += 256) {
