@@ -505,10 +505,12 @@ int paths_importance_rows_bwd(const float* dz_rows, const float* x, int D, const
 
 /* ---- dropout (training; reference nn.Transformer(..., dropout=p), model/aggregator.py:25-33: attention probabilities,
  * dropout1, dropout2, the feed-forward's inner dropout, dropout3).  Masks are never stored: element idx of site `key` is kept iff
- * hash(idx, key) >= p * 2^32 (csrc/dropout.h) and is regenerated by every kernel that needs it; kept values are scaled by
- * 1 / (1 - p).  The host derives one 64-bit key per (step seed, level, layer, site). */
+ * the 16-bit half (low for even idx, high for odd) of hash(idx & ~1, key) is >= round(p * 65536) (csrc/dropout.h: one 32-bit hash
+ * per pair of elements) and is regenerated by every kernel that needs it; kept values are scaled by 1 / (1 - p16), p16 =
+ * round(p * 65536) / 65536 the rate actually applied.  Attention probabilities of (slide, head) pair s: element (query q, key k)
+ * has idx = (s * T + q) * T' + k with T' = T rounded up to even.  The host derives one 64-bit key per (step seed, level, layer, site). */
 
-/* out[r, c] = (resid ? resid[r, c] : 0) + (vec ? vec[c] : x[r, c]) * mask(r * N + c) / (1 - p); exactly one of x / vec is given;
+/* out[r, c] = (resid ? resid[r, c] : 0) + (vec ? vec[c] : x[r, c]) * mask(r * N + c) / (1 - p16); exactly one of x / vec is given;
  * x, resid, out may alias.  Covers dropout1 / dropout3 (+ residual), the inner feed-forward dropout (in place), dropout2 on the
  * broadcast cross-attention bias (vec) and the masking of gradients in the backward pass. */
 int paths_dropout_rows(const float* x, int64_t ldx, const float* vec, const float* resid, int64_t ldr, float* out, int64_t ldo,
