@@ -273,8 +273,8 @@ def train_dtype(planes: int) -> str:
     fwd = "forward: f32 operands as 2 fp16 planes (22 bits), 3 MFMAs per product block, fp32 accumulate"
     if planes == 4:
         return ("mixed: " + fwd + "; gradient GEMMs (dX, dW): operands as 2 bf16 planes = 16 significant bits at fp32 range, 3 MFMAs per "
-                "block, fp32 accumulate (PATHS_TRAIN_PLANES=4, the default); attention backward: 3 exact bf16 planes; master weights, "
-                "gradients and AdamW state fp32")
+                "block, fp32 accumulate (PATHS_TRAIN_PLANES=4, the default); attention backward (the five products of dQ / dK / dV): "
+                "the same two bf16 planes (paths_attention_bwd_x6_planes); master weights, gradients and AdamW state fp32")
     return ("f32: " + fwd + "; gradient GEMMs and attention backward: operands as 3 exact bf16 planes (hi + mid + lo = the fp32 value), 6 "
             "MFMAs per block, fp32 accumulate (PATHS_TRAIN_PLANES=3); master weights, gradients and AdamW state fp32")
 
