@@ -349,6 +349,9 @@ int paths_attention_any(const float* qkv, int64_t ld, float* o, const int64_t* n
 int64_t paths_attention_h3_any_workspace(int B, int T, int H, int head_dim);
 int paths_attention_h3_any(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
                            void* workspace, paths_stream_t stream);
+/* ... on operand images already in the workspace (written by paths_token_layer_ws with d = 192, do_qkv only: head_dim 48, q scaled
+ * there; or head_dim 32): no prep launch. */
+int paths_attention_h3_any_img(float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, void* workspace, paths_stream_t stream);
 int paths_layernorm_rows(const float* x, int64_t ldx, const float* add, const float* gamma, const float* beta, float* y, int64_t ldy,
                          int64_t rows, int d, float eps, paths_stream_t stream);
 int paths_layernorm2_rows(const float* x, int64_t ldx, const float* g1, const float* b1, const float* add, const float* g2, const float* b2,

@@ -266,7 +266,7 @@ attn_h3_any_kernel(const char* __restrict__ qi, const char* __restrict__ ki, con
 
 template <int HD>
 int launch_h3_any(const float* qkv, int64_t ld, float qscale, float* o, const int64_t* num_ims, int B, int T, int H, void* workspace,
-                  hipStream_t stream) {
+                  hipStream_t stream, bool images_ready = false) {
   constexpr int NK = (HD + 31) / 32, NDV = HD / 16;
   constexpr int KB = 4 * NK * 2 * FB, VB = 2 * NDV * 2 * FB;
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
@@ -275,9 +275,11 @@ int launch_h3_any(const float* qkv, int64_t ld, float qscale, float* o, const in
   char* qi = reinterpret_cast<char*>(workspace);
   char* ki = qi + qk_img;
   char* vi = ki + qk_img;
-  hipLaunchKernelGGL(attn_h3_prep_kernel<HD>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, qkv, qkv + d, qkv + 2 * d, ld, (int64_t)HD,
-                     (int64_t)T * ld, qscale, qi, ki, vi, num_ims, T, Tp, H);
-  PATHS_LAUNCH_CHECK("attention_h3_any(prep)");
+  if (!images_ready) {
+    hipLaunchKernelGGL(attn_h3_prep_kernel<HD>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, qkv, qkv + d, qkv + 2 * d, ld, (int64_t)HD,
+                       (int64_t)T * ld, qscale, qi, ki, vi, num_ims, T, Tp, H);
+    PATHS_LAUNCH_CHECK("attention_h3_any(prep)");
+  }
   PATHS_LDS_OPT_IN(attn_h3_any_kernel<HD>, 2 * (KB + VB), "attention_h3_any");
   const int nqb = (T + 64 * QT - 1) / (64 * QT), npairs = H * B;
   hipLaunchKernelGGL(attn_h3_any_kernel<HD>, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 2 * (KB + VB), stream, qi, ki, vi, o, num_ims, T, Tp, H,
@@ -309,6 +311,18 @@ int paths_attention_h3_any(const float* qkv, int64_t ld, float* o, const int64_t
     case 48: return launch_h3_any<48>(qkv, ld, qscale, o, num_ims, B, T, H, workspace, stream);
     case 64: return launch_h3_any<64>(qkv, ld, qscale, o, num_ims, B, T, H, workspace, stream);
     default: return paths_set_error(PATHS_EUNSUPPORTED, "attention_h3_any: head_dim %d (supported: 16, 32, 48, 64)", head_dim);
+  }
+}
+
+// The same attention on operand images that are already in the workspace (paths_token_layer_ws wrote them: trans_dim 192 / 4 heads =
+// head_dim 48; q scaled there): no prep launch.
+int paths_attention_h3_any_img(float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, void* workspace, hipStream_t stream) {
+  PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && o && num_ims && workspace, "attention_h3_any_img: bad arguments B=%d T=%d H=%d", B, T, H);
+  PATHS_REQUIRE(((uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_h3_any_img: buffers must be 16-byte aligned");
+  switch (head_dim) {
+    case 32: return launch_h3_any<32>(nullptr, 0, 1.0f, o, num_ims, B, T, H, workspace, stream, true);
+    case 48: return launch_h3_any<48>(nullptr, 0, 1.0f, o, num_ims, B, T, H, workspace, stream, true);
+    default: return paths_set_error(PATHS_EUNSUPPORTED, "attention_h3_any_img: head_dim %d (supported: 32, 48)", head_dim);
   }
 }
 

@@ -451,10 +451,15 @@ tlayer_ws_kernel(WsParams p) {
       }
     });
   } else if constexpr (QKV) {
-    static_assert(OT == 2, "in_proj images: head_dim 32 (one k32 block per head)");
-    // ---- in_proj: wave w = head w.  q, k: features on the accumulator rows; v: operands swapped, tokens on the rows
-    const int64_t img = (int64_t)p.B * NW * p.Tp * 128;          // bytes of one of the three images (32 dims x 2 planes x 2 B)
-    char* const hbase = p.qkv_img + ((int64_t)b * NW + wave) * p.Tp * 128;
+    static_assert(OT == 2 || OT == 3, "in_proj images: head_dim 32 or 48 (wave = head)");
+    // ---- in_proj: wave w = head w (head_dim 16 OT).  q, k: features on the accumulator rows; v: operands swapped, tokens on the rows.
+    // Images in the layout csrc/attn_h3_any.hip documents (= csrc/attn_x6.hip's at head_dim 32): NKB k-blocks of 32 score dims per
+    // 16-token tile (head_dim 48: the second block holds dims 32..47 and 16 zeros - the same positions in Q and K), OT dv tiles per
+    // 32-key group.  The order of the dims inside a k-block is this kernel's accumulator order, identically for Q and K.
+    constexpr int NKB = (OT + 1) / 2;
+    const int64_t img_qk = (int64_t)p.B * NW * p.Tp * (NKB * 128);   // bytes of the Q (or K) image: 32 NKB dims x 2 planes x 2 B per token and head
+    char* const hbase = p.qkv_img + ((int64_t)b * NW + wave) * p.Tp * (NKB * 128);
+    char* const vbase = p.qkv_img + 2 * img_qk + ((int64_t)b * NW + wave) * p.Tp * (OT * 64);
     static_for<0, 2>([&](auto which_) {
       constexpr int which = decltype(which_)::value;
       f32x4 acc[OT][TT];
@@ -470,16 +475,22 @@ tlayer_ws_kernel(WsParams p) {
       for (int tt = 0; tt < TT; ++tt) {
         const int tok = t0 + 16 * tt + ql;
         const bool live = which == 0 ? tok < p.T : tok < len;    // masked keys: K = 0 (V = 0 below: 0 * garbage would poison O)
-        float v[8];
 #pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
+        for (int kk = 0; kk < NKB; ++kk) {
+          float v[8];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * ot + r] = live ? (acc[ot][tt][r] * p.inv_wqkv + bb[ot][r]) * sc : 0.f;
-        u32x4 hi, lo;
-        split8h(v, hi, lo);
-        char* dst = hbase + which * img + (int64_t)((t0 >> 4) + tt) * 2 * FRAG + lane * 16;   // Q6 / K6: [16-token tile][plane][lane]
-        *reinterpret_cast<u32x4*>(dst) = hi;
-        *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+          for (int o2 = 0; o2 < 2; ++o2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ot = 2 * kk + o2;
+              v[4 * o2 + r] = (ot < OT && live) ? (acc[ot < OT ? ot : 0][tt][r] * p.inv_wqkv + bb[ot < OT ? ot : 0][r]) * sc : 0.f;
+            }
+          u32x4 hi, lo;
+          split8h(v, hi, lo);
+          char* dst = hbase + which * img_qk + ((int64_t)((t0 >> 4) + tt) * NKB + kk) * 2 * FRAG + lane * 16;   // [16-token tile][k-block][plane][lane]
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+        }
       }
       WS_STAMP(12 + 2 * which);
     });
@@ -500,7 +511,7 @@ tlayer_ws_kernel(WsParams p) {
           }
           u32x4 hi, lo;
           split8h(v, hi, lo);
-          char* dst = hbase + 2 * img + (int64_t)(((t0 >> 5) + u) * 2 + ot) * 2 * FRAG + lane * 16;   // V6: [32 keys][dv tile][plane][lane]
+          char* dst = vbase + (int64_t)(((t0 >> 5) + u) * OT + ot) * 2 * FRAG + lane * 16;   // [32 keys][dv tile][plane][lane]
           *reinterpret_cast<u32x4*>(dst) = hi;
           *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
         }
@@ -600,8 +611,9 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
                          int* zero_words, int n_zero, hipStream_t stream) {
   // trans_dim 192 (the reference's dataclass default, config.py:30): the post-attention chain only, attention output as fp32 rows (its
   // in_proj and attention run on the shape-generic kernels, whose operands are token-major fp32)
-  PATHS_REQUIRE((d == 128 && H == 4) || (d == 192 && do_post && !do_qkv && attn != nullptr && attn_img == nullptr),
-                "token_layer_ws: trans_dim 128 / 4 heads, or trans_dim 192 with do_post only and fp32 attention rows (got %d, %d)", d, H);
+  // ... or the in_proj only, writing the head_dim-48 operand images of paths_attention_h3_any_img (4 heads: wave = head)
+  PATHS_REQUIRE((d == 128 && H == 4) || (d == 192 && do_post && !do_qkv && attn != nullptr && attn_img == nullptr) || (d == 192 && H == 4 && !do_post && do_qkv),
+                "token_layer_ws: trans_dim 128 / 4 heads, or trans_dim 192 with do_post only and fp32 attention rows, or 192 / 4 heads with do_qkv only (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && (do_post || do_qkv), "token_layer_ws: nothing to do");
   PATHS_REQUIRE(!skip_padding || num_ims, "token_layer_ws: skip_padding needs num_ims");
   PATHS_REQUIRE(x_in && (!do_post || ((attn || attn_img) && x_out && w_post && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b)),
@@ -618,7 +630,7 @@ int paths_token_layer_ws(const float* x_in, const float* attn, const void* attn_
              , g_ws_stamps
 #endif
   };
-  if (d == 192) return launch_ws<192, true, false>(p, stream);
+  if (d == 192) return do_qkv ? launch_ws<192, false, true>(p, stream) : launch_ws<192, true, false>(p, stream);
   if (do_post && do_qkv) return launch_ws<128, true, true>(p, stream);
   if (do_post) return launch_ws<128, true, false>(p, stream);
   return launch_ws<128, false, true>(p, stream);

@@ -383,6 +383,7 @@ def fast_path(mc) -> bool:
 
 GENERIC_ADD = os.environ.get("PATHS_GENERIC_ADD", "1") != "0"       # other geometries: tuned LSTM kernels, importance / proj on x + h1 in flight
 WS_CHAIN_192 = os.environ.get("PATHS_WS_CHAIN_192", "1") != "0"     # trans_dim 192: full layers' row chain on tlayer_ws_kernel<192>
+WS_IMAGES_192 = os.environ.get("PATHS_WS_IMAGES_192", "1") != "0"   # ... and the first in_proj straight into the attention's head_dim-48 operand images
 
 
 def wide_head(hd: int) -> bool:
@@ -619,7 +620,7 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     attn = (torch.zeros if fp8 else torch.empty)((B, T, d), **f32)
     rows, ldx = M, d                      # the current activation: `rows` rows, row stride ldx (the last layer keeps token 0 of every slide)
     ws192 = WS_CHAIN_192 and d == 192 and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and not wide
-    qkv_ready = False
+    qkv_ready = img_ready = False
     for l in range(L):
         lay, gl = lvl_pack["layers"][l], gp["layers"][l]
         last = l == L - 1
@@ -633,6 +634,12 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
 
         if qkv_ready:                         # the previous layer's chain launch already projected this layer's q | k | v
             qkv_ready = False
+        elif ws192 and WS_IMAGES_192 and h3 and not last and H == 4:
+            # q | k | v straight into the head_dim-48 operand images of the attention (no fp32 rows, no prep launch)
+            iq, sq = tlayer_ws_images(lay, 1)
+            _lib.call("paths_token_layer_ws", p(x), None, None, None, None, p(iq), None, None, None, None, None, None, None, None, None, None,
+                      p(lay["bqkv"]), 1.0, 1.0, 1.0, sq[0], p(wsh), p(num_ims), B, T, d, H, 0, 1, 1, qscale, lay["eps"], None, 0, st)
+            img_ready = True
         elif ws192:
             iq, sq = tlayer_ws_images(lay, 1)
             _lib.call("paths_token_layer_ws_rows", p(x), None, None, None, p(iq), None, None, None, None, None, None, None, None, None, None,
@@ -643,6 +650,9 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
         elif wide:
             _lib.call("paths_attention_wide_fwd", p(qkv), 3 * d, p(attn), None, p(num_ims), B, T, H, hd, qscale, 1 if last else 0, 0, 0.0, p(wsw), st)
+        elif h3 and not last and img_ready:
+            _lib.call("paths_attention_h3_any_img", p(attn), p(num_ims), B, T, H, hd, p(wsh), st)
+            img_ready = False
         elif h3 and not last:
             _lib.call("paths_attention_h3_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(wsh), st)
         elif last and GENERIC_SPLIT:

@@ -97,6 +97,9 @@ def test_single_level_other_aggregator_geometries(dev, tag):
     finally:
         O._lib.call = orig
     attn = {"paths_attention_h3_any", "paths_attention_token0_any"} if (O.GEMM_MODE == "h3" and O.GENERIC_SPLIT) else {"paths_attention_any"}
+    if tag.startswith("td192") and "paths_attention_h3_any" in attn and O.WS_CHAIN_192 and O.WS_IMAGES_192:
+        # trans_dim 192 / 4 heads: the first in_proj writes the attention's head_dim-48 operand images itself (csrc/tlayer_ws.hip), no prep launch
+        attn = {"paths_attention_h3_any_img", "paths_token_layer_ws", "paths_attention_token0_any"}
     assert attn | {"paths_layernorm_rows", "paths_tokens_assemble", "paths_importance_rows", "paths_final_head_any"} <= set(calls)
     np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
