@@ -450,7 +450,7 @@ def main():
     ap.add_argument("--rotate", type=int, default=3, help="infer mode: distinct resident slide batches (21 GiB each at K=2048) cycled "
                     "through the timed region, one recorded launch tape each; the headline is measured on the rotation (every step works "
                     "on different rows than the step before), the single-batch replay figure is reported beside it")
-    ap.add_argument("--train-steps", type=int, default=5, help="infer mode: timed steps of the short training measurement added to the "
+    ap.add_argument("--train-steps", type=int, default=10, help="infer mode: timed steps of the short training measurement added to the "
                     "line as 'train' (0 = skip); 3 warm-up steps")
     ap.add_argument("--cores-per-rank", type=int, default=0, help="pin this rank to N host cores (cores [rank N, rank N + N) of the "
                     "process's allowed set) BEFORE anything touches the GPU: what a rank gets when 8 ranks share one host's CPU share "
@@ -833,11 +833,11 @@ def main():
     train = None
     if args.train_steps > 0:
         try:
-            train = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 3)
+            train = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 5)
             log(f"train probe: {train['ms_per_step']} ms per step, all-reduce {train['allreduce_ms']} ms")
             # the same step with the OTHER gradient-operand setting (the fp32-accurate three-plane split unless that is the default)
             other = 3 if train["train_planes"] == 4 else 4
-            t2 = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 2, planes=other)
+            t2 = train_probe(cfg, model, slides, world, dev_reduce, pdist, putils, args.train_steps, 3, planes=other)
             train[f"planes{other}"] = {k: t2[k] for k in ("ms_per_step", "slides_per_s", "train_planes", "dtype")}
             log(f"train probe (PATHS_TRAIN_PLANES={other}): {t2['ms_per_step']} ms per step")
         except Exception as e:       # the headline (already measured above) must not be lost to a failure of the secondary probe
