@@ -32,6 +32,13 @@
 #define PATHS_X6_MIX16 1
 #endif
 
+// PATHS_X6_PART = 1 / 2 / 3: this translation unit defines one third of the C entry points (LSTM cell + weight packing, importance /
+// projection, the gemm_nt family) - the file takes 4.5 minutes to compile whole, __graft_entry__.build() compiles the parts in
+// parallel; 0 (default): everything in one object
+#ifndef PATHS_X6_PART
+#define PATHS_X6_PART 0
+#endif
+
 namespace {
 using namespace paths_epi;
 
@@ -589,11 +596,12 @@ inline bool pow2(float x) { int e; return x > 0.f && frexpf(x, &e) == 0.5f; }
 // ================================================================================================
 extern "C" {
 
-#ifdef PATHS_X6_DEBUG
+#if defined(PATHS_X6_DEBUG) && (PATHS_X6_PART == 0 || PATHS_X6_PART == 1)
 // development hook (tools/x6_stages.py, debug build only): buffer of 9 uint64 per wave, or NULL
 void paths_x6_debug_buffer(uint64_t* p) { g_x6_dbg = p; }
 #endif
 
+#if PATHS_X6_PART == 0 || PATHS_X6_PART == 1
 // bytes of the packed image of an [Npad, K] weight: planes x 2 bytes per element
 int64_t paths_x6_packed_bytes(int Npad, int K, int planes) { return (int64_t)Npad * K * 2 * plane_count(planes); }
 
@@ -677,6 +685,8 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
   return PATHS_OK;
 }
 
+#endif
+#if PATHS_X6_PART == 0 || PATHS_X6_PART == 2
 // paths_importance_proj with w_ip_x6 = pack([256, D], rows interleaved as paths_importance_proj documents).  y_add (optional): the
 // GEMM input is y + y_add, summed in fp32 while staging - the caller passes (x, h1) and never materialises Y = X + h1
 // (paths_lstm_cell_x6 with y = NULL)
@@ -744,6 +754,8 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
   return save_hid ? go(EpiImpProj<false, true>{}) : go(EpiImpProj<false, false>{});
 }
 
+#endif
+#if PATHS_X6_PART == 0 || PATHS_X6_PART == 3
 // out[M,N] (+)= maskop(act(A[M,K] * W[N,K]^T + b)) + residual with W given as the split image of an [Npad, Kpacked]
 // weight; k0 selects the column window [k0, k0 + K) of it (k0 % 16 == 0), Npad % 256 == 0.
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
@@ -789,5 +801,7 @@ int paths_gemm_add_nt_x6(const float* a, int64_t lda, const int64_t* a_rows, con
   return a_rows ? launch_x6_np<2, 2, 4, 2, true, true>(g, Npad, e, stream, "gemm_add_nt_x6(rows)")
                 : launch_x6_np<2, 2, 4, 2, true, false>(g, Npad, e, stream, "gemm_add_nt_x6");
 }
+
+#endif
 
 }  // extern "C"
