@@ -125,27 +125,50 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
     const int blk = c / count;
     i = c - blk * count;
     const int prow = keep_idx[(int64_t)b * ldk + i];
-    const int64_t px = locs[((int64_t)b * n_cur + prow) * 2] / patch_size;
-    const int64_t py = locs[((int64_t)b * n_cur + prow) * 2 + 1] / patch_size;
+    const int64_t lx = locs[((int64_t)b * n_cur + prow) * 2], ly = locs[((int64_t)b * n_cur + prow) * 2 + 1];
+    const bool small = (uint64_t)(lx | ly) < 0x80000000ull;       // (pixel coordinates: a 32-bit division is a fraction of the 64-bit one)
+    const int64_t px = small ? (int64_t)((int)lx / patch_size) : lx / patch_size;
+    const int64_t py = small ? (int64_t)((int)ly / patch_size) : ly / patch_size;
     const int64_t x = 2 * px + (blk >> 1), y = 2 * py + (blk & 1);
     cx = (int)x; cy = (int)y;
     if (x >= X || y >= Y) return false;
     return mask[(int64_t)x * Y + y] != 0;
   };
 
+  // the first candidates of this thread are evaluated ONCE (each evaluation is a chain of four dependent loads: kept index -> its
+  // location -> the tissue bit; at keep = 512 a thread owns two candidates) and kept in registers for the write pass below
+  constexpr int CACHE = 4;
+  int ccx[CACHE], ccy[CACHE], cci[CACHE];
+  bool ckeep[CACHE];
   int mine = 0;
-  for (int c = c0; c < c1; ++c) { int cx, cy, i; mine += child(c, cx, cy, i) ? 1 : 0; }
-  part[tid] = mine;
-  __syncthreads();
-  // inclusive Hillis-Steele scan over 1024 partials
-  for (int off = 1; off < 1024; off <<= 1) {
-    int v = tid >= off ? part[tid - off] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+#pragma unroll
+  for (int u = 0; u < CACHE; ++u) {
+    ckeep[u] = false;
+    if (c0 + u < c1) { ckeep[u] = child(c0 + u, ccx[u], ccy[u], cci[u]); mine += ckeep[u] ? 1 : 0; }
   }
-  int pos = part[tid] - mine;
-  const int n_out = part[1023];
+  for (int c = c0 + CACHE; c < c1; ++c) { int cx, cy, i; mine += child(c, cx, cy, i) ? 1 : 0; }
+  // inclusive scan over the 1024 partials: shuffles inside a wave, the 16 wave totals through LDS (two barriers instead of the twenty
+  // of a Hillis-Steele scan over LDS)
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if ((tid & 63) >= off) incl += v;
+  }
+  if ((tid & 63) == 63) part[tid >> 6] = incl;
+  __syncthreads();
+  if (tid < 16) {
+    int t = part[tid];
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const int v = __shfl_up(t, off);
+      if (tid >= off) t += v;
+    }
+    part[16 + tid] = t;                                 // inclusive totals of waves 0 .. tid
+  }
+  __syncthreads();
+  int pos = incl - mine + ((tid >> 6) ? part[16 + (tid >> 6) - 1] : 0);
+  const int n_out = part[31];
   if (tid == 0) {
     num_out[b] = n_out;
     if (n_out == 0) atomicOr(status, 1);               // reference falls back to "all cells" (slide.py:336-352)
@@ -154,7 +177,16 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
   if (n_out > n_next) return;
   for (int c = c0; c < c1; ++c) {
     int cx, cy, i;
-    const bool keepc = child(c, cx, cy, i);
+    bool keepc;
+    const int u = c - c0;
+    if (u < CACHE) {
+      keepc = false;
+#pragma unroll
+      for (int v = 0; v < CACHE; ++v)
+        if (v == u) { keepc = ckeep[v]; cx = ccx[v]; cy = ccy[v]; i = cci[v]; }
+    } else {
+      keepc = child(c, cx, cy, i);
+    }
     if (child_pos) child_pos[(int64_t)b * 4 * ldk + c] = keepc ? pos : -1;
     if (keepc) {
       const int64_t o = (int64_t)b * n_next + pos;
