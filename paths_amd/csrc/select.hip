@@ -102,7 +102,14 @@ static int launch_topk(const float* scores, int64_t ld, const int64_t* num_ims, 
 // expansion: kept patch (x,y) -> blocks (2x,2y) | (2x,2y+1) | (2x+1,2y) | (2x+1,2y+1), each in top-K
 // order (slide.py:307-315); keep child iff in bounds and tissue (slide.py:320-325); stable compaction.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
+#ifndef PATHS_EXPAND_THREADS
+#define PATHS_EXPAND_THREADS 512           // threads of the one workgroup per slide (a multiple of 64, <= 1024).  Alone the kernel is fastest at
+                                           // 1024 (11.7 us against 15.1 / 23.5 at 512 / 256), but a 16-wave workgroup has to wait for a CU with four free
+                                           // wave slots per SIMD beside the aggregator's kernels: in the recursion 512 gives 3,591-3,624 slides/s against
+                                           // 3,527-3,535 (sustained 3,717-3,731 against 3,609-3,616), 256 gives 3,589-3,618
+#endif
+constexpr int EXP_NT = PATHS_EXPAND_THREADS, EXP_NW = EXP_NT / 64;
+__global__ void __launch_bounds__(EXP_NT)
 expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restrict__ keep_count,
               const int64_t* __restrict__ locs, int64_t n_cur, int patch_size,
               const int* __restrict__ next_x, const int* __restrict__ next_y,          // [B] next-level grid dims
@@ -112,13 +119,13 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
               int* __restrict__ src_row, int* __restrict__ src_cell, int* __restrict__ status,
               int* __restrict__ child_pos /*[B, 4*ldk] or null: output row of every candidate child, -1 if dropped*/,
               int* __restrict__ hp_row /*[B, n_next] or null: row of the kept-parent table (b*ldk + i) of every child*/) {
-  __shared__ int part[1024];
+  __shared__ int part[2 * EXP_NW];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int count = keep_count[b];
   const int total = 4 * count;
   const int X = next_x[b], Y = next_y[b];
   const uint8_t* mask = reinterpret_cast<const uint8_t*>(mask_ptrs[b]);
-  const int per = (total + 1023) / 1024;
+  const int per = (total + EXP_NT - 1) / EXP_NT;
   const int c0 = tid * per, c1 = min(c0 + per, total);
 
   auto child = [&](int c, int& cx, int& cy, int& i) -> bool {
@@ -141,14 +148,42 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
   int ccx[CACHE], ccy[CACHE], cci[CACHE];
   bool ckeep[CACHE];
   int mine = 0;
+  {
+    // ... in three stages, so that the CACHE chains of a thread run side by side (all kept indices, then all locations, then all bits)
+    int blk[CACHE], prow[CACHE];
+    bool on[CACHE], inb[CACHE];
+    int64_t lx[CACHE], ly[CACHE];
 #pragma unroll
-  for (int u = 0; u < CACHE; ++u) {
-    ckeep[u] = false;
-    if (c0 + u < c1) { ckeep[u] = child(c0 + u, ccx[u], ccy[u], cci[u]); mine += ckeep[u] ? 1 : 0; }
+    for (int u = 0; u < CACHE; ++u) {
+      on[u] = c0 + u < c1;
+      const int c = on[u] ? c0 + u : 0;
+      blk[u] = count > 0 ? c / count : 0;
+      cci[u] = c - blk[u] * count;
+      prow[u] = on[u] ? keep_idx[(int64_t)b * ldk + cci[u]] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < CACHE; ++u) {
+      lx[u] = on[u] ? locs[((int64_t)b * n_cur + prow[u]) * 2] : 0;
+      ly[u] = on[u] ? locs[((int64_t)b * n_cur + prow[u]) * 2 + 1] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < CACHE; ++u) {
+      const bool small = (uint64_t)(lx[u] | ly[u]) < 0x80000000ull;
+      const int64_t px = small ? (int64_t)((int)lx[u] / patch_size) : lx[u] / patch_size;
+      const int64_t py = small ? (int64_t)((int)ly[u] / patch_size) : ly[u] / patch_size;
+      const int64_t x = 2 * px + (blk[u] >> 1), y = 2 * py + (blk[u] & 1);
+      ccx[u] = (int)x; ccy[u] = (int)y;
+      inb[u] = on[u] && x < X && y < Y;
+    }
+#pragma unroll
+    for (int u = 0; u < CACHE; ++u) {
+      ckeep[u] = inb[u] && mask[(int64_t)ccx[u] * Y + ccy[u]] != 0;
+      mine += ckeep[u] ? 1 : 0;
+    }
   }
   for (int c = c0 + CACHE; c < c1; ++c) { int cx, cy, i; mine += child(c, cx, cy, i) ? 1 : 0; }
-  // inclusive scan over the 1024 partials: shuffles inside a wave, the 16 wave totals through LDS (two barriers instead of the twenty
-  // of a Hillis-Steele scan over LDS)
+  // inclusive scan over the per-thread partials: shuffles inside a wave, the wave totals through LDS (two barriers instead of the
+  // twenty of a Hillis-Steele scan over LDS)
   int incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -157,18 +192,18 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
   }
   if ((tid & 63) == 63) part[tid >> 6] = incl;
   __syncthreads();
-  if (tid < 16) {
+  if (tid < EXP_NW) {
     int t = part[tid];
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
+    for (int off = 1; off < EXP_NW; off <<= 1) {
       const int v = __shfl_up(t, off);
       if (tid >= off) t += v;
     }
-    part[16 + tid] = t;                                 // inclusive totals of waves 0 .. tid
+    part[EXP_NW + tid] = t;                             // inclusive totals of waves 0 .. tid
   }
   __syncthreads();
-  int pos = incl - mine + ((tid >> 6) ? part[16 + (tid >> 6) - 1] : 0);
-  const int n_out = part[31];
+  int pos = incl - mine + ((tid >> 6) ? part[EXP_NW + (tid >> 6) - 1] : 0);
+  const int n_out = part[2 * EXP_NW - 1];
   if (tid == 0) {
     num_out[b] = n_out;
     if (n_out == 0) atomicOr(status, 1);               // reference falls back to "all cells" (slide.py:336-352)
@@ -200,7 +235,7 @@ expand_kernel(const int* __restrict__ keep_idx, int64_t ldk, const int* __restri
     }
   }
   // padding tail: zero the bookkeeping rows like collate_fn's zero padding (dataset.py:216-218)
-  for (int j = n_out + tid; j < n_next; j += 1024) {
+  for (int j = n_out + tid; j < n_next; j += EXP_NT) {
     const int64_t o = (int64_t)b * n_next + j;
     locs_out[2 * o] = 0; locs_out[2 * o + 1] = 0; parent_out[o] = 0; src_row[o] = -1; src_cell[o] = -1;
     if (hp_row) hp_row[o] = -1;
@@ -520,7 +555,7 @@ int paths_expand_children(const int* keep_idx, int64_t ldk, const int* keep_coun
                           int* src_cell, int* status, int* child_pos, int* hp_row, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && n_cur > 0 && n_next > 0 && patch_size > 0, "expand_children: bad shape");
   PATHS_REQUIRE(4 * ldk <= (int64_t)1 << 30, "expand_children: too many candidates");
-  hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(1024), 0, stream, keep_idx, ldk, keep_count, locs, n_cur, patch_size,
+  hipLaunchKernelGGL(expand_kernel, dim3(B), dim3(EXP_NT), 0, stream, keep_idx, ldk, keep_count, locs, n_cur, patch_size,
                      next_x, next_y, mask_ptrs, n_next, num_out, locs_out, parent_out, src_row, src_cell, status, child_pos, hp_row);
   PATHS_LAUNCH_CHECK("expand_children");
   return PATHS_OK;
