@@ -615,12 +615,14 @@ def main():
     # distinct slides pays), eager = every launch through the Python path, un-instrumented
     launch_modes = None
     if replays is not None and not args.graph and nrot > 1 and world == 1:
+        lm_steps = max(args.steps, 150)               # (10 steps = 22 ms read +- 3 % from run to run: too short to compare modes)
+
         def timed_loop(fn):
             for i in range(nrot):
                 fn(i)
             barrier()
             t1_ = time.perf_counter()
-            for i in range(args.steps):
+            for i in range(lm_steps):
                 fn(i)
             barrier()
             return time.perf_counter() - t1_
@@ -633,18 +635,19 @@ def main():
         # consecutive steps on ALTERNATING stream triples, each tape without its final join (TapedRecursion(lane=k), replay(join=False)):
         # step i+1's selection chain starts while step i's last aggregator still runs - what a serving loop with two in-flight
         # batches does.  Measured beside the headline, which keeps one stream triple (each step complete before the next starts).
-        lanes = [putils.TapedRecursion(model, b, cfg.top_k_patches, cfg.num_levels, lane=1 + i % 2).record() for i, b in enumerate(batches)]
-        el_2l = timed_loop(lambda i: lanes[i % nrot].replay(join=False))
+        pipe = putils.PipelinedRecursion(model, batches, cfg.top_k_patches, cfg.num_levels)
+        el_2l = timed_loop(lambda i: pipe.submit(i % nrot))
         torch.cuda.synchronize()
-        for t_ in lanes:
-            t_.join()
-            t_.close()
-        del lanes
+        ref_out = replays[0].replay()
+        two = pipe.result(0)
+        assert torch.equal(two["logits"], ref_out["logits"]), "two-lane replay changed the results"
+        pipe.close()
+        del pipe
         torch.cuda.synchronize()
-        launch_modes = {"steps": args.steps, "batches_rotated": nrot,
-                        "replay_slides_per_s": round(spg * args.steps / el_rp, 2), "rebind_slides_per_s": round(spg * args.steps / el_rb, 2),
-                        "eager_slides_per_s": round(spg * args.steps / el_eg, 2),
-                        "replay_two_lanes_slides_per_s": round(spg * args.steps / el_2l, 2),
+        launch_modes = {"steps": lm_steps, "batches_rotated": nrot,
+                        "replay_slides_per_s": round(spg * lm_steps / el_rp, 2), "rebind_slides_per_s": round(spg * lm_steps / el_rb, 2),
+                        "eager_slides_per_s": round(spg * lm_steps / el_eg, 2),
+                        "replay_two_lanes_slides_per_s": round(spg * lm_steps / el_2l, 2),
                         "note": "replay: one tape per resident batch; rebind: ONE tape, table tensors re-pointed at the next batch before "
                                 "every step (no re-recording); eager: Python launch path; replay_two_lanes: consecutive steps on alternating "
                                 "stream triples without the per-step join (two batches in flight: step i+1's selection chain starts under step "

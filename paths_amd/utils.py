@@ -252,6 +252,34 @@ class TapedRecursion:
         return out
 
 
+class PipelinedRecursion:
+    """Several resident batches served with TWO in flight: batch k is recorded as a :class:`TapedRecursion` on stream triple
+    ``1 + k % 2`` and :meth:`submit` replays it WITHOUT the tape's final join, so the next batch's selection chain (other streams)
+    starts while this batch's last aggregator still runs - the ~165-us gap a single stream triple leaves at every step boundary
+    (profiles/r04_experiments.md, selection-queue timeline; bench.py ``host.launch_modes.replay_two_lanes``: +2.7 %).
+    :meth:`result` joins batch k into the caller's stream and returns its outputs (valid until that batch is submitted again);
+    the status word is checked there like in ``TapedRecursion.run``.  Same launches, same buffers, same results as one lane."""
+
+    def __init__(self, model, batches, keep_patches: Sequence[int], num_levels: int, lanes: int = 2):
+        self.tapes = [TapedRecursion(model, b, keep_patches, num_levels, lane=1 + k % max(1, int(lanes))).record() for k, b in enumerate(batches)]
+
+    def submit(self, k: int):
+        self.tapes[k].replay(join=False)
+
+    def result(self, k: int, check: bool = True) -> Dict[str, torch.Tensor]:
+        t = self.tapes[k]
+        t.join()
+        if check and check_status_word(t.out["status"]):
+            with torch.no_grad():
+                return recurse(t.model, t.batch, t.keep, t.levels)
+        return t.out
+
+    def close(self):
+        for t in self.tapes:
+            t.close()
+        self.tapes = []
+
+
 OVERLAP_AGGREGATOR = os.environ.get("PATHS_OVERLAP_AGGREGATOR", "1") != "0"
 ROCTX_RANGES = os.environ.get("PATHS_ROCTX", "0") != "0"     # roctx ranges "level i: selection / aggregator / expansion" around the launches
                                                              # of each level (rocprofv3 --marker-trace; torch.cuda.nvtx = roctx on ROCm)

@@ -1085,6 +1085,25 @@ def test_replay_paths_raise_on_invalidating_status_bits(dev):
     t.close()
 
 
+def test_two_batches_in_flight_give_the_single_lane_results(dev):
+    """utils.PipelinedRecursion: batches replayed on alternating stream triples without the per-step join (two in flight) return,
+    bit for bit, what each batch's own single-lane tape returns - same launches on the same private buffers, only the streams differ."""
+    from paths_amd import utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    cfg, model, _ = build_model(dev, 3, top_k_patches=[16] * 4)
+    batches = [DeviceSlideBatch([DeviceSlide.synthetic(40 + k, s, (8, 8), p_bg=0.1, device=dev) for s in range(2)]) for k in range(3)]
+    with torch.no_grad():
+        ref = [putils.recurse(model, b, cfg.top_k_patches, 5) for b in batches]
+        pipe = putils.PipelinedRecursion(model, batches, cfg.top_k_patches, 5)
+        for rnd in range(3):
+            for k in range(3):
+                pipe.submit(k)
+            for k in range(3):
+                out = pipe.result(k)
+                assert torch.equal(out["logits"], ref[k]["logits"]) and torch.equal(out["ctx_slide"], ref[k]["ctx_slide"]), (rnd, k)
+        pipe.close()
+
+
 def test_tape_rebinds_to_other_batches(dev):
     """TapedRecursion.rebind (missing 6): ONE recorded tape pointed at other resident batches by copying their table
     tensors into the tape's own - same results as the eager recursion of each batch bit for bit, in any order, including a batch of
