@@ -84,12 +84,16 @@ def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=
               mp, ldm, 1 if accumulate else 0, _lib.stream())
 
 
+_TN_WGS = int(os.environ.get("PATHS_TN_WGS", "256"))      # workgroups of 256 x 256 tiles a weight-gradient launch aims at: ONE round of the 256 CUs
+                                                           # (two rounds = twice the split-M slabs to write and to sum: 13.83 / 14.68 ms per step against 13.65 / 14.45)
+
+
 def _splits_x6(M: int, N1: int, N2: int, nb0: int) -> int:
     """Row splits of the split-bf16 weight-gradient kernel: 256 x 256 tiles run one workgroup per CU, 128 x 128 tiles two; aim at
-    two full rounds of the 256 CUs with at least 128 rows (8 stages) per split."""
+    one full round of the 256 CUs (_TN_WGS) with at least 128 rows (8 stages) per split."""
     big = N1 % 256 == 0 and N2 % 256 == 0 and nb0 % 256 == 0
     tiles = (N1 // 256) * (N2 // 256) if big else (N1 // 128) * (N2 // 128)
-    return max(1, min(64, (512 if big else 1024) // tiles, M // 128))
+    return max(1, min(64, (_TN_WGS if big else 2 * _TN_WGS) // tiles, M // 128))
 
 
 # ---- the gradient side stream.  In a level's backward the dX chain is the critical path (each product feeds the next); the weight
