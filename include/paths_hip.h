@@ -101,6 +101,9 @@ int paths_importance_proj(const float* y, int64_t ldy, const float* w_ip, const 
 int64_t paths_x6_packed_bytes(int Npad, int K, int planes);
 int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int planes, float w_scale,
                           paths_stream_t stream);
+/* The image of W^T made from W: w is [Kvalid, N] fp32 (row stride ldw); the packed weight is [N, K] (rows n >= N and columns k >= Kvalid zero);
+ * planes 3 or 4 (bf16 planes, scale 1).  One launch instead of paths_transpose_f32 + paths_x6_pack_weights (the backward's dX products). */
+int paths_x6_pack_weights_t(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int Kvalid, int planes, paths_stream_t stream);
 /* w_gates_x6 = pack of the PACKED gate matrix [3Hc+D, 2D] of paths_lstm_cell (scale wg_scale); w_mem_x6 = pack of [D, Hc]
  * (scale wm_scale); D % 256 == 0; y may be NULL (Y = X + h1 not materialised).  x_rows (optional, planes = 2, needs hp / no
  * h0, y = NULL): [M] addresses of the feature rows - x is then read in place (paths_gather_rows row_ptrs), x / ldx unused.

@@ -26,6 +26,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_gemm_nt_f32": [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32, _vp],
     "paths_x6_pack_weights": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "paths_x6_pack_weights_t": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "paths_lstm_cell_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                            _i32, _i32, _i32, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _vp],
     "paths_importance_proj_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,

@@ -25,6 +25,7 @@ TN_SPLIT2 = int(os.environ.get("PATHS_TN_SPLIT2", "2"))
 TN_MODE = os.environ.get("PATHS_TN_MODE", "x6")
 # dX / recompute GEMMs go to the split-operand kernel when the output width is a multiple of this (128: the d = 128 products too)
 NT_X6_MIN_N = int(os.environ.get("PATHS_NT_X6_MIN_N", "128"))
+PACK_T = os.environ.get("PATHS_PACK_T", "1") != "0"        # dX products image W^T straight from W (one launch instead of transpose + pack)
 # Row counts from which the gradient GEMMs run on the split-bf16 kernels (below: the f32-input MFMA kernels, which are as fast there).
 # Module constants so that tests can force the split kernels onto the small shapes of the reference's trajectory fixtures.
 NT_X6_MIN_M = int(os.environ.get("PATHS_NT_X6_MIN_M", "1024"))
@@ -58,10 +59,39 @@ def transpose(w: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, o
     return out
 
 
+class Transposed:
+    """``transpose(w, rows, cols, ld, offset, pad_to)`` not yet materialised: the weight of a dX product (dX = dY W takes W^T).  The
+    split-bf16 GEMM images it straight from ``w`` (paths_x6_pack_weights_t: one launch instead of a transpose + a pack); every other
+    consumer calls :meth:`tensor`."""
+    __slots__ = ("w", "rows", "cols", "ld", "offset", "pad_to")
+
+    def __init__(self, w, rows, cols, ld=None, offset=0, pad_to=None):
+        self.w, self.rows, self.cols, self.ld, self.offset, self.pad_to = w, rows, cols, ld, offset, pad_to
+
+    def tensor(self) -> torch.Tensor:
+        return transpose(self.w, self.rows, self.cols, self.ld, self.offset, self.pad_to)
+
+
 def gemm_nt(a, lda, wt, out, ldo, M, N, K, bias=None, act=0, residual=None, ldr=0, mask=None, ldm=0, accumulate=False,
             ldw=None):
     """out[M,N] (+)= maskop(act(a[M,K] wt[N,K]^T + bias)) + residual; a/out/residual/mask may be raw pointers."""
     assert K % 32 == 0
+    if isinstance(wt, Transposed):
+        kfull = wt.pad_to if (wt.pad_to is not None and wt.pad_to > wt.rows) else wt.rows
+        if (ops.GEMM_MODE != "f32" and N % NT_X6_MIN_N == 0 and K >= 128 and K % 128 == 0 and M >= NT_X6_MIN_M and ldw is None and N == wt.cols and K == kfull
+                and ops.TRAIN_PLANES in (3, 4) and PACK_T):
+            pl = ops.TRAIN_PLANES
+            wx = torch.empty((N * K * 2 * (2 if pl == 4 else pl),), device=wt.w.device, dtype=torch.uint8)
+            _lib.call("paths_x6_pack_weights_t", wt.w.data_ptr() + 4 * wt.offset, wt.ld if wt.ld is not None else wt.w.stride(0), P(wx), N, N, K, wt.rows,
+                      pl, _lib.stream())
+            ap = a if isinstance(a, int) else a.data_ptr()
+            op = out if isinstance(out, int) else out.data_ptr()
+            rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
+            mp = None if mask is None else (mask if isinstance(mask, int) else mask.data_ptr())
+            _lib.call("paths_gemm_nt_x6", ap, lda, P(wx), K, 0, P(bias), op, ldo, M, N, N, K, act, rp, ldr, mp, ldm,
+                      1 if accumulate else 0, pl, 1.0, 1.0, _lib.stream())
+            return
+        wt = wt.tensor()
     ap = a if isinstance(a, int) else a.data_ptr()
     op = out if isinstance(out, int) else out.data_ptr()
     rp = None if residual is None else (residual if isinstance(residual, int) else residual.data_ptr())
@@ -366,7 +396,7 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
         grads["w_ip"] = torch.empty((Hi + d, D), **f32)
         gemm_tn(du, U, sv["y"], D, grads["w_ip"], M, Hi + d, D)
     dy = torch.empty((M, D), **f32)
-    w_ip_t = transpose(lvl_pack["w_ip"], Hi + d, D, pad_to=U)          # [D, U]
+    w_ip_t = Transposed(lvl_pack["w_ip"], Hi + d, D, pad_to=U)          # [D, U]
     gemm_nt(du, U, w_ip_t, dy, D, M, D, U)
 
     # ---- LSTM cell.  Y = X + h1  =>  dh1 = dY (+ gradient arriving at the h half of state_out)
@@ -381,7 +411,7 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
         grads["w_mem"] = torch.empty((D, Hc), **f32)
         gemm_tn(dpre_h, D, c1_ptr, Dp, grads["w_mem"], M, D, Hc)
     dc1_h = torch.empty((M, Hc), **f32)
-    w_mem_t = transpose(lstm_pack["w_mem"], D, Hc)                      # [Hc, D]
+    w_mem_t = Transposed(lstm_pack["w_mem"], D, Hc)                      # [Hc, D]
     gemm_nt(dpre_h, D, w_mem_t, dc1_h, Hc, M, Hc, D)
     par = sv.get("parent")
     d_state_prev = torch.empty((B, N, Dp), **f32) if state_prev is not None else None
@@ -404,7 +434,7 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
         grads["w_gates"] = torch.empty((G, 2 * D), **f32)
         gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, D, ldo=2 * D)                       # x panel: over the children
         gemm_tn(dhp, G, hk, D, grads["w_gates"][:, D:], M4, G, D, ldo=2 * D)               # h panel: over the kept parents
-        wh_t = transpose(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)                  # [D, G] = (W_gates[:, D:2D])^T
+        wh_t = Transposed(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)                  # [D, G] = (W_gates[:, D:2D])^T
         d_hk = torch.empty((M4, D), **f32)
         gemm_nt(dhp, G, wh_t, d_hk, D, M4, D, G)
         side_join(dev)
@@ -418,7 +448,7 @@ def selection_backward(mc, lstm_pack, lvl_pack, sv, d_tokens: torch.Tensor, d_st
         else:
             gemm_tn(dG, G, fts, D, grads["w_gates"], M, G, 2 * D, b1=state_prev.data_ptr(), ldb1=state_prev.stride(1), nb0=D)
     if state_prev is not None:
-        wh_t = transpose(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)   # [D, G] = (W_gates[:, D:2D])^T
+        wh_t = Transposed(lstm_pack["w_gates"], G, D, ld=2 * D, offset=D)   # [D, G] = (W_gates[:, D:2D])^T
         gemm_nt(dG, G, wh_t, d_state_prev.data_ptr(), Dp, M, D, G)
     side_join(dev)                     # (before the saved activations behind the raw pointers above can be freed)
     return grads, d_state_prev
@@ -493,7 +523,7 @@ def selection_backward_nolstm(mc, lvl_pack, sv, d_tokens: torch.Tensor, d_state_
     g["wp"] = torch.empty((d, D), **f32)
     gemm_tn(dpp, d, Z, D, g["wp"], M, d, D)
     dZ = torch.empty((M, D), **f32)
-    gemm_nt(dpp, d, transpose(wp, d, D), dZ, D, M, D, d, residual=d_state_out, ldr=D)
+    gemm_nt(dpp, d, Transposed(wp, d, D), dZ, D, M, D, d, residual=d_state_out, ldr=D)
     d_state_prev = None
     if sv["has_hctx"]:
         # hctx = Wh2 relu(Wh1 s + bh1) + bh2 added on valid rows; dZ is exactly zero on padded rows (no token, never kept)
@@ -503,12 +533,12 @@ def selection_backward_nolstm(mc, lvl_pack, sv, d_tokens: torch.Tensor, d_state_
         g["wh2"] = torch.empty((D, Hh), **f32)
         gemm_tn(dZ, D, hid_h, Hh, g["wh2"], M, D, Hh)
         dhh = torch.empty((M, Hh), **f32)
-        gemm_nt(dZ, D, transpose(lvl_pack["wh2"], D, Hh), dhh, Hh, M, Hh, D, mask=hid_h, ldm=Hh)
+        gemm_nt(dZ, D, Transposed(lvl_pack["wh2"], D, Hh), dhh, Hh, M, Hh, D, mask=hid_h, ldm=Hh)
         g["bh1"] = colsum(dhh, Hh, M, Hh)
         g["wh1"] = torch.empty((Hh, D), **f32)
         gemm_tn(dhh, Hh, state_prev, D, g["wh1"], M, Hh, D)
         d_state_prev = torch.empty((B, N, D), **f32)
-        gemm_nt(dhh, Hh, transpose(lvl_pack["wh1"], Hh, D), d_state_prev, D, M, D, Hh)
+        gemm_nt(dhh, Hh, Transposed(lvl_pack["wh1"], Hh, D), d_state_prev, D, M, D, Hh)
     if mc.importance_mode == "mul":
         dh = torch.empty((M, Hi), **f32)
         da = torch.empty((M,), **f32)
@@ -672,7 +702,7 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
         dffo = dropout_rows(du3, d, M, d, drop.key(layer, Drop.FF_OUT), p)
         g["b2"] = colsum(dffo, d, M, d)
     dhid = torch.empty((M, F), **f32)
-    gemm_nt(dffo, d, transpose(w["w2"], d, F), dhid, F, M, F, d, mask=hid, ldm=F)
+    gemm_nt(dffo, d, Transposed(w["w2"], d, F), dhid, F, M, F, d, mask=hid, ldm=F)
     if drop is not None:
         dropout_rows(dhid, F, M, F, drop.key(layer, Drop.FF_INNER), p, out=dhid, ldo=F)
     with side_stream(dev, dffo, hd, dhid, n2):
@@ -682,7 +712,7 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
         gemm_tn(dhid, F, n2, d, g["w1"], M, F, d)
         g["b1"] = colsum(dhid, F, M, F)
     dn2 = torch.empty((M, d), **f32)
-    gemm_nt(dhid, F, transpose(w["w1"], F, d), dn2, d, M, d, F, residual=du3, ldr=d)
+    gemm_nt(dhid, F, Transposed(w["w1"], F, d), dn2, d, M, d, F, residual=du3, ldr=d)
     du2, g["ln2g"], g["ln2b"], cs2 = _ln_bwd_sums(dn2, c["xh2"], c["rs2"], w["ln2g"], M, d)
     g["cab"] = cs2 if drop is None else colsum(dropout_rows(du2, d, M, d, drop.key(layer, Drop.CA_OUT), p), d, M, d)
     du1, g["ln1g"], g["ln1b"], cs1 = _ln_bwd_sums(du2, c["xh1"], c["rs1"], w["ln1g"], M, d)
@@ -692,7 +722,7 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
         dsa = dropout_rows(du1, d, M, d, drop.key(layer, Drop.SA_OUT), p)
         g["bo"] = colsum(dsa, d, M, d)
     dattn = torch.empty((M, d), **f32)
-    gemm_nt(dsa, d, transpose(w["wo"], d, d), dattn, d, M, d, d)
+    gemm_nt(dsa, d, Transposed(w["wo"], d, d), dattn, d, M, d, d)
     with side_stream(dev, dsa):
         g["wo"] = torch.empty((d, d), **f32)
         gemm_tn(dsa, d, attn_ptr, lda, g["wo"], M, d, d)

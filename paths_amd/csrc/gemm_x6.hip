@@ -484,6 +484,32 @@ __global__ void x6_pack_kernel(const float* __restrict__ w, int64_t ldw, uint16_
   }
 }
 
+// The same image from the TRANSPOSED source: element (n, k) = w[k * ldw + n] (w is [Kvalid, N] row-major; k >= Kvalid and n >= N are zero).
+// One thread per (n, eight consecutive k): eight reads coalesced across the lanes' n, one 16-byte write per plane.  The dX products of the
+// backward (dX = dY W) take W^T as their weight: this replaces a transpose launch + a pack launch per product by one.
+template <int NP>
+__global__ void x6_pack_t_kernel(const float* __restrict__ w, int64_t ldw, uint16_t* __restrict__ out, int N, int Npad, int K, int Kvalid) {
+  static_assert(NP == 3 || NP == 4, "bf16 planes (scale 1)");
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Npad * (K >> 3)) return;
+  const int n = (int)(i % Npad), k0 = (int)(i / Npad) * 8;
+  uint16_t h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = k0 + j;
+    const float v = (n < N && k < Kvalid) ? w[(int64_t)k * ldw + n] : 0.f;
+    const __bf16 hh = (__bf16)v; const float r1 = v - (float)hh;
+    const __bf16 mm = (__bf16)r1; const float r2 = r1 - (float)mm;
+    const __bf16 ll = (__bf16)r2;
+    h[j] = __builtin_bit_cast(uint16_t, hh); m[j] = __builtin_bit_cast(uint16_t, mm); l[j] = __builtin_bit_cast(uint16_t, ll);
+  }
+  uint16_t* o = out + ((int64_t)(n >> 5) * (K >> 4) + (k0 >> 4)) * (subt<NP>() / 2) + ((k0 >> 3) & 1) * 256 + (n & 31) * 8;
+  typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+  *reinterpret_cast<u16x8*>(o) = u16x8{h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]};
+  *reinterpret_cast<u16x8*>(o + FRAG / 2) = u16x8{m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]};
+  if constexpr (NP == 3) *reinterpret_cast<u16x8*>(o + FRAG) = u16x8{l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7]};
+}
+
 template <int NP, int WTM, int WTN, int PF, bool ADD, bool ROWS, class Epi, int OCC = 1>
 int launch_x6_np(const X6Operands& g, int Npad, const Epi& epi, hipStream_t stream, const char* name) {
   constexpr int BM = WTM * 64, BN = WTN * 64;
@@ -618,6 +644,20 @@ int paths_x6_pack_weights(const float* w, int64_t ldw, void* out, int N, int Npa
   else if (planes == 3) hipLaunchKernelGGL(x6_pack_kernel<3>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, 1.0f);
   else hipLaunchKernelGGL(x6_pack_kernel<2>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, w_scale);
   PATHS_LAUNCH_CHECK("x6_pack_weights");
+  return PATHS_OK;
+}
+
+// The image of W^T from W: w is [Kvalid, N] fp32 (row stride ldw), the packed weight is its transpose [N, K] with zero rows n >= N and
+// zero columns k >= Kvalid (K % 16 == 0); planes 3 or 4 (bf16, scale 1).
+int paths_x6_pack_weights_t(const float* w, int64_t ldw, void* out, int N, int Npad, int K, int Kvalid, int planes, hipStream_t stream) {
+  PATHS_REQUIRE(N > 0 && Npad >= N && Npad % 32 == 0 && K % 16 == 0 && Kvalid > 0 && Kvalid <= K, "x6_pack_weights_t: bad shape N=%d Npad=%d K=%d Kvalid=%d", N, Npad, K, Kvalid);
+  PATHS_REQUIRE(w != nullptr && out != nullptr && (uintptr_t)out % 16 == 0, "x6_pack_weights_t: null / unaligned operand");
+  PATHS_REQUIRE(planes == 3 || planes == 4, "x6_pack_weights_t: planes 3 or 4 (bf16)");
+  const int64_t n = (int64_t)Npad * (K / 8);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (planes == 4) hipLaunchKernelGGL(x6_pack_t_kernel<4>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, Kvalid);
+  else hipLaunchKernelGGL(x6_pack_t_kernel<3>, grid, dim3(256), 0, stream, w, ldw, reinterpret_cast<uint16_t*>(out), N, Npad, K, Kvalid);
+  PATHS_LAUNCH_CHECK("x6_pack_weights_t");
   return PATHS_OK;
 }
 
