@@ -59,6 +59,17 @@ def transpose(w: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, o
     return out
 
 
+def zeros_group(dev, *shapes):
+    """Several zero-filled fp32 tensors from ONE fill launch (each starts on a 256-byte boundary of one buffer)."""
+    sizes = [math.prod(int(v) for v in sh) for sh in shapes]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 63) // 64 * 64
+    buf = torch.zeros((tot,), **_f32(dev))
+    return [buf[o:o + n].view(*sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
 class Transposed:
     """``transpose(w, rows, cols, ld, offset, pad_to)`` not yet materialised: the weight of a dX product (dX = dY W takes W^T).  The
     split-bf16 GEMM images it straight from ``w`` (paths_x6_pack_weights_t: one launch instead of a transpose + a pack); every other
@@ -811,8 +822,7 @@ def transformer_forward_train(mc, lvl_pack, tokens, num_ims, ctx_prev, drop: Opt
     token_layer(x, None, None, layers[0], None, q, k, v)
     sv["drop"] = drop
     for l in range(L - 1):
-        attn = torch.zeros((B, T, d), **f32)
-        lse = torch.zeros((B, H, T), **f32)
+        attn, lse = zeros_group(q.device, (B, T, d), (B, H, T))
         q2, k2, v2 = (torch.empty((B, H, T, hd), **f32) for _ in range(3))
         if drop is None:
             attention(q, k, v, attn, lse, num_ims, B, T, H, hd, 0)
@@ -905,8 +915,7 @@ def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, 
     x = tokens
     qkv = in_proj(x, layers[0])
     for l in range(L - 1):
-        attn = torch.zeros((B, T, d), **f32)
-        lse = torch.zeros((B, H, T), **f32)
+        attn, lse = zeros_group(dev, (B, T, d), (B, H, T))
         _attention_generic(qkv, attn, lse, num_ims, B, T, H, hd, qscale, 0, drop, l)
         chain = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, M, dev, drop, l)
         x_out = chain["x3"].view(B, T, d)
@@ -914,8 +923,7 @@ def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, 
         x, qkv = x_out, in_proj(x_out, layers[l + 1])
     # last layer: only token 0 of its output is read (reference model/aggregator.py:75)
     w = layers[L - 1]
-    attn0 = torch.zeros((B, T, d), **f32)
-    lse0 = torch.zeros((B, H, T), **f32)
+    attn0, lse0 = zeros_group(dev, (B, T, d), (B, H, T))
     _attention_generic(qkv, attn0, lse0, num_ims, B, T, H, hd, qscale, 1, drop, L - 1)
     chain0 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)
     x3 = chain0["x3"]
@@ -1005,7 +1013,7 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
 
     # ---- last layer, token 0 only
     g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, a0_ptr, a0_ld, B, dx3, dev, drop, L - 1, saved=chain0)
-    dqkv = torch.zeros((B, T, 3 * d), **f32)
+    dqkv, dx = zeros_group(dev, (B, T, 3 * d), (B, T, d))                       # (dx: gradient of the last layer's input)
     if fast:
         ws = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), **f32)
         _lib.call("paths_attention_token0_bwd", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(lse0), P(num_ims), P(dqkv), P(ws),
@@ -1015,7 +1023,6 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         d_o[:, 0, :] = da0
         ws = torch.empty((B * H * T,), **f32)
         _attention_bwd_generic(last["qkv"], attn0, d_o, last["lse0"], num_ims, dqkv, ws, B, T, H, hd, d, qscale, 1, dk(L - 1))
-    dx = torch.zeros((B, T, d), **f32)                                       # gradient of the last layer's input
     dx[:, 0, :] = dx0
     g.update(qkv_backward(wl, x_last, dqkv, B * T, qscale, dx, fold_qscale=fast))
     grads["layers"][L - 1] = g
