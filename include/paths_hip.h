@@ -46,6 +46,13 @@ void* paths_event_create(void);
 void* paths_stream_create_masked(const uint32_t* cu_mask, int words);
 int paths_event_destroy(void* event);
 int paths_stream_wait(paths_stream_t dst, paths_stream_t src, void* event);
+/* Stop events: paths_set_stop_event(ev) makes the next stop-capable launch of this host thread (the importance / projection finish
+ * kernel of paths_importance_proj_x6, the kernel of paths_topk / paths_topk_rows) carry ev as its completion event - no event-record
+ * packet of its own in the launching queue; paths_flush_stop_event(src) records it on src the ordinary way if no launch took it;
+ * paths_stream_wait_event(dst, ev): dst waits for ev. */
+int paths_set_stop_event(void* event);
+int paths_flush_stop_event(paths_stream_t src);
+int paths_stream_wait_event(paths_stream_t dst, void* event);
 int paths_memset_zero(void* p, size_t bytes, paths_stream_t stream);
 
 /* LSTMCell.forward over depth + residual (reference model/interface.py:31-58, model/paths.py:78-91).

@@ -111,6 +111,9 @@ SIGNATURES = {
     "paths_attention_bwd_x6_dropout": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _vp],
     "paths_attention_bwd_x6_planes": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _u64, _f32, _i32, _vp],
     "paths_stream_wait": [_vp, _vp, _vp],
+    "paths_set_stop_event": [_vp],
+    "paths_flush_stop_event": [_vp],
+    "paths_stream_wait_event": [_vp, _vp],
     "paths_event_destroy": [_vp],
     "paths_memset_zero": [_vp, C.c_size_t, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
@@ -193,6 +196,45 @@ def stream_wait(dst: "torch.cuda.Stream", src: "torch.cuda.Stream"):
         ev = pool[0][pool[1]]
         pool[1] += 1
         TAPE.append((lib.paths_stream_wait, (dst.cuda_stream, src.cuda_stream, ev), "paths_stream_wait"))
+
+
+STOP_EVENTS = __import__("os").environ.get("PATHS_STOP_EVENTS", "1") != "0"
+
+
+class fork_behind:
+    """``with fork_behind([dst...], src): <launches on src>`` - afterwards every ``dst`` waits for what ran on ``src``.  While a
+    launch tape is recorded the join travels as a STOP EVENT of the block's stop-capable kernel (include/paths_hip.h:
+    paths_set_stop_event; the finish kernel of the importance / projection GEMM, the top-K kernel) instead of an event record behind it;
+    otherwise (eager launches, or PATHS_STOP_EVENTS=0) it is :func:`stream_wait` per destination."""
+
+    def __init__(self, dsts, src):
+        self.dsts, self.src = list(dsts), src
+        self.ev = None
+
+    def __enter__(self):
+        if TAPE is not None and STOP_EVENTS:
+            lib = load()
+            pool = TAPE_EVENTS if TAPE_EVENTS is not None else [[], 0]
+            if pool[1] == len(pool[0]):
+                e = lib.paths_event_create()
+                if not e:
+                    raise PathsHipError("paths_event_create failed")
+                pool[0].append(e)
+            self.ev = pool[0][pool[1]]
+            pool[1] += 1
+            call("paths_set_stop_event", self.ev)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.ev is not None:
+            call("paths_flush_stop_event", self.src.cuda_stream)
+            if et is None:
+                for d in self.dsts:
+                    call("paths_stream_wait_event", d.cuda_stream, self.ev)
+        elif et is None:
+            for d in self.dsts:
+                stream_wait(d, self.src)
+        return False
 
 
 def zeros(shape, **kw) -> torch.Tensor:

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libpaths_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -20,6 +21,18 @@ int paths_set_error(int code, const char* fmt, ...);
 #define PATHS_REQUIRE(cond, ...)                                     \
   do {                                                               \
     if (!(cond)) return paths_set_error(PATHS_EINVAL, __VA_ARGS__);  \
+  } while (0)
+
+// A launch that carries the host thread's pending STOP EVENT, if one was set (paths_set_stop_event): the event is attached to the
+// kernel's own completion signal (hipExtLaunchKernelGGL) instead of being recorded as a packet of its own behind it - an event record
+// costs the launching queue ~8 us before its next kernel starts (profiles/r04_experiments.md, selection-queue timeline), and the
+// recursion forks twice per level from its critical queue (tokens ready -> aggregator; top-K ready -> child expansion).
+hipEvent_t paths_take_stop_event(void);      // runtime.hip: returns and clears this thread's pending event (nullptr: none)
+#define PATHS_LAUNCH_STOP(kern, grid, block, lds, stream, ...)                                                  \
+  do {                                                                                                          \
+    hipEvent_t ev_ = paths_take_stop_event();                                                                   \
+    if (ev_ != nullptr) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, ev_, 0, __VA_ARGS__);   \
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                       \
   } while (0)
 
 #define PATHS_LAUNCH_CHECK(name)                                                              \

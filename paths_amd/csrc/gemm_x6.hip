@@ -778,11 +778,11 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
         PATHS_LDS_OPT_IN((x6_finish_kernel<2, decltype(epi)>), 84 * 1024, "importance_proj_x6(finish)");
         PATHS_LDS_OPT_IN((x6_finish_kernel<1, decltype(epi)>), 84 * 1024, "importance_proj_x6(finish)");
         if (IP_TILE128)
-          hipLaunchKernelGGL((x6_finish_kernel<1, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
-                             skip_padding ? num_ims : nullptr, rows_per_slide, e);
+          PATHS_LAUNCH_STOP((x6_finish_kernel<1, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
+                            skip_padding ? num_ims : nullptr, rows_per_slide, e);
         else
-          hipLaunchKernelGGL((x6_finish_kernel<2, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
-                             skip_padding ? num_ims : nullptr, rows_per_slide, e);
+          PATHS_LAUNCH_STOP((x6_finish_kernel<2, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
+                            skip_padding ? num_ims : nullptr, rows_per_slide, e);
         PATHS_LAUNCH_CHECK("importance_proj_x6(finish)");
         return PATHS_OK;
       }

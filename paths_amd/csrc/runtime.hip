@@ -3,6 +3,8 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+static thread_local hipEvent_t g_stop_event = nullptr;
+hipEvent_t paths_take_stop_event(void) { hipEvent_t ev = g_stop_event; g_stop_event = nullptr; return ev; }
 
 int paths_set_error(int code, const char* fmt, ...) {
   va_list ap;
@@ -36,6 +38,26 @@ int paths_stream_wait(hipStream_t dst, hipStream_t src, void* event) {
   PATHS_REQUIRE(event != nullptr, "stream_wait: null event");
   if (hipEventRecord(static_cast<hipEvent_t>(event), src) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "stream_wait: hipEventRecord failed");
   if (hipStreamWaitEvent(dst, static_cast<hipEvent_t>(event), 0) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "stream_wait: hipStreamWaitEvent failed");
+  return PATHS_OK;
+}
+// ---- stop events (common.h: PATHS_LAUNCH_STOP).  paths_set_stop_event(ev): the next stop-capable launch of this host thread (the
+// importance / projection finish kernel, the top-K kernel) carries `ev` as its completion event; paths_flush_stop_event(src): if no
+// launch took it, it is recorded on `src` the ordinary way (so a waiter never waits on an event nobody recorded);
+// paths_stream_wait_event(dst, ev): dst waits for ev.
+int paths_set_stop_event(void* event) {
+  PATHS_REQUIRE(event != nullptr, "set_stop_event: null event");
+  g_stop_event = static_cast<hipEvent_t>(event);
+  return PATHS_OK;
+}
+int paths_flush_stop_event(hipStream_t src) {
+  hipEvent_t ev = g_stop_event;
+  g_stop_event = nullptr;
+  if (ev != nullptr && hipEventRecord(ev, src) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "flush_stop_event: hipEventRecord failed");
+  return PATHS_OK;
+}
+int paths_stream_wait_event(hipStream_t dst, void* event) {
+  PATHS_REQUIRE(event != nullptr, "stream_wait_event: null event");
+  if (hipStreamWaitEvent(dst, static_cast<hipEvent_t>(event), 0) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "stream_wait_event: hipStreamWaitEvent failed");
   return PATHS_OK;
 }
 // A HIP stream restricted to the compute units whose bits are set in cu_mask (words x 32 bits; hipExtStreamCreateWithCUMask): the

@@ -93,8 +93,8 @@ static int launch_topk(const float* scores, int64_t ld, const int64_t* num_ims, 
   PATHS_LDS_OPT_IN(topk_rank_kernel, (TOPK_MAX + 2) * 8 + 1024, "topk");
   // x covers every element AND every position of the kept-row table (ldk may exceed n_max only through padding; both <= TOPK_MAX)
   const int cover = (int)(ldk > n_max ? ldk : n_max);
-  hipLaunchKernelGGL(topk_rank_kernel, dim3((cover + 63) / 64, B), dim3(256), lds, stream, scores, ld, num_ims, keep, keep_idx, ldk,
-                     keep_count, row_base, row_ld, slide_rows, kept_rows, zero_row);
+  PATHS_LAUNCH_STOP(topk_rank_kernel, dim3((cover + 63) / 64, B), dim3(256), lds, stream, scores, ld, num_ims, keep, keep_idx, ldk,
+                    keep_count, row_base, row_ld, slide_rows, kept_rows, zero_row);
   return 0;
 }
 

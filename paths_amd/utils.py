@@ -432,7 +432,9 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
             _lib.stream_wait(main_stream, par_stream)     # this level's rows / bookkeeping from the expansion branch are ready
             fork_pending = False
         imp_buf = imp_all[imp_off[i]:imp_off[i] + B * N].view(B, N) if N == sizes[i] else None
-        with _Range(f"level {i}: selection chain (LSTM gates, importance, projection)"):
+        # (the aggregator's fork travels as the stop event of the chain's last kernel where that kernel can carry one: _lib.fork_behind)
+        with _Range(f"level {i}: selection chain (LSTM gates, importance, projection)"), \
+                (_lib.fork_behind([side_stream], main_stream) if overlap else contextlib.nullcontext()):
             sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
                                         max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf)
         def aggregate():
@@ -440,8 +442,7 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
             return ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status)
 
-        if overlap:
-            _lib.stream_wait(side_stream, main_stream)    # tokens / num_ims of this level are ready
+        if overlap:                                       # (side_stream already waits for this level's tokens / num_ims: fork_behind above)
             keepalive.append((sel["tokens"], sel["num_ims"]))
             with torch.cuda.stream(side_stream), _Range(f"level {i}: aggregator (second stream)"):
                 agg = aggregate()
@@ -462,20 +463,19 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         keep_idx = torch.empty((B, cap_keep), **i32)
         keep_count = torch.empty((B,), **i32)
         kept_rows = None
-        if rows_in_place:
-            # ... with the addresses of the kept parents' h rows (row b, i -> ctx_patch[b, keep_idx[b, i], :D]) for the parent GEMM
-            kept_rows = torch.empty((B, cap_keep), **i64)
-            ops.timed("topk", lambda: _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep,
-                                                p(keep_count), p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st))
-        else:
-            _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
-        Nn = 4 * cap_keep
         # After the top-K the chain forks: the kept parents' h-partials (gather + GEMM, the longer branch) stay on this stream,
         # the child expansion and the row gathers (tiny latency-bound kernels) run beside them on a third stream and are joined
-        # before the next level's gate GEMMs.
+        # before the next level's gate GEMMs.  (The fork travels as the top-K kernel's stop event: _lib.fork_behind.)
         forked = overlap and par_stream is not None and share_parent
-        if forked:
-            _lib.stream_wait(par_stream, main_stream)      # top-K indices are ready
+        with (_lib.fork_behind([par_stream], main_stream) if forked else contextlib.nullcontext()):
+            if rows_in_place:
+                # ... with the addresses of the kept parents' h rows (row b, i -> ctx_patch[b, keep_idx[b, i], :D]) for the parent GEMM
+                kept_rows = torch.empty((B, cap_keep), **i64)
+                ops.timed("topk", lambda: _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep,
+                                                    p(keep_count), p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st))
+            else:
+                _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
+        Nn = 4 * cap_keep
         hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count, kept_rows) if share_parent else None
         st2 = par_stream.cuda_stream if forked else st
         with (torch.cuda.stream(par_stream) if forked else contextlib.nullcontext()):
