@@ -24,7 +24,11 @@ int paths_abi_version(void) { return 1; }
 // An event handle for paths_stream_wait (host object, created once per join of a tape, destroyed by paths_event_destroy).
 void* paths_event_create(void) {
   hipEvent_t ev = nullptr;
-  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { paths_set_error(PATHS_ELAUNCH, "event_create failed"); return nullptr; }
+  // (device-side joins of streams of ONE device only: no system-scope fence when the event is recorded - the kernel that carries it as its
+  // stop event would otherwise end with a release to the system.  PATHS_EVENT_FLAGS overrides, for A/B runs.)
+  static const unsigned flags = getenv("PATHS_EVENT_FLAGS") ? (unsigned)strtoul(getenv("PATHS_EVENT_FLAGS"), nullptr, 0)
+                                                            : (hipEventDisableTiming | hipEventDisableSystemFence);
+  if (hipEventCreateWithFlags(&ev, flags) != hipSuccess) { paths_set_error(PATHS_ELAUNCH, "event_create failed"); return nullptr; }
   return ev;
 }
 // Destroy an event made by paths_event_create (the launch tape destroys its events when it is closed / collected).
