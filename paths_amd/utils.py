@@ -388,8 +388,6 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
     f32 = dict(device=dev, dtype=torch.float32)
 
     grid_ptrs, mask_ptrs, gx, gy = batch.grid_ptrs, batch.mask_ptrs, batch.gx, batch.gy
-    status = _lib.zeros(1, **i32)
-
     N = batch.n0
     lstm_pack = ops.pack_lstm(model.lstm) if model.use_lstm else None
     share_parent = model.use_lstm          # siblings share the parent's h: h-half of the gate GEMM once per kept parent
@@ -422,7 +420,10 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         if i < num_levels - 1:
             keep = int(keep_patches[i])
             n_l = 4 * (n_l if keep < 0 else min(n_l, keep))
-    imp_all = _lib.zeros((B * sum(sizes),), **f32)
+    # (the status word rides on the same zero fill as the importance rows: one fill launch per step instead of two at its head)
+    zbuf = _lib.zeros((B * sum(sizes) + 64,), **f32)
+    imp_all = zbuf[:B * sum(sizes)]
+    status = zbuf[B * sum(sizes) + 32:B * sum(sizes) + 33].view(torch.int32)
     imp_off = [B * sum(sizes[:i]) for i in range(num_levels)]
     fork_pending = False
     for i in range(num_levels):
