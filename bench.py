@@ -76,6 +76,18 @@ def host_cpu_share() -> int:
     return max(1, min(n, int(os.environ.get("PATHS_CPU_THREADS", "16"))))
 
 
+def host_cpu_share_all() -> int:
+    """:func:`host_cpu_share` without the 16-thread cap: every core the job may use (self-launch splits them among its ranks)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def build_model(K: int, dev, dropout=None):
     from paths_amd import synthetic as syn
     from paths_amd.config import Config
@@ -152,25 +164,23 @@ def parity_check(cfg, model, K, ids, otrace, ohz, dev):
     return res
 
 
-def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
-    """Extra line (BASELINE.json configs[4] geometry): ONE level over K = 8192 patches of d = 1536 features per slide = full
-    quadratic attention over 8193 tokens, on the split-operand fp32-accurate kernels (the fp8 MFMA variant that config names
-    is not built; tests/test_gpu_parity.py::test_stress_shape_k8192_d1536_single_level_vs_oracle checks this shape)."""
+def stress_measure(trans_dim, trans_heads, fp8, steps, warmup, spg, rank, world, dev, dev_reduce, pdist, putils):
+    """BASELINE.json configs[4] geometry: ONE level over K = 8192 patches of d = 1536 features per slide = full quadratic attention
+    over 8193 tokens.  Measures the fp32-accurate (parity) path and, with ``fp8``, the opt-in e4m3 variants (whole aggregator; at
+    trans_dim 128 / 4 heads also attention only) with their logit distance from the accurate path.  Returns a dict."""
+    from paths_amd import ops
     from paths_amd import synthetic as syn
     from paths_amd.config import Config
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     cfg = Config.load(os.path.join(ROOT, "tests", "golden", "sample"), test_mode=True)
     cfg.model_config.patch_embed_dim, cfg.num_levels, cfg.top_k_patches = 1536, 1, []
-    cfg.model_config.trans_dim, cfg.model_config.trans_heads = args.trans_dim, args.trans_heads
+    cfg.model_config.trans_dim, cfg.model_config.trans_heads = trans_dim, trans_heads
     model = cfg.get_model()
     sd = syn.make_state_dict(0, {k: tuple(v.shape) for k, v in model.state_dict().items()})
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model = model.to(dev).eval()
-    spg = args.slides_per_gpu
     slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, rank * spg + i, (64, 128), dim=1536, num_levels=1, device=dev)
                                for i in range(spg)])
-
-    from paths_amd import ops
 
     def step():
         with torch.no_grad():
@@ -180,7 +190,7 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
         torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
 
     def timed_run():
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         barrier()
         ev = []
@@ -195,11 +205,13 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
 
         ops.KERNEL_TIMER, ops.TIMER_ALL = timer, True
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out_ = step()
-        barrier()
+        try:
+            for _ in range(steps):
+                out_ = step()
+            barrier()
+        finally:
+            ops.KERNEL_TIMER, ops.TIMER_ALL = None, False
         el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
-        ops.KERNEL_TIMER, ops.TIMER_ALL = None, False
         assert int(out_["status"].item()) == 0
         att = [e0.elapsed_time(e1) * 1e3 for n, e0, e1 in ev if n == "agg_attention"]
         agg = [e0.elapsed_time(e1) * 1e3 for n, e0, e1 in ev if n == "aggregator"]
@@ -208,60 +220,78 @@ def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
 
     elapsed, logits, attn_us = timed_run()
     agg_us = timed_run.agg_us
-    T_, d_, L_ = 8193, args.trans_dim, cfg.model_config.trans_layers
+    T_, d_, L_ = 8193, trans_dim, cfg.model_config.trans_layers
     # algorithmic FLOPs of the aggregator per step and GPU (24 T d^2 + 4 T^2 d per layer, degenerate cross-attention 0)
     agg_flops = spg * L_ * (24 * T_ * d_ * d_ + 4 * T_ * T_ * d_)
     fp8_agg = None
-    if args.fp8 and ops.fp8_supported(cfg.model_config):
+    if fp8 and ops.fp8_supported(cfg.model_config):
         # the whole aggregator's big products in e4m3 (csrc/gemm_fp8.hip + csrc/attn_fp8.hip): in_proj, the full layers' attention,
         # out_proj and the feed-forward pair; the first (warm-up) step calibrates the hidden layer's scale
         ops.AGG_FP8 = True
-        el8, logits8, _ = timed_run()
+        try:
+            el8, logits8, _ = timed_run()
+        finally:
+            ops.AGG_FP8 = False
         agg8_us = timed_run.agg_us
-        ops.AGG_FP8 = False
         diff = float((logits8 - logits).abs().max())
-        fp8_agg = {"slides_per_s": round(spg * world * args.steps / el8, 2), "ms_per_step": round(el8 / args.steps * 1e3, 3),
+        fp8_agg = {"slides_per_s": round(spg * world * steps / el8, 2), "ms_per_step": round(el8 / steps * 1e3, 3),
                    "aggregator_us": round(agg8_us, 1) if agg8_us else None, "aggregator_us_accurate_path": round(agg_us, 1) if agg_us else None,
                    "max_logit_diff_vs_accurate_path": diff, "meets_1e-4_logit_bar": bool(diff <= 1e-4),
                    "what": "in_proj, full-layer attention, out_proj, linear1 / linear2 with e4m3 operands and per-tensor scales "
-                           "(v_mfma_scale_f32_32x32x64_f8f6f4 GEMMs, 16x16x32 fp8 attention); LayerNorm, residuals, the last layer's "
+                           "(v_mfma_scale_f32_32x32x64_f8f6f4 GEMMs, fp8 attention); LayerNorm, residuals, the last layer's "
                            "token-0 row chain, the classifier and the whole selection chain (LSTM, importance, top-K) in fp32",
                    "roofline": None if not agg8_us else {
                        "bound": "mfma", "achieved": round(agg_flops / (agg8_us * 1e-6) / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
                        "frac": round(agg_flops / (agg8_us * 1e-6) / 1e12 / 5000.0, 4),
                        "note": "algorithmic aggregator FLOPs (L (24 T d^2 + 4 T^2 d) per slide) / event-timed aggregator span, against "
                                "the dense fp8 MFMA peak; the last layer runs at token 0 only, so the executed share is smaller"}}
-    fp8 = None
-    if args.fp8 and args.trans_dim == 128 and args.trans_heads == 4:
+    fp8_att = None
+    if fp8 and trans_dim == 128 and trans_heads == 4:
         # the e4m3 attention variant (csrc/attn_fp8.hip) on the same batch: its speed AND its distance from the fp32-accurate logits
         ops.ATTN_FP8 = True
-        el8, logits8, attn8_us = timed_run()
-        ops.ATTN_FP8 = False
-        T_, d_ = 8193, 128
-        afl = spg * 4 * T_ * T_ * d_                                           # the full attention of layer 0, per launch
-        fp8 = {"slides_per_s": round(spg * world * args.steps / el8, 2), "ms_per_step": round(el8 / args.steps * 1e3, 3),
-               "attention_us": round(attn8_us, 1), "attention_us_split_path": round(attn_us, 1),
-               "max_logit_diff_vs_split_path": float((logits8 - logits).abs().max()),
-               "meets_1e-4_logit_bar": bool(float((logits8 - logits).abs().max()) <= 1e-4),
-               "roofline": {"bound": "mfma", "achieved": round(afl / (attn8_us * 1e-6) / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
-                            "frac": round(afl / (attn8_us * 1e-6) / 1e12 / 5000.0, 4),
-                            "note": "algorithmic 4 T^2 d FLOPs of the one full attention launch / its event-timed duration, against the "
-                                    "dense fp8 MFMA peak; head_dim 32 gives one 16x16x32 k-step per score tile, the loop is exp2 / "
-                                    "conversion (VALU) bound"}}
+        try:
+            el8, logits8, attn8_us = timed_run()
+        finally:
+            ops.ATTN_FP8 = False
+        afl = spg * 4 * 8193 * 8193 * 128                                      # the full attention of layer 0, per launch
+        fp8_att = {"slides_per_s": round(spg * world * steps / el8, 2), "ms_per_step": round(el8 / steps * 1e3, 3),
+                   "attention_us": round(attn8_us, 1), "attention_us_split_path": round(attn_us, 1),
+                   "max_logit_diff_vs_split_path": float((logits8 - logits).abs().max()),
+                   "meets_1e-4_logit_bar": bool(float((logits8 - logits).abs().max()) <= 1e-4),
+                   "roofline": {"bound": "mfma", "achieved": round(afl / (attn8_us * 1e-6) / 1e12, 1), "peak": 5000.0, "unit": "TFLOP/s",
+                                "frac": round(afl / (attn8_us * 1e-6) / 1e12 / 5000.0, 4),
+                                "note": "algorithmic 4 T^2 d FLOPs of the one full attention launch / its event-timed duration, against the "
+                                        "dense fp8 MFMA peak; head_dim 32 gives one 16x16x32 k-step per score tile, the loop is exp2 / "
+                                        "conversion (VALU) bound"}}
+    del model, slides
+    torch.cuda.empty_cache()
+    return {"slides_per_s": round(spg * world * steps / elapsed, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "trans_dim": trans_dim, "trans_heads": trans_heads, "slides_per_gpu": spg,
+            "attn_ffn_flops_per_step": agg_flops * world, "attention_us": round(attn_us, 1) if attn_us else None,
+            "aggregator_us": round(agg_us, 1) if agg_us else None,
+            "aggregator_frac_of_fp32_product_peak": round(agg_flops / (agg_us * 1e-6) / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 3), 4) if agg_us else None,
+            "fp8_attention": fp8_att, "fp8_aggregator": fp8_agg}
+
+
+def stress_bench(args, rank, world, dev, dev_reduce, pdist, putils):
+    """Extra line (BASELINE.json configs[4] geometry): ONE level over K = 8192 patches of d = 1536 features per slide = full
+    quadratic attention over 8193 tokens, on the split-operand fp32-accurate kernels; --fp8 adds the opt-in e4m3 variants
+    (tests/test_gpu_parity.py::test_stress_shape_k8192_d1536_single_level_vs_oracle checks this shape on the accurate path)."""
+    spg = args.slides_per_gpu
+    m = stress_measure(args.trans_dim, args.trans_heads, args.fp8, args.steps, args.warmup, spg, rank, world, dev, dev_reduce, pdist, putils)
     if rank == 0:
-        flops = agg_flops * world                                             # attention + FFN, per step
         print(json.dumps({
-            "metric": "stress_slides_per_sec_1level_K8192_D1536", "value": round(spg * world * args.steps / elapsed, 2),
+            "metric": "stress_slides_per_sec_1level_K8192_D1536", "value": m["slides_per_s"],
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (two fp16 planes per operand, fp32 accumulate) - the parity path; 'fp8_attention' (--fp8) is the opt-in "
                      "e4m3 attention variant of BASELINE configs[4], outside the 1e-4 logit bar",
             "data": "synthetic",
             "config": {"workload": f"single level, 8192 patches x 1536 features per slide, {spg} slides per GPU, full quadratic "
                                    f"attention over 8193 tokens (BASELINE.json configs[4] geometry), trans_dim {args.trans_dim} / "
                                    f"{args.trans_heads} heads", "global_batch": spg * world},
-            "attn_ffn_flops_per_step": flops, "attention_us": round(attn_us, 1) if attn_us else None,
-            "aggregator_us": round(agg_us, 1) if agg_us else None, "fp8_attention": fp8, "fp8_aggregator": fp8_agg}), flush=True)
+            "attn_ffn_flops_per_step": m["attn_ffn_flops_per_step"], "attention_us": m["attention_us"],
+            "aggregator_us": m["aggregator_us"], "fp8_attention": m["fp8_attention"], "fp8_aggregator": m["fp8_aggregator"]}), flush=True)
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()
@@ -335,6 +365,31 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
         dist.destroy_process_group()
 
 
+def k1024_probe(model, cfg, spg, rank, world, dev, dev_reduce, pdist, putils, steps: int):
+    """BASELINE.json configs[1] ("5-level PATHS, K=1024 patches/level, d=1024, 1 x MI355X"): the headline's launch mode (recorded
+    tape) on this rank's own resident K = 1024 slides; whole-job slides/s."""
+    from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
+    K1 = 1024
+    keep = [K1 // 4] * (cfg.num_levels - 1)
+    batch = DeviceSlideBatch([DeviceSlide.synthetic(1234, 200000 + rank * spg + i, BASE_SHAPES[K1], device=dev) for i in range(spg)])
+    tape = putils.TapedRecursion(model, batch, keep, cfg.num_levels).record()
+    for _ in range(3):
+        tape.replay()
+    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tape.replay()
+    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+    el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
+    assert int(out["status"].item()) == 0
+    tape.close()
+    del tape, batch
+    torch.cuda.empty_cache()
+    return {"slides_per_s": round(spg * world * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+            "workload": f"5-level recursion, K=1024 patches/level (level-0 grid 32x32, top_k 256), D=1024, {spg} resident slides per GPU, "
+                        "launch tape replay (BASELINE.json configs[1]); parity at this size: tests/test_gpu_parity.py::test_headline_recursion_vs_oracle[1024]"}
+
+
 def self_launch(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher (no RANK / WORLD_SIZE in the environment): the parent - BEFORE any
     torch.cuda call, it never touches the GPU - starts N fresh child processes of this script, one per device, with the
@@ -350,7 +405,12 @@ def self_launch(n: int) -> int:
         # fewer devices than ranks: a rehearsal (ranks share devices), RCCL refuses two ranks of one communicator on one device
         env["PATHS_DIST_BACKEND"] = "gloo"
         log(f"self-launch: {torch.cuda.device_count()} device(s) for {n} ranks - rehearsal over gloo")
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+    argv = list(sys.argv[1:])
+    if not any(a == "--cores-per-rank" or a.startswith("--cores-per-rank=") for a in argv) and hasattr(os, "sched_getaffinity"):
+        # default: every child pinned to its own 1/N of this process's host cores (N ranks x unpinned torch / HIP runtime threads on
+        # one host share is the remaining risk for a host-paced training step); --cores-per-rank overrides
+        argv += ["--cores-per-rank", str(max(1, host_cpu_share_all() // n))]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
              for r in range(n)]
     rc = 0
     try:
@@ -452,6 +512,10 @@ def main():
                     "on different rows than the step before), the single-batch replay figure is reported beside it")
     ap.add_argument("--train-steps", type=int, default=10, help="infer mode: timed steps of the short training measurement added to the "
                     "line as 'train' (0 = skip); 3 warm-up steps")
+    ap.add_argument("--stress-steps", type=int, default=4, help="infer mode, N=1: timed steps of the 'stress' object (BASELINE configs[4]: one level, "
+                    "K = 8192 x d = 1536, fp32-accurate path and the opt-in e4m3 variants at trans_dim 128 / 4 heads and 1536 / 24 heads); 0 = skip")
+    ap.add_argument("--k1024-steps", type=int, default=20, help="infer mode: timed steps of the 'k1024' object (BASELINE configs[1]: the same "
+                    "5-level recursion at K = 1024 patches per level on one GPU's 8 resident slides); 0 = skip")
     ap.add_argument("--cores-per-rank", type=int, default=0, help="pin this rank to N host cores (cores [rank N, rank N + N) of the "
                     "process's allowed set) BEFORE anything touches the GPU: what a rank gets when 8 ranks share one host's CPU share "
                     "(0 = leave the affinity alone)")
@@ -861,6 +925,33 @@ def main():
         except Exception as e:       # the headline (already measured above) must not be lost to a failure of the secondary probe
             train = {"error": f"{type(e).__name__}: {e}"[:400]}
             log(f"train probe FAILED: {train['error']}")
+    # ---- BASELINE.json configs[1]: the same recursion at K = 1024 patches per level (same weights, top_k 256, level-0 grid 32 x 32)
+    k1024 = None
+    if K == 2048 and args.k1024_steps > 0:
+        try:
+            k1024 = k1024_probe(model, cfg, spg, rank, world, dev, dev_reduce, pdist, putils, args.k1024_steps)
+            log(f"k1024: {k1024['slides_per_s']} slides/s ({k1024['ms_per_step']} ms per step)")
+        except Exception as e:
+            k1024 = {"error": f"{type(e).__name__}: {e}"[:400]}
+            log(f"k1024 probe FAILED: {k1024['error']}")
+    # ---- BASELINE.json configs[4]: the stress geometry, accurate path + the opt-in e4m3 variants, so the driver's record carries it
+    stress = None
+    if world == 1 and args.stress_steps > 0:
+        try:
+            del replays, graphed, batches
+            torch.cuda.empty_cache()
+            stress = {"workload": "one level over 8192 patches x 1536 features per slide (full quadratic attention over 8193 tokens), "
+                                  f"{spg} slides per step (BASELINE.json configs[4])",
+                      "td128_h4": stress_measure(128, 4, True, args.stress_steps, 2, spg, rank, world, dev, dev_reduce, pdist, putils),
+                      "td1536_h24": stress_measure(1536, 24, True, args.stress_steps, 2, spg, rank, world, dev, dev_reduce, pdist, putils)}
+            for k_ in ("td128_h4", "td1536_h24"):
+                f8 = stress[k_].get("fp8_aggregator") or {}
+                log(f"stress {k_}: accurate {stress[k_]['ms_per_step']} ms per step, e4m3 aggregator {f8.get('ms_per_step')} ms "
+                    f"(frac of fp8 peak {(f8.get('roofline') or {}).get('frac')}, logit diff {f8.get('max_logit_diff_vs_accurate_path')})")
+        except Exception as e:
+            stress = {"error": f"{type(e).__name__}: {e}"[:400]}
+            log(f"stress probe FAILED: {stress['error']}")
+    per_rank_valid = pdist.gather_floats(float(sum(valid)))      # valid patches per step of every rank (what its step time follows)
     if rank == 0:
         total_slides = spg * world * args.steps
         line = {
@@ -868,6 +959,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "per_rank_ms_per_step": [round(v, 3) for v in per_rank], "rank_imbalance_max_over_min": round(max(per_rank) / max(min(per_rank), 1e-9), 4),
+            "per_rank_valid_patches_per_step": [int(v) for v in per_rank_valid],
             "vs_baseline": None,
             "dtype": ("f32 (products as 2 fp16 planes per operand = 22 bits, 3 fp16 MFMAs per block, fp32 accumulate)" if planes == 2 else
                       "f32 (products as 3 exact bf16 planes per operand, 6 bf16 MFMAs per block, fp32 accumulate)" if x6 else "f32"),
@@ -900,6 +992,10 @@ def main():
             line["train"] = train
         if sustained is not None:
             line["sustained"] = sustained
+        if k1024 is not None:
+            line["k1024"] = k1024
+        if stress is not None:
+            line["stress"] = stress
         if breakdown is not None:
             line["serialized_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:

@@ -36,6 +36,11 @@ typedef void* paths_stream_t; /* hipStream_t */
 
 const char* paths_last_error(void);
 const char* paths_build_info(void);
+/* 2 since round 5.  Differences a consumer built against ABI 1 must know: (a) dropout masks (paths_dropout_mask and every *_dropout /
+ * drop_key entry) are one 16-bit hash half per element - thr16 = round(p * 65536) clamped to [1, 65535] for p > 0, kept elements scaled by
+ * 1 / (1 - thr16 / 65536), attention mask rows T rounded up to even elements apart - so the same (key, p) yields other masks than ABI 1;
+ * p >= 1 is rejected by every entry point (p in (1 - 2^-16, 1) is applied as 65535 / 65536); (b) events of paths_event_create order
+ * streams of ONE device (created with hipEventDisableSystemFence): never wait for them on the host. */
 int paths_abi_version(void);
 
 /* Stream plumbing of the launch tape (paths_amd/utils.py:TapedRecursion replays a recorded recursion as a flat list of C calls;
@@ -49,9 +54,14 @@ int paths_stream_wait(paths_stream_t dst, paths_stream_t src, void* event);
 /* Stop events: paths_set_stop_event(ev) makes the next stop-capable launch of this host thread (the importance / projection finish
  * kernel of paths_importance_proj_x6, the kernel of paths_topk / paths_topk_rows) carry ev as its completion event - no event-record
  * packet of its own in the launching queue; paths_flush_stop_event(src) records it on src the ordinary way if no launch took it;
- * paths_stream_wait_event(dst, ev): dst waits for ev. */
+ * paths_stream_wait_event(dst, ev): dst waits for ev.  paths_stop_event_pending(): 1 while the armed event has not been taken;
+ * paths_clear_stop_event(): disarm without recording (error paths); paths_record_event(ev, s): plain hipEventRecord - the caller
+ * re-records ev behind launches that followed the stop-capable kernel, so the join covers them too (paths_amd/_lib.py:fork_behind). */
 int paths_set_stop_event(void* event);
 int paths_flush_stop_event(paths_stream_t src);
+int paths_stop_event_pending(void);
+int paths_clear_stop_event(void);
+int paths_record_event(void* event, paths_stream_t stream);
 int paths_stream_wait_event(paths_stream_t dst, void* event);
 int paths_memset_zero(void* p, size_t bytes, paths_stream_t stream);
 

@@ -136,7 +136,7 @@ def decoder_stack(p: Dict[str, Tensor], prefix: str, S: Tensor, key_pad: Tensor,
 # one magnification level                                         reference model/paths.py:66-146
 # ----------------------------------------------------------------------------------------------
 def process_level(p: Dict[str, Tensor], cfg: OracleConfig, depth: int, fts: Tensor, locs: Tensor,
-                  num_ims: Tensor, ctx_slide: Tensor, ctx_patch: Tensor) -> Dict[str, Tensor]:
+                  num_ims: Tensor, ctx_slide: Tensor, ctx_patch: Tensor, probe: Optional[dict] = None) -> Dict[str, Tensor]:
     """``RecursiveModel.forward(depth, PatchBatch)`` (interface.py:96-99 → paths.py:66-146).
 
     fts [B,N,D] (padded rows zero), locs [B,N,2] int64 pixel coords, num_ims [B] int64,
@@ -188,11 +188,15 @@ def process_level(p: Dict[str, Tensor], cfg: OracleConfig, depth: int, fts: Tens
     else:
         raise RuntimeError("reference raises a size mismatch for other pos_encoding_mode values (SURVEY §3.3)")
 
+    if probe is not None:                                          # (tests: the aggregator's input sequence / its raw output)
+        probe["xs"] = t
     # special token + key padding mask + decoder stack            aggregator.py:58-76, utils.py:97-103
     S = torch.cat((p[g + "special_token"].view(1, 1, -1).repeat(B, 1, 1), t), dim=1)
     key_pad = torch.arange(N + 1)[None, :] >= (num_ims + 1)[:, None]
     S = decoder_stack(p, g + "transformer", S, key_pad, cfg.trans_heads, cfg.trans_layers)
     agg = S[:, 0]                                                  # aggregator.py:75
+    if probe is not None:
+        probe["agg"] = agg
 
     if cfg.slide_ctx_mode == "residual" and ctx_slide.shape[1] > 0:   # paths.py:130-131
         agg = agg + ctx_slide[:, -1]

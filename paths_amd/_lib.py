@@ -114,14 +114,16 @@ SIGNATURES = {
     "paths_set_stop_event": [_vp],
     "paths_flush_stop_event": [_vp],
     "paths_stream_wait_event": [_vp, _vp],
+    "paths_record_event": [_vp, _vp],
     "paths_event_destroy": [_vp],
     "paths_memset_zero": [_vp, C.c_size_t, _vp],
     "paths_tissue_mask": [_vp, _i64, _i32, _vp, _vp],
     "paths_tissue_mask_absmax": [_vp, _i64, _i32, _vp, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],
 }
-_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_tlayer_ws_image_bytes": (C.c_int64, [_i32, _i32]), "paths_token0_ws_image_bytes": (C.c_int64, []), "paths_token0_ws_partials": (C.c_int64, [_i32, _i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_attention_fp8_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_bwd_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_token0_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_attention_h3_any_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, []), "paths_adamw_chunk": (_i32, []), "paths_attention_wide_workspace": (C.c_int64, [_i32, _i32]), "paths_event_create": (_vp, []), "paths_stream_create_masked": (_vp, [_vp, _i32])}
+_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_tlayer_ws_image_bytes": (C.c_int64, [_i32, _i32]), "paths_token0_ws_image_bytes": (C.c_int64, []), "paths_token0_ws_partials": (C.c_int64, [_i32, _i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_attention_fp8_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_bwd_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_token0_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_attention_h3_any_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, []), "paths_stop_event_pending": (_i32, []), "paths_clear_stop_event": (_i32, []), "paths_adamw_chunk": (_i32, []), "paths_attention_wide_workspace": (C.c_int64, [_i32, _i32]), "paths_event_create": (_vp, []), "paths_stream_create_masked": (_vp, [_vp, _i32])}
 
+ABI_VERSION = 2     # include/paths_hip.h: paths_abi_version() of the library this binding was written against
 _lib: Optional[C.CDLL] = None
 
 
@@ -137,6 +139,10 @@ def load() -> C.CDLL:
             raise PathsHipError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                                 "paths_amd has no CPU fallback")
         lib = C.CDLL(LIB_PATH)
+        lib.paths_abi_version.restype = _i32
+        if lib.paths_abi_version() != ABI_VERSION:
+            raise PathsHipError(f"{LIB_PATH} has ABI version {lib.paths_abi_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                                "(__graft_entry__.build())")
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = args, _i32
@@ -180,6 +186,9 @@ def call(name: str, *args):
         raise PathsHipError(f"{name} failed ({rc}): {lib.paths_last_error().decode()}")
     if TAPE is not None:
         TAPE.append((fn, args, name))
+        fb = fork_behind.active
+        if fb is not None and fb.taken_at is None and name != "paths_set_stop_event" and not lib.paths_stop_event_pending():
+            fb.taken_at = len(TAPE) - 1                  # this call's kernel carries the block's stop event
 
 
 def stream_wait(dst: "torch.cuda.Stream", src: "torch.cuda.Stream"):
@@ -201,15 +210,29 @@ def stream_wait(dst: "torch.cuda.Stream", src: "torch.cuda.Stream"):
 STOP_EVENTS = __import__("os").environ.get("PATHS_STOP_EVENTS", "1") != "0"
 
 
+# entries of a launch tape that are not kernel launches on the block's stream (fork_behind looks for the block's LAST launch)
+_TAPE_PLUMBING = {"paths_set_stop_event", "paths_flush_stop_event", "paths_stream_wait_event", "paths_stream_wait", "paths_record_event",
+                  "paths_clear_stop_event"}
+
+
 class fork_behind:
     """``with fork_behind([dst...], src): <launches on src>`` - afterwards every ``dst`` waits for what ran on ``src``.  While a
     launch tape is recorded the join travels as a STOP EVENT of the block's stop-capable kernel (include/paths_hip.h:
     paths_set_stop_event; the finish kernel of the importance / projection GEMM, the top-K kernel) instead of an event record behind it;
-    otherwise (eager launches, or PATHS_STOP_EVENTS=0) it is :func:`stream_wait` per destination."""
+    otherwise (eager launches, or PATHS_STOP_EVENTS=0) it is :func:`stream_wait` per destination.
+
+    The stop event covers the block only if the kernel that took it is the block's LAST launch on ``src``.  That is checked, not
+    assumed: the C call that owns the stop-capable kernel is the one during which ``paths_stop_event_pending()`` falls to 0
+    (:func:`call` notes it); if any launch was recorded after it the event is recorded again behind the block the ordinary way
+    (``paths_record_event``: waiters then wait for the later record), so a launch added behind the finish / top-K kernel cannot let
+    ``dst`` start early on a replayed tape."""
+
+    active = None        # the block being recorded (call() reports to it)
 
     def __init__(self, dsts, src):
         self.dsts, self.src = list(dsts), src
         self.ev = None
+        self.taken_at = None       # tape index of the call whose kernel took the event
 
     def __enter__(self):
         if TAPE is not None and STOP_EVENTS:
@@ -223,14 +246,20 @@ class fork_behind:
             self.ev = pool[0][pool[1]]
             pool[1] += 1
             call("paths_set_stop_event", self.ev)
+            self.prev, fork_behind.active = fork_behind.active, self
         return self
 
     def __exit__(self, et, ev, tb):
         if self.ev is not None:
+            fork_behind.active = self.prev
+            if et is not None:
+                load().paths_clear_stop_event()         # an exception inside the block: leave nothing armed for an unrelated launch
+                return False
             call("paths_flush_stop_event", self.src.cuda_stream)
-            if et is None:
-                for d in self.dsts:
-                    call("paths_stream_wait_event", d.cuda_stream, self.ev)
+            if self.taken_at is not None and any(nm not in _TAPE_PLUMBING for _, _, nm in TAPE[self.taken_at + 1:]):
+                call("paths_record_event", self.ev, self.src.cuda_stream)     # launches followed the stop-capable kernel: cover them
+            for d in self.dsts:
+                call("paths_stream_wait_event", d.cuda_stream, self.ev)
         elif et is None:
             for d in self.dsts:
                 stream_wait(d, self.src)

@@ -272,6 +272,49 @@ def _level_grads(mc, lstm, sg, tg, no_agg: bool, has_logits: bool):
     return grads
 
 
+def aggregator_params(agg) -> List[torch.nn.Parameter]:
+    """Live parameters of a standalone TransformerAggregator in the order AggregatorFn returns their gradients."""
+    dec = agg.transformer.decoder
+    out = []
+    for lyr in dec.layers:
+        sd = dict(lyr.named_parameters())
+        out += [sd[name] for name, _ in LAYER_ORDER]
+    return out + [dec.norm.weight, dec.norm.bias]
+
+
+class AggregatorFn(torch.autograd.Function):
+    """``TransformerAggregator.forward`` on its own (reference model/aggregator.py:58-76) under autograd: tokens [B, T, d] (special
+    token already prepended) -> token 0 of the decoder stack's output [B, d]; forward / backward are the launch sequences the levels
+    use (paths_amd/backward.py:transformer_forward_train / transformer_backward)."""
+
+    @staticmethod
+    def forward(ctx, agg, tokens, num_ims, *params):
+        mc, vp = agg._geometry(), ops.pack_aggregator(agg)
+        drop = None
+        if agg.training and agg.dropout_p > 0:
+            drop = bw.Drop(agg.dropout_p, next_dropout_seed(tokens.device), 0)
+        tr = bw.transformer_forward_train(mc, vp, tokens.detach(), num_ims, None, drop, None)
+        ctx.agg = agg
+        _, ctx.tr = _detached_saves({}, tr)
+        ctx.set_materialize_grads(False)
+        return tr["ctx_out"]
+
+    @staticmethod
+    def backward(ctx, d_out):
+        agg, tr = ctx.agg, ctx.tr
+        ctx.tr = None
+        if d_out is None:
+            return (None,) * (3 + len(aggregator_params(agg)))
+        mc, vp = agg._geometry(), ops.pack_aggregator(agg)
+        with bw.deferred_reductions():
+            tg, d_tok, _ = bw.transformer_backward(mc, vp, tr, None, d_out.contiguous())
+        grads = []
+        for g in tg["layers"]:
+            grads += [g[key] for _, key in LAYER_ORDER]
+        grads += [tg["lnfg"], tg["lnfb"]]
+        return (None, d_tok, None, *grads)
+
+
 class GatherParentFn(torch.autograd.Function):
     """Children of the kept patches in the once-per-parent form: gathered feature rows (not differentiable), the children's inherited
     memory cell c0 [B,n_next,Hc] and the kept parents' h rows h_kept [B*cap, D].  Backward: the parents' state gradient =

@@ -17,7 +17,10 @@ int paths_set_error(int code, const char* fmt, ...) {
 extern "C" {
 const char* paths_last_error(void) { return g_err; }
 const char* paths_build_info(void) { return "paths_hip gfx950 split-operand MFMA r2"; }
-int paths_abi_version(void) { return 1; }
+// 2 (round 5): dropout masks are one 16-bit hash half per element since round 4 (thr16 = round(p 65536), scale 1 / (1 - thr16 / 65536):
+// same (key, p) -> other masks than ABI 1), events of paths_event_create are device-side joins only (no system-scope fence: not for
+// host waits), paths_stop_event_pending / paths_record_event / paths_clear_stop_event added.
+int paths_abi_version(void) { return 2; }
 
 // ---- stream plumbing for the launch tape (paths_amd/utils.py:TapedRecursion): the recorded launch sequence of a recursion is
 // replayed as a flat list of C calls, so its cross-stream joins and zero fills are C calls too.
@@ -57,6 +60,16 @@ int paths_flush_stop_event(hipStream_t src) {
   hipEvent_t ev = g_stop_event;
   g_stop_event = nullptr;
   if (ev != nullptr && hipEventRecord(ev, src) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "flush_stop_event: hipEventRecord failed");
+  return PATHS_OK;
+}
+// 1 while an event armed by paths_set_stop_event has not been taken by a launch (nor flushed), else 0
+int paths_stop_event_pending(void) { return g_stop_event != nullptr ? 1 : 0; }
+// Disarm without recording (error paths of a tape replay: a later, unrelated stop-capable launch must not carry a stale event)
+int paths_clear_stop_event(void) { g_stop_event = nullptr; return PATHS_OK; }
+// hipEventRecord(event, stream): the ordinary record, for a join that must also cover launches enqueued AFTER the stop-capable kernel
+int paths_record_event(void* event, hipStream_t stream) {
+  PATHS_REQUIRE(event != nullptr, "record_event: null event");
+  if (hipEventRecord(static_cast<hipEvent_t>(event), stream) != hipSuccess) return paths_set_error(PATHS_ELAUNCH, "record_event: hipEventRecord failed");
   return PATHS_OK;
 }
 int paths_stream_wait_event(hipStream_t dst, void* event) {

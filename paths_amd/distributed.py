@@ -4,8 +4,10 @@ on ROCm; "gloo" for the CPU tests).
 The forward path shards naturally — a slide's recursion touches only its own rows (reference utils.py:252-258) —
 so there is NO data-path collective: ranks own disjoint slices of the slide batch, run the recursion
 independently, and only (a) barriers around a timed region, (b) a MAX-reduce of elapsed time and (c) an
-all-gather of the tiny per-slide outputs ([B, nbins] hazards) cross the fabric.  (The gradient all-reduce of
-the training step, SURVEY.md §8e, arrives with the backward kernels.)
+all-gather of the tiny per-slide outputs ([B, nbins] hazards) cross the fabric.  Training adds exactly one collective per
+step, AFTER the backward has finished: :func:`allreduce_gradients`, one flat-bucket all-reduce(sum) of the live gradients
+(not overlapped with the backward - the shared LSTM's gradient, more than half of the message, is only
+complete when the last backward call returns).
 """
 from __future__ import annotations
 
@@ -92,11 +94,19 @@ def allreduce_gradients(model, average: bool = False, num_levels: Optional[int] 
         return
     from . import autograd as pag
     params = pag.live_grad_params(model, num_levels)
-    for p in params:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
-    grads = [p.grad for p in params]
-    flat = torch.cat([g.reshape(-1) for g in grads])          # one message per step
+    flat, slices = _grad_bucket(model, params)
+    # One message per step, in PERSISTENT storage (round 4 allocated a 29 MB torch.cat result per step).  Gradients that are not
+    # already the bucket's own slices are copied in by one multi-tensor copy; a missing gradient counts as zeros.
+    todo_dst, todo_src = [], []
+    for p, sl in zip(params, slices):
+        g = p.grad
+        if g is None:
+            sl.zero_()
+        elif g.data_ptr() != sl.data_ptr():
+            todo_dst.append(sl)
+            todo_src.append(g.reshape(-1))
+    if todo_dst:
+        torch._foreach_copy_(todo_dst, todo_src)
     global LAST_ALLREDUCE_EVENTS
     ev = None
     if TIME_ALLREDUCE and flat.is_cuda:
@@ -114,9 +124,28 @@ def allreduce_gradients(model, average: bool = False, num_levels: Optional[int] 
     if average:
         flat /= dist.get_world_size()
     # the reduced bucket BECOMES the gradients: every .grad is re-pointed at its slice of the flat buffer (no copy back: round 3
-    # issued one copy_ launch per parameter here, ~150 launches on a host-bound step)
-    off = 0
-    for p, g in zip(params, grads):
-        n = g.numel()
-        p.grad = flat[off:off + n].view_as(g)
-        off += n
+    # issued one copy_ launch per parameter here, ~150 launches on a host-bound step).  NOTE: these .grad tensors alias ONE
+    # storage (16-byte aligned slices, so the one-launch AdamW keeps its float4 path); ``zero_grad(set_to_none=True)`` - what
+    # paths_amd.train and the reference's loop use - drops the views, ``set_to_none=False`` zeroes the bucket slice by slice.
+    for p, sl in zip(params, slices):
+        p.grad = sl.view_as(p)
+
+
+_BUCKET_ALIGN = 4        # floats: every slice starts on a 16-byte boundary
+
+
+def _grad_bucket(model, params):
+    """(flat, slices) - the model's persistent gradient bucket for this parameter list: each parameter's slice starts at an offset
+    rounded up to 4 floats (the padding words are zero and stay zero through the all-reduce)."""
+    key = (tuple(id(p) for p in params), params[0].device if params else None)
+    ent = getattr(model, "_paths_grad_bucket", None)
+    if ent is None or ent[0] != key:
+        offs, off = [], 0
+        for p in params:
+            offs.append(off)
+            off += (p.numel() + _BUCKET_ALIGN - 1) // _BUCKET_ALIGN * _BUCKET_ALIGN
+        flat = torch.zeros((max(off, _BUCKET_ALIGN),), dtype=torch.float32, device=key[1])
+        slices = [flat[o:o + p.numel()] for o, p in zip(offs, params)]
+        ent = (key, flat, slices)
+        object.__setattr__(model, "_paths_grad_bucket", ent)
+    return ent[1], ent[2]

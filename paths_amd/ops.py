@@ -337,19 +337,7 @@ def pack_level(proc) -> Dict[str, object]:
     with torch.no_grad():
         c = lambda t: t.detach().float().contiguous()
         d = agg.dim
-        layers = []
-        for lyr in agg.transformer.decoder.layers:
-            layers.append({
-                "wqkv": c(lyr.self_attn.in_proj_weight), "bqkv": c(lyr.self_attn.in_proj_bias),
-                "wo": c(lyr.self_attn.out_proj.weight), "bo": c(lyr.self_attn.out_proj.bias),
-                "cab": c(lyr.multihead_attn.out_proj.bias),
-                "ln1g": c(lyr.norm1.weight), "ln1b": c(lyr.norm1.bias),
-                "ln2g": c(lyr.norm2.weight), "ln2b": c(lyr.norm2.bias),
-                "ln3g": c(lyr.norm3.weight), "ln3b": c(lyr.norm3.bias),
-                "w1": c(lyr.linear1.weight), "b1": c(lyr.linear1.bias),
-                "w2": c(lyr.linear2.weight), "b2": c(lyr.linear2.bias),
-                "eps": float(lyr.norm1.eps),
-            })
+        layers = _pack_decoder_layers(agg)
         dev = agg.proj_in.weight.device
         div_1d, div_2d = _pe_divs(d, dev)
         packed = {
@@ -375,6 +363,52 @@ def pack_level(proc) -> Dict[str, object]:
     return packed
 
 
+def _pack_decoder_layers(agg) -> List[Dict[str, object]]:
+    """Per-layer tensors of the aggregator's decoder stack in the kernels' naming (only ``multihead_attn.out_proj.bias`` of the
+    cross-attention is live)."""
+    c = lambda t: t.detach().float().contiguous()
+    layers = []
+    for lyr in agg.transformer.decoder.layers:
+        layers.append({
+            "wqkv": c(lyr.self_attn.in_proj_weight), "bqkv": c(lyr.self_attn.in_proj_bias),
+            "wo": c(lyr.self_attn.out_proj.weight), "bo": c(lyr.self_attn.out_proj.bias),
+            "cab": c(lyr.multihead_attn.out_proj.bias),
+            "ln1g": c(lyr.norm1.weight), "ln1b": c(lyr.norm1.bias),
+            "ln2g": c(lyr.norm2.weight), "ln2b": c(lyr.norm2.bias),
+            "ln3g": c(lyr.norm3.weight), "ln3b": c(lyr.norm3.bias),
+            "w1": c(lyr.linear1.weight), "b1": c(lyr.linear1.bias),
+            "w2": c(lyr.linear2.weight), "b2": c(lyr.linear2.bias),
+            "eps": float(lyr.norm1.eps),
+        })
+    return layers
+
+
+def pack_aggregator(agg) -> Dict[str, object]:
+    """The aggregator's own tensors for a STANDALONE ``TransformerAggregator.forward`` (reference model/aggregator.py:58-76): the
+    decoder layers, the final norm, the special token and proj_in; the classifier slot of the token-0 tail is a zero [1, d] row
+    (its logit is discarded).  Cached on the module, invalidated by parameter version counters like :func:`pack_level`."""
+    params = getattr(agg, "_paths_param_list", None)
+    if params is None:
+        params = [agg.proj_in.weight, agg.proj_in.bias, agg.special_token] + list(agg.transformer.decoder.parameters())
+        object.__setattr__(agg, "_paths_param_list", params)
+    key = _versions(params)
+    cache = getattr(agg, "_paths_pack", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    with torch.no_grad():
+        c = lambda t: t.detach().float().contiguous()
+        d = agg.dim
+        dev = agg.proj_in.weight.device
+        div_1d, div_2d = _pe_divs(d, dev)
+        packed = {"layers": _pack_decoder_layers(agg), "lnfg": c(agg.transformer.decoder.norm.weight), "lnfb": c(agg.transformer.decoder.norm.bias),
+                  "lnf_eps": float(agg.transformer.decoder.norm.eps), "special": c(agg.special_token), "bp": c(agg.proj_in.bias),
+                  "wp": c(agg.proj_in.weight), "div_1d": div_1d, "div_2d": div_2d,
+                  "wcls": torch.zeros((1, d), device=dev, dtype=torch.float32), "bcls": torch.zeros((1,), device=dev, dtype=torch.float32),
+                  "_owner": agg}
+    agg._paths_pack = (key, packed)
+    return packed
+
+
 def fast_path(mc) -> bool:
     """The shipped aggregator geometry (trans_dim 128, 4 heads, importance hidden 128): specialised, tuned kernels.  Anything
     else the reference's config surface allows runs on the shape-generic kernels (csrc/generic.hip + the f32 GEMM)."""
@@ -389,6 +423,14 @@ WS_IMAGES_192 = os.environ.get("PATHS_WS_IMAGES_192", "1") != "0"   # ... and th
 def wide_head(hd: int) -> bool:
     """head_dim above the flash-style kernels' 64: the three-step form of csrc/attn_wide.hip (score matrix in scratch)."""
     return hd > 64 and hd % 32 == 0 and hd <= 1024
+
+
+def check_aggregator_geometry(d: int, H: int):
+    """(trans_dim, trans_heads) pairs the aggregator kernels run (standalone ``TransformerAggregator.forward``)."""
+    hd = d // max(H, 1)
+    if d % 32 or d > 2048 or H < 1 or d % H or not (hd in (16, 32, 48, 64) or wide_head(hd)):
+        raise NotImplementedError("the aggregator kernels need trans_dim % 32 == 0 (<= 2048) and head_dim in {16, 32, 48, 64} or a multiple "
+                                  f"of 32 above 64 (got trans_dim {d}, trans_heads {H})")
 
 
 def check_supported(mc, training: bool = False):

@@ -24,7 +24,6 @@ class HipAdamW(torch.optim.AdamW):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
         self._maps: Dict[tuple, dict] = {}          # per (group, set of stepped parameters): block map + device staging
-        self._slot = 0
         self._last_key = None
 
     def load_state_dict(self, state_dict):
@@ -93,11 +92,14 @@ class HipAdamW(torch.optim.AdamW):
             mp = {"n": n, "nblocks": len(blocks),
                   "blocks": torch.tensor(blocks, dtype=torch.int32, device=dev).contiguous(),
                   "numel": torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=dev),
-                  # host staging (pinned, 4 rotating slots: a slot is rewritten 4 steps after its async copy was enqueued)
+                  # host staging: pinned, 4 rotating slots PER MAP, each with the event recorded behind its last host-to-device copy;
+                  # the host waits for that event before it rewrites the slot (a loop that never syncs, or several parameter
+                  # groups stepping through one optimizer, must not let a queued copy pick up a later step's table)
                   "steps": [state[p]["step"] for p in ps], "step_vals": np.array([float(state[p]["step"]) for p in ps], dtype=np.float64),
                   "m_ptrs": [state[p]["exp_avg"].data_ptr() for p in ps], "v_ptrs": [state[p]["exp_avg_sq"].data_ptr() for p in ps],
                   "host": [torch.empty((6 * n,), dtype=torch.int64).pin_memory() for _ in range(4)],
-                  "dev": [torch.empty((6 * n,), dtype=torch.int64, device=dev) for _ in range(4)]}
+                  "dev": [torch.empty((6 * n,), dtype=torch.int64, device=dev) for _ in range(4)],
+                  "copied": [None] * 4, "slot": 0}
             self._maps[key] = mp
         n = mp["n"]
         if self._last_key != key:                    # another parameter set stepped in between: its counters moved, re-read them
@@ -108,8 +110,10 @@ class HipAdamW(torch.optim.AdamW):
         lr, (beta1, beta2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
         # scalars exactly as torch/optim/adam.py computes them (Python floats = doubles, rounded to fp32 when they enter a kernel)
         svals = mp["step_vals"]
-        slot = self._slot = (self._slot + 1) & 3
+        slot = mp["slot"] = (mp["slot"] + 1) & 3
         host, devbuf = mp["host"][slot], mp["dev"][slot]
+        if mp["copied"][slot] is not None:
+            mp["copied"][slot].synchronize()         # (four steps old: a no-op unless the device is that far behind)
         h = host.numpy()
         tab = h[:4 * n].reshape(n, 4)
         tab[:, 0] = [p.data_ptr() for p in ps]
@@ -125,6 +129,9 @@ class HipAdamW(torch.optim.AdamW):
             f[:n] = [(lr / (1 - beta1 ** float(t))) * -1 for t in svals]
             f[n:2 * n] = [(1 - beta2 ** float(t)) ** 0.5 for t in svals]
         devbuf.copy_(host, non_blocking=True)
+        if mp["copied"][slot] is None:
+            mp["copied"][slot] = torch.cuda.Event()
+        mp["copied"][slot].record()
         base = devbuf.data_ptr()
         _lib.call("paths_adamw_multi", base, _lib.ptr(mp["numel"]), _lib.ptr(mp["blocks"]), mp["nblocks"], base + 32 * n, base + 32 * n + 4 * n,
                   1 - lr * wd, 1 if wd != 0 else 0, 1 - beta1, beta2, 1 - beta2, eps, FLAVOR, _lib.stream())

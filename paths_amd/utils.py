@@ -135,6 +135,7 @@ class TapedRecursion:
         self.model, self.keep, self.levels, self.lane = model, list(keep_patches), int(num_levels), int(lane)
         self.batch = slides if isinstance(slides, DeviceSlideBatch) else DeviceSlideBatch(slides)
         self.tape, self.out, self.versions, self.stream_handle = None, None, None, None
+        self._unjoined = False               # a replay(join=False) whose streams the caller stream has not waited for yet
         self._rec_batch = None               # private copy of the recorded batch's table TENSORS: what the tape addresses (rebind() re-points them)
         self._events = [[], 0]               # HIP events of the tape's stream joins, re-used when the tape is recorded again
         # The tape holds raw device addresses of every intermediate of the recorded pass.  Those tensors are freed when the pass
@@ -211,6 +212,10 @@ class TapedRecursion:
             self.tape, self._rec_batch = None, None
             self.batch = new
             return self
+        if self._unjoined:
+            # the previous replay(join=False) may still be reading the tables on the lane's streams: the caller stream (which carries
+            # the copy below) waits for them first - a write-after-read race otherwise
+            self.join()
         with torch.no_grad():
             src, dst = new.flat_tables(), rec.flat_tables()
             if src.numel() == dst.numel():                 # same level count: ONE copy of all tables (a few hundred bytes)
@@ -227,7 +232,10 @@ class TapedRecursion:
     def _play(self, ops_):
         for fn, args, name in ops_:
             if fn(*args) != 0:
-                raise _lib.PathsHipError(f"{name} failed during tape replay: {_lib.load().paths_last_error().decode()}")
+                lib = _lib.load()
+                msg = lib.paths_last_error().decode()
+                lib.paths_clear_stop_event()      # a failure between paths_set_stop_event and the kernel that takes it: leave nothing armed
+                raise _lib.PathsHipError(f"{name} failed during tape replay: {msg}")
 
     def replay(self, join: bool = True) -> Dict[str, torch.Tensor]:
         """join=False leaves out the tape's last entry (the caller stream waiting for this lane's streams): several lanes
@@ -238,10 +246,12 @@ class TapedRecursion:
         assert torch.cuda.current_stream(self.batch.device).cuda_stream == self.stream_handle, "replay on the stream the tape was recorded on"
         assert self.tape[-1][2] == "paths_stream_wait"
         self._play(self.tape if join else self.tape[:-1])
+        self._unjoined = not join
         return self.out
 
     def join(self):
         self._play(self.tape[-1:])
+        self._unjoined = False
 
     def run(self) -> Dict[str, torch.Tensor]:
         """replay + the status check of :func:`recurse` (one host sync after the last level)."""

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
         assert m, name
         assert len([a for a in m.group(1).split(",") if a.strip()]) == len(args), name
     lib.paths_abi_version.restype = ctypes.c_int
-    assert lib.paths_abi_version() == 1
+    assert lib.paths_abi_version() == 2
 
 
 def test_invalid_arguments_are_reported_not_launched():
@@ -190,6 +190,14 @@ else:
 pd.allreduce_gradients(model, num_levels=cfg.num_levels)
 for i, p in enumerate(live):
     assert torch.equal(p.grad, torch.full_like(p, 1.0 + (i % 3))), i
+# the reduced bucket is persistent storage whose 16-byte aligned slices ARE the gradients (float4 path of the one-launch AdamW)
+flat = model._paths_grad_bucket[1]
+assert all(p.grad.data_ptr() % 16 == 0 and p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in live)
+pd.allreduce_gradients(model, num_levels=cfg.num_levels)       # second step: same storage, nothing re-allocated; values x world
+assert model._paths_grad_bucket[1] is flat
+for i, p in enumerate(live):
+    assert torch.equal(p.grad, torch.full_like(p, 2.0 * (1.0 + (i % 3)))), i
+    p.grad.div_(2.0)
 assert all(p.grad is None for p in unused)
 assert all(p.grad is not None and not p.grad.any() for p in pag.dead_params(model))
 opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)

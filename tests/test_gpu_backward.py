@@ -249,6 +249,44 @@ def test_transformer_backward(dev):
             assert rel_err(grads["layers"][l][k], ref) < tol, (l, k, rel_err(grads["layers"][l][k], ref))
 
 
+@pytest.mark.parametrize("over", [{}, {"trans_dim": 192}], ids=["shipped", "td192"])
+def test_standalone_aggregator_is_differentiable(dev, over):
+    """``TransformerAggregator.forward`` (reference model/aggregator.py:58-76) called on its own under autograd: output and the
+    gradients of the input sequence, the special token and every decoder parameter against the oracle's float64 autograd."""
+    from oracle import paths_oracle as orc
+    cfg, model, params = build_model(dev, 21, {"model_config": over} if over else None)
+    d = cfg.model_config.trans_dim
+    depth, B, N = 2, 2, 90
+    lengths = torch.tensor([90, 41])
+    g = torch.Generator().manual_seed(9)
+    seq = torch.randn(B, N, d, generator=g)
+    G_out = torch.randn(B, d, generator=g)
+    agg = model.procs[depth].global_agg
+    model.train()                                        # (dropout is 0 in the test config: train mode only selects the saving forward)
+    x = seq.to(dev).requires_grad_(True)
+    out = agg(torch.zeros((B, 0, d), device=dev), x, None, lengths.to(dev))
+    (out * G_out.to(dev)).sum().backward()
+    p = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    pre = f"procs.{depth}.global_agg."
+    xs = seq.double().requires_grad_(True)
+    S = torch.cat((p[pre + "special_token"].view(1, 1, -1).repeat(B, 1, 1), xs), dim=1)
+    key_pad = torch.arange(N + 1)[None, :] >= (lengths + 1)[:, None]
+    want = orc.decoder_stack(p, pre + "transformer", S, key_pad, cfg.model_config.trans_heads, cfg.model_config.trans_layers)[:, 0]
+    (want * G_out.double()).sum().backward()
+    assert rel_err(out.detach(), want.detach()) < 1e-5
+    tol = 3e-4
+    valid = ~key_pad[:, 1:]
+    assert rel_err(x.grad[valid.to(dev)], xs.grad[valid]) < tol
+    assert float(x.grad[~valid.to(dev)].abs().max()) == 0.0
+    assert rel_err(agg.special_token.grad, p[pre + "special_token"].grad) < tol
+    for name, prm in agg.transformer.decoder.named_parameters():
+        ref = p[pre + "transformer.decoder." + name].grad
+        if "multihead_attn" in name and not name.endswith("out_proj.bias"):
+            assert prm.grad is None                      # dead cross-attention matrices: no path to the output
+            continue
+        assert prm.grad is not None and rel_err(prm.grad, ref) < tol, (name, rel_err(prm.grad, ref))
+
+
 def _train_setup(dev, wseed=3, dseed=14, top_k=64, base=(16, 16), n_slides=4, cfg_over=None):
     from paths_amd import synthetic as syn
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
@@ -670,6 +708,40 @@ def test_hip_adamw_is_bitwise_torch_foreach(dev):
             a.grad, b.grad = gr.clone(), gr.clone()
         oa.step(); oc.step()
         assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+
+
+def test_hip_adamw_five_param_groups_without_host_sync(dev):
+    """HipAdamW as a drop-in for ``torch.optim.AdamW`` (reference train.py:49-50) in a loop that NEVER synchronises, with five
+    parameter groups (own lr / weight decay each): 12 steps enqueued back to back - gradients pre-generated on the device, so the
+    host runs ahead of the GPU by the whole loop and every pinned staging slot is rewritten while older copies are still queued
+    (the 4-slot ring is per parameter map and waits for the slot's own copy event).  Bit-identical to torch's foreach
+    update at the end."""
+    from paths_amd import optim as popt
+    shapes = [(1792, 2048), (1024,), (513, 3), (4097,), (128, 128), (1,), (3, 5, 7), (256, 1024), (64,), (1000, 130)]
+    g = torch.Generator().manual_seed(11)
+    base = [torch.randn(*sh, generator=g) * 0.1 for sh in shapes]
+    pa = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    groups = lambda ps: [{"params": ps[2 * i:2 * i + 2], "lr": 1e-3 * (i + 1), "weight_decay": 0.01 * (i % 3)} for i in range(5)]
+    oa, ob = torch.optim.AdamW(groups(pa), foreach=True), popt.HipAdamW(groups(pb))
+    steps = 12
+    grads = [[(torch.randn(sh, generator=g) * 2.0 ** float(torch.randint(-12, 2, (1,), generator=g))).to(dev) for sh in shapes] for _ in range(steps)]
+    big = torch.randn((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    for _ in range(40):                      # ~10 ms of queued device work: the optimizer loops below are enqueued far ahead of the GPU
+        big = big @ big * 1e-3
+    for it in range(steps):
+        for b, gr in zip(pb, grads[it]):
+            b.grad = gr
+        ob.step()
+    for it in range(steps):
+        for a, gr in zip(pa, grads[it]):
+            a.grad = gr
+        oa.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+        assert torch.equal(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) and torch.equal(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]), i
 
 
 def test_data_parallel_shards_sum_to_global_batch(dev):
