@@ -742,6 +742,12 @@ def main():
     d_t, L_t = cfg.model_config.trans_dim, cfg.model_config.trans_layers
     # F_layer = 24 T d^2 + 4 T^2 d per slide (QKV 6Td^2, out 2Td^2, FFN 16Td^2, QK^T + PV 4T^2 d), T = valid patches + 1
     f_agg = [float(sum(L_t * (24.0 * (n + 1) * d_t * d_t + 4.0 * (n + 1) ** 2 * d_t) for n in lv)) for lv in nims]
+    # FUSE_QKV (default): decoder layer 0's in_proj runs inside the importance / projection finish on the selection stream, OUTSIDE the
+    # timed aggregator span - its algorithmic FLOPs (6 T d^2 per slide) leave the span's numerator with it
+    fused_qkv = ops.FUSE_QKV in (1, 2) and ops.fast_path(cfg.model_config) and ops.GEMM_MODE == "h3"
+    f_inproj0 = [float(sum(6.0 * (n + 1) * d_t * d_t for n in lv)) for lv in nims]
+    if fused_qkv:
+        f_agg_full, f_agg = f_agg, [a - b for a, b in zip(f_agg, f_inproj0)]
 
     def gemm_o_roofline(samples):
         flop = sum(2.0 * valid[i % cfg.num_levels] * m["K"] * m["Ncols"] for i, (_, m) in enumerate(samples))
@@ -778,7 +784,9 @@ def main():
             with torch.no_grad():
                 tser = putils.TapedRecursion(model, batches[0], cfg.top_k_patches, cfg.num_levels).record()
             tp = tser.tape
-            starts = [i for i in range(len(tp) - 1) if tp[i][2] == "paths_token_layer_ws" and tp[i + 1][2] == "paths_attention_h3_img"]
+            # the span starts at the aggregator's first launch: the attention (FUSE_QKV: in_proj lives in the importance / projection
+            # finish), or the in_proj launch in front of it (PATHS_FUSE_QKV=0)
+            starts = [i - 1 if tp[i - 1][2] == "paths_token_layer_ws" else i for i in range(1, len(tp)) if tp[i][2] == "paths_attention_h3_img"]
             ends = []
             for i in starts:
                 ends.append(next(j for j in range(i, len(tp)) if tp[j][2] == "paths_token0_tail_ws"))
@@ -886,8 +894,13 @@ def main():
         fl, ms_a, n_a = agg_roofline(live["aggregator"])
         ach = fl / (ms_a * 1e-3) / 1e12 if ms_a > 0 else 0.0
         roofline_attn = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "kernels": "token-layer in_proj + attention + token-layer chain (out_proj, LN x3, FFN) + token-0 tail (last layer, one "
+                         "kernels": ("attention + token-layer chain (out_proj, LN x3, FFN) + token-0 tail (last layer, one launch), per level; the "
+                                     "first layer's in_proj runs inside the importance / projection finish (paths_importance_qkv_x6) and is "
+                                     "counted neither in the span nor in its FLOPs") if fused_qkv else
+                                    "token-layer in_proj + attention + token-layer chain (out_proj, LN x3, FFN) + token-0 tail (last layer, one "
                                     "launch), per level",
+                         "in_proj_fused_into_finish": bool(fused_qkv),
+                         "algorithmic_gflop_in_proj0_excluded": round(sum(f_inproj0) / len(f_inproj0) / 1e9, 3) if fused_qkv else 0.0,
                          "algorithmic_gflop_per_level_launch": round(fl / n_a / 1e9, 3), "avg_span_us": round(ms_a * 1e3 / n_a, 2),
                          "spans": n_a,
                          "flops_basis": "SURVEY 8(d): L * (24 T d^2 + 4 T^2 d) per slide, T = valid patches + 1, all L layers counted in "
@@ -978,7 +991,8 @@ def main():
             "roofline": dict(roofline, attn_ffn=None if roofline_attn is None else {
                 k: roofline_attn.get(k) for k in ("achieved", "peak", "unit", "frac", "avg_span_us", "serialized_span_us", "serialized_frac",
                                                    "serialized_span_replayed_us", "serialized_frac_replayed", "serialized_note",
-                                                   "serialized_frac_of_measured_peak", "algorithmic_gflop_per_level_launch")}),
+                                                   "serialized_frac_of_measured_peak", "algorithmic_gflop_per_level_launch",
+                                                   "in_proj_fused_into_finish", "algorithmic_gflop_in_proj0_excluded")}),
             "roofline_attn_ffn": roofline_attn,
             "host": {"launch_mode": launch_mode,
                      "t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3), "eager_instrumented_pass": eager,

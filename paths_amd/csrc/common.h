@@ -128,13 +128,14 @@ __device__ __forceinline__ int c32_row(int reg, int lane) { return (reg & 3) + 8
 
 // Is [m0, m0+rows) entirely padding?  Rows are laid out [slide][rows_per_slide]; slide b has
 // num_ims[b] valid rows at its start.  num_ims == nullptr disables skipping.
-__device__ __forceinline__ bool block_all_padding(const int64_t* num_ims, int rows_per_slide, int m0, int rows, int M) {
+// extra: valid rows per slide beyond num_ims[b] (1 for token-ordered rows: the special token's slot comes first).
+__device__ __forceinline__ bool block_all_padding(const int64_t* num_ims, int rows_per_slide, int m0, int rows, int M, int extra = 0) {
   if (num_ims == nullptr) return false;
   int last = min(m0 + rows, M) - 1;
   int b0 = m0 / rows_per_slide, b1 = last / rows_per_slide;
   for (int b = b0; b <= b1; ++b) {
     int lo = max(m0, b * rows_per_slide);
-    if (lo - b * rows_per_slide < (int)num_ims[b]) return false;
+    if (lo - b * rows_per_slide < (int)num_ims[b] + extra) return false;
   }
   return true;
 }

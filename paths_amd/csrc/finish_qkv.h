@@ -1,0 +1,32 @@
+// Hand-over between the split-K importance / projection GEMM (gemm_x6.hip) and its fused finish (tlayer_ws.hip:
+// tlayer_ws_kernel<128, false, true, false, FIN = true>): the finish workgroup of a 64-token tile sums the two k-half slabs, runs the
+// importance MLP's second layer + sigmoid + mask, builds the tokens (alpha * proj + bias + positional encoding, special token in slot 0)
+// AND multiplies them by the first decoder layer's in_proj, writing the attention kernel's q | k | v operand images - the launch that
+// used to re-read the tokens for that product (paths_token_layer_ws with do_qkv only) is gone.
+// Reference: model/paths.py:95-98,119-124; model/aggregator.py:37-65; nn.TransformerDecoderLayer self_attn in_proj (aggregator.py:70-72).
+#pragma once
+#include "common.h"
+
+struct FinQkvParams {
+  // ---- the raw GEMM result: ws [nz][Mt / 32][8][1024] floats in the accumulator layout (EpiRaw), rows TOKEN-ORDERED (X6Operands::tok_Tp)
+  const float* ws; int64_t zstride; int nz;
+  // ---- importance MLP tail + token assembly (EpiImpProj's operands)
+  const float* b1; const float* w2; const float* b2;
+  const float* bp; const float* special;
+  const float* pe_table; int pe_rows;          // paths_pe_table output (required)
+  const int64_t* locs;                         // [B * N, 2] pixel coordinates (2-D mode)
+  const int64_t* num_ims;                      // [B]
+  int N, T, Tp, B;                             // patches per slide (capacity), tokens = N + 1, T rounded up to 64
+  int patch_size, pe_mode, imp_mul, skip_padding;
+  float acc_scale;                             // 1 / (w_scale * a_scale) of the GEMM
+  int alpha_from_importance;                   // 1: alpha is READ from `importance` (an importance-only finish already ran), 0: computed and written
+  float* importance;                           // [B * N]
+  float* tokens;                               // [B, T, 128]
+  // ---- first decoder layer's in_proj (paths_tlayer_pack_ws part 1 image, scale s_wqkv) -> operand images of paths_attention_h3_img
+  const void* w_qkv; const float* bqkv; float inv_wqkv; float qscale;
+  void* qkv_img;
+};
+
+// defined in tlayer_ws.hip; launches on `stream` (stop-event capable: PATHS_LAUNCH_STOP)
+int paths_launch_finish_qkv(const FinQkvParams& p, hipStream_t stream);
+int paths_launch_finish_importance(const FinQkvParams& p, hipStream_t stream);

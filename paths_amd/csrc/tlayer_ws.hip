@@ -19,6 +19,8 @@
 // q / k images use the k-slot dim order (a permutation of the contraction index of q.k, harmless as long as q and k agree);
 // v is computed with the operands swapped (tokens as MFMA rows), which yields the V^T fragments of attn_x6.hip without shuffles.
 #include "common.h"
+#include "finish_qkv.h"
+#include "gemm_epi.h"
 
 namespace {
 
@@ -131,14 +133,125 @@ struct WsParams {
 #ifdef PATHS_WS_STAMPS
   unsigned long long* stamps;   // diagnostic build only: 16 s_memtime stamps per workgroup
 #endif
+  FinQkvParams fin;             // FIN kernels only (finish_qkv.h): the input rows are BUILT here from the raw importance / projection GEMM result
 };
+
+constexpr int TOK_LD = 132;     // FIN: row stride (floats) of the fp32 token tile in LDS (16-byte aligned rows, rows 4 banks apart)
+
+// FIN prologue, part 1 (all 4 waves = 2 x 2 over 64 token slots x 256 raw columns, the layout of x6_finish_kernel / EpiImpProj in
+// gemm_x6.hip / gemm_epi.h, rows TOKEN-ordered): sum the k-half slabs, importance logits -> alpha, tokens -> global + LDS (sTok).
+// Packed GEMM columns: [W1[0:64] ; Wp[0:64] ; W1[64:128] ; Wp[64:128]]: wave column half wn owns hidden units / token channels 64 wn ..
+__device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0, int tid, float* sTok, float* sAlpha) {
+  constexpr int d = 128;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int u0 = 64 * wn;
+  float acc[4][16];
+  {
+    const int64_t trow = (((int64_t)b * f.Tp + t0) >> 5) + wm;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = t[64 * q];
+        for (int z = 1; z < f.nz; ++z) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
+        acc[j][4 * q] = v[0]; acc[j][4 * q + 1] = v[1]; acc[j][4 * q + 2] = v[2]; acc[j][4 * q + 3] = v[3];
+      }
+    }
+  }
+  const int nim = (int)f.num_ims[b];
+  if (!f.alpha_from_importance) {
+    // ---- partial importance logits over this wave's 64 hidden units, summed over the 32 lanes of each half-wave by the halving
+    // butterfly of EpiImpProj (gemm_epi.h): afterwards lane l holds the total of row index rho(l) = bits 4..1 of l
+    float part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = u0 + 32 * j + (lane & 31);
+      const float bb = f.b1[u], w = f.w2[u];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[r] += fmaxf(fmaf(acc[j][r], f.acc_scale, bb), 0.f) * w;
+    }
+    float p8[8], p4[4], p2[2], p1;
+    {
+      const bool up = (lane & 16) != 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float keep = up ? part[8 + k] : part[k], send = up ? part[k] : part[8 + k]; p8[k] = keep + __shfl_xor(send, 16); }
+    }
+    {
+      const bool up = (lane & 8) != 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float keep = up ? p8[4 + k] : p8[k], send = up ? p8[k] : p8[4 + k]; p4[k] = keep + __shfl_xor(send, 8); }
+    }
+    {
+      const bool up = (lane & 4) != 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { const float keep = up ? p4[2 + k] : p4[k], send = up ? p4[k] : p4[2 + k]; p2[k] = keep + __shfl_xor(send, 4); }
+    }
+    {
+      const bool up = (lane & 2) != 0;
+      const float keep = up ? p2[1] : p2[0], send = up ? p2[0] : p2[1];
+      p1 = keep + __shfl_xor(send, 2);
+    }
+    p1 += __shfl_xor(p1, 1);
+    const int rho = (lane >> 1) & 15;
+    if ((lane & 1) == 0) sAlpha[wn * TOK + 32 * wm + c32_row(rho, lane)] = p1;
+  }
+  __syncthreads();
+  // ---- alpha of every row (both column halves compute the same value), tokens of this wave's 64 channels
+  const float b2v = *f.b2, ps_inv = 1.0f / (float)f.patch_size;
+  float bpv[2], spv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int c = u0 + 32 * j + (lane & 31); bpv[j] = f.bp[c]; spv[j] = f.special[c]; }
+  int64_t lp[16]; float aimp[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {                       // loads first (clamped indices: always legal), math after
+    const int t = t0 + 32 * wm + c32_row(r, lane);
+    const int64_t m = (int64_t)b * f.N + min(max(t - 1, 0), f.N - 1);
+    lp[r] = f.pe_mode == 2 ? f.locs[2 * m + wn] : 0;
+    aimp[r] = f.alpha_from_importance ? f.importance[m] : 0.f;
+  }
+  float pev[16][2]; float av[16]; bool valid[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lt = 32 * wm + c32_row(r, lane), t = t0 + lt, idx = t - 1;
+    valid[r] = t >= 1 && idx < nim;
+    float a = 0.f;
+    if (valid[r]) a = f.alpha_from_importance ? aimp[r] : sigmoid_acc((sAlpha[lt] + sAlpha[TOK + lt]) + b2v);
+    if (!f.alpha_from_importance && wn == 0 && (lane & 31) == 0 && t >= 1 && t <= f.N) f.importance[(int64_t)b * f.N + idx] = a;
+    av[r] = f.imp_mul ? a : 1.f;
+    const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
+    const int ipos = f.pe_mode == 2 ? paths_epi::div_u24(px24, f.patch_size, ps_inv) : max(idx, 0);
+    const int tp = min(ipos, f.pe_rows - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = u0 + 32 * j + (lane & 31);
+      pev[r][j] = f.pe_mode == 2 ? f.pe_table[(int64_t)tp * (d / 2) + (c & (d / 2 - 1))] : f.pe_table[(int64_t)tp * d + c];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int lt = 32 * wm + c32_row(r, lane), t = t0 + lt;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = u0 + 32 * j + (lane & 31);
+      // padded slots: the projection of a padded row may be anything (its LSTM tile may have been skipped): select, do not multiply
+      const float pj = valid[r] ? acc[2 + j][r] * f.acc_scale : 0.f;
+      const float v = t == 0 ? spv[j] : (t < f.T ? av[r] * pj + bpv[j] + pev[r][j] : 0.f);
+      sTok[lt * TOK_LD + c] = v;
+      if (t < f.T) f.tokens[((int64_t)b * f.T + t) * d + c] = v;
+    }
+  }
+}
 
 // One workgroup = 64 tokens of one slide.  Lane (ql = lane & 15, g = lane >> 4) of wave w holds, for token tile tt and output
 // tile ot, the features 16 (OT w + ot) + 4 g + r (r = 0..3) of token 16 tt + ql  -  the C layout of v_mfma_f32_16x16x32_f16 with the
 // weights as A (rows = output features) and the activations as B (columns = tokens).
-template <int DM, bool POST, bool QKV, bool ROWS = false>
+template <int DM, bool POST, bool QKV, bool ROWS = false, bool FIN = false>
 __global__ void __launch_bounds__(64 * NW, TT == 2 ? 2 : 1)
 tlayer_ws_kernel(WsParams p) {
+  static_assert(!FIN || (DM == 128 && !POST && QKV && !ROWS && TT == 4), "FIN: the fused finish of the importance / projection GEMM (trans_dim 128, in_proj only)");
   using G = Geo<DM>;
   constexpr int KB = G::KB, OT = G::OT;
   constexpr int POST_STEPS = POST ? G::N_POST * KB : 0, NSTEPS = POST_STEPS + (QKV ? G::N_QKV * KB : 0);
@@ -204,6 +317,24 @@ tlayer_ws_kernel(WsParams p) {
     for (int i = 0; i < G::ACT / (16 * 64 * NW); ++i) {
       const int piece = tid + i * 64 * NW, kb = piece / (ROWB / 16), r = piece % (ROWB / 16);
       *reinterpret_cast<u32x4*>(sAct + piece * 16) = ldg_u32x4(src + (int64_t)kb * (4 * 2 * FRAG) + r * 16);
+    }
+  } else if constexpr (FIN) {
+    // the input rows are built HERE from the raw result of the importance / projection GEMM (finish_qkv.h); the weight loads and
+    // the bias vector issued above land under it
+    float* const sTok = sBqkv + 3 * DM;
+    fin_tokens(p.fin, b, t0, tid, sTok, sTok + TOK * TOK_LD);
+    __syncthreads();
+    for (int kb = wave; kb < KB; kb += NW) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const float* row = sTok + (16 * tt + ql) * TOK_LD + 32 * kb + 4 * g;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(row), c = *reinterpret_cast<const f32x4*>(row + 16);
+        const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        u32x4 hi, lo;
+        split8h(v, hi, lo);
+        *reinterpret_cast<u32x4*>(sAct + ((kb * TT + tt) * 2) * FRAG + lane * 16) = hi;
+        *reinterpret_cast<u32x4*>(sAct + ((kb * TT + tt) * 2 + 1) * FRAG + lane * 16) = lo;
+      }
     }
   } else {
     const float* src = POST ? p.attn : p.x_in;
@@ -561,7 +692,89 @@ int launch_ws(const WsParams& p, hipStream_t stream) {
   return PATHS_OK;
 }
 
+// The importance half of the finish alone (phase 2 of paths_importance_qkv_x6): alpha of every token slot of a 64-slot tile from the
+// hidden-unit columns of the raw GEMM result; what the top-K waits for when the tokens / in_proj finish runs on another stream.
+__global__ void __launch_bounds__(256)
+finish_importance_kernel(FinQkvParams f) {
+  __shared__ float sAlpha[2 * TOK];
+  const int b = blockIdx.y, t0 = blockIdx.x * TOK, tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+  const int nim = (int)f.num_ims[b];
+  if (f.skip_padding && t0 >= nim + 1) return;
+  float part[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[r] = 0.f;
+  const int64_t trow = (((int64_t)b * f.Tp + t0) >> 5) + wm;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
+    const int u = 64 * wn + 32 * j + (lane & 31);
+    const float bb = f.b1[u], w = f.w2[u];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = t[64 * q];
+      for (int z = 1; z < f.nz; ++z) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[4 * q + e] += fmaxf(fmaf(v[e], f.acc_scale, bb), 0.f) * w;
+    }
+  }
+  // the same summation tree as fin_tokens / EpiImpProj (bit-identical alpha whichever kernel computes it)
+  float p8[8], p4[4], p2[2], p1;
+  {
+    const bool up = (lane & 16) != 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float keep = up ? part[8 + k] : part[k], send = up ? part[k] : part[8 + k]; p8[k] = keep + __shfl_xor(send, 16); }
+  }
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float keep = up ? p8[4 + k] : p8[k], send = up ? p8[k] : p8[4 + k]; p4[k] = keep + __shfl_xor(send, 8); }
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const float keep = up ? p4[2 + k] : p4[k], send = up ? p4[k] : p4[2 + k]; p2[k] = keep + __shfl_xor(send, 4); }
+  }
+  {
+    const bool up = (lane & 2) != 0;
+    const float keep = up ? p2[1] : p2[0], send = up ? p2[0] : p2[1];
+    p1 = keep + __shfl_xor(send, 2);
+  }
+  p1 += __shfl_xor(p1, 1);
+  if ((lane & 1) == 0) sAlpha[wn * TOK + 32 * wm + c32_row((lane >> 1) & 15, lane)] = p1;
+  __syncthreads();
+  if (tid < TOK) {
+    const int t = t0 + tid, idx = t - 1;
+    if (t >= 1 && t <= f.N) f.importance[(int64_t)b * f.N + idx] = idx < nim ? sigmoid_acc((sAlpha[tid] + sAlpha[TOK + tid]) + *f.b2) : 0.f;
+  }
+}
+
 }  // namespace
+
+// finish_qkv.h: phases bit 2 = the importance-only finish, bit 4 = tokens + in_proj images (alpha computed there unless
+// alpha_from_importance); both stop-event capable (the recursion's forks ride on them)
+int paths_launch_finish_importance(const FinQkvParams& f, hipStream_t stream) {
+  PATHS_LAUNCH_STOP(finish_importance_kernel, dim3(f.Tp / TOK, f.B), dim3(256), 0, stream, f);
+  PATHS_LAUNCH_CHECK("importance_qkv_x6(importance finish)");
+  return PATHS_OK;
+}
+
+int paths_launch_finish_qkv(const FinQkvParams& f, hipStream_t stream) {
+  static_assert(TT == 4, "the fused finish owns 64-token tiles");
+  WsParams p{};
+  p.bqkv = f.bqkv; p.inv_wo = p.inv_w1 = p.inv_w2 = 1.0f; p.inv_wqkv = f.inv_wqkv;
+  p.w_qkv = reinterpret_cast<const char*>(f.w_qkv);
+  p.qkv_img = reinterpret_cast<char*>(f.qkv_img);
+  p.num_ims = f.num_ims; p.T = f.T; p.Tp = f.Tp; p.B = f.B; p.skip_padding = f.skip_padding; p.qscale = f.qscale; p.eps = 0.f;
+  p.fin = f;
+  const size_t lds = ws_lds_bytes<128>(false, true) + (size_t)(TOK * TOK_LD + 2 * TOK) * sizeof(float);
+  PATHS_LDS_OPT_IN((tlayer_ws_kernel<128, false, true, false, true>), 160 * 1024, "importance_qkv_x6(finish)");
+  // (> 80 KiB per workgroup: one workgroup per CU - a grid of ~one workgroup per CU spreads over the whole chip)
+  const size_t ask = lds > 84 * 1024 ? lds : 84 * 1024;
+  PATHS_LAUNCH_STOP((tlayer_ws_kernel<128, false, true, false, true>), dim3(f.Tp / TOK, f.B), dim3(64 * NW), ask, stream, p);
+  PATHS_LAUNCH_CHECK("importance_qkv_x6(finish)");
+  return PATHS_OK;
+}
 
 #ifdef PATHS_WS_STAMPS
 static unsigned long long* g_ws_stamps = nullptr;

@@ -27,6 +27,10 @@ QKV_IMAGES = os.environ.get("PATHS_QKV_IMAGES", "1") != "0"
 TAIL_WS = os.environ.get("PATHS_TAIL_WS", "1") != "0"          # token-0 tail without K / V projections, one launch (csrc/token0_ws.hip)
 TLAYER_WS = os.environ.get("PATHS_TLAYER_WS", "1") != "0"      # weight-stationary token-layer kernel (csrc/tlayer_ws.hip)
 SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
+# The first decoder layer's in_proj inside the finish of the importance / projection GEMM (paths_importance_qkv_x6, round 5): 1 (default) = one
+# fused finish on the selection stream (importance + tokens + q | k | v operand images), 2 = importance-only finish on the selection
+# stream, tokens + images on the aggregator stream, 0 = the round-4 form (finish, then paths_token_layer_ws as the aggregator's first launch)
+FUSE_QKV = int(os.environ.get("PATHS_FUSE_QKV", "1"))
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 TIMER_ALL = False     # with KERNEL_TIMER: False = bracket only the dominant kernel and the aggregator span (the timed region of
                       # bench.py), True = every kernel group (bench.py's serialised breakdown pass)
@@ -762,7 +766,7 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
     ctx_prev [B,d] (residual source) or None; ctx_all [B,depth,d] contiguous (concat mode) or None."""
     sel = selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding)
     status = torch.zeros((1,), device=fts.device, dtype=torch.int32)
-    agg = aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status)
+    agg = aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status, qkv=sel)
     # the drop-in call is synchronous anyway (the range guard above it syncs): a token-0 tail whose bounded hand-off wait gave up
     # (status bit 2, csrc/token0_ws.hip) must not hand back its logits
     if int(status.item()) & 4:
@@ -812,6 +816,10 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
 
     generic = not fast_path(mc)
+    # default inference form of the shipped geometry: in_proj of decoder layer 0 inside the importance / projection finish (FUSE_QKV)
+    fuse_qkv = (FUSE_QKV in (1, 2) and not generic and x6 and split_planes() == 2 and mc.lstm and GEMM_MODE == "h3" and TLAYER_WS and QKV_IMAGES
+                and L > 1 and pe_tab is not None and not (ATTN_FP8 or AGG_FP8) and D % 64 == 0 and D >= 256 and B * ((T + 63) // 64 * 64) < (1 << 24))
+    fused: Dict[str, object] = {}
     # any aggregator geometry on the tuned LSTM kernels: the importance / projection products take x + h1 summed while staged
     generic_add = generic and x6 and split_planes() == 2 and mc.lstm and GENERIC_ADD and GENERIC_SPLIT and D % 128 == 0
 
@@ -827,9 +835,29 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                   M, D, mc.importance_mlp_hidden_dim, d, 1 if skip_padding else 0, st)
         if x6:
             wip, wip_s = _x6_of(lvl_pack, "w_ip_fwd")
+            splitk = SPLITK_IMPORTANCE and add is not None and split_planes() == 2 and (M + 127) // 128 <= 160
+            if splitk and fuse_qkv and imp_out is importance:
+                # GEMM rows in token order + a finish that also projects q | k | v of decoder layer 0 into the attention's operand images
+                lay0 = lvl_pack["layers"][0]
+                iq, sq = tlayer_ws_images(lay0, 1)
+                hd = d // H
+                ws = torch.empty((int(_lib.load().paths_importance_qkv_x6_workspace(B, N)),), device=dev, dtype=torch.uint8)
+                qkv_img = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, 2)),), device=dev, dtype=torch.uint8)
+                args = (p(src), D, p(x_rows) if src is None else None, p(add), add.stride(1), p(wip), p(lvl_pack["b1"]), p(lvl_pack["w2"]),
+                        p(lvl_pack["b2"]), p(lvl_pack["bp"]), p(lvl_pack["special"]), p(pe_tab), pe_tab.shape[0], p(locs), p(num_ims), B, N,
+                        mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), D, 1 if skip_padding else 0, wip_s, a_scale(), p(ws),
+                        p(iq), p(lay0["bqkv"]), sq[0], LOG2E / math.sqrt(hd), p(qkv_img))
+                if FUSE_QKV == 2:
+                    _lib.call("paths_importance_qkv_x6", *args, 3, 0, st)
+                    # (the aggregator stream finishes the tokens: ws / qkv_img travel with the closure)
+                    fused["finish"] = lambda: _lib.call("paths_importance_qkv_x6", *args, 4, 1, _lib.stream())
+                else:
+                    _lib.call("paths_importance_qkv_x6", *args, 5, 0, st)
+                fused["qkv_img"], fused["ws"] = qkv_img, ws
+                return
             # M/128 blocks fill half the chip at K = 2048 x 8 slides: two k halves on twice the blocks + an epilogue launch
             splitk_ws = None
-            if SPLITK_IMPORTANCE and add is not None and split_planes() == 2 and (M + 127) // 128 <= 160:
+            if splitk:
                 splitk_ws = torch.empty((int(_lib.load().paths_importance_proj_x6_workspace(M)),), device=dev, dtype=torch.uint8)
             _lib.call("paths_importance_proj_x6", p(src), D, p(x_rows) if src is None else None, p(add),
                       add.stride(1) if add is not None else 0,
@@ -911,7 +939,11 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         scratch_imp = torch.empty((B, N), **f32)
         importance_proj(state_out, 0, scratch_imp)               # pass 2: tokens = proj_in(Z) + PE
 
-    return {"ctx_patch": state_out, "importance": importance, "tokens": tokens, "num_ims": num_ims}
+    out = {"ctx_patch": state_out, "importance": importance, "tokens": tokens, "num_ims": num_ims}
+    if "qkv_img" in fused:
+        # the attention's operand images are ready (or, FUSE_QKV = 2, one call away: "qkv_finish" runs on the aggregator's stream)
+        out["qkv_img"], out["qkv_finish"], out["_qkv_ws"] = fused["qkv_img"], fused.get("finish"), fused["ws"]
+    return out
 
 
 def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, keep_count: torch.Tensor,
@@ -945,16 +977,22 @@ def parent_partials(lstm_pack, state_out: torch.Tensor, keep_idx: torch.Tensor, 
     return hp
 
 
-def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None) -> Dict[str, torch.Tensor]:
+def aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None, qkv=None) -> Dict[str, torch.Tensor]:
     """The transformer aggregator + classifier of a level (reference model/aggregator.py:58-76, model/paths.py:126-139).
     Nothing here feeds the next level's patch selection, so the device recursion runs it on a second HIP stream.
-    ``status`` (optional int32 [1] device tensor): bit 4 is set if a bounded in-launch hand-off wait gave up (csrc/token0_ws.hip)."""
-    return timed("aggregator", lambda: _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status),
+    ``status`` (optional int32 [1] device tensor): bit 4 is set if a bounded in-launch hand-off wait gave up (csrc/token0_ws.hip).
+    ``qkv`` (optional): the dict :func:`selection_forward` returned - when it carries "qkv_img" the first decoder layer's q | k | v
+    operand images were written by the importance / projection finish (FUSE_QKV) and the aggregator starts at the attention."""
+    qkv_img, qkv_finish = (qkv.get("qkv_img"), qkv.get("qkv_finish")) if qkv is not None else (None, None)
+    if qkv_finish is not None:
+        timed("agg_tokens_qkv", qkv_finish)            # FUSE_QKV = 2: tokens + images on THIS stream, outside the attention + FFN span
+    return timed("aggregator", lambda: _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status, qkv_img),
                  {"T": tokens.shape[1], "d": tokens.shape[2], "L": mc.trans_layers, "planes": split_planes() if GEMM_MODE != "f32" else 0},
                  detail=False)
 
 
-def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_img, q, k, v, xb, ctx_out, logits, token_layer_old, status=None):
+def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_img, q, k, v, xb, ctx_out, logits, token_layer_old, status=None,
+                           qkv_ready: bool = False):
     """Default-mode aggregator on the weight-stationary token-layer kernel (csrc/tlayer_ws.hip): in_proj writes the attention
     operand images, attention writes its output as the out_proj operand image, the chain kernel keeps weights in registers and
     shares only activations through LDS."""
@@ -980,7 +1018,8 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
                   1 if post is not None else 0, 1 if nxt is not None else 0, 1, qscale, w["eps"], None, 0, st)
 
     xa = tokens
-    timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0]))
+    if not qkv_ready:                       # (FUSE_QKV: the importance / projection finish already wrote layer 0's operand images)
+        timed("agg_in_proj", lambda: token_layer(xa, None, None, layers[0]))
     for l in range(L - 1):
         timed("agg_attention", lambda: _lib.call("paths_attention_h3_img", p(o_img), p(num_ims), B, T, H, hd, p(qkv_img), st))
         last = l + 1 == L - 1
@@ -1019,7 +1058,7 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
     return {"logits": logits, "ctx_slide": ctx_out}
 
 
-def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None) -> Dict[str, torch.Tensor]:
+def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=None, qkv_img=None) -> Dict[str, torch.Tensor]:
     _lib.require_cuda(tokens, num_ims, ctx_prev, ctx_all)
     if AGG_FP8:
         return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8=True)
@@ -1065,6 +1104,10 @@ def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status
     depth = cat.shape[1] if cat is not None else 0
 
     attn_ws = None
+    if qkv_img is not None:
+        assert GEMM_MODE == "h3" and TLAYER_WS and QKV_IMAGES and L > 1 and not ATTN_FP8
+        return _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_img, q, k, v, xb, ctx_out, logits, token_layer, status,
+                                      qkv_ready=True)
     fp8 = ATTN_FP8 and L > 1          # opt-in e4m3 attention (csrc/attn_fp8.hip: outside the 1e-4 logit bar, stress-config measurement only)
     if fp8:
         attn_ws = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=tokens.device, dtype=torch.uint8)

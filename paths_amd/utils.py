@@ -451,10 +451,10 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
-            return ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status)
+            return ops.aggregator_forward(mc, lvl_pack, sel["tokens"], sel["num_ims"], ctx_prev, ctx_all, status=status, qkv=sel)
 
         if overlap:                                       # (side_stream already waits for this level's tokens / num_ims: fork_behind above)
-            keepalive.append((sel["tokens"], sel["num_ims"]))
+            keepalive.append((sel["tokens"], sel["num_ims"], sel.get("qkv_img"), sel.get("_qkv_ws")))
             with torch.cuda.stream(side_stream), _Range(f"level {i}: aggregator (second stream)"):
                 agg = aggregate()
         else:

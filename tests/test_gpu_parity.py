@@ -1450,19 +1450,22 @@ def test_transformer_aggregator_forward_standalone(dev, name):
     want = orc.decoder_stack(params, g_ + "transformer", S, torch.zeros((B, N + 1), dtype=torch.bool), ocfg.trans_heads, ocfg.trans_layers)[:, 0]
     np.testing.assert_allclose(full.numpy(), want.numpy(), atol=LOGIT_TOL, rtol=0)
     # positional encodings on their own (model/aggregator.py:37-56), with and without the projection
+    z = torch.from_numpy(np.random.default_rng(3).standard_normal((B, N, d)).astype(np.float32))
     if ocfg.pos_encoding_mode == "2d":
         pl = torch.div(inp["locs"], ocfg.patch_size, rounding_mode="floor")
-        z = torch.from_numpy(np.random.default_rng(3).standard_normal((B, N, d)).astype(np.float32))
-        got = agg.pos_encode_2d(z.to(dev), pl.to(dev), project=False).cpu()
-        want = z + orc.positional_encoding_2d_from_pos(pl[..., 0].reshape(-1), pl[..., 1].reshape(-1), d).view(B, N, d)
-        np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-6, rtol=0)
-        y = torch.from_numpy(np.random.default_rng(4).standard_normal((B, N, ocfg.patch_embed_dim)).astype(np.float32)) * 0.5
-        got = agg.pos_encode_2d(y.to(dev), pl.to(dev)).cpu()
-        want = torch.nn.functional.linear(y, params[g_ + "proj_in.weight"], params[g_ + "proj_in.bias"]) + (want - z)
-        np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5, rtol=0)
+        with pytest.raises(NotImplementedError):         # on its own it is inference-only (training goes through the processor)
+            agg.pos_encode_2d(z.to(dev), pl.to(dev))
+        with torch.no_grad():
+            got = agg.pos_encode_2d(z.to(dev), pl.to(dev), project=False).cpu()
+            pe = orc.positional_encoding_2d_from_pos(pl[..., 0].reshape(-1), pl[..., 1].reshape(-1), d).view(B, N, d)
+            np.testing.assert_allclose(got.numpy(), (z + pe).numpy(), atol=2e-6, rtol=0)
+            y = torch.from_numpy(np.random.default_rng(4).standard_normal((B, N, ocfg.patch_embed_dim)).astype(np.float32)) * 0.5
+            got = agg.pos_encode_2d(y.to(dev), pl.to(dev)).cpu()
+            want = torch.nn.functional.linear(y, params[g_ + "proj_in.weight"], params[g_ + "proj_in.bias"]) + pe
+            np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-5, rtol=0)
     else:
-        z = torch.from_numpy(np.random.default_rng(3).standard_normal((B, N, d)).astype(np.float32))
-        got = agg.pos_encode_1d(z.to(dev), project=False).cpu()
+        with torch.no_grad():
+            got = agg.pos_encode_1d(z.to(dev), project=False).cpu()
         np.testing.assert_allclose(got.numpy(), (z + orc.positional_encoding(N, d)[None]).numpy(), atol=2e-6, rtol=0)
     with pytest.raises(NotImplementedError):
         agg(torch.zeros((B, 3, d), device=dev), probe["xs"].to(dev), None, None)
@@ -1506,3 +1509,59 @@ def test_fp8_stress_variant_at_its_own_size_k8192_d1536(dev, monkeypatch):
         assert 1e-4 < err < 0.5, errs
         assert torch.equal(tr8[0]["importance"], imp_ref) and torch.equal(out["ctx_patch"], ref["ctx_patch"])
     print("e4m3 aggregator at K=8192, d=1536, 1536/24 heads: max |logit - oracle| =", errs)
+
+
+@pytest.mark.parametrize("name", ["g1_level0_b2_k256", "g2_level2_b2_k256", "g9_level1_b2_k2048", "g5_pe1d_level1", "g5_impnone_level1"])
+def test_fused_importance_qkv_finish_equals_the_separate_launches(dev, monkeypatch, name):
+    """Round 5: the first decoder layer's in_proj inside the finish of the importance / projection GEMM (paths_importance_qkv_x6:
+    GEMM rows in token order, one fused finish writes importance, tokens AND the attention's q | k | v operand images) against the
+    round-4 form (finish, then paths_token_layer_ws as the aggregator's first launch).  Same products in the same order, the same
+    summation tree for alpha, the same token expression: the level's outputs must be IDENTICAL bit for bit, in both fused modes
+    (1 = one finish, 2 = importance-only finish + tokens / images finish), ragged slides and padding included; and equal to the
+    reference golden within the usual bars."""
+    from paths_amd import ops
+    if ops.GEMM_MODE != "h3":
+        pytest.skip("the fused finish is a default-mode (two-plane split) feature")
+    outs = {}
+    for mode in (0, 1, 2):
+        monkeypatch.setattr(ops, "FUSE_QKV", mode)
+        with H.spy_calls() as calls:
+            g, info, outs[mode] = run_single(dev, name)
+        assert ("paths_importance_qkv_x6" in calls) == (mode != 0), (mode, sorted(set(calls)))
+        assert ("paths_importance_proj_x6" in calls) == (mode == 0)
+    for mode in (1, 2):
+        for key in ("logits", "ctx_slide", "importance", "ctx_patch"):
+            assert torch.equal(outs[mode][key], outs[0][key]), (mode, key, float((outs[mode][key] - outs[0][key]).abs().max()))
+    np.testing.assert_allclose(outs[1]["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(outs[1]["importance"].numpy(), g["importance"], atol=STATE_TOL, rtol=0)
+
+
+def test_fused_importance_qkv_finish_in_the_recursion(dev, monkeypatch):
+    """The same equality through the device recursion (row-pointer GEMM operands, skipped padding tiles, the aggregator on its own
+    stream, launch tape): 4 slides x 5 levels at K = 256, every level's importance / kept indices / logits identical in the three
+    modes, eager and replayed."""
+    from paths_amd import ops, utils as putils
+    from paths_amd.data_utils.slide import DeviceSlide
+    if ops.GEMM_MODE != "h3":
+        pytest.skip("default-mode feature")
+    cfg, model, _ = build_model(dev, 3, top_k_patches=[64] * 4)
+    slides = [DeviceSlide.synthetic(14, s, (16, 16), device=dev) for s in range(4)]
+    res = {}
+    for mode in (0, 1, 2):
+        monkeypatch.setattr(ops, "FUSE_QKV", mode)
+        tr = []
+        with torch.no_grad():
+            out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=tr)
+            tape = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5).record()
+            rep = {k: v.clone() for k, v in tape.replay().items()}
+            rep2 = {k: v.clone() for k, v in tape.replay().items()}
+            tape.close()
+        torch.cuda.synchronize()
+        assert torch.equal(rep["logits"], out["logits"]) and torch.equal(rep2["logits"], out["logits"]), mode
+        res[mode] = (out["logits"].clone(), [(lv["importance"].clone(), lv["logits"].clone(), lv.get("keep_idx")) for lv in tr])
+    for mode in (1, 2):
+        assert torch.equal(res[mode][0], res[0][0]), mode
+        for l, ((ia, la, ka), (ib, lb, kb)) in enumerate(zip(res[mode][1], res[0][1])):
+            assert torch.equal(ia, ib) and torch.equal(la, lb), (mode, l)
+            if ka is not None:
+                assert torch.equal(ka, kb), (mode, l)
