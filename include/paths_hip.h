@@ -146,22 +146,24 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
  * workspace) and a second launch sums them and applies the epilogue on 64-row blocks.  null = one launch. */
 int64_t paths_importance_proj_x6_workspace(int M);
 /* Round 5: paths_importance_proj_x6 (split-K form) AND the first decoder layer's in_proj (paths_token_layer_ws with do_qkv only) as one
- * GEMM + one fused finish, for trans_dim 128 / 4 heads / importance hidden 128, two fp16 planes (reference model/paths.py:95-98,
- * 119-124; model/aggregator.py:37-65 and the self_attn in_proj of decoder layer 0, model/aggregator.py:70-72).  The GEMM's rows are
- * TOKEN-ORDERED: row b * Tp + t of its raw result (Tp = N + 1 rounded up to 64) is token slot t of slide b - slot 0 the special token,
- * slot t patch t - 1 - so that a 64-row finish block is one 64-token tile of the attention's operand images.  phases: bit 1 = the
- * split-K GEMM of (y | y_rows) + y_add into splitk_ws (paths_importance_qkv_x6_workspace(B, N) bytes); bit 2 = importance-only finish
- * (alpha -> importance [B, N]); bit 4 = tokens [B, N + 1, 128] + importance (or, alpha_from_importance != 0, importance READ back) +
- * q | k | v operand images of paths_attention_h3_img (qkv_images: paths_attention_x6_workspace(B, N + 1, 4, 32, 2) bytes; w_qkv:
- * paths_tlayer_pack_ws part 1 image with scale s_wqkv, qscale = log2(e) / sqrt(32)).  Bits 2 and 4 are stop-event capable launches
- * and may be issued by separate calls on different streams behind bit 1.  pe_table (paths_pe_table) is required. */
+ * GEMM + one fused finish, for trans_dim 128 / 4 heads / importance hidden 128, two fp16 planes, N % 64 == 0 (reference
+ * model/paths.py:95-98,119-124; model/aggregator.py:37-65 and the self_attn in_proj of decoder layer 0, model/aggregator.py:70-72).
+ * TOKEN ORDER of this form: patch i of slide b is token i and the special token sits at index num_ims[b], right behind the valid
+ * patches (the reference prepends it; masked self-attention is invariant under that permutation and only the special token's output
+ * row is read) - a 64-row block of the GEMM result is then one 64-token tile of the attention's operand images.  Consumers:
+ * paths_attention_h3_img, paths_token_layer_ws (position-agnostic) and paths_token0_tail_ws with special_last = 1.
+ * phases: bit 1 = the split-K GEMM of (y | y_rows) + y_add into splitk_ws (paths_importance_proj_x6_workspace(B * N) bytes); bit 2 =
+ * importance-only finish (alpha -> importance [B, N]); bit 4 = tokens [B, N + 1, 128] + importance (or, alpha_from_importance != 0,
+ * importance READ back) + q | k | v operand images of paths_attention_h3_img (qkv_images: paths_attention_x6_workspace(B, N + 1, 4, 32,
+ * 2) bytes; w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv, qscale = log2(e) / sqrt(32)).  Bits 2 and 4 are stop-event
+ * capable launches and may be issued by separate calls on different streams behind bit 1.  Positional encoding: pe_table
+ * (paths_pe_table, positions < pe_rows) or, with pe_table = NULL, sin / cos evaluated from div_term (as paths_importance_proj). */
 int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6,
                             const float* b1, const float* w2, const float* b2 /* device scalar */, const float* bp, const float* special,
-                            const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
+                            const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
                             int patch_size, int pe_mode, int imp_mul, float* importance, float* tokens, int D, int skip_padding,
                             float w_scale, float a_scale, float* splitk_ws, const void* w_qkv, const float* bqkv, float s_wqkv,
                             float qscale, void* qkv_images, int phases, int alpha_from_importance, paths_stream_t stream);
-int64_t paths_importance_qkv_x6_workspace(int B, int N);
 /* out (+)= maskop(act(a W[:, k0:k0+K]^T + b)) + residual, W = pack of an [Npad, Kpacked] weight; Npad % 128 == 0
  * (256-column tiles when Npad % 256 == 0, else 128-column tiles) */
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,
@@ -366,7 +368,8 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
                          const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
                          const float* wcls, const float* bcls, int num_logits, int cls_in,
                          float* ctx_out, float* logits, float* partials, int* counters, int* status, int B, int T, int d, int H,
-                         float eps, float eps_final, paths_stream_t stream);
+                         float eps, float eps_final, int special_last /* 1: the special token is row num_ims[b] (paths_importance_qkv_x6's
+                         token order) instead of row 0 */, paths_stream_t stream);
 
 /* ---- shape-generic kernels (csrc/generic.hip): any trans_dim (multiple of 32, <= 1024), head_dim in {16, 32, 48, 64}, any
  * importance_mlp_hidden_dim - e.g. the reference's dataclass defaults trans_dim 192 / 4 heads (config.py:30-36).  With

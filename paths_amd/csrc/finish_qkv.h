@@ -1,3 +1,8 @@
+// TOKEN ORDER: patch i of slide b is token i, the special token sits at index num_ims[b] (behind the valid patches; the reference
+// prepends it, model/aggregator.py:62-64 - masked self-attention is invariant under that permutation and only the special token's
+// output row is read).  A 64-row block of the GEMM result (rows b * N + 64 j ..) is then exactly token tile j of slide b; the extra
+// tile j = N / 64 exists for the one slot N the special token takes when a slide is full.
+//
 // Hand-over between the split-K importance / projection GEMM (gemm_x6.hip) and its fused finish (tlayer_ws.hip:
 // tlayer_ws_kernel<128, false, true, false, FIN = true>): the finish workgroup of a 64-token tile sums the two k-half slabs, runs the
 // importance MLP's second layer + sigmoid + mask, builds the tokens (alpha * proj + bias + positional encoding, special token in slot 0)
@@ -8,12 +13,13 @@
 #include "common.h"
 
 struct FinQkvParams {
-  // ---- the raw GEMM result: ws [nz][Mt / 32][8][1024] floats in the accumulator layout (EpiRaw), rows TOKEN-ORDERED (X6Operands::tok_Tp)
+  // ---- the raw GEMM result: ws [nz][M_pad / 32][8][1024] floats in the accumulator layout (EpiRaw), rows = patches (M = B * N)
   const float* ws; int64_t zstride; int nz;
   // ---- importance MLP tail + token assembly (EpiImpProj's operands)
   const float* b1; const float* w2; const float* b2;
   const float* bp; const float* special;
-  const float* pe_table; int pe_rows;          // paths_pe_table output (required)
+  const float* pe_table; int pe_rows;          // paths_pe_table output, or null: sin / cos evaluated here from div_term (the same values)
+  const float* div_term;                       // 2d: [d/4] ; 1d: [d/2]   (host: torch.exp(arange * -ln(1e4)/d), reference utils.py:18,56)
   const int64_t* locs;                         // [B * N, 2] pixel coordinates (2-D mode)
   const int64_t* num_ims;                      // [B]
   int N, T, Tp, B;                             // patches per slide (capacity), tokens = N + 1, T rounded up to 64

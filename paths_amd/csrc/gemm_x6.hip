@@ -87,11 +87,6 @@ struct X6Operands {
   int rows_per_slide;
   float a_scale;                   // NP == 2: activations are multiplied by this power of two before the fp16 split
   int ksplit = 1;                  // > 1 (single-panel launches only): blockIdx.z owns the k window [z K0/ksplit, (z+1) K0/ksplit)
-  // TOKEN-ORDERED rows (importance / projection GEMM feeding paths_importance_qkv_x6's fused finish): with tok_Tp > 0 the M = B * tok_Tp
-  // rows of this launch are token slots - row b * tok_Tp + t is patch t - 1 of slide b (t = 0: the special token's slot, t > tok_N:
-  // padding; both read a clamped source row and their results are discarded) - so that a 64-row block of the raw result is exactly
-  // one 64-token tile of the attention's operand images.  Source row (A0rows / A0 / Aadd index) = b * tok_N + clamp(t - 1, 0, tok_N - 1).
-  int tok_Tp = 0, tok_N = 0;
 #ifdef PATHS_X6_DEBUG
   uint64_t* dbg;                   // tools/x6_stages.py only: per-wave {init, loop, epilogue} shader-clock ticks, 100 MHz ticks, start/end 100 MHz stamps
 #endif
@@ -135,7 +130,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
   const int rows_in_grp = min(GM, nby - grp * GM);
   const int by = grp * GM + in_grp % rows_in_grp, bx = in_grp / rows_in_grp;
   const int m0 = by * BM, n0 = bx * BN;
-  if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M, g.tok_Tp > 0 ? 1 : 0)) return;
+  if (block_all_padding(g.num_ims, g.rows_per_slide, m0, BM, g.M)) return;
 #ifdef PATHS_X6_DEBUG
   const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
   uint64_t dbg_t1 = 0, dbg_t2 = 0, dbg_s[4] = {0, 0, 0, 0};
@@ -150,11 +145,7 @@ gemm_x6_kernel(X6Operands g, Epi epi) {
 #pragma unroll
   for (int p = 0; p < NA; ++p) {
     const int row = p * 64 + arow;
-    int64_t grow = min(m0 + row, g.M - 1);
-    if (g.tok_Tp > 0) {                                // token slot -> patch row (see X6Operands)
-      const int bsl = (int)grow / g.tok_Tp, tsl = (int)grow - bsl * g.tok_Tp;
-      grow = (int64_t)bsl * g.tok_N + min(max(tsl - 1, 0), g.tok_N - 1);
-    }
+    const int64_t grow = min(m0 + row, g.M - 1);
     aoff0[p] = ROWS ? 0u : (uint32_t)((grow * g.lda0 + 4 * ac) * 4);
     if constexpr (ROWS) rowp[p] = reinterpret_cast<gptr_f4>(static_cast<uintptr_t>(g.A0rows[grow]) + 16 * ac);
     aoff1[p] = (uint32_t)((grow * g.lda1 + 4 * ac) * 4);
@@ -805,45 +796,42 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
 }
 
 
-// The importance / projection GEMM with TOKEN-ORDERED rows and its fused finish (finish_qkv.h): the default inference form of
+// The split-K importance / projection GEMM and its FUSED finish (finish_qkv.h): the default inference form of
 // paths_importance_proj_x6 + paths_token_layer_ws(do_qkv only) for trans_dim 128 / 4 heads / importance hidden 128 (reference
 // model/paths.py:95-98,119-124, model/aggregator.py:37-65 and the first decoder layer's self_attn in_proj, aggregator.py:70-72).
-//   phases bit 1: the split-K GEMM over (y | y_rows) + y_add into splitk_ws (paths_importance_qkv_x6_workspace(B, N) bytes): row
-//                 b * Tp + t of the raw result is token slot t of slide b (t = 0 special token, patch t - 1 otherwise; Tp = N + 1
-//                 rounded up to 64);
+// TOKEN ORDER of this form: patch i of a slide is token i and the SPECIAL token sits at index num_ims[b], right behind the valid
+// patches (the reference prepends it, aggregator.py:62-64; self-attention with a key mask is invariant under that permutation and only
+// the special token's output row is read) - so a 64-row block of the GEMM result IS a 64-token tile of the attention's operand
+// images, with no shift by one.  Consumers: paths_attention_h3_img / paths_token_layer_ws (position-agnostic) and
+// paths_token0_tail_ws with special_last = 1.  N % 64 == 0.
+//   phases bit 1: the split-K GEMM over (y | y_rows) + y_add into splitk_ws (paths_importance_proj_x6_workspace(B * N) bytes);
 //          bit 2: the importance-only finish (alpha -> importance [B, N]);
-//          bit 4: the tokens + in_proj finish: importance (computed, or read back when alpha_from_importance), tokens [B, N + 1, 128],
+//          bit 4: the tokens + in_proj finish: importance (computed, or read back when alpha_from_importance), tokens [B, N + 1, 128]
 //                 and the q | k | v operand images of paths_attention_h3_img in qkv_images (paths_attention_x6_workspace(B, N + 1, 4, 32, 2)).
 // Bits 2 and 4 are stop-event capable launches; they may be issued by separate calls on different streams (the caller orders them
-// behind bit 1).  pe_table is required (paths_pe_table).  w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv.
-int64_t paths_importance_qkv_x6_workspace(int B, int N) {
-  const int Tp = (N + 1 + 63) / 64 * 64;
-  return 2ll * (((int64_t)B * Tp + 127) / 128 * 4) * 8 * 1024 * 4;
-}
-
+// behind bit 1).  pe_table (paths_pe_table) or, without it, div_term (sin / cos evaluated in the finish).  w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv.
 int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6,
                             const float* b1, const float* w2, const float* b2, const float* bp, const float* special,
-                            const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
+                            const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
                             int patch_size, int pe_mode, int imp_mul, float* importance, float* tokens, int D, int skip_padding,
                             float w_scale, float a_scale, float* splitk_ws, const void* w_qkv, const float* bqkv, float s_wqkv,
                             float qscale, void* qkv_images, int phases, int alpha_from_importance, hipStream_t stream) {
-  PATHS_REQUIRE(B > 0 && N > 0 && D % 64 == 0 && D >= 256, "importance_qkv_x6: bad shape B=%d N=%d D=%d", B, N, D);
+  PATHS_REQUIRE(B > 0 && N > 0 && N % 64 == 0 && D % 64 == 0 && D >= 256, "importance_qkv_x6: bad shape B=%d N=%d (a multiple of 64) D=%d", B, N, D);
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_qkv_x6: pe_mode must be 1 (1d) or 2 (2d)");
-  PATHS_REQUIRE(pe_table != nullptr && pe_rows > 0 && (pe_mode == 1 || locs != nullptr), "importance_qkv_x6: needs the positional-encoding table (and locs in 2d mode)");
+  PATHS_REQUIRE(((pe_table != nullptr && pe_rows > 0) || div_term != nullptr) && (pe_mode == 1 || locs != nullptr), "importance_qkv_x6: needs the positional-encoding table or div_term (and locs in 2d mode)");
   PATHS_REQUIRE(num_ims != nullptr && splitk_ws != nullptr && (uintptr_t)splitk_ws % 16 == 0, "importance_qkv_x6: num_ims and a 16-byte aligned workspace are required");
   PATHS_REQUIRE(phases > 0 && (phases & ~7) == 0, "importance_qkv_x6: phases is a mask of 1 (GEMM), 2 (importance finish), 4 (tokens + in_proj finish)");
   PATHS_REQUIRE(pow2(w_scale) && pow2(a_scale), "importance_qkv_x6: scales must be powers of two");
-  const int T = N + 1, Tp = (T + 63) / 64 * 64;
-  const int64_t Mt64 = (int64_t)B * Tp;
-  PATHS_REQUIRE(Mt64 < (1ll << 24), "importance_qkv_x6: B * Tp must stay below 2^24 token slots");
-  const int Mt = (int)Mt64;
-  const int mt = (Mt + 127) / 128 * 4;                               // 32-row tiles, padded to the GEMM's 128-row blocks
+  const int64_t M64 = (int64_t)B * N;
+  PATHS_REQUIRE(M64 < (1ll << 24), "importance_qkv_x6: B * N must stay below 2^24 rows");
+  const int M = (int)M64, T = N + 1, Tp = (T + 63) / 64 * 64;
+  const int mt = (M + 127) / 128 * 4;                                // 32-row tiles, padded to the GEMM's 128-row blocks
   const int64_t zstride = (int64_t)mt * 8 * 1024;
   if (phases & 1) {
     PATHS_REQUIRE(w_ip_x6 != nullptr && y_add != nullptr && (y != nullptr) != (y_rows != nullptr), "importance_qkv_x6: the GEMM takes (y or y_rows) + y_add");
     PATHS_REQUIRE(ldya % 4 == 0 && (uintptr_t)y_add % 16 == 0, "importance_qkv_x6: y_add must be 16-byte aligned with ldya %% 4 == 0");
-    X6Operands g{y, ldy, D, y_rows, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(2, D), Mt, skip_padding ? num_ims : nullptr, Tp, a_scale};
-    g.ksplit = 2; g.tok_Tp = Tp; g.tok_N = N;
+    X6Operands g{y, ldy, D, y_rows, nullptr, 0, 0, y_add, ldya, reinterpret_cast<const char*>(w_ip_x6), group_stride(2, D), M, skip_padding ? num_ims : nullptr, N, a_scale};
+    g.ksplit = 2;
     EpiRaw raw{splitk_ws, zstride, 8};
     const int rc = y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(g, 256, raw, stream, "importance_qkv_x6(split-k)")
                           : launch_x6_np<2, 2, 4, 2, true, false>(g, 256, raw, stream, "importance_qkv_x6(split-k)");
@@ -851,7 +839,7 @@ int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, 
   }
   if (phases & 6) {
     PATHS_REQUIRE(b1 && w2 && b2 && importance, "importance_qkv_x6: b1, w2, b2 (device scalar) and importance are required");
-    FinQkvParams f{splitk_ws, zstride, 2, b1, w2, b2, bp, special, pe_table, pe_rows, locs, num_ims, N, T, Tp, B, patch_size, pe_mode, imp_mul,
+    FinQkvParams f{splitk_ws, zstride, 2, b1, w2, b2, bp, special, pe_table, pe_table ? pe_rows : 0, div_term, locs, num_ims, N, T, Tp, B, patch_size, pe_mode, imp_mul,
                    skip_padding, 1.0f / (w_scale * a_scale), alpha_from_importance, importance, tokens, w_qkv, bqkv, 1.0f / s_wqkv, qscale, qkv_images};
     if (phases & 2) {
       const int rc = paths_launch_finish_importance(f, stream);

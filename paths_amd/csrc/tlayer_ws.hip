@@ -139,15 +139,35 @@ struct WsParams {
 constexpr int TOK_LD = 132;     // FIN: row stride (floats) of the fp32 token tile in LDS (16-byte aligned rows, rows 4 banks apart)
 
 // FIN prologue, part 1 (all 4 waves = 2 x 2 over 64 token slots x 256 raw columns, the layout of x6_finish_kernel / EpiImpProj in
-// gemm_x6.hip / gemm_epi.h, rows TOKEN-ordered): sum the k-half slabs, importance logits -> alpha, tokens -> global + LDS (sTok).
+// gemm_x6.hip / gemm_epi.h; token slot = patch row, special token at slot num_ims[b]: finish_qkv.h): sum the k-half slabs, importance logits -> alpha, tokens -> global + LDS (sTok).
 // Packed GEMM columns: [W1[0:64] ; Wp[0:64] ; W1[64:128] ; Wp[64:128]]: wave column half wn owns hidden units / token channels 64 wn ..
 __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0, int tid, float* sTok, float* sAlpha) {
   constexpr int d = 128;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int u0 = 64 * wn;
+  const int nim = (int)f.num_ims[b];
+  // loads that do not depend on the GEMM result first (their round trips - positions -> table rows are two dependent ones - run under
+  // the 128-KB slab stream below instead of behind the barrier)
+  const float b2v = *f.b2, ps_inv = 1.0f / (float)f.patch_size;
+  float bpv[2], spv[2], b1v[2], w2v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int c = u0 + 32 * j + (lane & 31); bpv[j] = f.bp[c]; spv[j] = f.special[c]; b1v[j] = f.b1[c]; w2v[j] = f.w2[c]; }
+  int64_t lp[16]; float aimp[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {                       // (clamped indices: always legal)
+    const int sl = t0 + 32 * wm + c32_row(r, lane);
+    const int64_t m = (int64_t)b * f.N + min(sl, f.N - 1);
+    lp[r] = f.pe_mode == 2 ? f.locs[2 * m + wn] : 0;
+    aimp[r] = f.alpha_from_importance ? f.importance[m] : 0.f;
+  }
   float acc[4][16];
-  {
-    const int64_t trow = (((int64_t)b * f.Tp + t0) >> 5) + wm;
+  if (t0 >= f.N) {                                     // the extra tile (slot N: the special token of a full slide): no GEMM rows behind it
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  } else {
+    const int64_t trow = (((int64_t)b * f.N + t0) >> 5) + wm;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
@@ -159,7 +179,29 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
       }
     }
   }
-  const int nim = (int)f.num_ims[b];
+  float pev[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {                       // positional-encoding rows: in flight while the logits are reduced
+    const int sl = t0 + 32 * wm + c32_row(r, lane);
+    const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
+    const int ipos = f.pe_mode == 2 ? paths_epi::div_u24(px24, f.patch_size, ps_inv) : min(sl, f.N - 1);
+    if (f.pe_table != nullptr) {
+      const int tp = min(ipos, f.pe_rows - 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = u0 + 32 * j + (lane & 31);
+        pev[r][j] = f.pe_mode == 2 ? f.pe_table[(int64_t)tp * (d / 2) + (c & (d / 2 - 1))] : f.pe_table[(int64_t)tp * d + c];
+      }
+    } else {                                           // no table (drop-in calls do not know the grid size): the same sinf / cosf values
+      const int ipos_f = f.pe_mode == 2 ? paths_epi::div_pos(lp[r], f.patch_size, ps_inv) : min(sl, f.N - 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = u0 + 32 * j + (lane & 31);
+        const float ang = (float)ipos_f * (f.pe_mode == 2 ? f.div_term[(c & (d / 2 - 1)) >> 1] : f.div_term[c >> 1]);
+        pev[r][j] = (c & 1) ? cosf(ang) : sinf(ang);
+      }
+    }
+  }
   if (!f.alpha_from_importance) {
     // ---- partial importance logits over this wave's 64 hidden units, summed over the 32 lanes of each half-wave by the halving
     // butterfly of EpiImpProj (gemm_epi.h): afterwards lane l holds the total of row index rho(l) = bits 4..1 of l
@@ -168,8 +210,7 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
     for (int r = 0; r < 16; ++r) part[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int u = u0 + 32 * j + (lane & 31);
-      const float bb = f.b1[u], w = f.w2[u];
+      const float bb = b1v[j], w = w2v[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) part[r] += fmaxf(fmaf(acc[j][r], f.acc_scale, bb), 0.f) * w;
     }
@@ -200,47 +241,27 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
   }
   __syncthreads();
   // ---- alpha of every row (both column halves compute the same value), tokens of this wave's 64 channels
-  const float b2v = *f.b2, ps_inv = 1.0f / (float)f.patch_size;
-  float bpv[2], spv[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { const int c = u0 + 32 * j + (lane & 31); bpv[j] = f.bp[c]; spv[j] = f.special[c]; }
-  int64_t lp[16]; float aimp[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {                       // loads first (clamped indices: always legal), math after
-    const int t = t0 + 32 * wm + c32_row(r, lane);
-    const int64_t m = (int64_t)b * f.N + min(max(t - 1, 0), f.N - 1);
-    lp[r] = f.pe_mode == 2 ? f.locs[2 * m + wn] : 0;
-    aimp[r] = f.alpha_from_importance ? f.importance[m] : 0.f;
-  }
-  float pev[16][2]; float av[16]; bool valid[16];
+  float av[16]; bool valid[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int lt = 32 * wm + c32_row(r, lane), t = t0 + lt, idx = t - 1;
-    valid[r] = t >= 1 && idx < nim;
+    const int lt = 32 * wm + c32_row(r, lane), sl = t0 + lt;          // token slot = patch index; the special token sits at slot nim
+    valid[r] = sl < nim;
     float a = 0.f;
     if (valid[r]) a = f.alpha_from_importance ? aimp[r] : sigmoid_acc((sAlpha[lt] + sAlpha[TOK + lt]) + b2v);
-    if (!f.alpha_from_importance && wn == 0 && (lane & 31) == 0 && t >= 1 && t <= f.N) f.importance[(int64_t)b * f.N + idx] = a;
+    if (!f.alpha_from_importance && wn == 0 && (lane & 31) == 0 && sl < f.N) f.importance[(int64_t)b * f.N + sl] = a;
     av[r] = f.imp_mul ? a : 1.f;
-    const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
-    const int ipos = f.pe_mode == 2 ? paths_epi::div_u24(px24, f.patch_size, ps_inv) : max(idx, 0);
-    const int tp = min(ipos, f.pe_rows - 1);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = u0 + 32 * j + (lane & 31);
-      pev[r][j] = f.pe_mode == 2 ? f.pe_table[(int64_t)tp * (d / 2) + (c & (d / 2 - 1))] : f.pe_table[(int64_t)tp * d + c];
-    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int lt = 32 * wm + c32_row(r, lane), t = t0 + lt;
+    const int lt = 32 * wm + c32_row(r, lane), sl = t0 + lt;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = u0 + 32 * j + (lane & 31);
       // padded slots: the projection of a padded row may be anything (its LSTM tile may have been skipped): select, do not multiply
       const float pj = valid[r] ? acc[2 + j][r] * f.acc_scale : 0.f;
-      const float v = t == 0 ? spv[j] : (t < f.T ? av[r] * pj + bpv[j] + pev[r][j] : 0.f);
+      const float v = sl == nim ? spv[j] : (sl < f.T ? av[r] * pj + bpv[j] + pev[r][j] : 0.f);
       sTok[lt * TOK_LD + c] = v;
-      if (t < f.T) f.tokens[((int64_t)b * f.T + t) * d + c] = v;
+      if (sl < f.T) f.tokens[((int64_t)b * f.T + sl) * d + c] = v;
     }
   }
 }
@@ -700,11 +721,11 @@ finish_importance_kernel(FinQkvParams f) {
   const int b = blockIdx.y, t0 = blockIdx.x * TOK, tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int nim = (int)f.num_ims[b];
-  if (f.skip_padding && t0 >= nim + 1) return;
+  if (t0 >= f.N || (f.skip_padding && t0 >= nim)) return;
   float part[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[r] = 0.f;
-  const int64_t trow = (((int64_t)b * f.Tp + t0) >> 5) + wm;
+  const int64_t trow = (((int64_t)b * f.N + t0) >> 5) + wm;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
@@ -744,8 +765,8 @@ finish_importance_kernel(FinQkvParams f) {
   if ((lane & 1) == 0) sAlpha[wn * TOK + 32 * wm + c32_row((lane >> 1) & 15, lane)] = p1;
   __syncthreads();
   if (tid < TOK) {
-    const int t = t0 + tid, idx = t - 1;
-    if (t >= 1 && t <= f.N) f.importance[(int64_t)b * f.N + idx] = idx < nim ? sigmoid_acc((sAlpha[tid] + sAlpha[TOK + tid]) + *f.b2) : 0.f;
+    const int sl = t0 + tid;
+    if (sl < f.N) f.importance[(int64_t)b * f.N + sl] = sl < nim ? sigmoid_acc((sAlpha[tid] + sAlpha[TOK + tid]) + *f.b2) : 0.f;
   }
 }
 

@@ -54,6 +54,7 @@ struct T0Params {
   int* counters;                   // [3 B] per slide: arrival ticket 1, "x is published" flag, arrival ticket 2; zero on entry, left zero
   int* status;                     // optional: bit 4 is set when a bounded hand-off wait of the distributed form gives up
   int T, nts; float eps, eps_f;
+  int special_last;                // 0: the special token is row 0 (the reference's order); 1: it is row num_ims[b] (paths_importance_qkv_x6's order)
 #ifdef PATHS_T0_STAMPS
   unsigned long long* stamps;
 #endif
@@ -112,7 +113,7 @@ token0_ws_kernel(T0Params p) {
 
   T0_STAMP(0);
   // ---- phase 0: qt = A_head x0 + a0_head
-  if (tid < DM) sX0[tid] = xb[tid];
+  if (tid < DM) sX0[tid] = xb[(p.special_last ? (int64_t)min((int)p.num_ims[b], p.T - 1) * DM : 0) + tid];
   __syncthreads();
   {
     const int c = tid & 127, kq = tid >> 7;
@@ -373,7 +374,7 @@ token0_dist_kernel(T0Params p) {
 
   T0_STAMP(0);
   // ---- phase 0: qt = A_head x0 + a0_head
-  if (tid < DM) sX0[tid] = xb[tid];
+  if (tid < DM) sX0[tid] = xb[(p.special_last ? (int64_t)min((int)p.num_ims[b], p.T - 1) * DM : 0) + tid];
   __syncthreads();
   {
     const float* A = W + OFF_A + (int64_t)head * DM * DM;
@@ -707,7 +708,7 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
                          const float* ctx_prev, int64_t ctx_stride, const float* ctx_all, int ctx_depth,
                          const float* wcls, const float* bcls, int num_logits, int cls_in,
                          float* ctx_out, float* logits, float* partials, int* counters, int* status, int B, int T, int d, int H,
-                         float eps, float eps_final, hipStream_t stream) {
+                         float eps, float eps_final, int special_last, hipStream_t stream) {
   PATHS_REQUIRE(d == DM && H == NH, "token0_tail_ws: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && x1 && num_ims && img && bv && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b && lnfg && lnfb,
                 "token0_tail_ws: null operand");
@@ -717,7 +718,7 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
   const int nd = dist_splits(B, T);
   const int nts = nd ? nd : chain_splits(T);
   T0Params p{x1, num_ims, reinterpret_cast<const float*>(img), bv, bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, lnfg, lnfb,
-             ctx_prev, ctx_stride, ctx_all, ctx_depth, wcls, bcls, num_logits, cls_in, ctx_out, logits, partials, counters, status, T, nts, eps, eps_final
+             ctx_prev, ctx_stride, ctx_all, ctx_depth, wcls, bcls, num_logits, cls_in, ctx_out, logits, partials, counters, status, T, nts, eps, eps_final, special_last ? 1 : 0
 #ifdef PATHS_T0_STAMPS
              , g_t0_stamps
 #endif

@@ -472,7 +472,9 @@ def generic_pack(lvl_pack: Dict[str, object], mc) -> Dict[str, object]:
     """Zero-padded fp32 weight copies for the generic path (cached in the level's pack dict, rebuilt with it)."""
     if "generic" not in lvl_pack:
         Hi = mc.importance_mlp_hidden_dim
-        g = {"w1": _pad_rows(lvl_pack["w_ip"][:Hi]), "wp": _pad_rows(lvl_pack["w_ip"][Hi:]), "layers": []}
+        g = {"layers": []}
+        if "w_ip" in lvl_pack:            # (absent in the pack of a standalone TransformerAggregator: pack_aggregator)
+            g.update({"w1": _pad_rows(lvl_pack["w_ip"][:Hi]), "wp": _pad_rows(lvl_pack["w_ip"][Hi:])})
         for lay in lvl_pack["layers"]:
             g["layers"].append({k: _pad_rows(lay[k]) for k in ("wqkv", "wo", "w1", "w2")})
         lvl_pack["generic"] = g
@@ -818,7 +820,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     generic = not fast_path(mc)
     # default inference form of the shipped geometry: in_proj of decoder layer 0 inside the importance / projection finish (FUSE_QKV)
     fuse_qkv = (FUSE_QKV in (1, 2) and not generic and x6 and split_planes() == 2 and mc.lstm and GEMM_MODE == "h3" and TLAYER_WS and QKV_IMAGES
-                and L > 1 and pe_tab is not None and not (ATTN_FP8 or AGG_FP8) and D % 64 == 0 and D >= 256 and B * ((T + 63) // 64 * 64) < (1 << 24))
+                and L > 1 and not (ATTN_FP8 or AGG_FP8) and D % 64 == 0 and D >= 256 and N % 64 == 0 and TAIL_WS)
     fused: Dict[str, object] = {}
     # any aggregator geometry on the tuned LSTM kernels: the importance / projection products take x + h1 summed while staged
     generic_add = generic and x6 and split_planes() == 2 and mc.lstm and GENERIC_ADD and GENERIC_SPLIT and D % 128 == 0
@@ -841,12 +843,14 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                 lay0 = lvl_pack["layers"][0]
                 iq, sq = tlayer_ws_images(lay0, 1)
                 hd = d // H
-                ws = torch.empty((int(_lib.load().paths_importance_qkv_x6_workspace(B, N)),), device=dev, dtype=torch.uint8)
+                ws = torch.empty((int(_lib.load().paths_importance_proj_x6_workspace(M)),), device=dev, dtype=torch.uint8)
                 qkv_img = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, 2)),), device=dev, dtype=torch.uint8)
                 args = (p(src), D, p(x_rows) if src is None else None, p(add), add.stride(1), p(wip), p(lvl_pack["b1"]), p(lvl_pack["w2"]),
-                        p(lvl_pack["b2"]), p(lvl_pack["bp"]), p(lvl_pack["special"]), p(pe_tab), pe_tab.shape[0], p(locs), p(num_ims), B, N,
+                        p(lvl_pack["b2"]), p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]),
+                        p(pe_tab), pe_tab.shape[0] if pe_tab is not None else 0, p(locs), p(num_ims), B, N,
                         mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), D, 1 if skip_padding else 0, wip_s, a_scale(), p(ws),
                         p(iq), p(lay0["bqkv"]), sq[0], LOG2E / math.sqrt(hd), p(qkv_img))
+                # (token order of this form: patch i = token i, the special token at index num_ims[b]; the tail is told: special_last)
                 if FUSE_QKV == 2:
                     _lib.call("paths_importance_qkv_x6", *args, 3, 0, st)
                     # (the aggregator stream finishes the tokens: ws / qkv_img travel with the closure)
@@ -1037,7 +1041,7 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
             p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
             res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, depth,
             p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), logits.shape[1], lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
-            p(part), p(cnt), p(status) if status is not None else None, B, T, d, H, w["eps"], lvl_pack["lnf_eps"], st)
+            p(part), p(cnt), p(status) if status is not None else None, B, T, d, H, w["eps"], lvl_pack["lnf_eps"], 1 if qkv_ready else 0, st)
 
     if TAIL_WS:
         timed("agg_token0_tail", tail_ws)

@@ -32,7 +32,7 @@ def run():
     _lib.call("paths_token0_tail_ws", p(x1), p(num_ims), p(img), w["bqkv"].data_ptr() + 8 * d, p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
               p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["b1"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]), p(lvl["lnfg"]), p(lvl["lnfb"]),
               p(res), res.stride(0), None, 0, p(lvl["wcls"]), p(lvl["bcls"]), 4, 128, p(ctx_out), p(logits), p(part), p(cnt), None, B, T, d, H,
-              w["eps"], lvl["lnf_eps"], st)
+              w["eps"], lvl["lnf_eps"], 0, st)
 run(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
