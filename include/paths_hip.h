@@ -156,11 +156,11 @@ int64_t paths_importance_proj_x6_workspace(int M);
  * importance-only finish (alpha -> importance [B, N]); bit 4 = tokens [B, N + 1, 128] + importance (or, alpha_from_importance != 0,
  * importance READ back) + q | k | v operand images of paths_attention_h3_img (qkv_images: paths_attention_x6_workspace(B, N + 1, 4, 32,
  * 2) bytes; w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv, qscale = log2(e) / sqrt(32)).  Bits 2 and 4 are stop-event
- * capable launches and may be issued by separate calls on different streams behind bit 1.  Positional encoding: pe_table
- * (paths_pe_table, positions < pe_rows) or, with pe_table = NULL, sin / cos evaluated from div_term (as paths_importance_proj). */
+ * capable launches and may be issued by separate calls on different streams behind bit 1.  pe_table (paths_pe_table) is required;
+ * positions must be < pe_rows (they are clamped for memory safety). */
 int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6,
                             const float* b1, const float* w2, const float* b2 /* device scalar */, const float* bp, const float* special,
-                            const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
+                            const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
                             int patch_size, int pe_mode, int imp_mul, float* importance, float* tokens, int D, int skip_padding,
                             float w_scale, float a_scale, float* splitk_ws, const void* w_qkv, const float* bqkv, float s_wqkv,
                             float qscale, void* qkv_images, int phases, int alpha_from_importance, paths_stream_t stream);

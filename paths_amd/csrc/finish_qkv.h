@@ -18,8 +18,7 @@ struct FinQkvParams {
   // ---- importance MLP tail + token assembly (EpiImpProj's operands)
   const float* b1; const float* w2; const float* b2;
   const float* bp; const float* special;
-  const float* pe_table; int pe_rows;          // paths_pe_table output, or null: sin / cos evaluated here from div_term (the same values)
-  const float* div_term;                       // 2d: [d/4] ; 1d: [d/2]   (host: torch.exp(arange * -ln(1e4)/d), reference utils.py:18,56)
+  const float* pe_table; int pe_rows;          // paths_pe_table output (required: an inline sinf / cosf path cost 6.8k instructions per lane)
   const int64_t* locs;                         // [B * N, 2] pixel coordinates (2-D mode)
   const int64_t* num_ims;                      // [B]
   int N, T, Tp, B;                             // patches per slide (capacity), tokens = N + 1, T rounded up to 64
@@ -31,6 +30,7 @@ struct FinQkvParams {
   // ---- first decoder layer's in_proj (paths_tlayer_pack_ws part 1 image, scale s_wqkv) -> operand images of paths_attention_h3_img
   const void* w_qkv; const float* bqkv; float inv_wqkv; float qscale;
   void* qkv_img;
+  int xcd_order;                               // finish workgroups in the XCD order of the GEMM that wrote the slabs (tlayer_ws.hip: fin_tile_of_workgroup)
 };
 
 // defined in tlayer_ws.hip; launches on `stream` (stop-event capable: PATHS_LAUNCH_STOP)

@@ -608,6 +608,7 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
 #define PATHS_H_OCC 3
 #endif
 constexpr int H_OCC = PATHS_H_OCC;
+static const bool FIN_XCD_ORDER = getenv("PATHS_FIN_XCD_ORDER") == nullptr || atoi(getenv("PATHS_FIN_XCD_ORDER")) != 0;   // A/B switch
 static const bool IP_TILE128 = getenv("PATHS_IP_TILE128") != nullptr && atoi(getenv("PATHS_IP_TILE128")) != 0;   // measured: 69 us vs 58 (split-K)
 static const bool O_RAW = getenv("PATHS_O_RAW") == nullptr || atoi(getenv("PATHS_O_RAW")) != 0;
 static const bool H_SMALL_TILES = getenv("PATHS_H_SMALL_TILES") == nullptr || atoi(getenv("PATHS_H_SMALL_TILES")) != 0;
@@ -809,16 +810,16 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
 //          bit 4: the tokens + in_proj finish: importance (computed, or read back when alpha_from_importance), tokens [B, N + 1, 128]
 //                 and the q | k | v operand images of paths_attention_h3_img in qkv_images (paths_attention_x6_workspace(B, N + 1, 4, 32, 2)).
 // Bits 2 and 4 are stop-event capable launches; they may be issued by separate calls on different streams (the caller orders them
-// behind bit 1).  pe_table (paths_pe_table) or, without it, div_term (sin / cos evaluated in the finish).  w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv.
+// behind bit 1).  pe_table is required (paths_pe_table; positions are clamped to its rows).  w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv.
 int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, const float* y_add, int64_t ldya, const void* w_ip_x6,
                             const float* b1, const float* w2, const float* b2, const float* bp, const float* special,
-                            const float* div_term, const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
+                            const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
                             int patch_size, int pe_mode, int imp_mul, float* importance, float* tokens, int D, int skip_padding,
                             float w_scale, float a_scale, float* splitk_ws, const void* w_qkv, const float* bqkv, float s_wqkv,
                             float qscale, void* qkv_images, int phases, int alpha_from_importance, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && N > 0 && N % 64 == 0 && D % 64 == 0 && D >= 256, "importance_qkv_x6: bad shape B=%d N=%d (a multiple of 64) D=%d", B, N, D);
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_qkv_x6: pe_mode must be 1 (1d) or 2 (2d)");
-  PATHS_REQUIRE(((pe_table != nullptr && pe_rows > 0) || div_term != nullptr) && (pe_mode == 1 || locs != nullptr), "importance_qkv_x6: needs the positional-encoding table or div_term (and locs in 2d mode)");
+  PATHS_REQUIRE(pe_table != nullptr && pe_rows > 0 && (pe_mode == 1 || locs != nullptr), "importance_qkv_x6: needs the positional-encoding table (and locs in 2d mode)");
   PATHS_REQUIRE(num_ims != nullptr && splitk_ws != nullptr && (uintptr_t)splitk_ws % 16 == 0, "importance_qkv_x6: num_ims and a 16-byte aligned workspace are required");
   PATHS_REQUIRE(phases > 0 && (phases & ~7) == 0, "importance_qkv_x6: phases is a mask of 1 (GEMM), 2 (importance finish), 4 (tokens + in_proj finish)");
   PATHS_REQUIRE(pow2(w_scale) && pow2(a_scale), "importance_qkv_x6: scales must be powers of two");
@@ -839,8 +840,9 @@ int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, 
   }
   if (phases & 6) {
     PATHS_REQUIRE(b1 && w2 && b2 && importance, "importance_qkv_x6: b1, w2, b2 (device scalar) and importance are required");
-    FinQkvParams f{splitk_ws, zstride, 2, b1, w2, b2, bp, special, pe_table, pe_table ? pe_rows : 0, div_term, locs, num_ims, N, T, Tp, B, patch_size, pe_mode, imp_mul,
-                   skip_padding, 1.0f / (w_scale * a_scale), alpha_from_importance, importance, tokens, w_qkv, bqkv, 1.0f / s_wqkv, qscale, qkv_images};
+    FinQkvParams f{splitk_ws, zstride, 2, b1, w2, b2, bp, special, pe_table, pe_rows, locs, num_ims, N, T, Tp, B, patch_size, pe_mode, imp_mul,
+                   skip_padding, 1.0f / (w_scale * a_scale), alpha_from_importance, importance, tokens, w_qkv, bqkv, 1.0f / s_wqkv, qscale, qkv_images,
+                   (B % 8 == 0 && (M / 128) % 8 == 0 && M % 128 == 0 && FIN_XCD_ORDER) ? 1 : 0};
     if (phases & 2) {
       const int rc = paths_launch_finish_importance(f, stream);
       if (rc != PATHS_OK) return rc;

@@ -141,24 +141,52 @@ constexpr int TOK_LD = 132;     // FIN: row stride (floats) of the fp32 token ti
 // FIN prologue, part 1 (all 4 waves = 2 x 2 over 64 token slots x 256 raw columns, the layout of x6_finish_kernel / EpiImpProj in
 // gemm_x6.hip / gemm_epi.h; token slot = patch row, special token at slot num_ims[b]: finish_qkv.h): sum the k-half slabs, importance logits -> alpha, tokens -> global + LDS (sTok).
 // Packed GEMM columns: [W1[0:64] ; Wp[0:64] ; W1[64:128] ; Wp[64:128]]: wave column half wn owns hidden units / token channels 64 wn ..
-__device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0, int tid, float* sTok, float* sAlpha) {
-  constexpr int d = 128;
+// Which (slide, token tile) a finish workgroup owns.  The split-K GEMM that wrote the slabs runs its 128-row blocks in an XCD-aware
+// order (gemm_x6.hip): with M / 128 a multiple of 8, XCD x computes - and leaves in ITS L2 - the rows [x M / 8, (x + 1) M / 8).  The
+// hardware places workgroup h of a launch on XCD h % 8, so with `xcd_order` (B % 8 == 0: whole slides per XCD) workgroup h takes the
+// (h / 8)-th tile of the slides of XCD h % 8 and reads its slabs from the L2 they were written to instead of across the fabric.
+// Otherwise: the natural (tile, slide) grid.
+__device__ __forceinline__ void fin_tile_of_workgroup(const FinQkvParams& f, int& b, int& t0) {
+  if (!f.xcd_order) return;
+  const int h = blockIdx.y * gridDim.x + blockIdx.x, x = h & 7, k = h >> 3;
+  const int tiles = f.Tp / TOK, spx = f.B >> 3;           // tiles per slide, slides per XCD
+  b = x * spx + k / tiles;
+  t0 = (k % tiles) * TOK;
+}
+
+#ifdef PATHS_WS_STAMPS
+#define FIN_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (stamps && tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_; } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FIN_STAMP(i) do { } while (0)
+#endif
+__device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0, int tid, float* sTok, float* sAlpha, unsigned long long* stamps) {
+  constexpr int d = 128, NZ = 2;                       // (two k halves: the only split the GEMM is launched with)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int u0 = 64 * wn;
   const int nim = (int)f.num_ims[b];
-  // loads that do not depend on the GEMM result first (their round trips - positions -> table rows are two dependent ones - run under
-  // the 128-KB slab stream below instead of behind the barrier)
-  const float b2v = *f.b2, ps_inv = 1.0f / (float)f.patch_size;
+  float* const sA = sAlpha + 2 * TOK;                  // [TOK] alpha of every slot of the tile
+  // loads that do not depend on the GEMM result first: their round trips (position -> table row are two dependent ones) run under the
+  // 128-KB slab stream below
   float bpv[2], spv[2], b1v[2], w2v[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) { const int c = u0 + 32 * j + (lane & 31); bpv[j] = f.bp[c]; spv[j] = f.special[c]; b1v[j] = f.b1[c]; w2v[j] = f.w2[c]; }
-  int64_t lp[16]; float aimp[16];
+  const float ps_inv = 1.0f / (float)f.patch_size;
+  int tp[16];
+  if (f.pe_mode == 2) {
+    int64_t lp[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {                       // (clamped indices: always legal)
-    const int sl = t0 + 32 * wm + c32_row(r, lane);
-    const int64_t m = (int64_t)b * f.N + min(sl, f.N - 1);
-    lp[r] = f.pe_mode == 2 ? f.locs[2 * m + wn] : 0;
-    aimp[r] = f.alpha_from_importance ? f.importance[m] : 0.f;
+    for (int r = 0; r < 16; ++r) {                     // (clamped indices: always legal)
+      const int sl = t0 + 32 * wm + c32_row(r, lane);
+      lp[r] = f.locs[2 * ((int64_t)b * f.N + min(sl, f.N - 1)) + wn];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
+      tp[r] = min(paths_epi::div_u24(px24, f.patch_size, ps_inv), f.pe_rows - 1);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tp[r] = min(min(t0 + 32 * wm + c32_row(r, lane), f.N - 1), f.pe_rows - 1);
   }
   float acc[4][16];
   if (t0 >= f.N) {                                     // the extra tile (slot N: the special token of a full slide): no GEMM rows behind it
@@ -168,40 +196,32 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   } else {
     const int64_t trow = (((int64_t)b * f.N + t0) >> 5) + wm;
+    f32x4 v[4][4][NZ];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
 #pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) v[j][q][z] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
       for (int q = 0; q < 4; ++q) {
-        f32x4 v = t[64 * q];
-        for (int z = 1; z < f.nz; ++z) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
-        acc[j][4 * q] = v[0]; acc[j][4 * q + 1] = v[1]; acc[j][4 * q + 2] = v[2]; acc[j][4 * q + 3] = v[3];
+        const f32x4 sum = v[j][q][0] + v[j][q][1];
+        acc[j][4 * q] = sum[0]; acc[j][4 * q + 1] = sum[1]; acc[j][4 * q + 2] = sum[2]; acc[j][4 * q + 3] = sum[3];
       }
-    }
   }
-  float pev[16][2];
+  FIN_STAMP(2);
+  float pev[16][2];                                    // positional-encoding values: in flight while the logits are reduced
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {                       // positional-encoding rows: in flight while the logits are reduced
-    const int sl = t0 + 32 * wm + c32_row(r, lane);
-    const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
-    const int ipos = f.pe_mode == 2 ? paths_epi::div_u24(px24, f.patch_size, ps_inv) : min(sl, f.N - 1);
-    if (f.pe_table != nullptr) {
-      const int tp = min(ipos, f.pe_rows - 1);
+  for (int r = 0; r < 16; ++r)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = u0 + 32 * j + (lane & 31);
-        pev[r][j] = f.pe_mode == 2 ? f.pe_table[(int64_t)tp * (d / 2) + (c & (d / 2 - 1))] : f.pe_table[(int64_t)tp * d + c];
-      }
-    } else {                                           // no table (drop-in calls do not know the grid size): the same sinf / cosf values
-      const int ipos_f = f.pe_mode == 2 ? paths_epi::div_pos(lp[r], f.patch_size, ps_inv) : min(sl, f.N - 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = u0 + 32 * j + (lane & 31);
-        const float ang = (float)ipos_f * (f.pe_mode == 2 ? f.div_term[(c & (d / 2 - 1)) >> 1] : f.div_term[c >> 1]);
-        pev[r][j] = (c & 1) ? cosf(ang) : sinf(ang);
-      }
+    for (int j = 0; j < 2; ++j) {
+      const int c = u0 + 32 * j + (lane & 31);
+      pev[r][j] = f.pe_mode == 2 ? f.pe_table[(int64_t)tp[r] * (d / 2) + (c & (d / 2 - 1))] : f.pe_table[(int64_t)tp[r] * d + c];
     }
-  }
   if (!f.alpha_from_importance) {
     // ---- partial importance logits over this wave's 64 hidden units, summed over the 32 lanes of each half-wave by the halving
     // butterfly of EpiImpProj (gemm_epi.h): afterwards lane l holds the total of row index rho(l) = bits 4..1 of l
@@ -240,29 +260,39 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
     if ((lane & 1) == 0) sAlpha[wn * TOK + 32 * wm + c32_row(rho, lane)] = p1;
   }
   __syncthreads();
-  // ---- alpha of every row (both column halves compute the same value), tokens of this wave's 64 channels
-  float av[16]; bool valid[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int lt = 32 * wm + c32_row(r, lane), sl = t0 + lt;          // token slot = patch index; the special token sits at slot nim
-    valid[r] = sl < nim;
+  FIN_STAMP(3);
+  // ---- alpha of the tile's 64 slots, once each (64 threads; one coalesced store of the importance row piece)
+  if (tid < TOK) {
+    const int sl = t0 + tid;
     float a = 0.f;
-    if (valid[r]) a = f.alpha_from_importance ? aimp[r] : sigmoid_acc((sAlpha[lt] + sAlpha[TOK + lt]) + b2v);
-    if (!f.alpha_from_importance && wn == 0 && (lane & 31) == 0 && sl < f.N) f.importance[(int64_t)b * f.N + sl] = a;
-    av[r] = f.imp_mul ? a : 1.f;
+    if (sl < nim) a = f.alpha_from_importance ? f.importance[(int64_t)b * f.N + sl] : sigmoid_acc((sAlpha[tid] + sAlpha[TOK + tid]) + *f.b2);
+    if (!f.alpha_from_importance && sl < f.N) f.importance[(int64_t)b * f.N + sl] = a;
+    sA[tid] = a;
   }
+  __syncthreads();
+  // ---- tokens of this wave's 64 channels -> LDS (fp32 rows; the in_proj's operand image is built from them)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int lt = 32 * wm + c32_row(r, lane), sl = t0 + lt;
+    const bool valid = sl < nim;
+    const float av = f.imp_mul ? sA[lt] : 1.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = u0 + 32 * j + (lane & 31);
       // padded slots: the projection of a padded row may be anything (its LSTM tile may have been skipped): select, do not multiply
-      const float pj = valid[r] ? acc[2 + j][r] * f.acc_scale : 0.f;
-      const float v = sl == nim ? spv[j] : (sl < f.T ? av[r] * pj + bpv[j] + pev[r][j] : 0.f);
-      sTok[lt * TOK_LD + c] = v;
-      if (sl < f.T) f.tokens[((int64_t)b * f.T + sl) * d + c] = v;
+      const float pj = valid ? acc[2 + j][r] * f.acc_scale : 0.f;
+      sTok[lt * TOK_LD + c] = sl == nim ? spv[j] : (sl < f.T ? av * pj + bpv[j] + pev[r][j] : 0.f);
     }
+  }
+  FIN_STAMP(4);
+}
+
+// the tile's fp32 token rows from LDS to tokens [B, T, 128]: whole 512-byte rows, 16 bytes per lane (call after a barrier behind fin_tokens)
+__device__ __forceinline__ void fin_store_tokens(const FinQkvParams& f, int b, int t0, int tid, const float* sTok) {
+#pragma unroll
+  for (int i = 0; i < TOK * 32 / (64 * NW); ++i) {
+    const int idx = tid + i * 64 * NW, lt = idx >> 5, c4 = idx & 31, sl = t0 + lt;
+    if (sl < f.T) *reinterpret_cast<f32x4*>(f.tokens + ((int64_t)b * f.T + sl) * 128 + 4 * c4) = *reinterpret_cast<const f32x4*>(sTok + lt * TOK_LD + 4 * c4);
   }
 }
 
@@ -284,7 +314,8 @@ tlayer_ws_kernel(WsParams p) {
   float* const sB1 = sVec + 9 * DM;
   float* const sBqkv = sVec + (POST ? 13 * DM : 0);
 
-  const int b = blockIdx.y, t0 = blockIdx.x * TOK;
+  int b = blockIdx.y, t0 = blockIdx.x * TOK;
+  if constexpr (FIN) fin_tile_of_workgroup(p.fin, b, t0);
   const int tid = threadIdx.x, lane = tid & 63, ql = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (POST && p.zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid < p.n_zero) p.zero_words[tid] = 0;
@@ -343,8 +374,13 @@ tlayer_ws_kernel(WsParams p) {
     // the input rows are built HERE from the raw result of the importance / projection GEMM (finish_qkv.h); the weight loads and
     // the bias vector issued above land under it
     float* const sTok = sBqkv + 3 * DM;
-    fin_tokens(p.fin, b, t0, tid, sTok, sTok + TOK * TOK_LD);
+#ifdef PATHS_WS_STAMPS
+    fin_tokens(p.fin, b, t0, tid, sTok, sTok + TOK * TOK_LD, p.stamps);
+#else
+    fin_tokens(p.fin, b, t0, tid, sTok, sTok + TOK * TOK_LD, nullptr);
+#endif
     __syncthreads();
+    fin_store_tokens(p.fin, b, t0, tid, sTok);
     for (int kb = wave; kb < KB; kb += NW) {
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -718,7 +754,9 @@ int launch_ws(const WsParams& p, hipStream_t stream) {
 __global__ void __launch_bounds__(256)
 finish_importance_kernel(FinQkvParams f) {
   __shared__ float sAlpha[2 * TOK];
-  const int b = blockIdx.y, t0 = blockIdx.x * TOK, tid = threadIdx.x;
+  int b = blockIdx.y, t0 = blockIdx.x * TOK;
+  fin_tile_of_workgroup(f, b, t0);
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
   const int nim = (int)f.num_ims[b];
   if (t0 >= f.N || (f.skip_padding && t0 >= nim)) return;
@@ -772,6 +810,11 @@ finish_importance_kernel(FinQkvParams f) {
 
 }  // namespace
 
+#ifdef PATHS_WS_STAMPS
+static unsigned long long* g_ws_stamps = nullptr;
+extern "C" void paths_ws_stamp_buffer(unsigned long long* p) { g_ws_stamps = p; }     // development hook (tools/ws_time.py)
+#endif
+
 // finish_qkv.h: phases bit 2 = the importance-only finish, bit 4 = tokens + in_proj images (alpha computed there unless
 // alpha_from_importance); both stop-event capable (the recursion's forks ride on them)
 int paths_launch_finish_importance(const FinQkvParams& f, hipStream_t stream) {
@@ -788,7 +831,10 @@ int paths_launch_finish_qkv(const FinQkvParams& f, hipStream_t stream) {
   p.qkv_img = reinterpret_cast<char*>(f.qkv_img);
   p.num_ims = f.num_ims; p.T = f.T; p.Tp = f.Tp; p.B = f.B; p.skip_padding = f.skip_padding; p.qscale = f.qscale; p.eps = 0.f;
   p.fin = f;
-  const size_t lds = ws_lds_bytes<128>(false, true) + (size_t)(TOK * TOK_LD + 2 * TOK) * sizeof(float);
+#ifdef PATHS_WS_STAMPS
+  p.stamps = g_ws_stamps;
+#endif
+  const size_t lds = ws_lds_bytes<128>(false, true) + (size_t)(TOK * TOK_LD + 3 * TOK) * sizeof(float);
   PATHS_LDS_OPT_IN((tlayer_ws_kernel<128, false, true, false, true>), 160 * 1024, "importance_qkv_x6(finish)");
   // (> 80 KiB per workgroup: one workgroup per CU - a grid of ~one workgroup per CU spreads over the whole chip)
   const size_t ask = lds > 84 * 1024 ? lds : 84 * 1024;
@@ -797,10 +843,6 @@ int paths_launch_finish_qkv(const FinQkvParams& f, hipStream_t stream) {
   return PATHS_OK;
 }
 
-#ifdef PATHS_WS_STAMPS
-static unsigned long long* g_ws_stamps = nullptr;
-extern "C" void paths_ws_stamp_buffer(unsigned long long* p) { g_ws_stamps = p; }     // development hook (tools/ws_time.py)
-#endif
 
 extern "C" {
 

@@ -815,12 +815,17 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
     x6 = use_x6(D, lstm_pack["Hc"] if mc.lstm else 64)
     assert x_rows is None or (x6 and split_planes() == 2 and mc.lstm), "row pointers need the default split mode and lstm=true"
     pe_rows = N if pe_mode == 1 else int(max_pos)
+    if pe_rows == 0 and FUSE_QKV in (1, 2) and fast_path(mc) and N % 64 == 0 and not torch.is_grad_enabled():
+        # a drop-in call (no grid size given): the fused finish reads its sin / cos values from the table only, so the table is sized
+        # from the batch's largest position - one host sync, in a call that is synchronous anyway (level_forward reads the status word)
+        top = int(locs.max().item()) // int(mc.patch_size) + 1 if locs.numel() else 0
+        pe_rows = top if 0 < top <= (1 << 16) else 0
     pe_tab = pe_table(lvl_pack, pe_mode, d, pe_rows) if pe_rows > 0 else None
 
     generic = not fast_path(mc)
     # default inference form of the shipped geometry: in_proj of decoder layer 0 inside the importance / projection finish (FUSE_QKV)
     fuse_qkv = (FUSE_QKV in (1, 2) and not generic and x6 and split_planes() == 2 and mc.lstm and GEMM_MODE == "h3" and TLAYER_WS and QKV_IMAGES
-                and L > 1 and not (ATTN_FP8 or AGG_FP8) and D % 64 == 0 and D >= 256 and N % 64 == 0 and TAIL_WS)
+                and L > 1 and pe_tab is not None and not (ATTN_FP8 or AGG_FP8) and D % 64 == 0 and D >= 256 and N % 64 == 0 and TAIL_WS)
     fused: Dict[str, object] = {}
     # any aggregator geometry on the tuned LSTM kernels: the importance / projection products take x + h1 summed while staged
     generic_add = generic and x6 and split_planes() == 2 and mc.lstm and GENERIC_ADD and GENERIC_SPLIT and D % 128 == 0
@@ -846,8 +851,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                 ws = torch.empty((int(_lib.load().paths_importance_proj_x6_workspace(M)),), device=dev, dtype=torch.uint8)
                 qkv_img = torch.empty((int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, 2)),), device=dev, dtype=torch.uint8)
                 args = (p(src), D, p(x_rows) if src is None else None, p(add), add.stride(1), p(wip), p(lvl_pack["b1"]), p(lvl_pack["w2"]),
-                        p(lvl_pack["b2"]), p(lvl_pack["bp"]), p(lvl_pack["special"]), p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]),
-                        p(pe_tab), pe_tab.shape[0] if pe_tab is not None else 0, p(locs), p(num_ims), B, N,
+                        p(lvl_pack["b2"]), p(lvl_pack["bp"]), p(lvl_pack["special"]), p(pe_tab), pe_tab.shape[0], p(locs), p(num_ims), B, N,
                         mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), D, 1 if skip_padding else 0, wip_s, a_scale(), p(ws),
                         p(iq), p(lay0["bqkv"]), sq[0], LOG2E / math.sqrt(hd), p(qkv_img))
                 # (token order of this form: patch i = token i, the special token at index num_ims[b]; the tail is told: special_last)
