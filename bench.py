@@ -900,6 +900,13 @@ def main():
                                     "token-layer in_proj + attention + token-layer chain (out_proj, LN x3, FFN) + token-0 tail (last layer, one "
                                     "launch), per level",
                          "in_proj_fused_into_finish": bool(fused_qkv),
+                         "fuse_qkv_mode": ops.FUSE_QKV if fused_qkv else 0,
+                         "fuse_qkv_note": (None if not fused_qkv else
+                                           "mode 1: ONE finish of the importance / projection GEMM on the selection stream writes importance, tokens and "
+                                           "layer 0's q | k | v operand images; mode 2 (default): an importance-only finish on the selection stream "
+                                           "(the top-K waits for nothing else), tokens + images by a second finish at the head of the aggregator "
+                                           "stream (serialized_breakdown: agg_tokens_qkv) - the successor of the round-4 finish kernel, which was "
+                                           "never part of this span either"),
                          "algorithmic_gflop_in_proj0_excluded": round(sum(f_inproj0) / len(f_inproj0) / 1e9, 3) if fused_qkv else 0.0,
                          "algorithmic_gflop_per_level_launch": round(fl / n_a / 1e9, 3), "avg_span_us": round(ms_a * 1e3 / n_a, 2),
                          "spans": n_a,
@@ -992,7 +999,7 @@ def main():
                 k: roofline_attn.get(k) for k in ("achieved", "peak", "unit", "frac", "avg_span_us", "serialized_span_us", "serialized_frac",
                                                    "serialized_span_replayed_us", "serialized_frac_replayed", "serialized_note",
                                                    "serialized_frac_of_measured_peak", "algorithmic_gflop_per_level_launch",
-                                                   "in_proj_fused_into_finish", "algorithmic_gflop_in_proj0_excluded")}),
+                                                   "in_proj_fused_into_finish", "algorithmic_gflop_in_proj0_excluded", "fuse_qkv_mode")}),
             "roofline_attn_ffn": roofline_attn,
             "host": {"launch_mode": launch_mode,
                      "t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3), "eager_instrumented_pass": eager,

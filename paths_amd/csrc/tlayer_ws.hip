@@ -196,22 +196,34 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   } else {
     const int64_t trow = (((int64_t)b * f.N + t0) >> 5) + wm;
-    f32x4 v[4][4][NZ];
+    // hidden-unit tiles (j = 0, 1) only when alpha is computed here; with alpha read back (an importance-only finish ran) only the
+    // projection half of the slabs is touched (64 KB per workgroup instead of 128)
+    auto load_pair = [&](int j0) __attribute__((always_inline)) {
+      f32x4 v[2][4][NZ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
+      for (int j = 0; j < 2; ++j) {
+        const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j0 + j) * 1024) + lane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int z = 0; z < NZ; ++z) v[j][q][z] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 sum = v[j][q][0] + v[j][q][1];
-        acc[j][4 * q] = sum[0]; acc[j][4 * q + 1] = sum[1]; acc[j][4 * q + 2] = sum[2]; acc[j][4 * q + 3] = sum[3];
+          for (int z = 0; z < NZ; ++z) v[j][q][z] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
       }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 sum = v[j][q][0] + v[j][q][1];
+          acc[j0 + j][4 * q] = sum[0]; acc[j0 + j][4 * q + 1] = sum[1]; acc[j0 + j][4 * q + 2] = sum[2]; acc[j0 + j][4 * q + 3] = sum[3];
+        }
+    };
+    if (!f.alpha_from_importance) load_pair(0);
+    else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+    load_pair(2);
   }
   FIN_STAMP(2);
   float pev[16][2];                                    // positional-encoding values: in flight while the logits are reduced

@@ -661,6 +661,7 @@ static int dist_limit() {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(token0_dist_kernel), NT, 0) != hipSuccess || occ <= 0) return 0;
     cached[dev] = cus * (occ > 1 ? 1 : occ) * 3 / 4;      // (counted at ONE workgroup per CU: a second one there would share its memory queue)
+    if (getenv("PATHS_T0_DIST_LIMIT") != nullptr && atoi(getenv("PATHS_T0_DIST_LIMIT")) > 0) cached[dev] = atoi(getenv("PATHS_T0_DIST_LIMIT"));   // A/B runs
   }
   return cached[dev];
 }

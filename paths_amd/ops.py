@@ -27,10 +27,10 @@ QKV_IMAGES = os.environ.get("PATHS_QKV_IMAGES", "1") != "0"
 TAIL_WS = os.environ.get("PATHS_TAIL_WS", "1") != "0"          # token-0 tail without K / V projections, one launch (csrc/token0_ws.hip)
 TLAYER_WS = os.environ.get("PATHS_TLAYER_WS", "1") != "0"      # weight-stationary token-layer kernel (csrc/tlayer_ws.hip)
 SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
-# The first decoder layer's in_proj inside the finish of the importance / projection GEMM (paths_importance_qkv_x6, round 5): 1 (default) = one
-# fused finish on the selection stream (importance + tokens + q | k | v operand images), 2 = importance-only finish on the selection
+# The first decoder layer's in_proj inside the finish of the importance / projection GEMM (paths_importance_qkv_x6, round 5): 1 = one
+# fused finish on the selection stream (importance + tokens + q | k | v operand images), 2 (default) = importance-only finish on the selection
 # stream, tokens + images on the aggregator stream, 0 = the round-4 form (finish, then paths_token_layer_ws as the aggregator's first launch)
-FUSE_QKV = int(os.environ.get("PATHS_FUSE_QKV", "1"))
+FUSE_QKV = int(os.environ.get("PATHS_FUSE_QKV", "2"))
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 TIMER_ALL = False     # with KERNEL_TIMER: False = bracket only the dominant kernel and the aggregator span (the timed region of
                       # bench.py), True = every kernel group (bench.py's serialised breakdown pass)

@@ -1,10 +1,10 @@
 set -o pipefail
-python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "standalone or fp8_stress or fused_importance or weight_stationary or headline or single_level_vs or recursion_vs_reference" > gpurun_out/r05e_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r05e_tests.log; tail -4 gpurun_out/r05e_tests.log
+python -m pytest tests -m gpu -q -x  > gpurun_out/r05i_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r05i_tests.log; tail -4 gpurun_out/r05i_tests.log
 for rep in 1 2; do for m in 0 1 2; do
-  PATHS_FUSE_QKV=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --stress-steps 0 --k1024-steps 0 > gpurun_out/r05e_bench_f${m}_${rep}.json 2> gpurun_out/r05e_bench_f${m}_${rep}.err
+  PATHS_FUSE_QKV=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --stress-steps 0 --k1024-steps 0 > gpurun_out/r05i_bench_f${m}_${rep}.json 2> gpurun_out/r05i_bench_f${m}_${rep}.err
   python - <<PY
 import json
-d=json.loads(open("gpurun_out/r05e_bench_f${m}_${rep}.json").read().strip().splitlines()[-1])
+d=json.loads(open("gpurun_out/r05i_bench_f${m}_${rep}.json").read().strip().splitlines()[-1])
 a=d["roofline"]["attn_ffn"]
 print("fuse=${m} rep=${rep}", d["value"], d["sustained"]["slides_per_s"], "attn_ffn ser", a["serialized_span_us"], a["serialized_frac"], "replayed", a.get("serialized_span_replayed_us"), a.get("serialized_frac_replayed"), "two lanes", d["host"]["launch_modes"]["replay_two_lanes_slides_per_s"])
 print({k: v for k, v in d["serialized_breakdown"]["us_per_launch"].items()})
