@@ -34,6 +34,9 @@ TN_X6_MIN_M = int(os.environ.get("PATHS_TN_X6_MIN_M", "512"))
 ATTN_BWD_MODE = os.environ.get("PATHS_ATTN_BWD_MODE", "x6q")
 
 
+TRAIN_SPLITK_IMPORTANCE = os.environ.get("PATHS_TRAIN_SPLITK_IMPORTANCE", "1") != "0"     # training: importance / proj GEMM as two k halves + finish
+
+
 def _f32(dev):
     return dict(device=dev, dtype=torch.float32)
 
@@ -362,7 +365,12 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
     if x6:
         TP = ops.TRAIN_FWD_PLANES
         wip, wip_s = ops._x6_of(lvl_pack, "w_ip_fwd", TP, lagged=True)
-        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, None, 0, P(wip), *tail[:-1], TP, wip_s, ops.A_SCALE if TP == 2 else 1.0, None, tail[-1])
+        # M / 128 blocks fill half the chip: two k halves on twice the blocks + the epilogue launch, as in inference (round 5)
+        splitk_ws = None
+        if TRAIN_SPLITK_IMPORTANCE and TP == 2 and (M + 127) // 128 <= 160:
+            splitk_ws = torch.empty((int(_lib.load().paths_importance_proj_x6_workspace(M)),), device=fts.device, dtype=torch.uint8)
+        _lib.call("paths_importance_proj_x6", P(sv["y"]), D, None, None, 0, P(wip), *tail[:-1], TP, wip_s, ops.A_SCALE if TP == 2 else 1.0,
+                  P(splitk_ws), tail[-1])
     else:
         _lib.call("paths_importance_proj", P(sv["y"]), D, P(lvl_pack["w_ip_fwd"]), *tail)
     return sv

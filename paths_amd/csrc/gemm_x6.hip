@@ -608,6 +608,11 @@ int launch_x6(int planes, const X6Operands& g, int Npad, const Epi& epi, hipStre
 #define PATHS_H_OCC 3
 #endif
 constexpr int H_OCC = PATHS_H_OCC;
+#ifndef PATHS_H_TRAIN_OCC
+#define PATHS_H_TRAIN_OCC 2
+#endif
+constexpr int H_TRAIN_OCC = PATHS_H_TRAIN_OCC;
+static const bool H_TRAIN_SMALL = getenv("PATHS_H_TRAIN_SMALL") == nullptr || atoi(getenv("PATHS_H_TRAIN_SMALL")) != 0;   // A/B switch
 static const bool FIN_XCD_ORDER = getenv("PATHS_FIN_XCD_ORDER") == nullptr || atoi(getenv("PATHS_FIN_XCD_ORDER")) != 0;   // A/B switch
 static const bool IP_TILE128 = getenv("PATHS_IP_TILE128") != nullptr && atoi(getenv("PATHS_IP_TILE128")) != 0;   // measured: 69 us vs 58 (split-K)
 static const bool O_RAW = getenv("PATHS_O_RAW") == nullptr || atoi(getenv("PATHS_O_RAW")) != 0;
@@ -708,7 +713,10 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
     PATHS_REQUIRE(save_tc == nullptr || y != nullptr, "lstm_cell_x6: save_tc (training) needs y");
     if (save_tc != nullptr) {
       EpiLstmH<true, true> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, save_tc, sm};
-      rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, save)");
+      // (round 5: the training form on the inference form's 128 x 128 tiles at H_TRAIN_OCC waves per SIMD: K = 256 is 16 k16 stages
+      // of MFMA against ~250 MB of epilogue traffic - several workgroups per CU hide each other's epilogue loads / stores)
+      if (planes == 2 && H_SMALL_TILES && H_TRAIN_SMALL) rc = launch_x6_np<2, 2, 2, 2, false, false, decltype(e), H_TRAIN_OCC>(gh, D, e, stream, "lstm_cell_x6(h, save, 128x128)");
+      else rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h, save)");
     } else if (y != nullptr) {
       EpiLstmH<true, false> e{b_mem, ws_o, D, x, ldx, state_out, ldso, y, ldy, D, nullptr, sm};
       rc = launch_x6<4, 4, 1, false>(planes, gh, D, e, stream, "lstm_cell_x6(h)");
@@ -755,23 +763,26 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
   auto go = [&](auto epi) {
     decltype(epi) e{b1, w2, b2, bp, special, div_term, locs, num_ims, rows_per_slide, patch_size, pe_mode, imp_mul, importance, tokens,
                     save_hid, save_pproj, pe_table, pe_table ? pe_rows : 0, sc};
-    if constexpr (!std::is_same<decltype(epi), EpiImpProj<true, true>>::value && !std::is_same<decltype(epi), EpiImpProj<false, true>>::value) {
-      // two launches (inference, default split, Y = X + h1 form): the GEMM stores RAW accumulators, the epilogue runs on 64-row
-      // blocks.  Default: split-K, two k halves of 128 x 256 tiles.  PATHS_IP_TILE128=1 (experiment, slower): 128 x 128 tiles over
-      // the full k at two waves per SIMD - the x + h1 operand is then staged twice as often.
-      if (splitk_ws != nullptr && planes == 2 && y_add != nullptr && D % 64 == 0 && D >= 256) {
+    {
+      // two launches (default split): the GEMM stores RAW accumulators, the epilogue runs on 64-row blocks.  Default: split-K, two k
+      // halves of 128 x 256 tiles.  PATHS_IP_TILE128=1 (experiment, slower, Y = X + h1 form only): 128 x 128 tiles over the full k at two
+      // waves per SIMD - the x + h1 operand is then staged twice as often.  Round 5: also the training form (a stored Y, the SAVE
+      // epilogues): one launch of M / 128 blocks fills half the chip there too (115 us against ~60).
+      if (splitk_ws != nullptr && planes == 2 && (y_add != nullptr || y_rows == nullptr) && D % 64 == 0 && D >= 256) {
         const int mt = (M + 127) / 128 * 4;                         // 32-row tiles, padded to the GEMM's 128-row blocks
         const int64_t zstride = (int64_t)mt * 8 * 1024;
         int rc;
-        if (IP_TILE128) {
+        const bool tile128 = IP_TILE128 && y_add != nullptr;
+        if (tile128) {
           EpiRaw raw{splitk_ws, zstride, 8};
           rc = y_rows ? launch_x6_np<2, 2, 2, 2, true, true, EpiRaw, 2>(g, 256, raw, stream, "importance_proj_x6(raw, 128x128)")
                       : launch_x6_np<2, 2, 2, 2, true, false, EpiRaw, 2>(g, 256, raw, stream, "importance_proj_x6(raw, 128x128)");
         } else {
           X6Operands gs = g; gs.ksplit = 2;
           EpiRaw raw{splitk_ws, zstride, 8};
-          rc = y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(gs, 256, raw, stream, "importance_proj_x6(split-k)")
-                      : launch_x6_np<2, 2, 4, 2, true, false>(gs, 256, raw, stream, "importance_proj_x6(split-k)");
+          rc = y_add == nullptr ? launch_x6_np<2, 2, 4, 2, false, false>(gs, 256, raw, stream, "importance_proj_x6(split-k, stored y)")
+               : y_rows ? launch_x6_np<2, 2, 4, 2, true, true>(gs, 256, raw, stream, "importance_proj_x6(split-k)")
+                        : launch_x6_np<2, 2, 4, 2, true, false>(gs, 256, raw, stream, "importance_proj_x6(split-k)");
         }
         if (rc != PATHS_OK) return rc;
         // the dispatcher packs a CU to its limit before it moves on: ask for LDS that spreads the blocks over all CUs
@@ -779,7 +790,7 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
         const int flds = fdepth == 1 ? 84 * 1024 : fdepth == 2 ? 54 * 1024 : fdepth == 3 ? 41 * 1024 : 1024;
         PATHS_LDS_OPT_IN((x6_finish_kernel<2, decltype(epi)>), 84 * 1024, "importance_proj_x6(finish)");
         PATHS_LDS_OPT_IN((x6_finish_kernel<1, decltype(epi)>), 84 * 1024, "importance_proj_x6(finish)");
-        if (IP_TILE128)
+        if (tile128)
           PATHS_LAUNCH_STOP((x6_finish_kernel<1, decltype(epi)>), dim3(fblk), dim3(256), flds, stream, splitk_ws, zstride, 8, M,
                             skip_padding ? num_ims : nullptr, rows_per_slide, e);
         else
