@@ -956,9 +956,10 @@ def main():
             log(f"k1024 probe FAILED: {k1024['error']}")
     # ---- BASELINE.json configs[4]: the stress geometry, accurate path + the opt-in e4m3 variants, so the driver's record carries it
     stress = None
+    replayed_launches = graphed is not None
     if world == 1 and args.stress_steps > 0:
         try:
-            del replays, graphed, batches
+            replays = graphed = batches = None          # (free the K = 2048 tapes and rotated batches: 43 GiB back to the allocator)
             torch.cuda.empty_cache()
             stress = {"workload": "one level over 8192 patches x 1536 features per slide (full quadratic attention over 8193 tokens), "
                                   f"{spg} slides per step (BASELINE.json configs[4])",
@@ -1005,7 +1006,7 @@ def main():
                      "t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3), "eager_instrumented_pass": eager,
                      "launch_modes": launch_modes,
                      "note": "roofline / roofline_attn_ffn event timings come from the eager instrumented pass of the same K steps "
-                             "(the replayed launch sequence carries no events)" if graphed is not None else None},
+                             "(the replayed launch sequence carries no events)" if replayed_launches else None},
         }
         if single is not None:
             line["single_batch"] = single

@@ -397,7 +397,7 @@ int paths_layernorm_rows(const float* x, int64_t ldx, const float* add, const fl
 int paths_layernorm2_rows(const float* x, int64_t ldx, const float* g1, const float* b1, const float* add, const float* g2, const float* b2,
                           float* y, int64_t ldy, int64_t rows, int d, float eps, paths_stream_t stream);   /* LN2(LN1(x) + add) in one pass */
 int paths_importance_rows(const float* hid, int64_t ldh, const float* w2, const float* b2, const int64_t* num_ims, int rows_per_slide,
-                          int64_t M, int Hi, float* importance, paths_stream_t stream);
+                          int64_t M, int Hi, float* importance, int relu /* 1: hid holds the pre-activation, relu applied here */, paths_stream_t stream);
 int paths_tokens_assemble(const float* P, int64_t ldp, const float* importance, int imp_mul, const float* bp, const float* special,
                           const float* div_term, const int64_t* locs, int rows_per_slide, int patch_size, int pe_mode, int d, int B,
                           float* tokens, paths_stream_t stream);

@@ -352,7 +352,7 @@ def selection_forward_train(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_p
         # and P = Y Wp^T for the backward (reference model/paths.py:95-98,119-124; model/aggregator.py:37-65)
         gp = ops.generic_pack(lvl_pack, mc)
         ops.gemm_f32(sv["y"], D, gp["w1"], lvl_pack["b1"], sv["hid"], Hi, M, Hi, D, act=1)
-        _lib.call("paths_importance_rows", P(sv["hid"]), Hi, P(lvl_pack["w2"]), P(lvl_pack["b2"]), P(num_ims), N, M, Hi, P(sv["importance"]), st)
+        _lib.call("paths_importance_rows", P(sv["hid"]), Hi, P(lvl_pack["w2"]), P(lvl_pack["b2"]), P(num_ims), N, M, Hi, P(sv["importance"]), 0, st)
         ops.gemm_f32(sv["y"], D, gp["wp"], None, sv["pproj"], d, M, d, D)
         _lib.call("paths_tokens_assemble", P(sv["pproj"]), d, P(sv["importance"]), 1 if mc.importance_mode == "mul" else 0, P(lvl_pack["bp"]),
                   P(lvl_pack["special"]), P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), P(locs), N, mc.patch_size, pe_mode, d, B,
@@ -495,7 +495,7 @@ def selection_forward_train_nolstm(mc, lvl_pack, fts, locs, num_ims, state_prev)
         if not ops.fast_path(mc):      # any widths: generic GEMMs + row kernels (tokens = P + bp + PE: src is already scaled)
             gp = ops.generic_pack(lvl_pack, mc)
             ops.gemm_f32(src, D, gp["w1"], lvl_pack["b1"], hid_out, Hi, M, Hi, D, act=1)
-            _lib.call("paths_importance_rows", P(hid_out), Hi, P(lvl_pack["w2"]), P(lvl_pack["b2"]), P(num_ims), N, M, Hi, P(imp_out), st)
+            _lib.call("paths_importance_rows", P(hid_out), Hi, P(lvl_pack["w2"]), P(lvl_pack["b2"]), P(num_ims), N, M, Hi, P(imp_out), 0, st)
             ops.gemm_f32(src, D, gp["wp"], None, pproj_out, d, M, d, D)
             _lib.call("paths_tokens_assemble", P(pproj_out), d, P(imp_out), 0, P(lvl_pack["bp"]), P(lvl_pack["special"]),
                       P(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), P(locs), N, mc.patch_size, pe_mode, d, B, P(sv["tokens"]), st)

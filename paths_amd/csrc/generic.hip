@@ -259,12 +259,13 @@ layernorm2_rows_kernel(const float* __restrict__ x, int64_t ldx, const float* __
 // ---- importance[m] = valid ? sigmoid(hid[m] . w2 + b2) : 0   (hid = relu(Y W1^T + b1) from the GEMM), one wave per row
 __global__ void __launch_bounds__(256)
 importance_rows_kernel(const float* __restrict__ hid, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ b2,
-                       const int64_t* __restrict__ num_ims, int rows_per_slide, int64_t M, int Hi, float* __restrict__ importance) {
+                       const int64_t* __restrict__ num_ims, int rows_per_slide, int64_t M, int Hi, float* __restrict__ importance, int relu) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   float acc = 0.f;
-  for (int c = lane; c < Hi; c += 64) acc = fmaf(hid[row * ldh + c], w2[c], acc);
+  // relu: hid holds the PRE-activation Y W1^T + b1 (the importance and projection products as ONE GEMM: the relu cannot sit in its epilogue)
+  for (int c = lane; c < Hi; c += 64) { const float h = hid[row * ldh + c]; acc = fmaf(relu ? fmaxf(h, 0.f) : h, w2[c], acc); }
   acc = wave_sum(acc);
   const int b = (int)(row / rows_per_slide), idx = (int)(row - (int64_t)b * rows_per_slide);
   if (lane == 0) importance[row] = idx < (int)num_ims[b] ? sigmoid_acc(acc + *b2) : 0.f;
@@ -412,9 +413,9 @@ int paths_layernorm2_rows(const float* x, int64_t ldx, const float* g1, const fl
 
 // importance[M] from the hidden layer of the importance MLP (reference model/paths.py:95 + utils.py:106-115), any hidden width
 int paths_importance_rows(const float* hid, int64_t ldh, const float* w2, const float* b2, const int64_t* num_ims, int rows_per_slide,
-                          int64_t M, int Hi, float* importance, hipStream_t stream) {
+                          int64_t M, int Hi, float* importance, int relu, hipStream_t stream) {
   PATHS_REQUIRE(M > 0 && Hi > 0 && rows_per_slide > 0 && hid && w2 && b2 && num_ims && importance, "importance_rows: bad arguments");
-  hipLaunchKernelGGL(importance_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, hid, ldh, w2, b2, num_ims, rows_per_slide, M, Hi, importance);
+  hipLaunchKernelGGL(importance_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, hid, ldh, w2, b2, num_ims, rows_per_slide, M, Hi, importance, relu ? 1 : 0);
   PATHS_LAUNCH_CHECK("importance_rows");
   return PATHS_OK;
 }

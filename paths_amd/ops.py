@@ -514,7 +514,7 @@ def importance_proj_generic(mc, lvl_pack, src, ld_src: int, locs, num_ims, B: in
     p = _lib.ptr
     hid = torch.empty((M, Hi), device=dev, dtype=torch.float32)
     gemm_f32(src, ld_src, gp["w1"], lvl_pack["b1"], hid, Hi, M, Hi, D, act=1, split=(gp, "w1"))
-    _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), st)
+    _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), 0, st)
     proj = torch.empty((M, d), device=dev, dtype=torch.float32)
     gemm_f32(src, ld_src, gp["wp"], None, proj, d, M, d, D, split=(gp, "wp"))
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
@@ -533,22 +533,24 @@ def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B
     p = _lib.ptr
     nim = p(num_ims) if skip_padding else None
 
-    def gemm(key, n, bias, out, act):
-        k6 = f"{key}_x6_{split_planes()}"
-        if k6 not in gp:
-            gp[k6] = x6_pack(gp[key][:n].contiguous(), n_pad=(n + 255) // 256 * 256)
-        img, ws = gp[k6]
-        _lib.call("paths_gemm_add_nt_x6", p(src) if x_rows is None else None, D, p(x_rows), p(add), add.stride(1), img.data_ptr(), D, p(bias), p(out), n,
-                  M, n, (n + 255) // 256 * 256, D, act, nim, N, ws, a_scale(), st)
-
+    # ONE product for the importance hidden layer and the projection (round 5): [W1 ; Wp] as one [Hi + d, D] weight - two launches of
+    # M / 128 blocks each filled half the chip one after the other (2 x 56 us on the critical path at trans_dim 192), one launch of
+    # twice the column tiles fills it once.  The relu of the hidden layer moves into paths_importance_rows (relu = 1).
+    n = Hi + d
+    n_pad = (n + 255) // 256 * 256
+    k6 = f"w1p_x6_{split_planes()}"
+    if k6 not in gp:
+        gp["w1p"] = torch.cat([gp["w1"][:Hi], gp["wp"][:d]], dim=0).contiguous()
+        gp["b1p"] = torch.cat([lvl_pack["b1"], torch.zeros((d,), device=dev, dtype=torch.float32)])
+        gp[k6] = x6_pack(gp["w1p"], n_pad=n_pad)
+    img, ws = gp[k6]
     # (skipped tiles of padding stay defined; _lib.zeros: the fill is repeated when a recorded launch tape is replayed)
-    hid = (_lib.zeros if skip_padding else torch.empty)((M, Hi), device=dev, dtype=torch.float32)
-    gemm("w1", Hi, lvl_pack["b1"], hid, 1)
-    _lib.call("paths_importance_rows", p(hid), Hi, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), st)
-    proj = (_lib.zeros if skip_padding else torch.empty)((M, d), device=dev, dtype=torch.float32)
-    gemm("wp", d, None, proj, 0)
+    hp_ = (_lib.zeros if skip_padding else torch.empty)((M, n), device=dev, dtype=torch.float32)
+    _lib.call("paths_gemm_add_nt_x6", p(src) if x_rows is None else None, D, p(x_rows), p(add), add.stride(1), img.data_ptr(), D, p(gp["b1p"]), p(hp_), n,
+              M, n, n_pad, D, 0, nim, N, ws, a_scale(), st)
+    _lib.call("paths_importance_rows", p(hp_), n, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), 1, st)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
-    _lib.call("paths_tokens_assemble", p(proj), d, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
+    _lib.call("paths_tokens_assemble", hp_.data_ptr() + 4 * Hi, n, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
               p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
 
 
