@@ -780,9 +780,12 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
 def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool,
                       parent=None, max_pos: int = 0, x_rows=None, feat_dim: Optional[int] = None,
-                      importance_out: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                      importance_out: Optional[torch.Tensor] = None, last_level: bool = False) -> Dict[str, torch.Tensor]:
     """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
     (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims.
+
+    ``last_level`` (device recursion): no top-K follows, so nothing waits for the importance alone - the fused finish then runs as ONE
+    launch (FUSE_QKV mode 1) instead of an importance-only finish plus the tokens / images finish.
 
     ``max_pos`` (optional): an upper bound (exclusive) of ``locs // patch_size`` known to the caller (the grid size of the level);
     positional-encoding values are then read from a cached table instead of evaluated per token element.
@@ -857,7 +860,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                         mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), D, 1 if skip_padding else 0, wip_s, a_scale(), p(ws),
                         p(iq), p(lay0["bqkv"]), sq[0], LOG2E / math.sqrt(hd), p(qkv_img))
                 # (token order of this form: patch i = token i, the special token at index num_ims[b]; the tail is told: special_last)
-                if FUSE_QKV == 2:
+                if FUSE_QKV == 2 and not last_level:
                     _lib.call("paths_importance_qkv_x6", *args, 3, 0, st)
                     # (the aggregator stream finishes the tokens: ws / qkv_img travel with the closure)
                     fused["finish"] = lambda: _lib.call("paths_importance_qkv_x6", *args, 4, 1, _lib.stream())

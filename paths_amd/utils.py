@@ -447,7 +447,8 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
         with _Range(f"level {i}: selection chain (LSTM gates, importance, projection)"), \
                 (_lib.fork_behind([side_stream], main_stream) if overlap else contextlib.nullcontext()):
             sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
-                                        max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf)
+                                        max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf,
+                                        last_level=i == num_levels - 1)
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
