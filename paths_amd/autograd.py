@@ -29,12 +29,26 @@ LAYER_ORDER = [("self_attn.in_proj_weight", "wqkv"), ("self_attn.in_proj_bias", 
 
 
 def lstm_params(lstm) -> List[torch.nn.Parameter]:
-    sd = dict(lstm.named_parameters())
-    return [sd[k] for k in LSTM_ORDER]
+    cached = lstm.__dict__.get("_paths_lstm_params")          # (Parameter objects are stable; the module walk was 0.1 ms per call)
+    if cached is None:
+        sd = dict(lstm.named_parameters())
+        cached = [sd[k] for k in LSTM_ORDER]
+        object.__setattr__(lstm, "_paths_lstm_params", cached)
+    return list(cached)
 
 
 def level_params(proc) -> List[torch.nn.Parameter]:
-    """Live parameters of one level in the order LevelFn returns their gradients."""
+    """Live parameters of one level in the order LevelFn returns their gradients (cached on the module: walking named_parameters()
+    of every decoder layer was 0.5 ms of host time per training step)."""
+    cached = proc.__dict__.get("_paths_level_params")
+    if cached is not None:
+        return list(cached)
+    out = _level_params(proc)
+    object.__setattr__(proc, "_paths_level_params", out)
+    return list(out)
+
+
+def _level_params(proc) -> List[torch.nn.Parameter]:
     out = [proc.importance_mlp[0].weight, proc.importance_mlp[0].bias, proc.importance_mlp[2].weight, proc.importance_mlp[2].bias,
            proc.global_agg.proj_in.weight, proc.global_agg.proj_in.bias, proc.global_agg.special_token]
     dec = proc.global_agg.transformer.decoder

@@ -668,10 +668,11 @@ def chain_forward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, d
     f32 = _f32(dev)
     eps = w["eps"]
     d, F = w["wo"].shape[0], w["w1"].shape[0]            # trans_dim, dim_feedforward (= 4 trans_dim, reference model/aggregator.py:30)
+    di = w["wo"].shape[1]                                # inner width of the attention (= d, or H x the padded head width: ops.padded_head_dim)
     c: Dict[str, object] = {}
     if drop is None:
         u1 = torch.empty((M, d), **f32)
-        gemm_nt(attn_ptr, lda, w["wo"], u1, d, M, d, d, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
+        gemm_nt(attn_ptr, lda, w["wo"], u1, d, M, d, di, bias=w["bo"], residual=x_in_ptr, ldr=ldx)
         n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps, d=d)
         n2, c["xh2"], c["rs2"] = _ln_fwd(n1, w["cab"], w["ln2g"], w["ln2b"], M, eps, d=d)
         hid = torch.empty((M, F), **f32)
@@ -682,7 +683,7 @@ def chain_forward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, d
     else:
         p = drop.p
         sa = torch.empty((M, d), **f32)
-        gemm_nt(attn_ptr, lda, w["wo"], sa, d, M, d, d, bias=w["bo"])
+        gemm_nt(attn_ptr, lda, w["wo"], sa, d, M, d, di, bias=w["bo"])
         u1 = dropout_rows(sa, d, M, d, drop.key(layer, Drop.SA_OUT), p, out=sa, ldo=d, resid=x_in_ptr, ldr=ldx)       # x + dropout1(sa)
         n1, c["xh1"], c["rs1"] = _ln_fwd(u1, None, w["ln1g"], w["ln1b"], M, eps, d=d)
         u2 = dropout_rows(None, 0, M, d, drop.key(layer, Drop.CA_OUT), p, resid=n1, ldr=d, vec=w["cab"])                 # n1 + dropout2(cab)
@@ -707,6 +708,7 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
     Returns (grads, dx_in [M,128], dattn [M,128])."""
     f32 = _f32(dev)
     d, F = w["wo"].shape[0], w["w1"].shape[0]
+    di = w["wo"].shape[1]                                # (see chain_forward)
     g: Dict[str, torch.Tensor] = {}
     # ``saved``: the dict the training forward's chain_forward returned (kept when the forward ran on these very kernels: dropout
     # on, or a shape-generic geometry); otherwise the fused forward kept nothing and the chain is recomputed here
@@ -740,11 +742,11 @@ def chain_backward(w, x_in_ptr: int, ldx: int, attn_ptr: int, lda: int, M: int, 
     else:
         dsa = dropout_rows(du1, d, M, d, drop.key(layer, Drop.SA_OUT), p)
         g["bo"] = colsum(dsa, d, M, d)
-    dattn = torch.empty((M, d), **f32)
-    gemm_nt(dsa, d, Transposed(w["wo"], d, d), dattn, d, M, d, d)
+    dattn = torch.empty((M, di), **f32)
+    gemm_nt(dsa, d, Transposed(w["wo"], d, di), dattn, di, M, di, d)
     with side_stream(dev, dsa):
-        g["wo"] = torch.empty((d, d), **f32)
-        gemm_tn(dsa, d, attn_ptr, lda, g["wo"], M, d, d)
+        g["wo"] = torch.empty((d, di), **f32)
+        gemm_tn(dsa, d, attn_ptr, lda, g["wo"], M, d, di)
     return g, du1, dattn
 
 
@@ -753,16 +755,16 @@ def qkv_backward(w, x_in: torch.Tensor, dqkv: torch.Tensor, M: int, qscale: floa
     q is stored pre-scaled): dq is the gradient of the SCALED q, so d(q_scaled)/d(q) is folded into the weight copy and into the
     q rows of the weight / bias gradients; the shape-generic attention backward returns the gradient of the unscaled q."""
     f32 = _f32(x_in.device)
-    d = w["wo"].shape[0]
+    d, di = w["wo"].shape                                     # model width, inner width of the attention (ops.padded_head_dim)
     g: Dict[str, torch.Tensor] = {}
-    wt = transpose(w["wqkv"], 3 * d, d)                       # [d, 3d]
+    wt = transpose(w["wqkv"], 3 * di, d)                      # [d, 3 di]
     if fold_qscale:
-        wt[:, :d] *= qscale
-    gemm_nt(dqkv, 3 * d, wt, dx_accum, d, M, d, 3 * d, accumulate=True)
+        wt[:, :di] *= qscale
+    gemm_nt(dqkv, 3 * di, wt, dx_accum, d, M, d, 3 * di, accumulate=True)
     with side_stream(x_in.device, dqkv, x_in):
-        g["wqkv"] = torch.empty((3 * d, d), **f32)
-        gemm_tn(dqkv, 3 * d, x_in, d, g["wqkv"], M, 3 * d, d)
-        g["bqkv"] = colsum(dqkv, 3 * d, M, 3 * d)
+        g["wqkv"] = torch.empty((3 * di, d), **f32)
+        gemm_tn(dqkv, 3 * di, x_in, d, g["wqkv"], M, 3 * di, d)
+        g["bqkv"] = colsum(dqkv, 3 * di, M, 3 * di)
         if fold_qscale:
             after_reductions(lambda w_=g["wqkv"], b_=g["bqkv"]: (w_[:d].mul_(qscale), b_[:d].mul_(qscale)))
     return g
@@ -900,10 +902,11 @@ def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, 
     recomputes.  q, k, v stay token-major ([B*T, 3d], q unscaled: the attention kernels scale it on load)."""
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
-    hd = d // H
+    hd = ops.padded_head_dim(d // H)        # the width the kernels run: narrower heads are zero-padded in the pack (ops.padded_head_dim)
+    di = H * hd
     dev = tokens.device
     f32 = _f32(dev)
-    qscale = LOG2E / math.sqrt(hd)
+    qscale = LOG2E / math.sqrt(d // H)
     layers = lvl_pack["layers"]
     M = B * T
     assert ctx_prev is None or ctx_all is None
@@ -914,26 +917,26 @@ def _transformer_forward_train_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, 
     spare = 128 if ops.wide_head(hd) else 0          # wide heads: the score products read whole 128-row tiles of k / v
 
     def in_proj(x, w):
-        qkv = torch.empty((M + spare, 3 * d), **f32)
+        qkv = torch.empty((M + spare, 3 * di), **f32)
         if spare:
             qkv[M:].zero_()
-        gemm_nt(x.view(M, d), d, w["wqkv"], qkv, 3 * d, M, 3 * d, d, bias=w["bqkv"])
+        gemm_nt(x.view(M, d), d, w["wqkv"], qkv, 3 * di, M, 3 * di, d, bias=w["bqkv"])
         return qkv
 
     x = tokens
     qkv = in_proj(x, layers[0])
     for l in range(L - 1):
-        attn, lse = zeros_group(dev, (B, T, d), (B, H, T))
+        attn, lse = zeros_group(dev, (B, T, di), (B, H, T))
         _attention_generic(qkv, attn, lse, num_ims, B, T, H, hd, qscale, 0, drop, l)
-        chain = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), d, M, dev, drop, l)
+        chain = chain_forward(layers[l], x.data_ptr(), d, attn.data_ptr(), di, M, dev, drop, l)
         x_out = chain["x3"].view(B, T, d)
         sv["layers"].append({"x_in": x, "qkv": qkv, "attn": attn, "lse": lse, "chain": chain})
         x, qkv = x_out, in_proj(x_out, layers[l + 1])
     # last layer: only token 0 of its output is read (reference model/aggregator.py:75)
     w = layers[L - 1]
-    attn0, lse0 = zeros_group(dev, (B, T, d), (B, H, T))
+    attn0, lse0 = zeros_group(dev, (B, T, di), (B, H, T))
     _attention_generic(qkv, attn0, lse0, num_ims, B, T, H, hd, qscale, 1, drop, L - 1)
-    chain0 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * d, B, dev, drop, L - 1)
+    chain0 = chain_forward(w, x.data_ptr(), T * d, attn0.data_ptr(), T * di, B, dev, drop, L - 1)
     x3 = chain0["x3"]
     nlog = lvl_pack["wcls"].shape[0]
     ctx_out = torch.empty((B, d), **f32)
@@ -954,11 +957,12 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
     tokens, num_ims, ctx_prev = sv["tokens"], sv["num_ims"], sv["ctx_prev"]
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
-    hd = d // H
+    hd = ops.padded_head_dim(d // H)        # (the shipped geometry: 32 = its own width)
+    di = H * hd
     dev = tokens.device
     f32 = _f32(dev)
     st = _lib.stream()
-    qscale = LOG2E / math.sqrt(hd)
+    qscale = LOG2E / math.sqrt(d // H)
     layers = lvl_pack["layers"]
     grads = {"layers": [None] * L}
     nlog = lvl_pack["wcls"].shape[0]
@@ -980,8 +984,8 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
             a0, lse0 = attention_token0(last["q"], last["k"], last["v"], num_ims, B, T, H, hd, *dk(L - 1))
         a0_ptr, a0_ld = a0.data_ptr(), d
     else:
-        attn0 = last["attn0"]                                  # [B, T, d], row 0 of every slide filled
-        a0_ptr, a0_ld = attn0.data_ptr(), T * d
+        attn0 = last["attn0"]                                  # [B, T, di], row 0 of every slide filled
+        a0_ptr, a0_ld = attn0.data_ptr(), T * di
     if chain0 is None:
         chain0 = chain_forward(wl, x_last.data_ptr(), T * d, a0_ptr, a0_ld, B, dev, drop, L - 1)
     x3 = chain0["x3"]
@@ -1021,13 +1025,13 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
 
     # ---- last layer, token 0 only
     g, dx0, da0 = chain_backward(wl, x_last.data_ptr(), T * d, a0_ptr, a0_ld, B, dx3, dev, drop, L - 1, saved=chain0)
-    dqkv, dx = zeros_group(dev, (B, T, 3 * d), (B, T, d))                       # (dx: gradient of the last layer's input)
+    dqkv, dx = zeros_group(dev, (B, T, 3 * di), (B, T, d))                      # (dx: gradient of the last layer's input)
     if fast:
         ws = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), **f32)
         _lib.call("paths_attention_token0_bwd", P(last["q"]), P(last["k"]), P(last["v"]), P(a0), P(da0), P(lse0), P(num_ims), P(dqkv), P(ws),
                   B, T, H, hd, *dk(L - 1), st)
     else:
-        d_o = torch.zeros((B, T, d), **f32)                                  # only token 0 carries an output gradient
+        d_o = torch.zeros((B, T, di), **f32)                                 # only token 0 carries an output gradient
         d_o[:, 0, :] = da0
         ws = torch.empty((B * H * T,), **f32)
         _attention_bwd_generic(last["qkv"], attn0, d_o, last["lse0"], num_ims, dqkv, ws, B, T, H, hd, d, qscale, 1, dk(L - 1))
@@ -1040,9 +1044,9 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         lv = sv["layers"][l]
         w = layers[l]
         M = B * T
-        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), d, M, dx.view(M, d), dev, drop, l,
+        g, dx_in, dattn = chain_backward(w, lv["x_in"].data_ptr(), d, lv["attn"].data_ptr(), di, M, dx.view(M, d), dev, drop, l,
                                          saved=lv.get("chain"))
-        dqkv = torch.zeros((B, T, 3 * d), **f32)
+        dqkv = torch.zeros((B, T, 3 * di), **f32)
         ws = torch.empty((B * H * T,), **f32)
         if not fast:
             _attention_bwd_generic(lv["qkv"], lv["attn"], dattn, lv["lse"], num_ims, dqkv, ws, B, T, H, hd, d, qscale, 0, dk(l))
@@ -1058,4 +1062,14 @@ def transformer_backward(mc, lvl_pack, sv, d_logits: Optional[torch.Tensor], d_c
         grads["layers"][l] = g
         dx = dx_in.view(B, T, d)
     side_join(dev)                     # the weight / bias gradients issued on the side stream (chain_backward, qkv_backward)
+    # zero-padded heads (ops.padded_head_dim): gradients of the padded in_proj / out_proj images back to the parameters' own rows /
+    # columns (once the deferred slab reductions that produce them have run)
+    for l in range(L):
+        if "_unpad" in layers[l]:
+            def unpad(g_=grads["layers"][l], idx=layers[l]["_unpad"]):
+                row, col = idx
+                g_["wqkv"] = g_["wqkv"].index_select(0, row)
+                g_["bqkv"] = g_["bqkv"].index_select(0, row)
+                g_["wo"] = g_["wo"].index_select(1, col)
+            after_reductions(unpad)
     return grads, dx, d_ctx_prev

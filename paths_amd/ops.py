@@ -372,6 +372,17 @@ def _pack_decoder_layers(agg) -> List[Dict[str, object]]:
     cross-attention is live)."""
     c = lambda t: t.detach().float().contiguous()
     layers = []
+    d, H = agg.dim, agg.nhead
+    hd = d // H
+    hdp = padded_head_dim(hd)
+    pad = None
+    if hdp != hd:
+        # zero-padded heads (see padded_head_dim): "wqkv" [3 H hdp, d], "bqkv" [3 H hdp], "wo" [d, H hdp]; "_unpad" = where the true rows /
+        # columns sit, for the gradients' way back (paths_amd/autograd.py:_level_grads)
+        dev = agg.proj_in.weight.device
+        col = (torch.arange(d, device=dev) // hd) * hdp + torch.arange(d, device=dev) % hd          # true inner index -> padded inner index
+        row = torch.cat([col + k * H * hdp for k in range(3)])
+        pad = (row, col, H * hdp)
     for lyr in agg.transformer.decoder.layers:
         layers.append({
             "wqkv": c(lyr.self_attn.in_proj_weight), "bqkv": c(lyr.self_attn.in_proj_bias),
@@ -384,6 +395,16 @@ def _pack_decoder_layers(agg) -> List[Dict[str, object]]:
             "w2": c(lyr.linear2.weight), "b2": c(lyr.linear2.bias),
             "eps": float(lyr.norm1.eps),
         })
+        if pad is not None:
+            row, col, di = pad
+            lay = layers[-1]
+            wq = torch.zeros((3 * di, d), device=row.device, dtype=torch.float32)
+            wq[row] = lay["wqkv"]
+            bq = torch.zeros((3 * di,), device=row.device, dtype=torch.float32)
+            bq[row] = lay["bqkv"]
+            wo = torch.zeros((d, di), device=row.device, dtype=torch.float32)
+            wo[:, col] = lay["wo"]
+            lay.update({"wqkv": wq, "bqkv": bq, "wo": wo, "_unpad": (row, col)})
     return layers
 
 
@@ -424,6 +445,16 @@ WS_CHAIN_192 = os.environ.get("PATHS_WS_CHAIN_192", "1") != "0"     # trans_dim 
 WS_IMAGES_192 = os.environ.get("PATHS_WS_IMAGES_192", "1") != "0"   # ... and the first in_proj straight into the attention's head_dim-48 operand images
 
 
+def padded_head_dim(hd: int) -> int:
+    """The head width the attention kernels run for a reference head_dim ``hd`` (reference model/aggregator.py:25-33 accepts any
+    trans_dim % trans_heads == 0): 16 / 32 / 48 / 64 up to 64, multiples of 32 above.  A head that is narrower than that is ZERO-PADDED
+    (rows of in_proj, columns of out_proj: :func:`_pack_decoder_layers`): padded q / k dims add nothing to a score, padded v dims yield
+    zeros that meet zero columns of out_proj - the same function, evaluated on the supported width (softmax scale from the TRUE width)."""
+    if hd <= 64:
+        return next(w for w in (16, 32, 48, 64) if w >= hd)
+    return (hd + 31) // 32 * 32
+
+
 def wide_head(hd: int) -> bool:
     """head_dim above the flash-style kernels' 64: the three-step form of csrc/attn_wide.hip (score matrix in scratch)."""
     return hd > 64 and hd % 32 == 0 and hd <= 1024
@@ -431,20 +462,19 @@ def wide_head(hd: int) -> bool:
 
 def check_aggregator_geometry(d: int, H: int):
     """(trans_dim, trans_heads) pairs the aggregator kernels run (standalone ``TransformerAggregator.forward``)."""
-    hd = d // max(H, 1)
-    if d % 32 or d > 2048 or H < 1 or d % H or not (hd in (16, 32, 48, 64) or wide_head(hd)):
-        raise NotImplementedError("the aggregator kernels need trans_dim % 32 == 0 (<= 2048) and head_dim in {16, 32, 48, 64} or a multiple "
-                                  f"of 32 above 64 (got trans_dim {d}, trans_heads {H})")
+    if d % 32 or d > 2048 or H < 1 or d % H or padded_head_dim(d // H) > 1024 or H * padded_head_dim(d // H) > 2048:
+        raise NotImplementedError("the aggregator kernels need trans_dim % 32 == 0 (<= 2048, also after padding its heads to 16 / 32 / 48 / 64 "
+                                  f"or a multiple of 32) and trans_dim % trans_heads == 0 (got trans_dim {d}, trans_heads {H})")
 
 
 def check_supported(mc, training: bool = False):
     """Configurations this build runs on the HIP path; everything else is rejected loudly."""
     if not fast_path(mc):
         d, H, Hi = mc.trans_dim, mc.trans_heads, mc.importance_mlp_hidden_dim
-        hd = d // max(H, 1)
-        if d % 32 or d > 2048 or H < 1 or d % H or not (hd in (16, 32, 48, 64) or wide_head(hd)) or Hi < 1 or Hi > 1024:
-            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 2048), head_dim in {16, 32, 48, 64} or a multiple "
-                                      f"of 32 above 64, and importance_mlp_hidden_dim <= 1024 (got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
+        if d % 32 or d > 2048 or H < 1 or d % H or padded_head_dim(d // H) > 1024 or H * padded_head_dim(d // H) > 2048 or Hi < 1 or Hi > 1024:
+            raise NotImplementedError("the shape-generic aggregator kernels need trans_dim % 32 == 0 (<= 2048, also after padding its heads to 16 / 32 / 48 / 64 "
+                                      "or a multiple of 32), trans_dim % trans_heads == 0 and importance_mlp_hidden_dim <= 1024 "
+                                      f"(got trans_dim {d}, trans_heads {H}, importance hidden {Hi})")
         if training and Hi % 4:
             raise NotImplementedError("training at aggregator geometries other than trans_dim=128 / 4 heads / importance hidden 128 needs "
                                       f"importance_mlp_hidden_dim % 4 == 0 (got {Hi}); inference runs")
@@ -642,12 +672,14 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     gp = generic_pack(lvl_pack, mc)
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
-    hd = d // H
+    hd_true = d // H
+    hd = padded_head_dim(hd_true)         # the head width the kernels run (narrower heads are zero-padded in the pack: padded_head_dim)
+    di = H * hd                           # inner width of the attention: q | k | v are [M, 3 di], the attention output [B, T, di]
     dev = tokens.device
     st = _lib.stream()
     p = _lib.ptr
     f32 = dict(device=dev, dtype=torch.float32)
-    qscale = LOG2E / math.sqrt(hd)
+    qscale = LOG2E / math.sqrt(hd_true)
     M = B * T
     if fp8 and not fp8_supported(mc):
         raise NotImplementedError(f"the e4m3 aggregator needs trans_dim % 64 == 0 and head_dim 32 or 64 (got {d} / {H} heads)")
@@ -662,14 +694,15 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     h3 = (not fp8) and GENERIC_SPLIT and GEMM_MODE == "h3" and L > 1 and not wide
     wsh = torch.empty((int(_lib.load().paths_attention_h3_any_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if h3 else None
     x = tokens.view(M, d)
-    qkv = torch.empty((M + (128 if wide else 0), 3 * d), **f32)      # (wide heads: the score product reads whole 128-row tiles of k)
+    qkv = torch.empty((M + (128 if wide else 0), 3 * di), **f32)     # (wide heads: the score product reads whole 128-row tiles of k)
     if wide:
         qkv[M:].zero_()
     # rows of padded queries are never written by the attention kernels: harmless row-wise garbage on the accurate path, but the e4m3
     # path takes max|.| over WHOLE activation matrices for its per-tensor scales - there they must be defined (zero)
-    attn = (torch.zeros if fp8 else torch.empty)((B, T, d), **f32)
+    attn = (torch.zeros if fp8 else torch.empty)((B, T, di), **f32)
     rows, ldx = M, d                      # the current activation: `rows` rows, row stride ldx (the last layer keeps token 0 of every slide)
-    ws192 = WS_CHAIN_192 and d == 192 and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and not wide
+    lda_attn = di                         # row stride of the attention output as the out_proj operand (T * di for the last layer's token-0 rows)
+    ws192 = WS_CHAIN_192 and d == 192 and hd == hd_true and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and not wide
     qkv_ready = img_ready = False
     for l in range(L):
         lay, gl = lvl_pack["layers"][l], gp["layers"][l]
@@ -695,23 +728,23 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             _lib.call("paths_token_layer_ws_rows", p(x), None, None, None, p(iq), None, None, None, None, None, None, None, None, None, None,
                       p(lay["bqkv"]), 1.0, 1.0, 1.0, sq[0], p(qkv), 3 * d, p(num_ims), B, T, d, 0, 1, 1, lay["eps"], st)
         else:
-            gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * d, M, 3 * d, d, low=fp8)          # (the last layer's K / V cover all tokens too)
+            gemm(x, d, "wqkv", lay["bqkv"], qkv, 3 * di, M, 3 * di, d, low=fp8)        # (the last layer's K / V cover all tokens too)
         if big:
-            _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
+            _lib.call("paths_attention_fp8_qkv", p(qkv), 3 * di, p(attn), p(num_ims), B, T, H, hd, qscale, p(ws8), st)
         elif wide:
-            _lib.call("paths_attention_wide_fwd", p(qkv), 3 * d, p(attn), None, p(num_ims), B, T, H, hd, qscale, 1 if last else 0, 0, 0.0, p(wsw), st)
+            _lib.call("paths_attention_wide_fwd", p(qkv), 3 * di, p(attn), None, p(num_ims), B, T, H, hd, qscale, 1 if last else 0, 0, 0.0, p(wsw), st)
         elif h3 and not last and img_ready:
             _lib.call("paths_attention_h3_any_img", p(attn), p(num_ims), B, T, H, hd, p(wsh), st)
             img_ready = False
         elif h3 and not last:
-            _lib.call("paths_attention_h3_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, p(wsh), st)
+            _lib.call("paths_attention_h3_any", p(qkv), 3 * di, p(attn), p(num_ims), B, T, H, hd, qscale, p(wsh), st)
         elif last and GENERIC_SPLIT:
             # single query per (slide, head), keys split over workgroups (csrc/attn_token0.hip): [B, d] instead of row 0 of [B, T, d]
-            a0 = torch.empty((B, d), **f32)
+            a0 = torch.empty((B, di), **f32)
             ws0 = torch.empty((int(_lib.load().paths_attention_token0_workspace(B, T, H)),), **f32)
-            _lib.call("paths_attention_token0_any", p(qkv), 3 * d, p(num_ims), p(a0), p(ws0), B, T, H, hd, qscale, st)
+            _lib.call("paths_attention_token0_any", p(qkv), 3 * di, p(num_ims), p(a0), p(ws0), B, T, H, hd, qscale, st)
         else:
-            _lib.call("paths_attention_any", p(qkv), 3 * d, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
+            _lib.call("paths_attention_any", p(qkv), 3 * di, p(attn), p(num_ims), B, T, H, hd, qscale, 1 if last else 0, st)
         if ws192 and not last:
             # the reference's dataclass-default width (config.py:30): out_proj + norm1 + cross-attention bias + norm2 + feed-forward +
             # norm3 of a full layer AND the next layer's in_proj in ONE launch of the weight-stationary chain kernel (csrc/tlayer_ws.hip
@@ -727,12 +760,12 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             x, ldx, qkv, qkv_ready = x3, d, qkv_next, True
             continue
         if last:
-            rows, ldx = B, T * d          # rows = token 0 of every slide: row stride T * d into the [B, T, d] tensors
+            rows, ldx, lda_attn = B, T * d, T * di    # rows = token 0 of every slide: row stride T * d (T * di) into the [B, T, .] tensors
         y1 = torch.empty((rows, d), **f32)
         if last and GENERIC_SPLIT and not wide:
-            gemm(a0, d, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx)
+            gemm(a0, di, "wo", lay["bo"], y1, d, rows, d, di, residual=x, ldr=ldx)
         else:
-            gemm(attn, ldx, "wo", lay["bo"], y1, d, rows, d, d, residual=x, ldr=ldx, low=big)
+            gemm(attn, lda_attn, "wo", lay["bo"], y1, d, rows, d, di, residual=x, ldr=ldx, low=big)
         x1 = torch.empty((rows, d), **f32)
         x2 = y1                           # (in place: every wave reads its row before it writes it)
         _lib.call("paths_layernorm2_rows", p(y1), d, p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]), p(lay["ln2g"]), p(lay["ln2b"]), p(x2), d,

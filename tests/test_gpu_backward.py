@@ -494,9 +494,10 @@ def test_variant_training_gradients_vs_oracle_autograd(dev, over):
                                   {"trans_dim": 96, "trans_heads": 6, "importance_mode": "none", "pos_encoding_mode": "1d"},
                                   {"trans_dim": 192, "lstm": False}, {"trans_dim": 64, "trans_heads": 1, "importance_mlp_hidden_dim": 36, "lstm": False},
                                   {"trans_dim": 256, "trans_heads": 2}, {"trans_dim": 384, "trans_heads": 1, "importance_mlp_hidden_dim": 64},
-                                  {"trans_dim": 1536, "trans_heads": 4}],
+                                  {"trans_dim": 1536, "trans_heads": 4}, {"trans_dim": 160, "trans_heads": 4}, {"trans_dim": 320, "trans_heads": 4},
+                                  {"trans_dim": 128, "trans_heads": 16}],
                          ids=["td192_default", "td64_h2_hi64", "td192_h3_hi96_concat", "td96_h6_impnone_pe1d", "td192_nolstm", "td64_h1_hi36_nolstm",
-                              "td256_h2_hd128", "td384_h1_hd384", "td1536_h4_hd384"])
+                              "td256_h2_hd128", "td384_h1_hd384", "td1536_h4_hd384", "td160_h4_hd40_padded", "td320_h4_hd80_padded", "td128_h16_hd8_padded"])
 def test_training_other_aggregator_geometries_vs_oracle_autograd(dev, over):
     """the reference's config surface (config.py:30-36) trains too - trans_dim 192 / head_dim 48 is its dataclass
     default.  5-level training forward / backward on the shape-generic kernels (csrc/generic.hip TRAIN attention, csrc/generic_bwd.hip)
@@ -625,7 +626,7 @@ def test_gemm_nt_train_planes_matches_fp64(dev, monkeypatch, planes, M, N, K):
 
 
 @pytest.mark.parametrize("name,forced", [("g6_train_16x16_top64", False), ("g13_train_td192_8x8_top16", False), ("g13_train_td64_h2_hi32_8x8_top16", False),
-                                         ("g14_train_td256_h2_8x8_top16", False),
+                                         ("g14_train_td256_h2_8x8_top16", False), ("g15_train_td160_h4_8x8_top16", False),
                                          ("g6_train_16x16_top64", True), ("g13_train_td192_8x8_top16", True)])
 def test_three_adamw_steps_match_reference_g6(dev, monkeypatch, name, forced):
     """Reference train-step semantics (train.py:49-50,59-68): losses of 3 AdamW steps vs the fixtures captured from the

@@ -107,6 +107,18 @@ def test_single_level_other_aggregator_geometries(dev, tag):
     np.testing.assert_allclose(out["ctx_patch"].numpy(), g["ctx_patch"], atol=STATE_TOL, rtol=0)
 
 
+@pytest.mark.parametrize("tag", ["td160_h4_hd40", "td320_h4_hd80", "td96_h4_hd24_pe1d"])
+def test_single_level_odd_head_dims(dev, tag):
+    """g15 (reference model/aggregator.py:25-33: any trans_dim % trans_heads == 0): head dims 40, 80 and 24 run as ZERO-PADDED heads
+    of 48, 96 and 32 (ops.padded_head_dim: padded rows of in_proj, padded columns of out_proj, softmax scale from the true width) on
+    the shape-generic kernels; the reference's outputs within the usual bars."""
+    g, info, out = run_single(dev, f"g15_{tag}_level1")
+    np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["importance"].numpy(), g["importance"], atol=STATE_TOL, rtol=0)
+    np.testing.assert_allclose(out["ctx_patch"].numpy(), g["ctx_patch"], atol=STATE_TOL, rtol=0)
+
+
 def test_recursion_trans_dim_192_vs_reference_golden(dev):
     """g12 recursion: 5 levels at the reference's default trans_dim 192 through the device recursion (sync-free pass, launch tape
     included) - per-level num_ims / locations / kept sets / parents exact, hazards within the bar."""
@@ -129,14 +141,15 @@ def test_recursion_trans_dim_192_vs_reference_golden(dev):
 
 
 def test_unsupported_config_rejected(dev):
-    """Configurations outside what the kernels cover fail loudly (never approximated): a head_dim the generic attention does not
-    have (inference and training), and training with an importance hidden width the generic backward cannot address (% 4)."""
+    """Configurations outside what the kernels cover fail loudly (never approximated): a head count that does not divide trans_dim
+    (the reference's own nn.Transformer refuses it too), and training with an importance hidden width the generic backward cannot
+    address (% 4).  (Head dims outside 16 / 32 / 48 / 64 / multiples of 32 run since round 5 as zero-padded heads: g15.)"""
     from paths_amd.data_utils.patch_batch import PatchBatch
     from paths_amd import utils as putils
     from paths_amd.data_utils.slide import DeviceSlide
     g, info = load_golden("g1_level0_b2_k256")
     cfg, model, _ = build_model(dev, info["wseed"], None)
-    model.procs[0].config.trans_heads = 16         # head_dim 8: not built
+    model.procs[0].config.trans_heads = 3          # 128 % 3 != 0
     inp = H.single_level_inputs(info, H.oracle_config())
     pb = PatchBatch(**{k: torch.from_numpy(v).to(dev) for k, v in inp.items()})
     with pytest.raises(NotImplementedError):
@@ -144,7 +157,7 @@ def test_unsupported_config_rejected(dev):
     model.procs[0].config.trans_heads = 4
     g2, info2 = load_golden("g12_recursion_td192_6x7_top5")
     slides = [DeviceSlide.synthetic(info2["dseed"], sid, tuple(info2["base_shape"]), p_bg=info2["p_bg"], device=dev) for sid in info2["slide_ids"]]
-    for over in ({"trans_dim": 192, "trans_heads": 24}, {"trans_dim": 192, "importance_mlp_hidden_dim": 30}):
+    for over in ({"trans_dim": 192, "importance_mlp_hidden_dim": 30},):
         cfg2, model2, _ = build_model(dev, info2["wseed"], {"model_config": over}, top_k_patches=[info2["top_k"]] * 4)
         with pytest.raises(NotImplementedError):
             putils.recurse_train(model2.train(), slides, cfg2.top_k_patches, cfg2.num_levels)

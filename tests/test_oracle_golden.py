@@ -62,6 +62,15 @@ def test_single_level_wide_heads(tag):
         np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("tag", ["td160_h4_hd40", "td320_h4_hd80", "td96_h4_hd24_pe1d"])
+def test_single_level_odd_head_dims(tag):
+    """g15: head dims that are neither 16 / 32 / 48 / 64 nor a multiple of 32 (40, 80, 24: reference model/aggregator.py:25-33 accepts any
+    trans_dim % trans_heads == 0) - the oracle against the reference's outputs."""
+    g, info, out = _run_single(f"g15_{tag}_level1")
+    for k in ("logits", "ctx_slide", "importance", "ctx_patch"):
+        np.testing.assert_allclose(out[k].numpy(), g[k], atol=ATOL, rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["g8_level0_b1_k2048", "g9_level1_b2_k2048"])
 def test_single_level_k2048(name):
     g, info, out = _run_single(name)

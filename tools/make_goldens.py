@@ -504,6 +504,16 @@ def main():
         }.items():
             single_level(ref, f"g14_{tag}_level1", 1, 2, 64, [64, 50], wseed=4, dseed=15, cfg_over=over)
         training(ref, "g14_train_td256_h2_8x8_top16", (8, 8), 16, 3, wseed=7, dseed=23, cfg_over={"model_config": {"trans_dim": 256, "trans_heads": 2}})
+    if want("g15"):
+        # head dims that are NEITHER 16 / 32 / 48 / 64 NOR a multiple of 32 (reference model/aggregator.py:25-33 accepts any
+        # trans_dim % trans_heads == 0; config.py:30-36): 160 / 4 heads = 40 and 320 / 4 heads = 80 run as zero-padded heads of 48 / 96
+        for tag, over in {
+            "td160_h4_hd40": {"model_config": {"trans_dim": 160, "trans_heads": 4}},
+            "td320_h4_hd80": {"model_config": {"trans_dim": 320, "trans_heads": 4}},
+            "td96_h4_hd24_pe1d": {"model_config": {"trans_dim": 96, "trans_heads": 4, "pos_encoding_mode": "1d"}},
+        }.items():
+            single_level(ref, f"g15_{tag}_level1", 1, 2, 64, [64, 50], wseed=4, dseed=15, cfg_over=over)
+        training(ref, "g15_train_td160_h4_8x8_top16", (8, 8), 16, 3, wseed=8, dseed=24, cfg_over={"model_config": {"trans_dim": 160, "trans_heads": 4}})
     if want("g6"):
         training(ref, "g6_train_16x16_top64", (16, 16), 64, 4, wseed=3, dseed=14)
     if want("g13"):
