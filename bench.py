@@ -513,7 +513,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10, help="infer mode: timed steps of the short training measurement added to the "
                     "line as 'train' (0 = skip); 3 warm-up steps")
     ap.add_argument("--stress-steps", type=int, default=4, help="infer mode, N=1: timed steps of the 'stress' object (BASELINE configs[4]: one level, "
-                    "K = 8192 x d = 1536, fp32-accurate path and the opt-in e4m3 variants at trans_dim 128 / 4 heads and 1536 / 24 heads); 0 = skip")
+                    "K = 8192 x d = 1536, fp32-accurate path and the opt-in e4m3 variants at trans_dim 128 / 4 heads, 1536 / 24 heads and 1536 / 4 heads); 0 = skip")
     ap.add_argument("--k1024-steps", type=int, default=20, help="infer mode: timed steps of the 'k1024' object (BASELINE configs[1]: the same "
                     "5-level recursion at K = 1024 patches per level on one GPU's 8 resident slides); 0 = skip")
     ap.add_argument("--cores-per-rank", type=int, default=0, help="pin this rank to N host cores (cores [rank N, rank N + N) of the "
@@ -964,8 +964,11 @@ def main():
             stress = {"workload": "one level over 8192 patches x 1536 features per slide (full quadratic attention over 8193 tokens), "
                                   f"{spg} slides per step (BASELINE.json configs[4])",
                       "td128_h4": stress_measure(128, 4, True, args.stress_steps, 2, spg, rank, world, dev, dev_reduce, pdist, putils),
-                      "td1536_h24": stress_measure(1536, 24, True, args.stress_steps, 2, spg, rank, world, dev, dev_reduce, pdist, putils)}
-            for k_ in ("td128_h4", "td1536_h24"):
+                      "td1536_h24": stress_measure(1536, 24, True, args.stress_steps, 2, spg, rank, world, dev, dev_reduce, pdist, putils),
+                      # SURVEY 8(d) writes the wide stress row as 1536 / 4 heads = head_dim 384: accurate path on csrc/attn_wide.hip,
+                      # e4m3 attention on the wide instantiation of csrc/attn_fp8.hip (round 5)
+                      "td1536_h4": stress_measure(1536, 4, True, max(2, args.stress_steps // 2), 1, spg, rank, world, dev, dev_reduce, pdist, putils)}
+            for k_ in ("td128_h4", "td1536_h24", "td1536_h4"):
                 f8 = stress[k_].get("fp8_aggregator") or {}
                 log(f"stress {k_}: accurate {stress[k_]['ms_per_step']} ms per step, e4m3 aggregator {f8.get('ms_per_step')} ms "
                     f"(frac of fp8 peak {(f8.get('roofline') or {}).get('frac')}, logit diff {f8.get('max_logit_diff_vs_accurate_path')})")

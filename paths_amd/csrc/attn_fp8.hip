@@ -21,7 +21,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int F8 = 512;                    // bytes of one 16-row x 32-k fp8 fragment (64 lanes x 8 bytes)
 constexpr int KSTEP = 64;                  // keys per LDS buffer
-constexpr int QT = 2;                      // 16-query tiles per wave
+// QT = 16-query tiles per wave: 2 up to head_dim 64; 1 for wide heads (head_dim 128 .. 384: the output accumulators alone are
+// HD / 4 registers per query tile, and the K / V^T fragment sets of a 64-key step grow to 24 KB each at 384)
 constexpr float P_SCALE = 256.0f;
 
 __device__ __forceinline__ u32x2 fp8x8(const float (&x)[8], float scale) {
@@ -52,7 +53,8 @@ attn_fp8_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, c
                      int64_t bstride, float qmul, char* __restrict__ q8, char* __restrict__ k8, char* __restrict__ v8,
                      const int64_t* __restrict__ num_ims, int T, int Tp, int H) {
   constexpr int NK = HD / 32, NDV = HD / 16;
-  __shared__ float sv[KSTEP][HD + 1];
+  extern __shared__ __attribute__((aligned(16))) char smem_prep[];
+  float (*sv)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem_prep);          // [KSTEP][HD + 1]
   const int b = blockIdx.z, head = blockIdx.y, t0 = blockIdx.x * KSTEP;
   const int len = min((int)num_ims[b] + 1, T);
   const int tid = threadIdx.x;
@@ -91,13 +93,15 @@ attn_fp8_prep_kernel(const float* __restrict__ q, const float* __restrict__ k, c
   }
 }
 
-template <int HD>
-__global__ void __launch_bounds__(256, 2)
+template <int HD, int QT>
+__global__ void __launch_bounds__(256, HD <= 64 ? 2 : 1)
 attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const char* __restrict__ v8,
                 float* __restrict__ o, const int64_t* __restrict__ num_ims, int T, int Tp, int H, int npairs, int nqb) {
   constexpr int NK = HD / 32, NDV = HD / 16;
   constexpr int KB = 4 * NK * F8, VB = 2 * NDV * F8;      // bytes of K / V^T fragments per 64-key step
-  __shared__ __attribute__((aligned(16))) char sKb[2][KB], sVb[2][VB];
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];              // sKb [2][KB] | sVb [2][VB]
+  char (*sKb)[KB] = reinterpret_cast<char (*)[KB]>(smem_attn);
+  char (*sVb)[VB] = reinterpret_cast<char (*)[VB]>(smem_attn + 2 * KB);
   // XCD-aware placement as in attn_x6.hip: pair p only ever runs on the XCD group p % 8
   const int lin = blockIdx.x, xg = lin & 7, jx = lin >> 3;
   const int cnt = (npairs - xg + 7) >> 3;
@@ -241,18 +245,36 @@ attn_fp8_kernel(const char* __restrict__ q8, const char* __restrict__ k8, const 
 template <int HD>
 int launch_fp8(const float* q, const float* k, const float* v, int64_t ld, int64_t hstride, int64_t bstride, float qmul, float* o,
                const int64_t* num_ims, int B, int T, int H, void* workspace, hipStream_t stream) {
+  constexpr int QT = HD <= 64 ? 2 : 1;
+  constexpr size_t lds_prep = (size_t)KSTEP * (HD + 1) * sizeof(float), lds_attn = 2ull * (4 * (HD / 32) * F8 + 2 * (HD / 16) * F8);
+  PATHS_LDS_OPT_IN((attn_fp8_prep_kernel<HD>), lds_prep, "attention_fp8(prep)");
+  PATHS_LDS_OPT_IN((attn_fp8_kernel<HD, QT>), lds_attn, "attention_fp8");
   const int Tp = (T + KSTEP - 1) / KSTEP * KSTEP;
   const int64_t img = (int64_t)B * H * Tp * HD;
   char* q8 = reinterpret_cast<char*>(workspace);
   char* k8 = q8 + img;
   char* v8 = k8 + img;
-  hipLaunchKernelGGL(attn_fp8_prep_kernel<HD>, dim3(Tp / KSTEP, H, B), dim3(256), 0, stream, q, k, v, ld, hstride, bstride, qmul, q8, k8, v8,
+  hipLaunchKernelGGL(attn_fp8_prep_kernel<HD>, dim3(Tp / KSTEP, H, B), dim3(256), lds_prep, stream, q, k, v, ld, hstride, bstride, qmul, q8, k8, v8,
                      num_ims, T, Tp, H);
   PATHS_LAUNCH_CHECK("attention_fp8(prep)");
   const int nqb = (T + 64 * QT - 1) / (64 * QT), npairs = H * B;
-  hipLaunchKernelGGL(attn_fp8_kernel<HD>, dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), 0, stream, q8, k8, v8, o, num_ims, T, Tp, H, npairs, nqb);
+  hipLaunchKernelGGL((attn_fp8_kernel<HD, QT>), dim3(8 * ((npairs + 7) / 8) * nqb), dim3(256), lds_attn, stream, q8, k8, v8, o, num_ims, T, Tp, H, npairs, nqb);
   PATHS_LAUNCH_CHECK("attention_fp8");
   return PATHS_OK;
+}
+
+inline bool fp8_head_dim_ok(int hd) { return hd == 32 || hd == 64 || hd == 128 || hd == 256 || hd == 384; }
+// head_dim 128 / 256 / 384 (round 5: the stress row's own 1536 / 4 heads form): the same kernel with 4 / 8 / 12 k-steps per
+// score tile and 8 / 16 / 24 output-dim tiles, one 16-query tile per wave
+int dispatch_fp8(int hd, const float* q, const float* k, const float* v, int64_t ld, int64_t hstride, int64_t bstride, float qmul, float* o,
+                 const int64_t* num_ims, int B, int T, int H, void* workspace, hipStream_t stream) {
+  switch (hd) {
+    case 32: return launch_fp8<32>(q, k, v, ld, hstride, bstride, qmul, o, num_ims, B, T, H, workspace, stream);
+    case 64: return launch_fp8<64>(q, k, v, ld, hstride, bstride, qmul, o, num_ims, B, T, H, workspace, stream);
+    case 128: return launch_fp8<128>(q, k, v, ld, hstride, bstride, qmul, o, num_ims, B, T, H, workspace, stream);
+    case 256: return launch_fp8<256>(q, k, v, ld, hstride, bstride, qmul, o, num_ims, B, T, H, workspace, stream);
+    default: return launch_fp8<384>(q, k, v, ld, hstride, bstride, qmul, o, num_ims, B, T, H, workspace, stream);
+  }
 }
 
 }  // namespace
@@ -269,25 +291,23 @@ int64_t paths_attention_fp8_workspace(int B, int T, int H, int head_dim) {
 // q, k, v head-major [B][H][T][hd] fp32, q pre-scaled by log2(e)/sqrt(head_dim); keys >= num_ims[b] + 1 are masked.
 int paths_attention_fp8(const float* q, const float* k, const float* v, float* o, const int64_t* num_ims, int B, int T, int H,
                         int head_dim, void* workspace, hipStream_t stream) {
-  PATHS_REQUIRE(head_dim == 32 || head_dim == 64, "attention_fp8: head_dim must be 32 or 64 (got %d)", head_dim);
+  PATHS_REQUIRE(fp8_head_dim_ok(head_dim), "attention_fp8: head_dim must be 32, 64, 128, 256 or 384 (got %d)", head_dim);
   PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && q && k && v && o && num_ims && workspace, "attention_fp8: bad arguments B=%d T=%d H=%d", B, T, H);
   PATHS_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_fp8: buffers must be 16-byte aligned");
   const int64_t hs = (int64_t)T * head_dim, bs = (int64_t)H * T * head_dim;
-  return head_dim == 32 ? launch_fp8<32>(q, k, v, head_dim, hs, bs, 1.0f, o, num_ims, B, T, H, workspace, stream)
-                        : launch_fp8<64>(q, k, v, head_dim, hs, bs, 1.0f, o, num_ims, B, T, H, workspace, stream);
+  return dispatch_fp8(head_dim, q, k, v, head_dim, hs, bs, 1.0f, o, num_ims, B, T, H, workspace, stream);
 }
 
 // The same on the token-major in_proj output qkv [B*T, 3d] (row stride ld; q | k | v blocks of d = H * head_dim columns, q UNscaled:
 // qscale = log2(e) / sqrt(head_dim) is applied while the operand images are written).
 int paths_attention_fp8_qkv(const float* qkv, int64_t ld, float* o, const int64_t* num_ims, int B, int T, int H, int head_dim, float qscale,
                             void* workspace, hipStream_t stream) {
-  PATHS_REQUIRE(head_dim == 32 || head_dim == 64, "attention_fp8_qkv: head_dim must be 32 or 64 (got %d)", head_dim);
+  PATHS_REQUIRE(fp8_head_dim_ok(head_dim), "attention_fp8_qkv: head_dim must be 32, 64, 128, 256 or 384 (got %d)", head_dim);
   PATHS_REQUIRE(B > 0 && T > 0 && H > 0 && qkv && o && num_ims && workspace && ld >= 3 * H * head_dim, "attention_fp8_qkv: bad arguments B=%d T=%d H=%d", B, T, H);
   PATHS_REQUIRE(((uintptr_t)qkv | (uintptr_t)o | (uintptr_t)workspace) % 16 == 0, "attention_fp8_qkv: buffers must be 16-byte aligned");
   const int d = H * head_dim;
   const int64_t bs = (int64_t)T * ld;
-  return head_dim == 32 ? launch_fp8<32>(qkv, qkv + d, qkv + 2 * d, ld, head_dim, bs, qscale, o, num_ims, B, T, H, workspace, stream)
-                        : launch_fp8<64>(qkv, qkv + d, qkv + 2 * d, ld, head_dim, bs, qscale, o, num_ims, B, T, H, workspace, stream);
+  return dispatch_fp8(head_dim, qkv, qkv + d, qkv + 2 * d, ld, head_dim, bs, qscale, o, num_ims, B, T, H, workspace, stream);
 }
 
 }  // extern "C"

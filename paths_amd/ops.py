@@ -658,9 +658,12 @@ def ffn_fp8(fp, lay8, x2, d: int, b1, b2, y2, M: int, tok=None):
               y2.data_ptr(), d, M, d, F, 0, x2.data_ptr(), d, st)
 
 
+FP8_HEAD_DIMS = (32, 64, 128, 256, 384)      # csrc/attn_fp8.hip (round 5: the wide ones - 1536 / 4 heads = 384 is the stress row's own form)
+
+
 def fp8_supported(mc) -> bool:
     d, H = mc.trans_dim, mc.trans_heads
-    return d % 128 == 0 and d % H == 0 and (d // H) in (32, 64)      # paths_gemm_nt_fp8 needs K % 128 == 0 (one 64-k instruction pair per stage)
+    return d % 128 == 0 and d % H == 0 and (d // H) in FP8_HEAD_DIMS      # paths_gemm_nt_fp8 needs K % 128 == 0 (one 64-k instruction pair per stage)
 
 
 def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8: bool = False) -> Dict[str, torch.Tensor]:
@@ -682,14 +685,12 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     qscale = LOG2E / math.sqrt(hd_true)
     M = B * T
     if fp8 and not fp8_supported(mc):
-        raise NotImplementedError(f"the e4m3 aggregator needs trans_dim % 64 == 0 and head_dim 32 or 64 (got {d} / {H} heads)")
+        raise NotImplementedError(f"the e4m3 aggregator needs trans_dim % 128 == 0 and head_dim in {FP8_HEAD_DIMS} (got {d} / {H} heads)")
     fp = fp8_pack(lvl_pack, mc) if fp8 else None
     ws8 = torch.empty((int(_lib.load().paths_attention_fp8_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if (fp8 and L > 1) else None
     # full layers' attention on the split-fp16 matrix-core kernel for any head_dim (the arithmetic of the tuned path), unless the
     # f32 mode is selected; the last layer's single query stays on the f32-input kernel
     wide = wide_head(hd)
-    if wide and fp8:
-        raise NotImplementedError(f"the e4m3 aggregator needs head_dim 32 or 64 (got {hd})")
     wsw = torch.empty((int(_lib.load().paths_attention_wide_workspace(T, hd)),), **f32) if wide else None
     h3 = (not fp8) and GENERIC_SPLIT and GEMM_MODE == "h3" and L > 1 and not wide
     wsh = torch.empty((int(_lib.load().paths_attention_h3_any_workspace(B, T, H, hd)),), device=dev, dtype=torch.uint8) if h3 else None

@@ -1309,7 +1309,9 @@ def test_gemm_fp8_matches_float64_on_the_same_quantised_operands(dev, M, N, K, a
         assert abs(float(amax.view(torch.float32)) - float(o.abs().max())) < 1e-4 * float(o.abs().max())
 
 
-@pytest.mark.parametrize("over", [{}, {"trans_heads": 2}, {"trans_dim": 256, "trans_heads": 4}], ids=["td128_hd32", "td128_hd64", "td256_hd64"])
+@pytest.mark.parametrize("over", [{}, {"trans_heads": 2}, {"trans_dim": 256, "trans_heads": 4}, {"trans_dim": 256, "trans_heads": 2},
+                                  {"trans_dim": 1536, "trans_heads": 4}],
+                         ids=["td128_hd32", "td128_hd64", "td256_hd64", "td256_hd128_wide", "td1536_hd384_wide"])
 def test_fp8_aggregator_variant_error_is_measured(dev, monkeypatch, over):
     """ops.AGG_FP8 (BASELINE configs[4]: "fp8 (e4m3, per-tensor scale) on K3-K5"): the aggregator's products over all tokens with e4m3
     operands.  NOT a parity test - it pins the error band (finite, logits within a coarse band of the fp32-accurate path and far
@@ -1334,7 +1336,7 @@ def test_fp8_aggregator_variant_error_is_measured(dev, monkeypatch, over):
         err = float((out["logits"] - ref["logits"]).abs().max())
         assert torch.isfinite(out["logits"]).all() and 1e-4 < err < 0.3, err
         assert torch.equal(out["importance"], ref["importance"]) and torch.equal(out["ctx_patch"], ref["ctx_patch"])
-    model.procs[info["depth"]].config.trans_heads = 8 if not over.get("trans_dim") else 16       # head_dim 16: no e4m3 attention
+    model.procs[info["depth"]].config.trans_heads = {128: 8, 256: 16, 1536: 96}[over.get("trans_dim", 128)]      # head_dim 16: no e4m3 attention
     with pytest.raises(NotImplementedError), torch.no_grad():
         model(info["depth"], pb)
 
