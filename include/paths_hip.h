@@ -153,7 +153,9 @@ int64_t paths_importance_proj_x6_workspace(int M);
  * row is read) - a 64-row block of the GEMM result is then one 64-token tile of the attention's operand images.  Consumers:
  * paths_attention_h3_img, paths_token_layer_ws (position-agnostic) and paths_token0_tail_ws with special_last = 1.
  * phases: bit 1 = the split-K GEMM of (y | y_rows) + y_add into splitk_ws (paths_importance_proj_x6_workspace(B * N) bytes); bit 2 =
- * importance-only finish (alpha -> importance [B, N]); bit 4 = tokens [B, N + 1, 128] + importance (or, alpha_from_importance != 0,
+ * importance-only finish (alpha -> importance [B, N]); bit 8 (instead of 2) = that finish AND the top-K of every slide in ONE launch
+ * (keep_idx / keep_count / kept_rows as paths_topk_rows writes them; a workgroup publishes its 64 alphas, waits for the slide's other
+ * workgroups - all part of the launch - and ranks its elements); bit 4 = tokens [B, N + 1, 128] + importance (or, alpha_from_importance != 0,
  * importance READ back) + q | k | v operand images of paths_attention_h3_img (qkv_images: paths_attention_x6_workspace(B, N + 1, 4, 32,
  * 2) bytes; w_qkv: paths_tlayer_pack_ws part 1 image with scale s_wqkv, qscale = log2(e) / sqrt(32)).  Bits 2 and 4 are stop-event
  * capable launches and may be issued by separate calls on different streams behind bit 1.  pe_table (paths_pe_table) is required;
@@ -163,7 +165,10 @@ int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, 
                             const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
                             int patch_size, int pe_mode, int imp_mul, float* importance, float* tokens, int D, int skip_padding,
                             float w_scale, float a_scale, float* splitk_ws, const void* w_qkv, const float* bqkv, float s_wqkv,
-                            float qscale, void* qkv_images, int phases, int alpha_from_importance, paths_stream_t stream);
+                            float qscale, void* qkv_images, int phases, int alpha_from_importance,
+                            /* phase 8 (importance finish + top-K in one launch, instead of phase 2): the outputs of paths_topk_rows */
+                            int keep, int* keep_idx, int64_t ldk, int* keep_count, const float* row_base, int64_t row_ld, int64_t* kept_rows,
+                            const float* zero_row, int* counters /* 2 B int32, zero on entry, left zero */, int* status, paths_stream_t stream);
 /* out (+)= maskop(act(a W[:, k0:k0+K]^T + b)) + residual, W = pack of an [Npad, Kpacked] weight; Npad % 128 == 0
  * (256-column tiles when Npad % 256 == 0, else 128-column tiles) */
 int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked, int k0, const float* b, float* out, int64_t ldo,

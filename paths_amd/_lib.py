@@ -32,7 +32,8 @@ SIGNATURES = {
     "paths_importance_proj_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp],
     "paths_importance_qkv_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _f32, _f32, _vp, _i32, _i32, _vp],
+                                _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _f32, _f32, _vp, _i32, _i32,
+                                _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "paths_gemm_nt_x6": [_vp, _i64, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _i32,
                          _i32, _f32, _f32, _vp],
     "paths_gemm_add_nt_x6": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _f32, _vp],

@@ -33,6 +33,18 @@ struct FinQkvParams {
   int xcd_order;                               // finish workgroups in the XCD order of the GEMM that wrote the slabs (tlayer_ws.hip: fin_tile_of_workgroup)
 };
 
+// top-K operands of the fused importance + top-K finish (phase 8; paths_topk_rows' outputs)
+struct FinTopkParams {
+  int keep;                        // < 0: keep all, original order
+  int* keep_idx; int64_t ldk;      // [B, ldk] kept indices by (score descending, index ascending)
+  int* keep_count;                 // [B]
+  const float* row_base; int64_t row_ld;   // optional: kept_rows[b, i] = address of row_base[b, keep_idx[b, i], :] (rows of N per slide)
+  int64_t* kept_rows; const float* zero_row;
+  int* counters;                   // [2 B] int32: arrival / departure counts per slide, zero on entry, left zero
+  int* status;                     // optional: bit 4 set if the bounded arrival wait gave up
+};
+
 // defined in tlayer_ws.hip; launches on `stream` (stop-event capable: PATHS_LAUNCH_STOP)
 int paths_launch_finish_qkv(const FinQkvParams& p, hipStream_t stream);
 int paths_launch_finish_importance(const FinQkvParams& p, hipStream_t stream);
+int paths_launch_finish_importance_topk(const FinQkvParams& p, const FinTopkParams& k, hipStream_t stream);

@@ -818,6 +818,10 @@ int paths_importance_proj_x6(const float* y, int64_t ldy, const int64_t* y_rows,
 // paths_token0_tail_ws with special_last = 1.  N % 64 == 0.
 //   phases bit 1: the split-K GEMM over (y | y_rows) + y_add into splitk_ws (paths_importance_proj_x6_workspace(B * N) bytes);
 //          bit 2: the importance-only finish (alpha -> importance [B, N]);
+//          bit 8: (instead of bit 2) the importance finish AND the top-K of every slide in one launch: keep_idx [B, ldk] (score descending,
+//                 index ascending; keep < 0: all, original order), keep_count [B], optionally kept_rows [B, ldk] = addresses of
+//                 row_base[b, keep_idx[b, i], :] (row stride row_ld floats, N rows per slide; zero_row beyond the count) - the outputs of
+//                 paths_topk_rows; counters: 2 B int32 words, zero on entry, left zero; status (optional): bit 4 on a timed-out arrival wait;
 //          bit 4: the tokens + in_proj finish: importance (computed, or read back when alpha_from_importance), tokens [B, N + 1, 128]
 //                 and the q | k | v operand images of paths_attention_h3_img in qkv_images (paths_attention_x6_workspace(B, N + 1, 4, 32, 2)).
 // Bits 2 and 4 are stop-event capable launches; they may be issued by separate calls on different streams (the caller orders them
@@ -827,12 +831,14 @@ int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, 
                             const float* pe_table, int pe_rows, const int64_t* locs, const int64_t* num_ims, int B, int N,
                             int patch_size, int pe_mode, int imp_mul, float* importance, float* tokens, int D, int skip_padding,
                             float w_scale, float a_scale, float* splitk_ws, const void* w_qkv, const float* bqkv, float s_wqkv,
-                            float qscale, void* qkv_images, int phases, int alpha_from_importance, hipStream_t stream) {
+                            float qscale, void* qkv_images, int phases, int alpha_from_importance,
+                            int keep, int* keep_idx, int64_t ldk, int* keep_count, const float* row_base, int64_t row_ld, int64_t* kept_rows,
+                            const float* zero_row, int* counters, int* status, hipStream_t stream) {
   PATHS_REQUIRE(B > 0 && N > 0 && N % 64 == 0 && D % 64 == 0 && D >= 256, "importance_qkv_x6: bad shape B=%d N=%d (a multiple of 64) D=%d", B, N, D);
   PATHS_REQUIRE(pe_mode == 1 || pe_mode == 2, "importance_qkv_x6: pe_mode must be 1 (1d) or 2 (2d)");
   PATHS_REQUIRE(pe_table != nullptr && pe_rows > 0 && (pe_mode == 1 || locs != nullptr), "importance_qkv_x6: needs the positional-encoding table (and locs in 2d mode)");
   PATHS_REQUIRE(num_ims != nullptr && splitk_ws != nullptr && (uintptr_t)splitk_ws % 16 == 0, "importance_qkv_x6: num_ims and a 16-byte aligned workspace are required");
-  PATHS_REQUIRE(phases > 0 && (phases & ~7) == 0, "importance_qkv_x6: phases is a mask of 1 (GEMM), 2 (importance finish), 4 (tokens + in_proj finish)");
+  PATHS_REQUIRE(phases > 0 && (phases & ~15) == 0 && (phases & 10) != 10, "importance_qkv_x6: phases is a mask of 1 (GEMM), 2 (importance finish) or 8 (importance + top-K finish), 4 (tokens + in_proj finish)");
   PATHS_REQUIRE(pow2(w_scale) && pow2(a_scale), "importance_qkv_x6: scales must be powers of two");
   const int64_t M64 = (int64_t)B * N;
   PATHS_REQUIRE(M64 < (1ll << 24), "importance_qkv_x6: B * N must stay below 2^24 rows");
@@ -849,13 +855,20 @@ int paths_importance_qkv_x6(const float* y, int64_t ldy, const int64_t* y_rows, 
                           : launch_x6_np<2, 2, 4, 2, true, false>(g, 256, raw, stream, "importance_qkv_x6(split-k)");
     if (rc != PATHS_OK) return rc;
   }
-  if (phases & 6) {
+  if (phases & 14) {
     PATHS_REQUIRE(b1 && w2 && b2 && importance, "importance_qkv_x6: b1, w2, b2 (device scalar) and importance are required");
     FinQkvParams f{splitk_ws, zstride, 2, b1, w2, b2, bp, special, pe_table, pe_rows, locs, num_ims, N, T, Tp, B, patch_size, pe_mode, imp_mul,
                    skip_padding, 1.0f / (w_scale * a_scale), alpha_from_importance, importance, tokens, w_qkv, bqkv, 1.0f / s_wqkv, qscale, qkv_images,
                    (B % 8 == 0 && (M / 128) % 8 == 0 && M % 128 == 0 && FIN_XCD_ORDER) ? 1 : 0};
     if (phases & 2) {
       const int rc = paths_launch_finish_importance(f, stream);
+      if (rc != PATHS_OK) return rc;
+    }
+    if (phases & 8) {
+      PATHS_REQUIRE(keep_idx && keep_count && counters && ldk > 0 && ldk <= N && N <= 8192 && (kept_rows == nullptr || (row_base && zero_row)),
+                    "importance_qkv_x6: the importance + top-K finish needs keep_idx [B, ldk <= N], keep_count, counters (2 B zeroed int32), N <= 8192");
+      FinTopkParams tk{keep, keep_idx, ldk, keep_count, row_base, row_ld, kept_rows, zero_row, counters, status};
+      const int rc = paths_launch_finish_importance_topk(f, tk, stream);
       if (rc != PATHS_OK) return rc;
     }
     if (phases & 4) {

@@ -761,35 +761,36 @@ int launch_ws(const WsParams& p, hipStream_t stream) {
   return PATHS_OK;
 }
 
-// The importance half of the finish alone (phase 2 of paths_importance_qkv_x6): alpha of every token slot of a 64-slot tile from the
-// hidden-unit columns of the raw GEMM result; what the top-K waits for when the tokens / in_proj finish runs on another stream.
-__global__ void __launch_bounds__(256)
-finish_importance_kernel(FinQkvParams f) {
-  __shared__ float sAlpha[2 * TOK];
-  int b = blockIdx.y, t0 = blockIdx.x * TOK;
-  fin_tile_of_workgroup(f, b, t0);
-  const int tid = threadIdx.x;
+// Partial importance logits of a 64-slot tile -> sAlpha [2][TOK] (the two column halves' sums; the caller adds them after a barrier):
+// the hidden-unit columns of the raw GEMM result, the same summation tree as fin_tokens / EpiImpProj (bit-identical alpha whichever
+// kernel computes it).  All 256 threads.
+__device__ __forceinline__ void fin_alpha_partials(const FinQkvParams& f, int b, int t0, int tid, float* sAlpha) {
+  constexpr int NZ = 2;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
-  const int nim = (int)f.num_ims[b];
-  if (t0 >= f.N || (f.skip_padding && t0 >= nim)) return;
   float part[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[r] = 0.f;
   const int64_t trow = (((int64_t)b * f.N + t0) >> 5) + wm;
+  f32x4 v[2][4][NZ];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j) * 1024) + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int z = 0; z < NZ; ++z) v[j][q][z] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
     const int u = 64 * wn + 32 * j + (lane & 31);
     const float bb = f.b1[u], w = f.w2[u];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 v = t[64 * q];
-      for (int z = 1; z < f.nz; ++z) v += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
+      const f32x4 sum = v[j][q][0] + v[j][q][1];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) part[4 * q + e] += fmaxf(fmaf(v[e], f.acc_scale, bb), 0.f) * w;
+      for (int e = 0; e < 4; ++e) part[4 * q + e] += fmaxf(fmaf(sum[e], f.acc_scale, bb), 0.f) * w;
     }
   }
-  // the same summation tree as fin_tokens / EpiImpProj (bit-identical alpha whichever kernel computes it)
   float p8[8], p4[4], p2[2], p1;
   {
     const bool up = (lane & 16) != 0;
@@ -813,10 +814,120 @@ finish_importance_kernel(FinQkvParams f) {
   }
   p1 += __shfl_xor(p1, 1);
   if ((lane & 1) == 0) sAlpha[wn * TOK + 32 * wm + c32_row((lane >> 1) & 15, lane)] = p1;
+}
+
+// The importance half of the finish alone (phase 2 of paths_importance_qkv_x6): alpha of every token slot of a 64-slot tile from the
+// hidden-unit columns of the raw GEMM result; what the top-K waits for when the tokens / in_proj finish runs on another stream.
+__global__ void __launch_bounds__(256)
+finish_importance_kernel(FinQkvParams f) {
+  __shared__ float sAlpha[2 * TOK];
+  int b = blockIdx.y, t0 = blockIdx.x * TOK;
+  fin_tile_of_workgroup(f, b, t0);
+  const int tid = threadIdx.x;
+  const int nim = (int)f.num_ims[b];
+  if (t0 >= f.N || (f.skip_padding && t0 >= nim)) return;
+  fin_alpha_partials(f, b, t0, tid, sAlpha);
   __syncthreads();
   if (tid < TOK) {
     const int sl = t0 + tid;
     if (sl < f.N) f.importance[(int64_t)b * f.N + sl] = sl < nim ? sigmoid_acc((sAlpha[tid] + sAlpha[TOK + tid]) + *f.b2) : 0.f;
+  }
+}
+
+// ---- importance finish AND top-K in one launch (phase 8 of paths_importance_qkv_x6; reference model/paths.py:95 +
+// data_utils/slide.py:294-301).  The two were tiny latency-bound kernels back to back on the recursion's critical path (8 + 12 us
+// and two launch boundaries for ~0.3 us of arithmetic).  A workgroup owns 64 slots of one slide in both halves: it finishes their
+// alpha, publishes them (write-through stores, drained, then ONE release add on the slide's arrival counter), waits until the
+// slide's ceil(num_ims / 64) workgroups have arrived (bounded spin; the waited-for workgroups are part of this launch and small
+// enough - 20 KB of LDS - to be resident together even beside other kernels), then ranks its 64 elements against all scores of the
+// slide exactly as topk_rank_kernel (csrc/select.hip) does: 64-bit keys (score descending, index ascending), rank = number of
+// smaller keys, kept iff rank < count, output position = rank.  The last workgroup of a slide to leave zeroes its two counters.
+__device__ __forceinline__ unsigned long long fin_topk_key(float score, int idx) {
+  uint32_t u = __float_as_uint(score);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // monotone float -> uint
+  return ((unsigned long long)(~u) << 32) | (uint32_t)idx;
+}
+
+__global__ void __launch_bounds__(256)
+finish_importance_topk_kernel(FinQkvParams f, FinTopkParams k) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+  float* const sAlpha = reinterpret_cast<float*>(smem_tk);                                   // [2][TOK]
+  int* const part = reinterpret_cast<int*>(smem_tk + 2 * TOK * sizeof(float));              // [4][64] partial counts
+  int* const sFlag = part + 256;
+  unsigned long long* const keys = reinterpret_cast<unsigned long long*>(smem_tk + 2 * TOK * sizeof(float) + 260 * sizeof(int));   // (1552 bytes in: 16-byte aligned)
+  const int b = blockIdx.y, t0 = blockIdx.x * TOK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = (int)f.num_ims[b];
+  const int count = k.keep < 0 ? n : min(n, k.keep);
+  const int i = t0 + lane;                              // this lane's element in the ranking
+  if (blockIdx.x == 0 && tid == 0) k.keep_count[b] = count;
+  auto row_addr = [&](int idx) { return (int64_t)reinterpret_cast<uintptr_t>(k.row_base + ((int64_t)b * f.N + idx) * k.row_ld); };
+  // entries [count, ldk) of the row table point at the zero row (every workgroup covers its own 64 positions)
+  if (k.kept_rows && wave == 0 && i >= count && i < k.ldk) k.kept_rows[(int64_t)b * k.ldk + i] = (int64_t)reinterpret_cast<uintptr_t>(k.zero_row);
+  if (t0 >= f.N || t0 >= n) return;                     // no valid slot here (workgroup-uniform; the importance buffer is zero there)
+  // ---- alpha of this tile
+  fin_alpha_partials(f, b, t0, tid, sAlpha);
+  __syncthreads();
+  if (tid < TOK) {
+    const int sl = t0 + tid;
+    if (sl < f.N) __hip_atomic_store(f.importance + (int64_t)b * f.N + sl, sl < n ? sigmoid_acc((sAlpha[tid] + sAlpha[TOK + tid]) + *f.b2) : 0.f,
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (k.keep < 0) {                                     // keep all, original order (slide.py:294 not taken): nothing to wait for
+    if (wave == 0 && i < n) {
+      k.keep_idx[(int64_t)b * k.ldk + i] = i;
+      if (k.kept_rows) k.kept_rows[(int64_t)b * k.ldk + i] = row_addr(i);
+    }
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- arrival of the slide's workgroups
+  const int need = (n + TOK - 1) / TOK;
+  int* const cnt = k.counters + 2 * b;
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 22)) {                        // give up loudly rather than hang: this slide's selection is garbage
+        if (k.status) atomicOr(k.status, 4);
+        ok = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *sFlag = ok;
+  }
+  __syncthreads();
+  // ---- all n scores of the slide -> keys in LDS (agent-scope loads: other workgroups of this launch wrote them)
+  const int np = (n + 7) & ~7;
+  const float* s = f.importance + (int64_t)b * f.N;
+  for (int j = tid; j < np; j += 256) keys[j] = j < n ? fin_topk_key(__hip_atomic_load(s + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j) : ~0ull;
+  __syncthreads();
+  const unsigned long long mine = i < n ? keys[i] : 0ull;
+  const int pairs = np >> 1, q0 = (pairs * wave) >> 2, q1 = (pairs * (wave + 1)) >> 2;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* kp = reinterpret_cast<const u64x2*>(keys);
+  int c = 0, q = q0;
+  for (; q + 4 <= q1; q += 4) {
+    const u64x2 a = kp[q], cc = kp[q + 1], d = kp[q + 2], e = kp[q + 3];
+    c += (a[0] < mine) + (a[1] < mine) + (cc[0] < mine) + (cc[1] < mine) + (d[0] < mine) + (d[1] < mine) + (e[0] < mine) + (e[1] < mine);
+  }
+  for (; q < q1; ++q) { const u64x2 a = kp[q]; c += (a[0] < mine) + (a[1] < mine); }
+  part[wave * 64 + lane] = c;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    const int rank = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    if (rank < count) {
+      k.keep_idx[(int64_t)b * k.ldk + rank] = i;
+      if (k.kept_rows) k.kept_rows[(int64_t)b * k.ldk + rank] = row_addr(i);
+    }
+  }
+  // ---- the last workgroup of the slide to get here leaves the counters zero for the next launch
+  if (tid == 0 && __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == need - 1) {
+    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -832,6 +943,15 @@ extern "C" void paths_ws_stamp_buffer(unsigned long long* p) { g_ws_stamps = p; 
 int paths_launch_finish_importance(const FinQkvParams& f, hipStream_t stream) {
   PATHS_LAUNCH_STOP(finish_importance_kernel, dim3(f.Tp / TOK, f.B), dim3(256), 0, stream, f);
   PATHS_LAUNCH_CHECK("importance_qkv_x6(importance finish)");
+  return PATHS_OK;
+}
+
+int paths_launch_finish_importance_topk(const FinQkvParams& f, const FinTopkParams& k, hipStream_t stream) {
+  const size_t lds = 2 * TOK * sizeof(float) + 260 * sizeof(int) + (size_t)(((f.N + 7) & ~7) + 2) * 8;
+  PATHS_LDS_OPT_IN(finish_importance_topk_kernel, 2 * TOK * sizeof(float) + 260 * sizeof(int) + (8192 + 2) * 8, "importance_qkv_x6(importance + top-K finish)");
+  // the grid covers every slot of the slide AND every position of the kept-row table (ldk <= N)
+  PATHS_LAUNCH_STOP(finish_importance_topk_kernel, dim3((f.N + TOK - 1) / TOK, f.B), dim3(256), lds, stream, f, k);
+  PATHS_LAUNCH_CHECK("importance_qkv_x6(importance + top-K finish)");
   return PATHS_OK;
 }
 

@@ -31,6 +31,11 @@ SPLITK_IMPORTANCE = os.environ.get("PATHS_SPLITK_IMPORTANCE", "1") != "0"
 # fused finish on the selection stream (importance + tokens + q | k | v operand images), 2 (default) = importance-only finish on the selection
 # stream, tokens + images on the aggregator stream, 0 = the round-4 form (finish, then paths_token_layer_ws as the aggregator's first launch)
 FUSE_QKV = int(os.environ.get("PATHS_FUSE_QKV", "2"))
+# ... and (FUSE_QKV = 2, device recursion) the top-K of the level inside that importance finish: one launch instead of two tiny ones on the
+# recursion's critical path (paths_importance_qkv_x6 phase 8).  Built, bit-identical to the separate launch - and SLOWER: 23.5 us against
+# 7.0 + 9.7 (tools/fin_time.py): a device-side arrival barrier (write-through stores, drain, release add, polling, acquire, L2-bypassing
+# re-reads of 2,048 scores per workgroup) costs more than the kernel boundary it replaces.  Off by default; kept for A/B runs.
+FUSE_TOPK = os.environ.get("PATHS_FUSE_TOPK", "0") != "0"
 KERNEL_TIMER = None   # optional hook: fn(name, launch_callable, meta) — set by bench.py only
 TIMER_ALL = False     # with KERNEL_TIMER: False = bracket only the dominant kernel and the aggregator span (the timed region of
                       # bench.py), True = every kernel group (bench.py's serialised breakdown pass)
@@ -224,6 +229,21 @@ def token0_ws_image(layer: Dict[str, object], qscale: float) -> torch.Tensor:
 
 _T0_COUNTERS: Dict[tuple, torch.Tensor] = {}
 _T0_RETIRED: List[torch.Tensor] = []
+
+
+_TOPK_COUNTERS: Dict[tuple, torch.Tensor] = {}
+
+
+def topk_counters(dev, B: int) -> torch.Tensor:
+    """Arrival / departure counters of the fused importance + top-K finish (paths_importance_qkv_x6 phase 8): 2 int32 words per slide
+    that are zero between launches; one buffer per (device, stream), never handed back (recorded launch tapes hold its address)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _lib.stream())
+    t = _TOPK_COUNTERS.get(key)
+    if t is None or t.numel() < 2 * B:
+        if t is not None:
+            _T0_RETIRED.append(t)
+        t = _TOPK_COUNTERS[key] = torch.zeros((max(512, 2 * B),), device=dev, dtype=torch.int32)
+    return t
 
 
 def token0_counters(dev, B: int) -> torch.Tensor:
@@ -814,12 +834,18 @@ def level_forward(mc, lstm_pack, lvl_pack, fts: torch.Tensor, locs: torch.Tensor
 
 def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, skip_padding: bool,
                       parent=None, max_pos: int = 0, x_rows=None, feat_dim: Optional[int] = None,
-                      importance_out: Optional[torch.Tensor] = None, last_level: bool = False) -> Dict[str, torch.Tensor]:
+                      importance_out: Optional[torch.Tensor] = None, last_level: bool = False,
+                      topk: Optional[Dict[str, object]] = None) -> Dict[str, torch.Tensor]:
     """The part of a level that decides the NEXT level: LSTM state update, importance, token projection
     (reference model/paths.py:71-124).  Returns ctx_patch (new state), importance, tokens, num_ims.
 
     ``last_level`` (device recursion): no top-K follows, so nothing waits for the importance alone - the fused finish then runs as ONE
     launch (FUSE_QKV mode 1) instead of an importance-only finish plus the tokens / images finish.
+
+    ``topk`` (device recursion, optional) = {"keep": int, "zero_row": tensor, "status": tensor}: the caller will select the ``keep`` most
+    important patches of every slide next.  When the fused finish runs in mode 2 the selection happens INSIDE the importance finish
+    (FUSE_TOPK) and the result comes back as "keep_idx" [B, cap] int32, "keep_count" [B] int32 and "kept_rows" [B, cap] int64 (addresses
+    of the kept patches' h rows in ctx_patch) - exactly what paths_topk_rows would write; absent keys = the caller runs the top-K itself.
 
     ``max_pos`` (optional): an upper bound (exclusive) of ``locs // patch_size`` known to the caller (the grid size of the level);
     positional-encoding values are then read from a cached table instead of evaluated per token element.
@@ -894,12 +920,22 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
                         mc.patch_size, pe_mode, imp_mul, p(imp_out), p(tokens), D, 1 if skip_padding else 0, wip_s, a_scale(), p(ws),
                         p(iq), p(lay0["bqkv"]), sq[0], LOG2E / math.sqrt(hd), p(qkv_img))
                 # (token order of this form: patch i = token i, the special token at index num_ims[b]; the tail is told: special_last)
+                no_topk = (0, None, 0, None, None, 0, None, None, None, None)
                 if FUSE_QKV == 2 and not last_level:
-                    _lib.call("paths_importance_qkv_x6", *args, 3, 0, st)
+                    if topk is not None and FUSE_TOPK and N <= 8192:
+                        keep = int(topk["keep"])
+                        cap = N if keep < 0 else min(N, keep)
+                        fused["keep_idx"] = torch.empty((B, cap), device=dev, dtype=torch.int32)
+                        fused["keep_count"] = torch.empty((B,), device=dev, dtype=torch.int32)
+                        fused["kept_rows"] = torch.empty((B, cap), device=dev, dtype=torch.int64)
+                        _lib.call("paths_importance_qkv_x6", *args, 9, 0, keep, p(fused["keep_idx"]), cap, p(fused["keep_count"]), p(state_out), Dp,
+                                  p(fused["kept_rows"]), p(topk["zero_row"]), p(topk_counters(dev, B)), p(topk.get("status")), st)
+                    else:
+                        _lib.call("paths_importance_qkv_x6", *args, 3, 0, *no_topk, st)
                     # (the aggregator stream finishes the tokens: ws / qkv_img travel with the closure)
-                    fused["finish"] = lambda: _lib.call("paths_importance_qkv_x6", *args, 4, 1, _lib.stream())
+                    fused["finish"] = lambda: _lib.call("paths_importance_qkv_x6", *args, 4, 1, *no_topk, _lib.stream())
                 else:
-                    _lib.call("paths_importance_qkv_x6", *args, 5, 0, st)
+                    _lib.call("paths_importance_qkv_x6", *args, 5, 0, *no_topk, st)
                 fused["qkv_img"], fused["ws"] = qkv_img, ws
                 return
             # M/128 blocks fill half the chip at K = 2048 x 8 slides: two k halves on twice the blocks + an epilogue launch
@@ -987,6 +1023,9 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
         importance_proj(state_out, 0, scratch_imp)               # pass 2: tokens = proj_in(Z) + PE
 
     out = {"ctx_patch": state_out, "importance": importance, "tokens": tokens, "num_ims": num_ims}
+    for key in ("keep_idx", "keep_count", "kept_rows"):
+        if key in fused:
+            out[key] = fused[key]
     if "qkv_img" in fused:
         # the attention's operand images are ready (or, FUSE_QKV = 2, one call away: "qkv_finish" runs on the aggregator's stream)
         out["qkv_img"], out["qkv_finish"], out["_qkv_ws"] = fused["qkv_img"], fused.get("finish"), fused["ws"]

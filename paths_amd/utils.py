@@ -444,11 +444,19 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
             fork_pending = False
         imp_buf = imp_all[imp_off[i]:imp_off[i] + B * N].view(B, N) if N == sizes[i] else None
         # (the aggregator's fork travels as the stop event of the chain's last kernel where that kernel can carry one: _lib.fork_behind)
+        # Round 5: where the importance finish also selects the top-K (ops.FUSE_TOPK) the expansion stream's fork rides on the same kernel.
+        last = i == num_levels - 1
+        keep = None if last else int(keep_patches[i])
+        forked = overlap and par_stream is not None and share_parent and not last
+        want_topk = forked and rows_in_place and ops.FUSE_TOPK and ops.FUSE_QKV == 2
+        dsts = ([side_stream] if overlap else []) + ([par_stream] if want_topk else [])
         with _Range(f"level {i}: selection chain (LSTM gates, importance, projection)"), \
-                (_lib.fork_behind([side_stream], main_stream) if overlap else contextlib.nullcontext()):
+                (_lib.fork_behind(dsts, main_stream) if overlap else contextlib.nullcontext()):
             sel = ops.selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, True, parent=parent,
                                         max_pos=batch.max_dim[i], x_rows=x_rows, feat_dim=D, importance_out=imp_buf,
-                                        last_level=i == num_levels - 1)
+                                        last_level=last,
+                                        topk={"keep": keep, "zero_row": zero_row, "status": status} if want_topk else None)
+        fused_topk = "keep_idx" in sel           # (else: the top-K launch below carries the expansion stream's fork, as before)
         def aggregate():
             ctx_prev = ctx_hist[-1] if (ctx_hist and mc.slide_ctx_mode == "residual") else None
             ctx_all = torch.stack(ctx_hist, dim=1) if (ctx_hist and mc.slide_ctx_mode == "concat") else None
@@ -472,21 +480,26 @@ def _recurse_body(model, slides, keep_patches: Sequence[int], num_levels: int,
             break
         keep = int(keep_patches[i])
         cap_keep = N if keep < 0 else min(N, keep)
-        keep_idx = torch.empty((B, cap_keep), **i32)
-        keep_count = torch.empty((B,), **i32)
-        kept_rows = None
         # After the top-K the chain forks: the kept parents' h-partials (gather + GEMM, the longer branch) stay on this stream,
         # the child expansion and the row gathers (tiny latency-bound kernels) run beside them on a third stream and are joined
         # before the next level's gate GEMMs.  (The fork travels as the top-K kernel's stop event: _lib.fork_behind.)
         forked = overlap and par_stream is not None and share_parent
-        with (_lib.fork_behind([par_stream], main_stream) if forked else contextlib.nullcontext()):
-            if rows_in_place:
-                # ... with the addresses of the kept parents' h rows (row b, i -> ctx_patch[b, keep_idx[b, i], :D]) for the parent GEMM
-                kept_rows = torch.empty((B, cap_keep), **i64)
-                ops.timed("topk", lambda: _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep,
-                                                    p(keep_count), p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st))
-            else:
-                _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
+        if fused_topk:
+            # the importance finish of this level already selected (ops.FUSE_TOPK); the expansion stream waits on that kernel's stop event
+            keep_idx, keep_count, kept_rows = sel["keep_idx"], sel["keep_count"], sel["kept_rows"]
+            keepalive.append((keep_idx, keep_count, kept_rows))
+        else:
+            keep_idx = torch.empty((B, cap_keep), **i32)
+            keep_count = torch.empty((B,), **i32)
+            kept_rows = None
+            with (_lib.fork_behind([par_stream], main_stream) if forked else contextlib.nullcontext()):
+                if rows_in_place:
+                    # ... with the addresses of the kept parents' h rows (row b, i -> ctx_patch[b, keep_idx[b, i], :D]) for the parent GEMM
+                    kept_rows = torch.empty((B, cap_keep), **i64)
+                    ops.timed("topk", lambda: _lib.call("paths_topk_rows", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep,
+                                                        p(keep_count), p(out["ctx_patch"]), Dp, N, p(kept_rows), p(zero_row), st))
+                else:
+                    _lib.call("paths_topk", p(out["importance"]), N, p(num_ims), B, N, keep, p(keep_idx), cap_keep, p(keep_count), st)
         Nn = 4 * cap_keep
         hp = ops.parent_partials(lstm_pack, out["ctx_patch"], keep_idx, keep_count, kept_rows) if share_parent else None
         st2 = par_stream.cuda_stream if forked else st

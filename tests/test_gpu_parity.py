@@ -1170,13 +1170,19 @@ def test_tape_owns_its_buffers(dev):
     with torch.no_grad():
         held = putils.recurse(model, other, cfg.top_k_patches, 5, trace=trace)
     torch.cuda.synchronize()
-    tensors = [v for rec in trace for v in rec.values() if torch.is_tensor(v)] + [v for v in held.values() if torch.is_tensor(v)]
+    named = [(f"level {li}: {k}", v) for li, rec in enumerate(trace) for k, v in rec.items() if torch.is_tensor(v)] + \
+            [(f"out: {k}", v) for k, v in held.items() if torch.is_tensor(v)]
+    tensors = [v for _, v in named]
     copies = [v.clone() for v in tensors]
     torch.cuda.synchronize()
     for _ in range(3):
         out = t.replay()
     torch.cuda.synchronize()
-    assert len(tensors) >= 40 and all(torch.equal(a, b) for a, b in zip(tensors, copies))
+    # (bit patterns: rows of padding in ctx_patch are never written - uninitialised memory that may hold NaN, which no value comparison
+    # calls equal to itself; seen when an earlier test of the session had left such patterns in the recycled block)
+    bits = lambda v: v.contiguous().view(torch.int32) if v.dtype == torch.float32 else v
+    changed = [(n, tuple(a.shape), int((bits(a) != bits(b_)).sum())) for (n, a), b_ in zip(named, copies) if not torch.equal(bits(a), bits(b_))]
+    assert len(tensors) >= 40 and not changed, changed
     assert torch.equal(out["logits"], ref["logits"]) and torch.equal(out["importance"], ref["importance"])
     assert not torch.equal(held["logits"], ref["logits"])
 
@@ -1568,11 +1574,15 @@ def test_fused_importance_qkv_finish_in_the_recursion(dev, monkeypatch):
     cfg, model, _ = build_model(dev, 3, top_k_patches=[64] * 4)
     slides = [DeviceSlide.synthetic(14, s, (16, 16), device=dev) for s in range(4)]
     res = {}
-    for mode in (0, 1, 2):
-        monkeypatch.setattr(ops, "FUSE_QKV", mode)
+    for mode in (0, 1, 2, 3):
+        # (3 = mode 2 WITHOUT the top-K inside the importance finish: paths_importance_qkv_x6 phase 2 + paths_topk_rows instead of phase 8)
+        monkeypatch.setattr(ops, "FUSE_QKV", min(mode, 2))
+        monkeypatch.setattr(ops, "FUSE_TOPK", mode != 3)
         tr = []
         with torch.no_grad():
-            out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=tr)
+            with H.spy_calls() as calls:
+                out = putils.recurse(model, slides, cfg.top_k_patches, 5, trace=tr)
+            assert ("paths_topk_rows" in calls) == (mode != 2), (mode, sorted(set(calls)))
             tape = putils.TapedRecursion(model, slides, cfg.top_k_patches, 5).record()
             rep = {k: v.clone() for k, v in tape.replay().items()}
             rep2 = {k: v.clone() for k, v in tape.replay().items()}
@@ -1580,7 +1590,7 @@ def test_fused_importance_qkv_finish_in_the_recursion(dev, monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(rep["logits"], out["logits"]) and torch.equal(rep2["logits"], out["logits"]), mode
         res[mode] = (out["logits"].clone(), [(lv["importance"].clone(), lv["logits"].clone(), lv.get("keep_idx")) for lv in tr])
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         assert float((res[mode][0] - res[0][0]).abs().max()) < 2e-6 and torch.equal(res[mode][0], res[1][0]), mode
         for l, ((ia, la, ka), (ib, lb, kb)) in enumerate(zip(res[mode][1], res[0][1])):
             # selection chain: bit-identical (the slide context it does NOT depend on differs in the last bits: special token last)

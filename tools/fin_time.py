@@ -30,6 +30,12 @@ imp = torch.zeros(B, N, device=dev)
 tokens = torch.empty(B, T, d, device=dev)
 ws = torch.empty(int(_lib.load().paths_importance_proj_x6_workspace(M)), device=dev, dtype=torch.uint8)
 qkv = torch.empty(int(_lib.load().paths_attention_x6_workspace(B, T, H, hd, 2)), device=dev, dtype=torch.uint8)
+KEEP = 512
+keep_idx = torch.empty(B, KEEP, device=dev, dtype=torch.int32)
+keep_count = torch.empty(B, device=dev, dtype=torch.int32)
+kept_rows = torch.empty(B, KEEP, device=dev, dtype=torch.int64)
+zero_row = torch.zeros(D, device=dev)
+counters = torch.zeros(2 * B, device=dev, dtype=torch.int32)
 p, st = _lib.ptr, _lib.stream()
 qs = math.log2(math.e) / math.sqrt(hd)
 lib = _lib.load()
@@ -42,7 +48,9 @@ if hasattr(lib, "paths_ws_stamp_buffer"):
 
 def fused(phases, afi=0):
     _lib.call("paths_importance_qkv_x6", p(x), D, None, p(h1), D + 256, p(wip), p(b1), p(w2), p(b2), p(bp), p(sp), p(pe_tab), 1024, p(locs),
-              p(num_ims), B, N, 256, 2, 1, p(imp), p(tokens), D, 1, wip_s, 16.0, p(ws), p(iq), p(bqkv), sq[0], qs, p(qkv), phases, afi, st)
+              p(num_ims), B, N, 256, 2, 1, p(imp), p(tokens), D, 1, wip_s, 16.0, p(ws), p(iq), p(bqkv), sq[0], qs, p(qkv), phases, afi,
+              *((KEEP, p(keep_idx), KEEP, p(keep_count), p(h1), D + 256, p(kept_rows), p(zero_row), p(counters), None) if phases & 8 else
+                (0, None, 0, None, None, 0, None, None, None, None)), st)
 
 
 def old_pair(which):
@@ -72,6 +80,23 @@ timeit("fused: tokens + in_proj finish (phase 4)", lambda: fused(4))
 timeit("fused: tokens + in_proj finish, alpha read (4)", lambda: fused(4, 1))
 timeit("fused: GEMM + fused finish (5)", lambda: fused(5))
 timeit("fused: GEMM + importance finish (3)", lambda: fused(3))
+timeit("fused: importance + top-K finish (8)", lambda: fused(8))
+timeit("fused: GEMM + importance + top-K finish (9)", lambda: fused(9))
+
+
+def old_topk():
+    _lib.call("paths_topk_rows", p(imp), N, p(num_ims), B, N, KEEP, p(keep_idx), KEEP, p(keep_count), p(h1), D + 256, N, p(kept_rows), p(zero_row), st)
+
+
+timeit("round 4: paths_topk_rows", old_topk)
+timeit("importance finish (2) + paths_topk_rows", lambda: (fused(2), old_topk()))
+# the fused selection against the separate one
+fused(2); old_topk(); torch.cuda.synchronize()
+ref = (keep_idx.clone(), keep_count.clone(), kept_rows.clone(), imp.clone())
+keep_idx.fill_(-7); keep_count.fill_(-7); kept_rows.fill_(-7); imp.zero_()
+fused(8); torch.cuda.synchronize()
+print("fused top-K == separate top-K:", bool(torch.equal(keep_idx, ref[0]) and torch.equal(keep_count, ref[1]) and torch.equal(kept_rows, ref[2]) and torch.equal(imp, ref[3])),
+      "counters left zero:", bool((counters == 0).all()))
 if stamps is not None:
     stamps.zero_(); fused(4); torch.cuda.synchronize()
     s = stamps.cpu()
