@@ -367,27 +367,35 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
 
 def k1024_probe(model, cfg, spg, rank, world, dev, dev_reduce, pdist, putils, steps: int):
     """BASELINE.json configs[1] ("5-level PATHS, K=1024 patches/level, d=1024, 1 x MI355X"): the headline's launch mode (recorded
-    tape) on this rank's own resident K = 1024 slides; whole-job slides/s."""
+    tape) on this rank's own resident K = 1024 slides; whole-job slides/s.  Measured at the headline's batch (``spg`` slides per step
+    and GPU) AND at twice that: at K = 1024 eight slides put 128 workgroups on a 256-CU chip in the gate GEMMs (half a round) -
+    sixteen fill it (the config names no batch size)."""
     from paths_amd.data_utils.slide import DeviceSlide, DeviceSlideBatch
     K1 = 1024
     keep = [K1 // 4] * (cfg.num_levels - 1)
-    batch = DeviceSlideBatch([DeviceSlide.synthetic(1234, 200000 + rank * spg + i, BASE_SHAPES[K1], device=dev) for i in range(spg)])
-    tape = putils.TapedRecursion(model, batch, keep, cfg.num_levels).record()
-    for _ in range(3):
-        tape.replay()
-    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = tape.replay()
-    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
-    el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
-    assert int(out["status"].item()) == 0
-    tape.close()
-    del tape, batch
-    torch.cuda.empty_cache()
-    return {"slides_per_s": round(spg * world * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
-            "workload": f"5-level recursion, K=1024 patches/level (level-0 grid 32x32, top_k 256), D=1024, {spg} resident slides per GPU, "
-                        "launch tape replay (BASELINE.json configs[1]); parity at this size: tests/test_gpu_parity.py::test_headline_recursion_vs_oracle[1024]"}
+
+    def run(nsl):
+        batch = DeviceSlideBatch([DeviceSlide.synthetic(1234, 200000 + rank * nsl + i, BASE_SHAPES[K1], device=dev) for i in range(nsl)])
+        tape = putils.TapedRecursion(model, batch, keep, cfg.num_levels).record()
+        for _ in range(3):
+            tape.replay()
+        torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = tape.replay()
+        torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+        el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
+        assert int(out["status"].item()) == 0
+        tape.close()
+        del tape, batch
+        torch.cuda.empty_cache()
+        return {"slides_per_s": round(nsl * world * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "slides_per_gpu": nsl}
+
+    small, big = run(spg), run(2 * spg)
+    return dict(big, steps=steps, at_headline_batch=small,
+                workload=f"5-level recursion, K=1024 patches/level (level-0 grid 32x32, top_k 256), D=1024, {2 * spg} resident slides per GPU "
+                         f"per step (at_headline_batch: {spg}), launch tape replay (BASELINE.json configs[1]); parity at this size: "
+                         "tests/test_gpu_parity.py::test_headline_recursion_vs_oracle[1024]")
 
 
 def self_launch(n: int) -> int:
@@ -981,7 +989,7 @@ def main():
     if K == 2048 and args.k1024_steps > 0:
         try:
             k1024 = k1024_probe(model, cfg, spg, rank, world, dev, dev_reduce, pdist, putils, args.k1024_steps)
-            log(f"k1024: {k1024['slides_per_s']} slides/s ({k1024['ms_per_step']} ms per step)")
+            log(f"k1024: {k1024['slides_per_s']} slides/s at {k1024['slides_per_gpu']} slides per step, {k1024['at_headline_batch']['slides_per_s']} at {spg}")
         except Exception as e:
             k1024 = {"error": f"{type(e).__name__}: {e}"[:400]}
             log(f"k1024 probe FAILED: {k1024['error']}")

@@ -561,7 +561,14 @@ struct EpiRaw {
       for (int j = 0; j < WTN; ++j) {
         f32x4* t = reinterpret_cast<f32x4*>(base + ((int64_t)((row0 >> 5) + i) * ntn + (col0 >> 5) + j) * 1024) + lane;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[64 * q] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+#ifdef PATHS_RAW_NT
+          __builtin_nontemporal_store(v, t + 64 * q);     // experiment: streaming stores leave no dirty lines for the kernel-end write-back
+#else
+          t[64 * q] = v;
+#endif
+        }
       }
   }
 };
