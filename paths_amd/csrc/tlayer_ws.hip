@@ -39,9 +39,10 @@ constexpr int TT = PATHS_WS_TT;    // 16-token tiles per workgroup (4: 64 tokens
 constexpr int TOK = 16 * TT;
 constexpr int NFF = 4;             // feed-forward hidden chunks of DM features (dim_feedforward = 4 DM, reference aggregator.py:29)
 #ifndef PATHS_WS_NPF
-#define PATHS_WS_NPF 4
+#define PATHS_WS_NPF 6
 #endif
-constexpr int NPF = PATHS_WS_NPF;  // weight prefetch ring: k32 steps in flight per wave
+constexpr int NPF = PATHS_WS_NPF;  // weight prefetch ring: k32 steps in flight per wave (6: inside a level the weights come from beyond the L2 - it is
+                                   // invalidated at every launch boundary; row chain 24.1 -> 22.9 us in the recursion, 4 = 8 in a hot loop)
 
 template <int DM> struct Geo {
   static_assert(DM % 64 == 0, "trans_dim must be a multiple of 64");
