@@ -362,11 +362,20 @@ int paths_attention_h3_img(void* o_img, const int64_t* num_ims, int B, int T, in
  * every workgroup pushes its partial through its head's Wv / Wo slices before the ticket and carries a slice of the feed-forward
  * after a flag hop, so that no CU pulls more than ~100 KB of weights.  partials: paths_token0_ws_partials(B, T) floats of scratch;
  * counters: 3 B int32 words, zero on entry, left zero; status (optional): bit 4 set if a bounded hand-off wait gave up.
- * Exact fp32 FMA chains. */
+ * Exact fp32 FMA chains.
+ * Widths: trans_dim d = 128 (both forms) and d = 192, the reference's dataclass default (config.py:30; distributed form only, 4 heads
+ * of 48: 768 threads per workgroup, x1 [B,T,192]) - the _d entry points take d, the ones without it are the d = 128 forms kept for
+ * existing callers.  paths_token0_ws_supported(B, T, d, H): 1 if paths_token0_tail_ws can run the shape (at 192: while the
+ * distributed launch fits the chip, B <= 24 on an MI355X, T > 128), else 0 - the caller then takes the generic launches. */
 int64_t paths_token0_ws_image_bytes(void);
+int64_t paths_token0_ws_image_bytes_d(int d);
 int64_t paths_token0_ws_partials(int B, int T);
+int64_t paths_token0_ws_partials_d(int B, int T, int d);
+int paths_token0_ws_supported(int B, int T, int d, int H);
 int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
                          void* out, paths_stream_t stream);
+int paths_token0_pack_ws_d(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
+                           int d, void* out, paths_stream_t stream);
 int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* img, const float* bv, const float* bo,
                          const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
                          const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "paths_token_layer_ws": [_vp] * 17 + [_f32, _f32, _f32, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _i32, _vp],
     "paths_token_layer_ws_rows": [_vp] * 16 + [_f32, _f32, _f32, _f32, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "paths_token0_pack_ws": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp],
+    "paths_token0_pack_ws_d": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp],
     "paths_token0_tail_ws": [_vp] * 16 + [_vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "paths_attention_any": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "paths_attention_any_train": [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _u64, _f32, _vp],
@@ -124,7 +125,7 @@ SIGNATURES = {
     "paths_tissue_mask_absmax": [_vp, _i64, _i32, _vp, _vp, _vp],
     "paths_synth_grid": [_vp, _i32, _i32, _i32, _u32, _i32, _u64, _vp],
 }
-_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_tlayer_ws_image_bytes": (C.c_int64, [_i32, _i32]), "paths_token0_ws_image_bytes": (C.c_int64, []), "paths_token0_ws_partials": (C.c_int64, [_i32, _i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_attention_fp8_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_bwd_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_token0_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_attention_h3_any_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, []), "paths_stop_event_pending": (_i32, []), "paths_clear_stop_event": (_i32, []), "paths_adamw_chunk": (_i32, []), "paths_attention_wide_workspace": (C.c_int64, [_i32, _i32]), "paths_event_create": (_vp, []), "paths_stream_create_masked": (_vp, [_vp, _i32])}
+_PLAIN = {"paths_gemm_tn_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_x6_packed_bytes": (C.c_int64, [_i32, _i32, _i32]), "paths_tlayer_h3_image_bytes": (C.c_int64, [_i32]), "paths_tlayer_ws_image_bytes": (C.c_int64, [_i32, _i32]), "paths_token0_ws_image_bytes": (C.c_int64, []), "paths_token0_ws_partials": (C.c_int64, [_i32, _i32]), "paths_token0_ws_image_bytes_d": (C.c_int64, [_i32]), "paths_token0_ws_partials_d": (C.c_int64, [_i32, _i32, _i32]), "paths_token0_ws_supported": (_i32, [_i32, _i32, _i32, _i32]), "paths_attention_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32, _i32]), "paths_attention_fp8_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_bwd_x6_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_attention_token0_workspace": (C.c_int64, [_i32, _i32, _i32]), "paths_attention_h3_any_workspace": (C.c_int64, [_i32, _i32, _i32, _i32]), "paths_importance_proj_x6_workspace": (C.c_int64, [_i32]), "paths_last_error": (C.c_char_p, []), "paths_build_info": (C.c_char_p, []), "paths_abi_version": (_i32, []), "paths_stop_event_pending": (_i32, []), "paths_clear_stop_event": (_i32, []), "paths_adamw_chunk": (_i32, []), "paths_attention_wide_workspace": (C.c_int64, [_i32, _i32]), "paths_event_create": (_vp, []), "paths_stream_create_masked": (_vp, [_vp, _i32])}
 
 ABI_VERSION = 2     # include/paths_hip.h: paths_abi_version() of the library this binding was written against
 _lib: Optional[C.CDLL] = None

@@ -303,7 +303,8 @@ tokens_assemble_kernel(const float* __restrict__ P, int64_t ldp, const float* __
       const float ang = (float)(t - 1) * div_term[c >> 1];
       pe = (c & 1) ? cosf(ang) : sinf(ang);
     }
-    out[c] = a * P[m * ldp + c] + bp[c] + pe;
+    // a == 0: a padded row (importance is written as exactly 0 there) - its P may be undefined (a skipped all-padding tile): select, do not multiply
+    out[c] = ((imp_mul && a == 0.f) ? 0.f : a * P[m * ldp + c]) + bp[c] + pe;
   }
 }
 

@@ -339,34 +339,104 @@ token0_ws_kernel(T0Params p) {
 // ================================================================================================================================
 constexpr int SPIN_LIMIT = 1 << 22;
 
-__global__ void __launch_bounds__(NT)
+// Geometry of the distributed form for trans_dim D (4 heads): 4 D threads, thread (f = tid % D, kq = tid / D) owns output f and one k
+// quarter of every D-wide product; the token pass gives one token to each half-wave, D / 32 features per lane.
+template <int D_>
+struct T0G {
+  static_assert(D_ % 64 == 0 && D_ >= 128 && D_ <= 256, "token0 distributed form: trans_dim 128 or 192 (256 untested)");
+  static constexpr int DM = D_, DFF = 4 * D_, HD = D_ / NH, NT = 4 * D_, SLOTS = NT / 32, FPL = D_ / 32, REC = 4 + D_;
+  static constexpr int NV = D_ / 64;                  // 16-byte loads of a thread's piece of Wv_head (HD x D) and of Wo[:, head] (D x HD)
+  static constexpr int NQ = D_ / 16;                  // ... of its k quarter of A_head
+  static constexpr int MAXLD = D_ == 128 ? 8 : D_ / 32;   // ... of its pieces of the W1 / W2 slices at the coarsest split (128: nts = 1; wider: nts = 2 - 12 waves of 168 registers)
+  static constexpr int RT = D_ == 128 ? 8 : 4;        // tokens per half-wave and round of the token pass (two register sets of RT x FPL)
+  static constexpr int OFF_A = 0;                                  // [4 heads][D/4 k4][D c][4]  A_h^T4
+  static constexpr int OFF_A0 = OFF_A + NH * DM * DM;              // [4][D]
+  static constexpr int OFF_WV = OFF_A0 + NH * DM;                  // [D/4 k4][D f][4]
+  static constexpr int OFF_WO = OFF_WV + DM * DM;                  // [D/4 k4][D f][4]
+  static constexpr int OFF_W1 = OFF_WO + DM * DM;                  // [D/4 k4][4D n][4]
+  static constexpr int OFF_W2 = OFF_W1 + DFF * DM;                 // [D k4][D f][4]
+  static constexpr int OFF_OB = OFF_W2 + DM * DFF;                 // [D] Wo bv + bo
+  static constexpr int IMG_FLOATS = OFF_OB + DM;
+  static constexpr int SMEM = SLOTS * DM + 4 * DFF + 8 * DM + 64;  // floats
+};
+static_assert(T0G<128>::OFF_OB == OFF_OB && T0G<128>::IMG_FLOATS == IMG_FLOATS && T0G<128>::REC == REC && T0G<128>::NT == NT, "one image layout at 128");
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// FPL consecutive floats of a row (FPL = 4: one 16-byte load; 6: three 8-byte loads) through a GLOBAL address-space pointer
+template <int FPL>
+__device__ __forceinline__ void ld_feats(const float* p, float (&x)[FPL]) {
+  if constexpr (FPL == 4) {
+    const f32x4 t = ldg_f32x4(p);
+    x[0] = t[0]; x[1] = t[1]; x[2] = t[2]; x[3] = t[3];
+  } else {
+    static_assert(FPL % 2 == 0, "features per lane");
+    typedef const f32x2 __attribute__((address_space(1))) * gptr;
+#pragma unroll
+    for (int i = 0; i < FPL / 2; ++i) {
+      const f32x2 t = *reinterpret_cast<gptr>(reinterpret_cast<uintptr_t>(p + 2 * i));
+      x[2 * i] = t[0]; x[2 * i + 1] = t[1];
+    }
+  }
+}
+template <int FPL>
+__device__ __forceinline__ float dot_feats(const float (&a)[FPL], const float (&b)[FPL]) {
+  float acc = a[0] * b[0];
+#pragma unroll
+  for (int i = 1; i < FPL; ++i) acc = fmaf(a[i], b[i], acc);
+  return acc;
+}
+// wave 0 normalises v[0:D] in place (D / 64 values per lane); every thread must call it
+template <int D>
+__device__ __forceinline__ void block_layernorm_d(float* v, const float* g, const float* bta, float eps, int tid) {
+  if (tid < 64) {
+    constexpr int VP = D / 64;
+    float a[VP], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VP; ++i) { a[i] = v[tid + 64 * i]; s += a[i]; }
+    const float mean = wave_sum64(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VP; ++i) { a[i] -= mean; q = fmaf(a[i], a[i], q); }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < VP; ++i) v[tid + 64 * i] = a[i] * rstd * g[tid + 64 * i] + bta[tid + 64 * i];
+  }
+  __syncthreads();
+}
+
+template <int D_>
+__global__ void __launch_bounds__(4 * D_)
 token0_dist_kernel(T0Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[SLOTS * DM + 4 * DFF + 8 * DM + 64];
-  float* const sZ = smem;                    // phase 1: [16 slots][128]
-  float* const sRed = smem + SLOTS * DM;     // [2048] k-split partial sums
+  using G_ = T0G<D_>;
+  constexpr int DM = G_::DM, DFF = G_::DFF, HD = G_::HD, NT = G_::NT, SLOTS = G_::SLOTS, FPL = G_::FPL, REC = G_::REC;
+  constexpr int NV = G_::NV, NQ = G_::NQ, MAXLD = G_::MAXLD, RT = G_::RT;
+  constexpr int OFF_A = G_::OFF_A, OFF_A0 = G_::OFF_A0, OFF_WV = G_::OFF_WV, OFF_WO = G_::OFF_WO, OFF_W1 = G_::OFF_W1, OFF_W2 = G_::OFF_W2, OFF_OB = G_::OFF_OB;
+  __shared__ __attribute__((aligned(16))) float smem[G_::SMEM];
+  float* const sZ = smem;                    // phase 1: [SLOTS][D]
+  float* const sRed = smem + SLOTS * DM;     // [16 D] k-split partial sums
   float* const sV = sRed + 4 * DFF;
   float* const sX0 = sV, *const sQ = sV + DM, *const sNum = sV + 2 * DM, *const sXa = sV + 3 * DM, *const sH = sV + 4 * DM;
-  float* const sML = sV + 5 * DM;            // [16][2] slot (m, l); then [0] = M, [1] = den
-  float* const sVv = sV + 5 * DM + 2 * SLOTS + 8;      // [32]
+  float* const sML = sV + 5 * DM;            // [SLOTS][2] slot (m, l)
+  float* const sVv = sV + 5 * DM + 2 * SLOTS + 8;      // [HD]
   int* const sFlag = reinterpret_cast<int*>(sV + 5 * DM + 2 * SLOTS);
-  const int G = NH * p.nts, HS = DFF / G, nld = HS / 16;               // HS in {16, 32, 64, 128}
+  const int G = NH * p.nts, HS = DFF / G, nld = HS / 16;               // HS = D / nts; nld 16-byte loads per thread and slice
   const int b = blockIdx.y, j = blockIdx.x, head = j & 3, ts = j >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xb = p.x1 + (int64_t)b * p.T * DM;
   const float* W = p.img;
 
-  // ---- this workgroup's weight slices, issued first: Wv_head / Wo[:, head] (2 + 2 loads), W1 / W2 slices (nld + nld loads)
-  const int o5 = tid & 31, kq5 = tid >> 5;             // 32 outputs x 16 k-groups of 8
-  const int f7 = tid & 127, kq7 = tid >> 7;            // 128 outputs x 4 k-groups
-  const int n1 = tid % HS, kq1 = tid / HS;             // HS outputs x (512 / HS) k-groups of HS / 4
-  f32x4 wv[2], wo[2], w1[8], w2[8];
+  // ---- this workgroup's weight slices, issued first: Wv_head / Wo[:, head] (NV + NV loads), W1 / W2 slices (nld + nld loads)
+  const int o5 = tid % HD, kq5 = tid / HD;             // HD outputs x 16 k-groups of D / 16
+  const int f7 = tid % DM, kq7 = tid / DM;             // D outputs x 4 k-groups
+  const int n1 = tid % HS, kq1 = tid / HS;             // HS outputs x (4 D / HS) k-groups of HS / 4
+  f32x4 wv[NV], wo[NV], w1[MAXLD], w2[MAXLD];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    wv[i] = ldg_f32x4(W + OFF_WV + ((2 * kq5 + i) * DM + 32 * head + o5) * 4);
-    wo[i] = ldg_f32x4(W + OFF_WO + ((8 * head + 2 * kq7 + i) * DM + f7) * 4);
+  for (int i = 0; i < NV; ++i) {
+    wv[i] = ldg_f32x4(W + OFF_WV + ((NV * kq5 + i) * DM + HD * head + o5) * 4);
+    wo[i] = ldg_f32x4(W + OFF_WO + (((HD / 4) * head + NV * kq7 + i) * DM + f7) * 4);
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MAXLD; ++i)
     if (i < nld) {
       w1[i] = ldg_f32x4(W + OFF_W1 + ((kq1 * nld + i) * DFF + j * HS + n1) * 4);
       w2[i] = ldg_f32x4(W + OFF_W2 + (((j * HS) / 4 + kq7 * nld + i) * DM + f7) * 4);
@@ -378,12 +448,12 @@ token0_dist_kernel(T0Params p) {
   __syncthreads();
   {
     const float* A = W + OFF_A + (int64_t)head * DM * DM;
-    f32x4 w[8];
+    f32x4 w[NQ];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = ldg_f32x4(A + ((8 * kq7 + i) * DM + f7) * 4);
+    for (int i = 0; i < NQ; ++i) w[i] = ldg_f32x4(A + ((NQ * kq7 + i) * DM + f7) * 4);
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc += dot4(w[i], *reinterpret_cast<const f32x4*>(sX0 + 32 * kq7 + 4 * i));
+    for (int i = 0; i < NQ; ++i) acc += dot4(w[i], *reinterpret_cast<const f32x4*>(sX0 + (DM / 4) * kq7 + 4 * i));
     sRed[kq7 * DM + f7] = acc;
   }
   __syncthreads();
@@ -391,52 +461,59 @@ token0_dist_kernel(T0Params p) {
   __syncthreads();
 
   T0_STAMP(1);
-  // ---- phase 1 (as in token0_ws_kernel): online softmax over this workgroup's tokens, z = sum p x
+  // ---- phase 1: online softmax over this workgroup's tokens, z = sum p x; one token per half-wave and iteration, FPL features per lane
   const int len = min((int)p.num_ims[b] + 1, p.T);
   const int chunk = (len + p.nts - 1) / p.nts;
   const int k0 = ts * chunk, k1 = min(len, k0 + chunk);
   const int l5 = lane & 31, slot = wave * 2 + (lane >> 5);
-  const f32x4 qv = *reinterpret_cast<const f32x4*>(sQ + 4 * l5);
-  float m = -1e30f, l = 0.f;
-  f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  // rounds of 8 tokens per half-wave; the row pieces of round r + 1 are in flight while round r is reduced (two register sets)
-  f32x4 xa[8], xn[8];
-  auto fetch = [&](f32x4 (&dst)[8], int base) __attribute__((always_inline)) {
+  float qv[FPL];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) dst[u] = ldg_f32x4(xb + (int64_t)max(min(base + u * SLOTS + slot, k1 - 1), 0) * DM + 4 * l5);
+  for (int e = 0; e < FPL; ++e) qv[e] = sQ[FPL * l5 + e];
+  float m = -1e30f, l = 0.f;
+  float z[FPL];
+#pragma unroll
+  for (int e = 0; e < FPL; ++e) z[e] = 0.f;
+  // rounds of RT tokens per half-wave; the row pieces of round r + 1 are in flight while round r is reduced (two register sets)
+  float xa[RT][FPL], xn[RT][FPL];
+  auto fetch = [&](float (&dst)[RT][FPL], int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < RT; ++u) ld_feats<FPL>(xb + (int64_t)max(min(base + u * SLOTS + slot, k1 - 1), 0) * DM + FPL * l5, dst[u]);
   };
-  auto reduce = [&](const f32x4 (&x)[8], int base) __attribute__((always_inline)) {
-    float s[8];
-    bool ok[8];
+  auto reduce = [&](const float (&x)[RT][FPL], int base) __attribute__((always_inline)) {
+    float s[RT];
+    bool ok[RT];
     float mx = m;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < RT; ++u) {
       ok[u] = base + u * SLOTS + slot < k1;
-      s[u] = ok[u] ? half_sum32(dot4(qv, x[u])) : -1e30f;
+      s[u] = ok[u] ? half_sum32(dot_feats<FPL>(qv, x[u])) : -1e30f;
       mx = fmaxf(mx, s[u]);
     }
     const float alpha = __builtin_amdgcn_exp2f(m - mx);
     float ps = 0.f;
-    z = z * alpha;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int e = 0; e < FPL; ++e) z[e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
       const float pu = ok[u] ? __builtin_amdgcn_exp2f(s[u] - mx) : 0.f;
       ps += pu;
-      z = z + x[u] * pu;
+#pragma unroll
+      for (int e = 0; e < FPL; ++e) z[e] = fmaf(x[u][e], pu, z[e]);
     }
     l = l * alpha + ps;
     m = mx;
   };
   if (k0 < k1) fetch(xa, k0);
-  for (int base = k0; base < k1; base += 16 * SLOTS) {
-    if (base + 8 * SLOTS < k1) fetch(xn, base + 8 * SLOTS);
+  for (int base = k0; base < k1; base += 2 * RT * SLOTS) {
+    if (base + RT * SLOTS < k1) fetch(xn, base + RT * SLOTS);
     reduce(xa, base);
-    if (base + 8 * SLOTS < k1) {
-      if (base + 16 * SLOTS < k1) fetch(xa, base + 16 * SLOTS);
-      reduce(xn, base + 8 * SLOTS);
+    if (base + RT * SLOTS < k1) {
+      if (base + 2 * RT * SLOTS < k1) fetch(xa, base + 2 * RT * SLOTS);
+      reduce(xn, base + RT * SLOTS);
     }
   }
-  *reinterpret_cast<f32x4*>(sZ + slot * DM + 4 * l5) = z;
+#pragma unroll
+  for (int e = 0; e < FPL; ++e) sZ[slot * DM + FPL * l5 + e] = z[e];
   if (l5 == 0) { sML[2 * slot] = m; sML[2 * slot + 1] = l; }
   __syncthreads();
   T0_STAMP(2);
@@ -453,21 +530,31 @@ token0_dist_kernel(T0Params p) {
 #pragma unroll
   for (int sl = 0; sl < SLOTS; ++sl) den = fmaf(sML[2 * sl + 1], __builtin_amdgcn_exp2f(sML[2 * sl] - Mloc), den);
   __syncthreads();
-  // ---- v = Wv_head z (32 values), u = Wo[:, head] v (128 values): this workgroup's record is (M, den, u)
-  sRed[kq5 * 32 + o5] = dot4(wv[0], *reinterpret_cast<const f32x4*>(sNum + 8 * kq5)) + dot4(wv[1], *reinterpret_cast<const f32x4*>(sNum + 8 * kq5 + 4));
-  __syncthreads();
-  if (tid < 32) {
+  // ---- v = Wv_head z (HD values), u = Wo[:, head] v (D values): this workgroup's record is (M, den, u)
+  {
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc += sRed[k * 32 + tid];
+    for (int i = 0; i < NV; ++i) acc += dot4(wv[i], *reinterpret_cast<const f32x4*>(sNum + 4 * (NV * kq5 + i)));
+    sRed[kq5 * HD + o5] = acc;
+  }
+  __syncthreads();
+  if (tid < HD) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT / HD; ++k) acc += sRed[k * HD + tid];
     sVv[tid] = acc;
   }
   __syncthreads();
-  sRed[1024 + kq7 * DM + f7] = dot4(wo[0], *reinterpret_cast<const f32x4*>(sVv + 8 * kq7)) + dot4(wo[1], *reinterpret_cast<const f32x4*>(sVv + 8 * kq7 + 4));
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc += dot4(wo[i], *reinterpret_cast<const f32x4*>(sVv + 4 * (NV * kq7 + i)));
+    sRed[2 * DFF + kq7 * DM + f7] = acc;
+  }
   __syncthreads();
   float* rec = p.partials + ((int64_t)b * G + j) * REC;
   if (tid < DM) {
-    const float* r4 = sRed + 1024 + tid;
+    const float* r4 = sRed + 2 * DFF + tid;
     st_agent(rec + 4 + tid, (r4[0] + r4[DM]) + (r4[2 * DM] + r4[3 * DM]));
     if (tid == 0) { st_agent(rec, Mloc); st_agent(rec + 1, den); }
   }
@@ -520,16 +607,16 @@ token0_dist_kernel(T0Params p) {
   __syncthreads();
   if (tid < DM) sXa[tid] = sX0[tid] + (((sRed[tid] + sRed[DM + tid]) + (sRed[2 * DM + tid] + sRed[3 * DM + tid])) + W[OFF_OB + tid]);
   __syncthreads();
-  block_layernorm(sXa, p.ln1g, p.ln1b, p.eps, tid);
+  block_layernorm_d<DM>(sXa, p.ln1g, p.ln1b, p.eps, tid);
   if (tid < DM) sXa[tid] += p.cab[tid];
   __syncthreads();
-  block_layernorm(sXa, p.ln2g, p.ln2b, p.eps, tid);
+  block_layernorm_d<DM>(sXa, p.ln2g, p.ln2b, p.eps, tid);
   T0_STAMP(4);
   // ---- feed-forward slice j: h = relu(W1[j HS .., :] x + b1), y_j = W2[:, j HS ..] h
   {
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MAXLD; ++i)
       if (i < nld) acc += dot4(w1[i], *reinterpret_cast<const f32x4*>(sXa + (kq1 * nld + i) * 4));
     sRed[kq1 * HS + n1] = acc;
   }
@@ -544,14 +631,14 @@ token0_dist_kernel(T0Params p) {
   {
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < MAXLD; ++i)
       if (i < nld) acc += dot4(w2[i], *reinterpret_cast<const f32x4*>(sH + (kq7 * nld + i) * 4));
-    sRed[1024 + kq7 * DM + f7] = acc;
+    sRed[2 * DFF + kq7 * DM + f7] = acc;
   }
   __syncthreads();
   float* rec2 = p.partials + (int64_t)gridDim.y * (G * REC + DM) + ((int64_t)b * G + j) * DM;
   if (tid < DM) {
-    const float* r4 = sRed + 1024 + tid;
+    const float* r4 = sRed + 2 * DFF + tid;
     st_agent(rec2 + tid, (r4[0] + r4[DM]) + (r4[2 * DM] + r4[3 * DM]));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -575,8 +662,8 @@ token0_dist_kernel(T0Params p) {
   __syncthreads();
   if (tid < DM) sXa[tid] = sXa[tid] + (((sRed[tid] + sRed[DM + tid]) + (sRed[2 * DM + tid] + sRed[3 * DM + tid])) + p.b2[tid]);
   __syncthreads();
-  block_layernorm(sXa, p.ln3g, p.ln3b, p.eps, tid);
-  block_layernorm(sXa, p.lnfg, p.lnfb, p.eps_f, tid);
+  block_layernorm_d<DM>(sXa, p.ln3g, p.ln3b, p.eps, tid);
+  block_layernorm_d<DM>(sXa, p.lnfg, p.lnfb, p.eps_f, tid);
   if (tid < DM) {
     float v = sXa[tid];
     if (p.ctx_prev) v += p.ctx_prev[(int64_t)b * p.ctx_stride + tid];
@@ -591,46 +678,50 @@ token0_dist_kernel(T0Params p) {
       for (int i = lane; i < p.ctx_depth * DM; i += 64) acc += w[i] * p.ctx_all[(int64_t)b * p.ctx_depth * DM + i];
       w += p.ctx_depth * DM;
     }
-    acc += w[lane] * sXa[lane] + w[lane + 64] * sXa[lane + 64];
+#pragma unroll
+    for (int i = 0; i < DM / 64; ++i) acc += w[lane + 64 * i] * sXa[lane + 64 * i];
     acc = wave_sum64(acc);
     if (lane == 0) p.logits[(int64_t)b * p.num_logits + jj] = acc + p.bcls[jj];
   }
   T0_STAMP(9);
 }
 
-// ---- packing: A_h = c Wk_h^T Wq_h (fp32 FMA chains over the 32 head dims), a0_h = c Wk_h^T bq_h, and the T4 transposes
+// ---- packing: A_h = c Wk_h^T Wq_h (fp32 FMA chains over the head dims), a0_h = c Wk_h^T bq_h, and the T4 transposes
 // out[(k4 * N + n) * 4 + e] = W[n][4 k4 + e]
+template <int D_>
 __global__ void __launch_bounds__(256)
 token0_pack_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv, const float* __restrict__ wo, const float* __restrict__ bo,
                    const float* __restrict__ w1, const float* __restrict__ w2, float qscale, float* __restrict__ out) {
+  using G_ = T0G<D_>;
+  constexpr int DM = G_::DM, DFF = G_::DFF, HD = G_::HD;
   const int job = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (job == 0) {                    // A: [h][k4][c][e] <- c * sum_i Wk[32h+i][c] Wq[32h+i][4 k4 + e];  i in [0, 4*32*128*4)
+  if (job == 0) {                    // A: [h][k4][c][e] <- c * sum_i Wk[HD h + i][c] Wq[HD h + i][4 k4 + e]
     if (i >= NH * DM * DM) return;
-    const int e = i & 3, c = (i >> 2) & 127, k4 = (i >> 9) & 31, h = i >> 14;
+    const int e = i & 3, c = (i >> 2) % DM, r_ = (i >> 2) / DM, k4 = r_ % (DM / 4), h = r_ / (DM / 4);
     const float* wq = wqkv + (int64_t)(HD * h) * DM + 4 * k4 + e;
     const float* wk = wqkv + (int64_t)(DM + HD * h) * DM + c;
     float acc = 0.f;
     for (int r = 0; r < HD; ++r) acc = fmaf(wk[r * DM], wq[r * DM], acc);
-    out[OFF_A + i] = acc * qscale;
+    out[G_::OFF_A + i] = acc * qscale;
   } else if (job == 1) {             // a0: [h][c]
     if (i >= NH * DM) return;
-    const int c = i & 127, h = i >> 7;
+    const int c = i % DM, h = i / DM;
     const float* wk = wqkv + (int64_t)(DM + HD * h) * DM + c;
     float acc = 0.f;
     for (int r = 0; r < HD; ++r) acc = fmaf(wk[r * DM], bqkv[HD * h + r], acc);
-    out[OFF_A0 + i] = acc * qscale;
+    out[G_::OFF_A0 + i] = acc * qscale;
   } else if (job == 6) {             // ob[f] = Wo[f] . bv + bo[f]
     if (i >= DM) return;
     float acc = 0.f;
     for (int k = 0; k < DM; ++k) acc = fmaf(wo[(int64_t)i * DM + k], bqkv[2 * DM + k], acc);
-    out[OFF_OB + i] = acc + bo[i];
+    out[G_::OFF_OB + i] = acc + bo[i];
   } else {                           // T4 transposes: Wv (rows 2 DM.. of wqkv), Wo, W1, W2
     const float* src; int N, K, off;
-    if (job == 2) { src = wqkv + 2 * DM * DM; N = DM; K = DM; off = OFF_WV; }
-    else if (job == 3) { src = wo; N = DM; K = DM; off = OFF_WO; }
-    else if (job == 4) { src = w1; N = DFF; K = DM; off = OFF_W1; }
-    else { src = w2; N = DM; K = DFF; off = OFF_W2; }
+    if (job == 2) { src = wqkv + 2 * DM * DM; N = DM; K = DM; off = G_::OFF_WV; }
+    else if (job == 3) { src = wo; N = DM; K = DM; off = G_::OFF_WO; }
+    else if (job == 4) { src = w1; N = DFF; K = DM; off = G_::OFF_W1; }
+    else { src = w2; N = DM; K = DFF; off = G_::OFF_W2; }
     if (i >= N * K) return;
     const int e = i & 3, n = (i >> 2) % N, k4 = (i >> 2) / N;
     out[off + i] = src[(int64_t)n * K + 4 * k4 + e];
@@ -644,14 +735,12 @@ static unsigned long long* g_t0_stamps = nullptr;
 extern "C" void paths_t0_stamp_buffer(unsigned long long* p) { g_t0_stamps = p; }     // development hook (tools/t0_time.py)
 #endif
 
-extern "C" {
-
-int64_t paths_token0_ws_image_bytes(void) { return (int64_t)IMG_FLOATS * 4; }
-
-// token splits of the distributed form: the largest nts in {8, 4, 2, 1} with 128-token splits whose launch fits the chip with room
+// token splits of the distributed form: the largest nts in {8, 4, 2, 1} (trans_dim 192: {4, 2} - a feed-forward slice must be a
+// multiple of 16 hidden units, and a thread holds at most 6 loads of it) with 128-token splits whose launch fits the chip with room
 // to spare - every workgroup of a slide spins on its siblings' arrival, so ALL of them must be resident at once: at most 3/4 of
-// (CUs x resident 512-thread workgroups of this kernel per CU, both asked from the runtime per device; 192 on an MI355X in SPX
+// (CUs x resident workgroups of this kernel per CU, both asked from the runtime per device; 192 on an MI355X in SPX
 // mode) - the rest of the chip may hold another stream's kernels; 0 = use the single-chain form
+template <int D_>
 static int dist_limit() {
   static int cached[64] = {0};
   int dev = 0;
@@ -659,17 +748,17 @@ static int dist_limit() {
   if (cached[dev] == 0) {
     int cus = 0, occ = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(token0_dist_kernel), NT, 0) != hipSuccess || occ <= 0) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(token0_dist_kernel<D_>), T0G<D_>::NT, 0) != hipSuccess || occ <= 0) return 0;
     cached[dev] = cus * (occ > 1 ? 1 : occ) * 3 / 4;      // (counted at ONE workgroup per CU: a second one there would share its memory queue)
     if (getenv("PATHS_T0_DIST_LIMIT") != nullptr && atoi(getenv("PATHS_T0_DIST_LIMIT")) > 0) cached[dev] = atoi(getenv("PATHS_T0_DIST_LIMIT"));   // A/B runs
   }
   return cached[dev];
 }
-static int dist_splits(int B, int T) {
+static int dist_splits(int B, int T, int d) {
   static const bool off = getenv("PATHS_T0_DIST") != nullptr && atoi(getenv("PATHS_T0_DIST")) == 0;
   if (off) return 0;
-  const int limit = dist_limit();
-  for (int nts = 8; nts >= 1; nts >>= 1)
+  const int limit = d == 192 ? dist_limit<192>() : dist_limit<128>();
+  for (int nts = d == 192 ? 4 : 8; nts >= (d == 192 ? 2 : 1); nts >>= 1)
     if (NH * nts * B <= limit && (nts == 1 || (nts - 1) * TS_TOKENS < T)) return nts;
   return 0;
 }
@@ -678,31 +767,56 @@ static int chain_splits(int T) {
   return nts < 1 ? 1 : nts > MAX_TS ? MAX_TS : nts;
 }
 
-// floats of the partials scratch of paths_token0_tail_ws
-int64_t paths_token0_ws_partials(int B, int T) {
-  const int64_t chain = (int64_t)B * NH * chain_splits(T) * REC;
-  const int nd = dist_splits(B, T);
-  const int64_t dist = nd ? (int64_t)B * (NH * nd * (REC + DM) + DM) : 0;
-  return chain > dist ? chain : dist;
+extern "C" {
+
+// trans_dim d in {128, 192} (4 heads).  The _d forms take the width; the forms without it are the trans_dim-128 ones.
+int64_t paths_token0_ws_image_bytes_d(int d) { return d == 192 ? (int64_t)T0G<192>::IMG_FLOATS * 4 : d == 128 ? (int64_t)IMG_FLOATS * 4 : 0; }
+int64_t paths_token0_ws_image_bytes(void) { return paths_token0_ws_image_bytes_d(128); }
+
+// Can paths_token0_tail_ws run this shape?  trans_dim 128: always (two forms); 192: only the distributed form exists, i.e. while
+// its 4 * nts * B workgroups (nts >= 2) fit the chip together (B <= 24 on an MI355X) and T > 128.
+int paths_token0_ws_supported(int B, int T, int d, int H) {
+  if (H != NH || B <= 0 || T <= 0) return 0;
+  if (d == 128) return 1;
+  if (d == 192) return dist_splits(B, T, d) > 0 ? 1 : 0;
+  return 0;
 }
 
-// Weight image of paths_token0_tail_ws for one (last) decoder layer: wqkv [384,128], bqkv [384], wo [128,128], w1 [512,128],
-// bo [128], w2 [128,512]; qscale = log2(e) / sqrt(head_dim).  Rebuilt whenever the weights change.
-int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
-                         void* out, hipStream_t stream) {
+// floats of the partials scratch of paths_token0_tail_ws
+int64_t paths_token0_ws_partials_d(int B, int T, int d) {
+  const int rec = 4 + d;
+  const int64_t chain = d == 128 ? (int64_t)B * NH * chain_splits(T) * rec : 0;
+  const int nd = dist_splits(B, T, d);
+  const int64_t dist = nd ? (int64_t)B * (NH * nd * (rec + d) + d) : 0;
+  return chain > dist ? chain : dist;
+}
+int64_t paths_token0_ws_partials(int B, int T) { return paths_token0_ws_partials_d(B, T, 128); }
+
+// Weight image of paths_token0_tail_ws for one (last) decoder layer: wqkv [3d,d], bqkv [3d], wo [d,d], w1 [4d,d],
+// bo [d], w2 [d,4d]; qscale = log2(e) / sqrt(head_dim).  Rebuilt whenever the weights change.
+int paths_token0_pack_ws_d(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
+                           int d, void* out, hipStream_t stream) {
   PATHS_REQUIRE(wqkv && bqkv && wo && bo && w1 && w2 && out && (uintptr_t)out % 16 == 0, "token0_pack_ws: bad arguments");
-  hipLaunchKernelGGL(token0_pack_kernel, dim3(256, 7), dim3(256), 0, stream, wqkv, bqkv, wo, bo, w1, w2, qscale, reinterpret_cast<float*>(out));
+  PATHS_REQUIRE(d == 128 || d == 192, "token0_pack_ws: trans_dim must be 128 or 192 (got %d)", d);
+  const dim3 grid((unsigned)(4 * d * d / 256), 7);
+  if (d == 192) hipLaunchKernelGGL(token0_pack_kernel<192>, grid, dim3(256), 0, stream, wqkv, bqkv, wo, bo, w1, w2, qscale, reinterpret_cast<float*>(out));
+  else hipLaunchKernelGGL(token0_pack_kernel<128>, grid, dim3(256), 0, stream, wqkv, bqkv, wo, bo, w1, w2, qscale, reinterpret_cast<float*>(out));
   PATHS_LAUNCH_CHECK("token0_pack_ws");
   return PATHS_OK;
 }
+int paths_token0_pack_ws(const float* wqkv, const float* bqkv, const float* wo, const float* bo, const float* w1, const float* w2, float qscale,
+                         void* out, hipStream_t stream) {
+  return paths_token0_pack_ws_d(wqkv, bqkv, wo, bo, w1, w2, qscale, 128, out, stream);
+}
 
 // The last decoder layer at token 0 (reference model/aggregator.py:70-75) + decoder.norm + slide-context residual / concat +
-// classifier (model/paths.py:130-139) from the layer's INPUT rows x1 [B,T,128]: no K / V projection, one launch.
-// img: paths_token0_pack_ws image; bv = in_proj_bias + 256; partials: paths_token0_ws_partials(B, T) floats of scratch;
+// classifier (model/paths.py:130-139) from the layer's INPUT rows x1 [B,T,d]: no K / V projection, one launch.  d in {128, 192}, 4 heads.
+// img: paths_token0_pack_ws_d image; bv = in_proj_bias + 2 d; partials: paths_token0_ws_partials_d(B, T, d) floats of scratch;
 // counters: 3 B int32 words that are ZERO on entry (they are left zero: the last arrivers reset them); status (optional): an int32
 // word whose bit 4 is set if a bounded hand-off wait of the distributed form gave up (never observed; the result is then invalid).
 // Two forms, same results to fp32 rounding: up to 192 workgroups in the launch -> the DISTRIBUTED form (every workgroup of a slide
-// carries a slice of the row chain's weights); larger batches -> one row-chain workgroup per slide (PATHS_T0_DIST=0 forces it).
+// carries a slice of the row chain's weights); larger batches -> one row-chain workgroup per slide (PATHS_T0_DIST=0 forces it;
+// trans_dim 128 only: at 192 check paths_token0_ws_supported first).
 int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* img, const float* bv, const float* bo,
                          const float* ln1g, const float* ln1b, const float* cab, const float* ln2g, const float* ln2b,
                          const float* b1, const float* b2, const float* ln3g, const float* ln3b, const float* lnfg, const float* lnfb,
@@ -710,13 +824,15 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
                          const float* wcls, const float* bcls, int num_logits, int cls_in,
                          float* ctx_out, float* logits, float* partials, int* counters, int* status, int B, int T, int d, int H,
                          float eps, float eps_final, int special_last, hipStream_t stream) {
-  PATHS_REQUIRE(d == DM && H == NH, "token0_tail_ws: this build supports trans_dim=128, 4 heads (got %d, %d)", d, H);
+  PATHS_REQUIRE((d == 128 || d == 192) && H == NH, "token0_tail_ws: this build supports trans_dim 128 or 192 with 4 heads (got %d, %d)", d, H);
   PATHS_REQUIRE(B > 0 && T > 0 && x1 && num_ims && img && bv && bo && ln1g && ln1b && cab && ln2g && ln2b && b1 && b2 && ln3g && ln3b && lnfg && lnfb,
                 "token0_tail_ws: null operand");
   PATHS_REQUIRE(wcls && bcls && ctx_out && logits && partials && counters, "token0_tail_ws: null output / scratch");
-  PATHS_REQUIRE(num_logits > 0 && cls_in == (ctx_all ? (ctx_depth + 1) * DM : DM), "token0_tail_ws: bad classifier shape");
+  PATHS_REQUIRE(num_logits > 0 && cls_in == (ctx_all ? (ctx_depth + 1) * d : d), "token0_tail_ws: bad classifier shape");
   PATHS_REQUIRE(((uintptr_t)x1 | (uintptr_t)img) % 16 == 0, "token0_tail_ws: buffers must be 16-byte aligned");
-  const int nd = dist_splits(B, T);
+  const int nd = dist_splits(B, T, d);
+  if (d != 128 && nd == 0)
+    return paths_set_error(PATHS_EUNSUPPORTED, "token0_tail_ws: trans_dim %d has the distributed form only and %d slides do not fit it (paths_token0_ws_supported)", d, B);
   const int nts = nd ? nd : chain_splits(T);
   T0Params p{x1, num_ims, reinterpret_cast<const float*>(img), bv, bo, ln1g, ln1b, cab, ln2g, ln2b, b1, b2, ln3g, ln3b, lnfg, lnfb,
              ctx_prev, ctx_stride, ctx_all, ctx_depth, wcls, bcls, num_logits, cls_in, ctx_out, logits, partials, counters, status, T, nts, eps, eps_final, special_last ? 1 : 0
@@ -724,7 +840,8 @@ int paths_token0_tail_ws(const float* x1, const int64_t* num_ims, const void* im
              , g_t0_stamps
 #endif
   };
-  if (nd) hipLaunchKernelGGL(token0_dist_kernel, dim3(NH * nts, B), dim3(NT), 0, stream, p);
+  if (nd && d == 192) hipLaunchKernelGGL(token0_dist_kernel<192>, dim3(NH * nts, B), dim3(T0G<192>::NT), 0, stream, p);
+  else if (nd) hipLaunchKernelGGL(token0_dist_kernel<128>, dim3(NH * nts, B), dim3(NT), 0, stream, p);
   else hipLaunchKernelGGL(token0_ws_kernel, dim3(NH * nts, B), dim3(NT), 0, stream, p);
   PATHS_LAUNCH_CHECK("token0_tail_ws");
   return PATHS_OK;

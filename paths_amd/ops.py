@@ -220,9 +220,10 @@ def tlayer_ws_images(layer: Dict[str, object], part: int):
 def token0_ws_image(layer: Dict[str, object], qscale: float) -> torch.Tensor:
     """Weight image of paths_token0_tail_ws for the LAST decoder layer (cached in the layer's pack dict)."""
     if "t0_image" not in layer:
-        img = torch.empty((int(_lib.load().paths_token0_ws_image_bytes()),), device=layer["wo"].device, dtype=torch.uint8)
-        _lib.call("paths_token0_pack_ws", _lib.ptr(layer["wqkv"]), _lib.ptr(layer["bqkv"]), _lib.ptr(layer["wo"]), _lib.ptr(layer["bo"]),
-                  _lib.ptr(layer["w1"]), _lib.ptr(layer["w2"]), qscale, _lib.ptr(img), _lib.stream())
+        d = int(layer["wo"].shape[0])          # trans_dim: 128 or 192 (csrc/token0_ws.hip)
+        img = torch.empty((int(_lib.load().paths_token0_ws_image_bytes_d(d)),), device=layer["wo"].device, dtype=torch.uint8)
+        _lib.call("paths_token0_pack_ws_d", _lib.ptr(layer["wqkv"]), _lib.ptr(layer["bqkv"]), _lib.ptr(layer["wo"]), _lib.ptr(layer["bo"]),
+                  _lib.ptr(layer["w1"]), _lib.ptr(layer["w2"]), qscale, d, _lib.ptr(img), _lib.stream())
         layer["t0_image"] = img
     return layer["t0_image"]
 
@@ -463,6 +464,7 @@ def fast_path(mc) -> bool:
 GENERIC_ADD = os.environ.get("PATHS_GENERIC_ADD", "1") != "0"       # other geometries: tuned LSTM kernels, importance / proj on x + h1 in flight
 WS_CHAIN_192 = os.environ.get("PATHS_WS_CHAIN_192", "1") != "0"     # trans_dim 192: full layers' row chain on tlayer_ws_kernel<192>
 WS_IMAGES_192 = os.environ.get("PATHS_WS_IMAGES_192", "1") != "0"   # ... and the first in_proj straight into the attention's head_dim-48 operand images
+TAIL_WS_192 = os.environ.get("PATHS_TAIL_WS_192", "1") != "0"       # ... and the last layer at token 0 + head in ONE launch (token0_dist_kernel<192>)
 
 
 def padded_head_dim(hd: int) -> int:
@@ -594,8 +596,10 @@ def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B
         gp["b1p"] = torch.cat([lvl_pack["b1"], torch.zeros((d,), device=dev, dtype=torch.float32)])
         gp[k6] = x6_pack(gp["w1p"], n_pad=n_pad)
     img, ws = gp[k6]
-    # (skipped tiles of padding stay defined; _lib.zeros: the fill is repeated when a recorded launch tape is replayed)
-    hp_ = (_lib.zeros if skip_padding else torch.empty)((M, n), device=dev, dtype=torch.float32)
+    # (skipped tiles of padding stay undefined: paths_importance_rows writes 0 for padded rows without looking at them and
+    # paths_tokens_assemble selects on that 0 - only when the importance does not multiply the tokens does the buffer need a fill;
+    # _lib.zeros: the fill is repeated when a recorded launch tape is replayed)
+    hp_ = (_lib.zeros if (skip_padding and not imp_mul) else torch.empty)((M, n), device=dev, dtype=torch.float32)
     _lib.call("paths_gemm_add_nt_x6", p(src) if x_rows is None else None, D, p(x_rows), p(add), add.stride(1), img.data_ptr(), D, p(gp["b1p"]), p(hp_), n,
               M, n, n_pad, D, 0, nim, N, ws, a_scale(), st)
     _lib.call("paths_importance_rows", p(hp_), n, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), 1, st)
@@ -686,7 +690,7 @@ def fp8_supported(mc) -> bool:
     return d % 128 == 0 and d % H == 0 and (d // H) in FP8_HEAD_DIMS      # paths_gemm_nt_fp8 needs K % 128 == 0 (one 64-k instruction pair per stage)
 
 
-def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8: bool = False) -> Dict[str, torch.Tensor]:
+def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8: bool = False, status=None) -> Dict[str, torch.Tensor]:
     """The aggregator for any (trans_dim, heads): generic GEMMs + csrc/generic.hip (reference model/aggregator.py:58-76 with torch's
     post-LN decoder layers, model/paths.py:130-139).  The last layer is evaluated at token 0 only (its other rows are never read).
     ``fp8`` (ops.AGG_FP8, the BASELINE configs[4] stress variant, NOT a parity path): the products over all tokens - in_proj, the full
@@ -724,6 +728,10 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     rows, ldx = M, d                      # the current activation: `rows` rows, row stride ldx (the last layer keeps token 0 of every slide)
     lda_attn = di                         # row stride of the attention output as the out_proj operand (T * di for the last layer's token-0 rows)
     ws192 = WS_CHAIN_192 and d == 192 and hd == hd_true and not fp8 and GEMM_MODE == "h3" and GENERIC_SPLIT and not wide
+    # ... and the LAST layer + decoder.norm + context + classifier in the one launch of the token-0 tail (csrc/token0_ws.hip at 192:
+    # the K / V projections folded into the query, so the chain launch in front of it stops at the layer's input rows)
+    tail192 = (ws192 and TAIL_WS and TAIL_WS_192 and H == 4 and L >= 2 and h3
+               and bool(_lib.load().paths_token0_ws_supported(B, T, d, H)))
     qkv_ready = img_ready = False
     for l in range(L):
         lay, gl = lvl_pack["layers"][l], gp["layers"][l]
@@ -772,8 +780,14 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
             # instantiated at 192; attention output in, q | k | v out as fp32 rows) instead of four GEMMs and two LayerNorm launches
             nxt = lvl_pack["layers"][l + 1]
             ip, sp = tlayer_ws_images(lay, 0)
-            iq, sq = tlayer_ws_images(nxt, 1)
             x3 = torch.empty((M, d), **f32)
+            if tail192 and l + 1 == L - 1:
+                _lib.call("paths_token_layer_ws_rows", p(x), p(attn), p(x3), p(ip), None, p(lay["bo"]), p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]),
+                          p(lay["ln2g"]), p(lay["ln2b"]), p(lay["b1"]), p(lay["b2"]), p(lay["ln3g"]), p(lay["ln3b"]), None, sp[0], sp[1], sp[2],
+                          1.0, None, 0, p(num_ims), B, T, d, 1, 0, 1, lay["eps"], st)
+                x = x3
+                break
+            iq, sq = tlayer_ws_images(nxt, 1)
             qkv_next = torch.empty((M, 3 * d), **f32)
             _lib.call("paths_token_layer_ws_rows", p(x), p(attn), p(x3), p(ip), p(iq), p(lay["bo"]), p(lay["ln1g"]), p(lay["ln1b"]), p(lay["cab"]),
                       p(lay["ln2g"]), p(lay["ln2b"]), p(lay["b1"]), p(lay["b2"]), p(lay["ln3g"]), p(lay["ln3b"]), p(nxt["bqkv"]), sp[0], sp[1], sp[2],
@@ -806,6 +820,20 @@ def _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all
     logits = torch.empty((B, nlog), **f32)
     res = ctx_prev if mc.slide_ctx_mode == "residual" else None
     cat = ctx_all.contiguous() if (mc.slide_ctx_mode == "concat" and ctx_all is not None and ctx_all.shape[1] > 0) else None
+    if tail192:
+        # x: the last layer's input rows [B, T, d] (special token first: the reference's order)
+        w = lvl_pack["layers"][L - 1]
+        img = token0_ws_image(w, qscale)
+        part = torch.empty((int(_lib.load().paths_token0_ws_partials_d(B, T, d)),), **f32)
+        cnt = token0_counters(dev, B)
+        _lib.call(
+            "paths_token0_tail_ws", p(x), p(num_ims), p(img), w["bqkv"].data_ptr() + 4 * 2 * d, p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
+            p(w["cab"]), p(w["ln2g"]), p(w["ln2b"]), p(w["b1"]), p(w["b2"]), p(w["ln3g"]), p(w["ln3b"]),
+            p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
+            res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, cat.shape[1] if cat is not None else 0,
+            p(lvl_pack["wcls"]), p(lvl_pack["bcls"]), nlog, lvl_pack["wcls"].shape[1], p(ctx_out), p(logits),
+            p(part), p(cnt), p(status) if status is not None else None, B, T, d, H, w["eps"], lvl_pack["lnf_eps"], 0, st)
+        return {"logits": logits, "ctx_slide": ctx_out}
     # x: [B, d] if the loop ended on the last layer's token-0 rows (L >= 1), row stride d
     _lib.call("paths_final_head_any", p(x), d if L >= 1 else T * d, p(lvl_pack["lnfg"]), p(lvl_pack["lnfb"]), p(res) if res is not None else None,
               res.stride(0) if res is not None else 0, p(cat) if cat is not None else None, cat.shape[1] if cat is not None else 0,
@@ -1115,7 +1143,7 @@ def _aggregator_forward_ws(mc, lvl_pack, tokens, num_ims, res, cat, depth, qkv_i
 
     def tail_ws():
         img = token0_ws_image(w, qscale)
-        part = torch.empty((int(_lib.load().paths_token0_ws_partials(B, T)),), device=tokens.device, dtype=torch.float32)
+        part = torch.empty((int(_lib.load().paths_token0_ws_partials_d(B, T, d)),), device=tokens.device, dtype=torch.float32)
         cnt = token0_counters(tokens.device, B)
         _lib.call(
             "paths_token0_tail_ws", p(xa), p(num_ims), p(img), w["bqkv"].data_ptr() + 4 * 2 * d, p(w["bo"]), p(w["ln1g"]), p(w["ln1b"]),
@@ -1149,7 +1177,7 @@ def _aggregator_forward(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status
     if AGG_FP8:
         return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, fp8=True)
     if not fast_path(mc):
-        return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all)
+        return _aggregator_forward_generic(mc, lvl_pack, tokens, num_ims, ctx_prev, ctx_all, status=status)
     B, T, d = tokens.shape
     H, L = mc.trans_heads, mc.trans_layers
     st = _lib.stream()

@@ -856,14 +856,18 @@ def test_weight_stationary_aggregator_path(dev, name):
         assert torch.equal(again["logits"], out_ws["logits"]) and torch.equal(again["ctx_slide"], out_ws["ctx_slide"])
 
 
+@pytest.mark.parametrize("d", [128, 192])
 @pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37, 129]), (65, [64, 65]), (8193, [8193, 5000])])
-def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens):
+def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens, d):
     """paths_token_layer_ws (in_proj -> attention image -> post chain) and paths_token0_tail_ws on random weights and ragged slides
-    against a float64 torch evaluation of the same decoder layers (reference model/aggregator.py:70-75)."""
+    against a float64 torch evaluation of the same decoder layers (reference model/aggregator.py:70-75), at the shipped width (128)
+    and at the reference's dataclass default (192, config.py:30: chain kernel and token-0 tail instantiated at 192 / head_dim 48;
+    T = 65 is below what the distributed tail splits and takes the generic launches)."""
     from paths_amd import _lib, ops
     if ops.GEMM_MODE != "h3":
         pytest.skip("default-mode kernels")
-    B, d, Hh, hd = len(lens), 128, 4, 32
+    B, Hh, hd = len(lens), 4, d // 4
+    assert bool(_lib.load().paths_token0_ws_supported(B, T, d, Hh)) == (d == 128 or T > 128)
     gen = torch.Generator(device=dev); gen.manual_seed(T)
     rnd = lambda *s: torch.rand(*s, device=dev, generator=gen) * 2 - 1
     layers = []

@@ -27,7 +27,7 @@ def build(td, heads, hid):
 slides = DeviceSlideBatch([DeviceSlide.synthetic(1234, i, (32, 64), device=dev) for i in range(spg)])
 labels = np.asarray([s.synthetic_spec.label(4) for s in slides.slides], np.int64)
 batch = {"slide": slides, "survival_bin": torch.from_numpy(labels[:, 0]), "censored": torch.from_numpy(labels[:, 1])}
-for geo in ((128, 4, 128), (td, heads, hid)):
+for geo in (((td, heads, hid),) if os.environ.get("GEO_ONLY") else ((128, 4, 128), (td, heads, hid))):
     cfg, model = build(*geo)
     with torch.no_grad():
         for _ in range(3):
