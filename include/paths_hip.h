@@ -415,6 +415,15 @@ int paths_importance_rows(const float* hid, int64_t ldh, const float* w2, const 
 int paths_tokens_assemble(const float* P, int64_t ldp, const float* importance, int imp_mul, const float* bp, const float* special,
                           const float* div_term, const int64_t* locs, int rows_per_slide, int patch_size, int pe_mode, int d, int B,
                           float* tokens, paths_stream_t stream);
+/* The importance-rows and tokens-assemble launches (above) as ONE launch over the rows of the [W1 ; Wp] product (csrc/generic.hip; reference
+ * model/paths.py:95-98,119-124, model/aggregator.py:37-65, utils.py:16-23,47-67): hid [M, ldh] holds the importance MLP's hidden
+ * pre-activations (Hi columns) and the projection (d columns) of every patch row; writes importance [M] (0 for padded rows) and
+ * tokens [B, rows_per_slide + 1, d] (special token first; padded rows bp + PE).  The positional encoding is read from pe_table
+ * (the table built by paths_pe_table for this pe_mode, d and pe_rows): same values as the sin / cos calls of the tokens-assemble launch. */
+int paths_importance_tokens_rows(const float* hid, int64_t ldh, const float* w2, const float* b2, const int64_t* num_ims, int rows_per_slide,
+                                 int64_t M, int Hi, float* importance, int relu, int imp_mul, const float* bp, const float* special,
+                                 const float* pe_table, int pe_rows, const int64_t* locs, int patch_size, int pe_mode, int d, float* tokens,
+                                 paths_stream_t stream);
 int paths_final_head_any(const float* x, int64_t slide_stride, const float* lng, const float* lnb, const float* ctx_prev, int64_t ctx_stride,
                          const float* ctx_all, int ctx_depth, const float* wcls, const float* bcls, int num_logits, int cls_in,
                          float* ctx_out, float* logits, int B, int d, float eps, paths_stream_t stream);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "paths_layernorm_rows": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
     "paths_layernorm2_rows": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _f32, _vp],
     "paths_importance_rows": [_vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp],
+    "paths_importance_tokens_rows": [_vp, _i64, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp],
     "paths_tokens_assemble": [_vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "paths_final_head_any": [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _f32, _vp],
     "paths_attention_h3_img": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],

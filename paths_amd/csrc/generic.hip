@@ -308,6 +308,50 @@ tokens_assemble_kernel(const float* __restrict__ P, int64_t ldp, const float* __
   }
 }
 
+// ---- importance_rows + tokens_assemble in ONE pass over the rows of the [W1 ; Wp] product (hid [M, >= Hi + d]: hidden pre-activations |
+// projection): one wave per patch row computes the importance logit, writes importance[m] and the token row alpha * P + bp + PE with
+// the sin / cos values read from paths_pe_table's table (the values tokens_assemble computes: same expression, same libm calls);
+// the wave of a slide's first row also writes the special token.  Padded rows: importance 0, token bp + PE (P is not read).
+__global__ void __launch_bounds__(256)
+importance_tokens_rows_kernel(const float* __restrict__ hid, int64_t ldh, const float* __restrict__ w2, const float* __restrict__ b2,
+                              const int64_t* __restrict__ num_ims, int rows_per_slide, int64_t M, int Hi, float* __restrict__ importance,
+                              int relu, int imp_mul, const float* __restrict__ bp, const float* __restrict__ special,
+                              const float* __restrict__ pe_table, int pe_rows, const int64_t* __restrict__ locs, int patch_size, int pe_mode,
+                              int d, float* __restrict__ tokens) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int b = (int)(row / rows_per_slide), idx = (int)(row - (int64_t)b * rows_per_slide);
+  const bool valid = idx < (int)num_ims[b];
+  const float* h = hid + row * ldh;
+  float acc = 0.f;
+  if (valid)
+    for (int c = lane; c < Hi; c += 64) { const float v = h[c]; acc = fmaf(relu ? fmaxf(v, 0.f) : v, w2[c], acc); }
+  acc = wave_sum(acc);
+  const float imp = valid ? sigmoid_acc(acc + *b2) : 0.f;
+  if (lane == 0) importance[row] = imp;
+  const float a = imp_mul ? imp : 1.f;
+  float* out = tokens + ((int64_t)b * (rows_per_slide + 1) + idx + 1) * d;
+  const int half = d / 2;
+  const int px = (int)min(max(locs[2 * row] / patch_size, (int64_t)0), (int64_t)(pe_rows - 1));
+  const int py = (int)min(max(locs[2 * row + 1] / patch_size, (int64_t)0), (int64_t)(pe_rows - 1));
+  const int pi = min(idx, pe_rows - 1);
+  for (int c = lane; c < d; c += 64) {
+    float pe;
+    if (pe_mode == 2) {
+      const int cc = c < half ? c : c - half;
+      pe = pe_table[(int64_t)(c < half ? px : py) * half + cc];
+    } else {
+      pe = pe_table[(int64_t)pi * d + c];
+    }
+    out[c] = (valid ? a * h[Hi + c] : 0.f) + bp[c] + pe;
+  }
+  if (idx == 0) {
+    float* sp = tokens + (int64_t)b * (rows_per_slide + 1) * d;
+    for (int c = lane; c < d; c += 64) sp[c] = special[c];
+  }
+}
+
 // ---- final head for any d <= 2048: decoder.norm(token 0) + slide-context residual -> ctx_out ; classifier over [concat ctx | f]
 __global__ void __launch_bounds__(64)
 final_head_any_kernel(const float* __restrict__ x, int64_t slide_stride, const float* __restrict__ lng, const float* __restrict__ lnb,
@@ -418,6 +462,23 @@ int paths_importance_rows(const float* hid, int64_t ldh, const float* w2, const 
   PATHS_REQUIRE(M > 0 && Hi > 0 && rows_per_slide > 0 && hid && w2 && b2 && num_ims && importance, "importance_rows: bad arguments");
   hipLaunchKernelGGL(importance_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, hid, ldh, w2, b2, num_ims, rows_per_slide, M, Hi, importance, relu ? 1 : 0);
   PATHS_LAUNCH_CHECK("importance_rows");
+  return PATHS_OK;
+}
+
+// paths_importance_rows + paths_tokens_assemble in one launch (reference model/paths.py:95-98,119-124, model/aggregator.py:37-65):
+// hid [M, ldh] = [hidden pre-activations (Hi) | projection (d)] per patch row; pe_table: paths_pe_table(div, pe_mode, d, pe_rows)
+// covering every position of the batch (pe_mode 2: locs / patch_size < pe_rows; 1: rows_per_slide <= pe_rows).
+int paths_importance_tokens_rows(const float* hid, int64_t ldh, const float* w2, const float* b2, const int64_t* num_ims, int rows_per_slide,
+                                 int64_t M, int Hi, float* importance, int relu, int imp_mul, const float* bp, const float* special,
+                                 const float* pe_table, int pe_rows, const int64_t* locs, int patch_size, int pe_mode, int d, float* tokens,
+                                 hipStream_t stream) {
+  PATHS_REQUIRE(M > 0 && Hi > 0 && rows_per_slide > 0 && M % rows_per_slide == 0 && hid && w2 && b2 && num_ims && importance, "importance_tokens_rows: bad arguments");
+  PATHS_REQUIRE(d > 0 && d % 2 == 0 && ldh >= Hi + d && patch_size > 0 && (pe_mode == 1 || pe_mode == 2) && bp && special && pe_table && pe_rows > 0 && locs && tokens,
+                "importance_tokens_rows: bad token arguments");
+  PATHS_REQUIRE(pe_mode == 2 || pe_rows >= rows_per_slide, "importance_tokens_rows: the 1-D table must cover %d rows (has %d)", rows_per_slide, pe_rows);
+  hipLaunchKernelGGL(importance_tokens_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, hid, ldh, w2, b2, num_ims, rows_per_slide, M, Hi,
+                     importance, relu ? 1 : 0, imp_mul ? 1 : 0, bp, special, pe_table, pe_rows, locs, patch_size, pe_mode, d, tokens);
+  PATHS_LAUNCH_CHECK("importance_tokens_rows");
   return PATHS_OK;
 }
 

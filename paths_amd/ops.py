@@ -465,6 +465,7 @@ GENERIC_ADD = os.environ.get("PATHS_GENERIC_ADD", "1") != "0"       # other geom
 WS_CHAIN_192 = os.environ.get("PATHS_WS_CHAIN_192", "1") != "0"     # trans_dim 192: full layers' row chain on tlayer_ws_kernel<192>
 WS_IMAGES_192 = os.environ.get("PATHS_WS_IMAGES_192", "1") != "0"   # ... and the first in_proj straight into the attention's head_dim-48 operand images
 TAIL_WS_192 = os.environ.get("PATHS_TAIL_WS_192", "1") != "0"       # ... and the last layer at token 0 + head in ONE launch (token0_dist_kernel<192>)
+FUSE_IMPORTANCE_TOKENS = os.environ.get("PATHS_FUSE_IMPORTANCE_TOKENS", "1") != "0"   # generic geometries: importance + token rows in one launch, PE from the table
 
 
 def padded_head_dim(hd: int) -> int:
@@ -574,7 +575,8 @@ def importance_proj_generic(mc, lvl_pack, src, ld_src: int, locs, num_ims, B: in
               p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
 
 
-def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B: int, N: int, D: int, imp_mul: int, imp_out, tokens, skip_padding: bool):
+def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B: int, N: int, D: int, imp_mul: int, imp_out, tokens, skip_padding: bool,
+                                pe_tab=None):
     """:func:`importance_proj_generic` on the split-operand kernel with the GEMM input ``src + add`` summed while it is staged (the
     Y = X + h1 form of the tuned path: Y is never stored, ``src`` may be row addresses into the resident grids): the LSTM part of the
     selection chain does not depend on the aggregator's geometry, so every geometry gets the tuned gate kernels."""
@@ -602,8 +604,13 @@ def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B
     hp_ = (_lib.zeros if (skip_padding and not imp_mul) else torch.empty)((M, n), device=dev, dtype=torch.float32)
     _lib.call("paths_gemm_add_nt_x6", p(src) if x_rows is None else None, D, p(x_rows), p(add), add.stride(1), img.data_ptr(), D, p(gp["b1p"]), p(hp_), n,
               M, n, n_pad, D, 0, nim, N, ws, a_scale(), st)
-    _lib.call("paths_importance_rows", p(hp_), n, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), 1, st)
     pe_mode = 2 if mc.pos_encoding_mode == "2d" else 1
+    if pe_tab is not None and FUSE_IMPORTANCE_TOKENS:
+        # importance + tokens in one pass over the product's rows, sin / cos from the table (csrc/generic.hip: 6.5 + 13.8 us -> one launch)
+        _lib.call("paths_importance_tokens_rows", p(hp_), n, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), 1, imp_mul,
+                  p(lvl_pack["bp"]), p(lvl_pack["special"]), p(pe_tab), pe_tab.shape[0], p(locs), mc.patch_size, pe_mode, d, p(tokens), st)
+        return
+    _lib.call("paths_importance_rows", p(hp_), n, p(lvl_pack["w2"]), p(lvl_pack["b2"]), p(num_ims), N, M, Hi, p(imp_out), 1, st)
     _lib.call("paths_tokens_assemble", hp_.data_ptr() + 4 * Hi, n, p(imp_out), imp_mul, p(lvl_pack["bp"]), p(lvl_pack["special"]),
               p(lvl_pack["div_2d" if pe_mode == 2 else "div_1d"]), p(locs), N, mc.patch_size, pe_mode, d, B, p(tokens), st)
 
@@ -1024,7 +1031,7 @@ def selection_forward(mc, lstm_pack, lvl_pack, fts, locs, num_ims, state_prev, s
             timed("lstm_mem_to_out", lambda: lstm(4))
         if generic_add:
             timed("importance_proj", lambda: importance_proj_generic_add(mc, lvl_pack, fts, x_rows, state_out, locs, num_ims, B, N, D,
-                                                                         1 if mc.importance_mode == "mul" else 0, importance, tokens, skip_padding))
+                                                                         1 if mc.importance_mode == "mul" else 0, importance, tokens, skip_padding, pe_tab=pe_tab))
         elif x6 and not generic:
             timed("importance_proj", lambda: importance_proj(fts, 1 if mc.importance_mode == "mul" else 0, importance, add=state_out))
         else:

@@ -100,7 +100,11 @@ def test_single_level_other_aggregator_geometries(dev, tag):
     if tag.startswith("td192") and "paths_attention_h3_any" in attn and O.WS_CHAIN_192 and O.WS_IMAGES_192:
         # trans_dim 192 / 4 heads: the first in_proj writes the attention's head_dim-48 operand images itself (csrc/tlayer_ws.hip), no prep launch
         attn = {"paths_attention_h3_any_img", "paths_token_layer_ws", "paths_attention_token0_any"}
-    assert attn | {"paths_layernorm_rows", "paths_tokens_assemble", "paths_importance_rows", "paths_final_head_any"} <= set(calls)
+    # (1-D encoding: the table is sized by the row count, so importance + tokens run as the one fused launch; the drop-in 2-D call has no
+    # grid size to size a table from and keeps the two launches)
+    rows_k = {"paths_importance_tokens_rows"} if ("paths_importance_tokens_rows" in calls) else {"paths_tokens_assemble", "paths_importance_rows"}
+    assert ("paths_importance_tokens_rows" in calls) == (tag.endswith("pe1d") and O.FUSE_IMPORTANCE_TOKENS and "paths_gemm_add_nt_x6" in calls)
+    assert attn | rows_k | {"paths_layernorm_rows", "paths_final_head_any"} <= set(calls)
     np.testing.assert_allclose(out["logits"].numpy(), g["logits"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out["ctx_slide"].numpy(), g["ctx_slide"], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(out["importance"].numpy(), g["importance"], atol=STATE_TOL, rtol=0)
