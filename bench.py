@@ -88,12 +88,14 @@ def host_cpu_share_all() -> int:
     return max(1, n)
 
 
-def build_model(K: int, dev, dropout=None):
+def build_model(K: int, dev, dropout=None, trans_dim=None):
     from paths_amd import synthetic as syn
     from paths_amd.config import Config
     cfg = Config.load(os.path.join(ROOT, "tests", "golden", "sample"), test_mode=True)
     if dropout is not None:               # (None: the shipped value, models/sample/config.json: 0.05; only train mode reads it)
         cfg.model_config.dropout = float(dropout)
+    if trans_dim is not None:             # (td192 probe: the reference's dataclass default width, config.py:30)
+        cfg.model_config.trans_dim = int(trans_dim)
     cfg.top_k_patches = [K // 4] * (cfg.num_levels - 1)
     model = cfg.get_model()
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -365,6 +367,30 @@ def train_bench(args, cfg, model, slides, rank, world, dev, pdist, putils, _unus
         dist.destroy_process_group()
 
 
+def td192_probe(slides, K, spg, rank, world, dev, dev_reduce, pdist, putils, steps: int):
+    """The headline workload (same resident slides, 5 levels, K = 2048) with the aggregator at the reference's dataclass-default width
+    (trans_dim 192 = 4 heads of 48, reference config.py:30; the shipped models/sample/config.json says 128): weight-stationary chain and
+    token-0 tail instantiated at 192, attention on the head_dim-48 split-operand kernel; launch tape replay; whole-job slides/s."""
+    cfg, model, _ = build_model(K, dev, None, trans_dim=192)
+    tape = putils.TapedRecursion(model, slides, cfg.top_k_patches, cfg.num_levels).record()
+    for _ in range(3):
+        tape.replay()
+    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = tape.replay()
+    torch.cuda.synchronize(); pdist.barrier(); torch.cuda.synchronize()
+    el = pdist.max_over_ranks(time.perf_counter() - t0, dev_reduce)
+    assert int(out["status"].item()) == 0
+    tape.close()
+    del tape, model
+    torch.cuda.empty_cache()
+    return {"slides_per_s": round(spg * world * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "slides_per_gpu": spg,
+            "trans_dim": 192, "trans_heads": 4,
+            "workload": "the headline recursion (5 levels, K = 2048, same resident slides) at the reference's dataclass-default aggregator width "
+                        "(config.py:30); parity at this width: tests/test_gpu_parity.py::test_recursion_trans_dim_192_at_k1024_vs_oracle, G12 / G13 fixtures"}
+
+
 def k1024_probe(model, cfg, spg, rank, world, dev, dev_reduce, pdist, putils, steps: int):
     """BASELINE.json configs[1] ("5-level PATHS, K=1024 patches/level, d=1024, 1 x MI355X"): the headline's launch mode (recorded
     tape) on this rank's own resident K = 1024 slides; whole-job slides/s.  Measured at the headline's batch (``spg`` slides per step
@@ -524,6 +550,8 @@ def main():
                     "K = 8192 x d = 1536, fp32-accurate path and the opt-in e4m3 variants at trans_dim 128 / 4 heads, 1536 / 24 heads and 1536 / 4 heads); 0 = skip")
     ap.add_argument("--k1024-steps", type=int, default=20, help="infer mode: timed steps of the 'k1024' object (BASELINE configs[1]: the same "
                     "5-level recursion at K = 1024 patches per level on one GPU's 8 resident slides); 0 = skip")
+    ap.add_argument("--td192-steps", type=int, default=20, help="infer mode: timed steps of the 'trans_dim_192' object (the headline workload at the "
+                    "reference's dataclass-default aggregator width, config.py:30); 0 = skip")
     ap.add_argument("--cores-per-rank", type=int, default=0, help="pin this rank to N host cores (cores [rank N, rank N + N) of the "
                     "process's allowed set) BEFORE anything touches the GPU: what a rank gets when 8 ranks share one host's CPU share "
                     "(0 = leave the affinity alone)")
@@ -993,6 +1021,15 @@ def main():
         except Exception as e:
             k1024 = {"error": f"{type(e).__name__}: {e}"[:400]}
             log(f"k1024 probe FAILED: {k1024['error']}")
+    # ---- the reference's dataclass-default aggregator width on the headline workload (second-class speed is visible in the record)
+    td192 = None
+    if K == 2048 and args.td192_steps > 0:
+        try:
+            td192 = td192_probe(slides, K, spg, rank, world, dev, dev_reduce, pdist, putils, args.td192_steps)
+            log(f"trans_dim 192: {td192['slides_per_s']} slides/s")
+        except Exception as e:
+            td192 = {"error": f"{type(e).__name__}: {e}"[:400]}
+            log(f"trans_dim 192 probe FAILED: {td192['error']}")
     # ---- BASELINE.json configs[4]: the stress geometry, accurate path + the opt-in e4m3 variants, so the driver's record carries it
     stress = None
     replayed_launches = graphed is not None
@@ -1059,6 +1096,8 @@ def main():
             line["sustained"] = sustained
         if k1024 is not None:
             line["k1024"] = k1024
+        if td192 is not None:
+            line["trans_dim_192"] = td192
         if stress is not None:
             line["stress"] = stress
         if breakdown is not None:

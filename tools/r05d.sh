@@ -1,7 +1,7 @@
 set -o pipefail
 python -m pytest tests -m gpu -q -x  > gpurun_out/r05i_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r05i_tests.log; tail -4 gpurun_out/r05i_tests.log
 for rep in 1 2; do for m in 0 1 2; do
-  PATHS_FUSE_QKV=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --stress-steps 0 --k1024-steps 0 > gpurun_out/r05i_bench_f${m}_${rep}.json 2> gpurun_out/r05i_bench_f${m}_${rep}.err
+  PATHS_FUSE_QKV=$m python bench.py --steps 20 --warmup 5 --no-cpu-baseline --train-steps 0 --stress-steps 0 --k1024-steps 0 --td192-steps 0 > gpurun_out/r05i_bench_f${m}_${rep}.json 2> gpurun_out/r05i_bench_f${m}_${rep}.err
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/r05i_bench_f${m}_${rep}.json").read().strip().splitlines()[-1])
