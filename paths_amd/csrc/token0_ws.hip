@@ -442,15 +442,37 @@ token0_dist_kernel(T0Params p) {
       w2[i] = ldg_f32x4(W + OFF_W2 + (((j * HS) / 4 + kq7 * nld + i) * DM + f7) * 4);
     }
 
+  // (trans_dim 128: the A_head quarter and the first round of this workgroup's token rows go out with the slices, ahead of the x0 row
+  // and the query they are multiplied with - their round trips (from beyond the L2 inside a level) run under phase 0; at 192 the
+  // 12 waves have no registers for it)
+  constexpr bool A_EARLY = DM == 128;
+  const float* const A = W + OFF_A + (int64_t)head * DM * DM;
+  f32x4 w[NQ];
+  if constexpr (A_EARLY) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) w[i] = ldg_f32x4(A + ((NQ * kq7 + i) * DM + f7) * 4);
+  }
+  const int len = min((int)p.num_ims[b] + 1, p.T);
+  const int chunk = (len + p.nts - 1) / p.nts;
+  const int k0 = ts * chunk, k1 = min(len, k0 + chunk);
+  const int l5 = lane & 31, slot = wave * 2 + (lane >> 5);
+  // rounds of RT tokens per half-wave; the row pieces of round r + 1 are in flight while round r is reduced (two register sets)
+  float xa[RT][FPL], xn[RT][FPL];
+  auto fetch = [&](float (&dst)[RT][FPL], int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < RT; ++u) ld_feats<FPL>(xb + (int64_t)max(min(base + u * SLOTS + slot, k1 - 1), 0) * DM + FPL * l5, dst[u]);
+  };
+  if (A_EARLY && k0 < k1) fetch(xa, k0);
+
   T0_STAMP(0);
   // ---- phase 0: qt = A_head x0 + a0_head
   if (tid < DM) sX0[tid] = xb[(p.special_last ? (int64_t)min((int)p.num_ims[b], p.T - 1) * DM : 0) + tid];
   __syncthreads();
   {
-    const float* A = W + OFF_A + (int64_t)head * DM * DM;
-    f32x4 w[NQ];
+    if constexpr (!A_EARLY) {
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) w[i] = ldg_f32x4(A + ((NQ * kq7 + i) * DM + f7) * 4);
+      for (int i = 0; i < NQ; ++i) w[i] = ldg_f32x4(A + ((NQ * kq7 + i) * DM + f7) * 4);
+    }
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) acc += dot4(w[i], *reinterpret_cast<const f32x4*>(sX0 + (DM / 4) * kq7 + 4 * i));
@@ -462,10 +484,6 @@ token0_dist_kernel(T0Params p) {
 
   T0_STAMP(1);
   // ---- phase 1: online softmax over this workgroup's tokens, z = sum p x; one token per half-wave and iteration, FPL features per lane
-  const int len = min((int)p.num_ims[b] + 1, p.T);
-  const int chunk = (len + p.nts - 1) / p.nts;
-  const int k0 = ts * chunk, k1 = min(len, k0 + chunk);
-  const int l5 = lane & 31, slot = wave * 2 + (lane >> 5);
   float qv[FPL];
 #pragma unroll
   for (int e = 0; e < FPL; ++e) qv[e] = sQ[FPL * l5 + e];
@@ -473,12 +491,6 @@ token0_dist_kernel(T0Params p) {
   float z[FPL];
 #pragma unroll
   for (int e = 0; e < FPL; ++e) z[e] = 0.f;
-  // rounds of RT tokens per half-wave; the row pieces of round r + 1 are in flight while round r is reduced (two register sets)
-  float xa[RT][FPL], xn[RT][FPL];
-  auto fetch = [&](float (&dst)[RT][FPL], int base) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < RT; ++u) ld_feats<FPL>(xb + (int64_t)max(min(base + u * SLOTS + slot, k1 - 1), 0) * DM + FPL * l5, dst[u]);
-  };
   auto reduce = [&](const float (&x)[RT][FPL], int base) __attribute__((always_inline)) {
     float s[RT];
     bool ok[RT];
@@ -503,7 +515,7 @@ token0_dist_kernel(T0Params p) {
     l = l * alpha + ps;
     m = mx;
   };
-  if (k0 < k1) fetch(xa, k0);
+  if (!A_EARLY && k0 < k1) fetch(xa, k0);
   for (int base = k0; base < k1; base += 2 * RT * SLOTS) {
     if (base + RT * SLOTS < k1) fetch(xn, base + RT * SLOTS);
     reduce(xa, base);
