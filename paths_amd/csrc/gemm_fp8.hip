@@ -25,9 +25,10 @@ namespace {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int ROWB = 80;                       // bytes per LDS row (64 + 16 pad)
-constexpr int TILE_B = BM * ROWB;              // 20 KiB per operand tile
+constexpr int BM = 256, BN = 256;
+// k bytes per stage BK = 64 (any K % 128 == 0) or 128 (K % 256 == 0: two MFMA k-steps per barrier, whole 128-byte lines per row piece);
+// LDS rows of BK + 16 bytes: 80 / 144 bytes = 20 / 36 dwords, both conflict-free for the 16-byte fragment reads of 16 consecutive rows
+template <int BK> struct Fp8Tile { static constexpr int ROWB = BK + 16, TILE_B = BM * ROWB; };
 constexpr int SCALE_ONE = 0x7F7F7F7F;          // E8M0 127 = 2^0 in every byte
 
 __device__ __forceinline__ uint32_t fp8x4(float a, float b, float c, float d) {
@@ -93,8 +94,11 @@ struct Fp8Gemm {
   unsigned int* out_absmax;          // optional: max |result| as float bits (atomicMax), for calibrating out_scale
 };
 
+template <int BK>
 __global__ void __launch_bounds__(256)
 gemm_fp8_kernel(Fp8Gemm g) {
+  constexpr int ROWB = Fp8Tile<BK>::ROWB, TILE_B = Fp8Tile<BK>::TILE_B;
+  constexpr int LPR = BK / 16, RPP = 256 / LPR, NPASS = 256 / RPP;     // 16-byte pieces per row, rows per pass of the 256 threads, passes per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];        // [2 buffers][A tile | B tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -106,15 +110,15 @@ gemm_fp8_kernel(Fp8Gemm g) {
   const int mt = xcd + 8 * (4 * grp + (rem & 3)), nt = rem >> 2;
   if (mt >= g.MT) return;
   const int m0 = mt * BM, n0 = nt * BN;
-  // staging: a 256 x 64-byte tile per operand and stage = 4 x 16-byte loads per thread (4 lanes per 64-byte row piece)
-  const int sr = tid >> 2, sq = tid & 3;
-  u32x4 ra[2][4], rb[2][4];                  // two register sets: the loads of stage k + 2 are issued while stage k computes
+  // staging: a 256 x BK-byte tile per operand and stage = NPASS x 16-byte loads per thread (LPR lanes per row piece)
+  const int sr = tid / LPR, sq = tid % LPR;
+  u32x4 ra[2][NPASS], rb[2][NPASS];                  // two register sets: the loads of stage k + 2 are issued while stage k computes
   auto gload = [&](int kt, auto set) {
     constexpr int S = decltype(set)::value;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      ra[S][p] = *reinterpret_cast<const u32x4*>(g.A8 + (int64_t)(m0 + sr + 64 * p) * g.K + kt * BK + 16 * sq);
-      rb[S][p] = *reinterpret_cast<const u32x4*>(g.W8 + (int64_t)(n0 + sr + 64 * p) * g.K + kt * BK + 16 * sq);
+    for (int p = 0; p < NPASS; ++p) {
+      ra[S][p] = *reinterpret_cast<const u32x4*>(g.A8 + (int64_t)(m0 + sr + RPP * p) * g.K + kt * BK + 16 * sq);
+      rb[S][p] = *reinterpret_cast<const u32x4*>(g.W8 + (int64_t)(n0 + sr + RPP * p) * g.K + kt * BK + 16 * sq);
     }
   };
   auto swrite = [&](int buf, auto set) {
@@ -122,8 +126,8 @@ gemm_fp8_kernel(Fp8Gemm g) {
     char* sA = smem + buf * 2 * TILE_B;
     char* sB = sA + TILE_B;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = sr + 64 * p;
+    for (int p = 0; p < NPASS; ++p) {
+      const int row = sr + RPP * p;
       *reinterpret_cast<u32x4*>(sA + row * ROWB + 16 * sq) = ra[S][p];
       *reinterpret_cast<u32x4*>(sB + row * ROWB + 16 * sq) = rb[S][p];
     }
@@ -150,6 +154,10 @@ gemm_fp8_kernel(Fp8Gemm g) {
     const u32x4 hi = *reinterpret_cast<const u32x4*>(base + 16);
     return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
   };
+  i32x8 bf[2][4], af01[2], af23[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bf[1][j] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+  af23[0] = af23[1] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
   // One stage, as ONE basic block with the phase order pinned by hand -
   // hipcc otherwise waits for the next stage's global loads and writes them to LDS BEFORE the MFMAs of this stage (a full memory
   // round trip exposed per 64 k: 0.7 PFLOP/s).  Stage j's operands travel in register set j & 1.  Stage k (LDS buffer k & 1): global
@@ -165,21 +173,31 @@ gemm_fp8_kernel(Fp8Gemm g) {
     gload(min(kt + 2, nk - 1), set);             // set k & 1 is free: stage k went to LDS during stage k - 1
     const char* sA = smem + buf * 2 * TILE_B + (wm * 128 + fr) * ROWB + 32 * fh;
     const char* sB = smem + buf * 2 * TILE_B + TILE_B + (wn * 128 + fr) * ROWB + 32 * fh;
-    i32x8 bf[4], af[4];
+    // Software pipeline over the 64-k steps (t = running step): fragments of step t are read (B tiles + A rows 0, 1), then the MFMAs of
+    // rows 2, 3 of step t - 1 run on the fragments that are still in registers (bf[old], af23) while those reads land, then A rows 2, 3
+    // of step t are read under ... and the MFMAs of rows 0, 1 of step t run.  The matrix pipe never waits for an LDS read (it did for
+    // ~900 of every ~2,000 cycles: 16 MFMAs = 1,024).  bf is double-buffered (cur = step parity), af01 / af23 single sets.
+    static_for<0, BK / 64>([&](auto ks_) {
+      constexpr int ks = decltype(ks_)::value;
+      constexpr int cur = BK == 64 ? SET : ks;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = frag(sB + j * 32 * ROWB);
-    af[0] = frag(sA);
-    af[1] = frag(sA + 32 * ROWB);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 4; ++j) bf[cur][j] = frag(sB + j * 32 * ROWB + 64 * ks);
+      af01[0] = frag(sA + 64 * ks);
+      af01[1] = frag(sA + 32 * ROWB + 64 * ks);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[0], bf[j], acc[0][j], 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
-    af[2] = frag(sA + 2 * 32 * ROWB);
-    af[3] = frag(sA + 3 * 32 * ROWB);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 1; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af23[i], bf[cur ^ 1][j], acc[2 + i][j], 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
+      __builtin_amdgcn_sched_barrier(0);
+      af23[0] = frag(sA + 2 * 32 * ROWB + 64 * ks);
+      af23[1] = frag(sA + 3 * 32 * ROWB + 64 * ks);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af[i], bf[j], acc[i][j], 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af01[i], bf[cur][j], acc[i][j], 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
+    });
     __builtin_amdgcn_sched_barrier(0);
     swrite(buf ^ 1, std::integral_constant<int, SET ^ 1>{});
     __syncthreads();
@@ -188,50 +206,124 @@ gemm_fp8_kernel(Fp8Gemm g) {
     stage(kt, S0{});
     stage(kt + 1, S1{});
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(af23[i], bf[1][j], acc[2 + i][j], 0, 0, 0, SCALE_ONE, 0, SCALE_ONE);
 
-  // epilogue: C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Rows past M are
-  // read (residual) from row M - 1 and never stored: the loads of a tile go out together instead of one branch each.
+  // epilogue: C/D map of the 32 x 32 forms: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Written straight from that
+  // layout a tile left as 256 four-byte stores per lane to 64 K scattered 128-byte pieces: 54 us (e4m3 bytes) to 80 us (fp32 + residual)
+  // per tile, as long as the whole k loop at K = 1536 (tools/fp8_gemm_time.py).  Each wave now turns its 32-row bands through its own
+  // 17 KB of the (dead) staging LDS - row stride 136 floats: the two half-waves of a write land 32 banks apart, a 16-byte read covers all
+  // 64 banks once - and stores whole row pieces: 16 bytes per lane, 512 contiguous bytes per half-wave (fp32) or 128 per 8 lanes (e4m3).
   const float inv = 1.0f / (*g.a_scale * *g.w_scale);
   const float oscale = g.out8 ? *g.out_scale : 1.0f;
   float amax = 0.f;
+  constexpr int STG_LD = 136;
+  __syncthreads();                                       // every wave is done with the operand tiles
+  float* const stg = reinterpret_cast<float*>(smem) + wave * (32 * STG_LD);
+  const int colw = n0 + wn * 128;                        // first column of this wave
+  if (g.out8) {
+    const int c16 = (lane & 7) * 16, rl0 = lane >> 3;    // 16 columns per lane, 8 rows per pass
+    float bv[16];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int col = n0 + wn * 128 + 32 * j + fr;
-    const int colc = min(col, g.N - 1);
-    const float bv = g.bias ? g.bias[colc] : 0.f;
-    const float* rp = g.residual ? g.residual + colc : nullptr;
-    float* op = g.out + col;
+    for (int e = 0; e < 16; ++e) bv[e] = (g.bias && colw + c16 + e < g.N) ? g.bias[colw + c16 + e] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int rbase = m0 + wm * 128 + 32 * i + 4 * fh + 16 * half;       // rows rbase + (r & 3) + 8 (r >> 2), r = 0 .. 7
-        float res[8];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 8; ++r) res[r] = rp ? rp[(int64_t)min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1) * g.ldr] : 0.f;
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * fh) * STG_LD + 32 * j + fr] = acc[i][j][r];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          float v = acc[i][j][8 * half + r] * inv + bv;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          v += res[r];
-          if (row < g.M && col < g.N) {
-            amax = fmaxf(amax, fabsf(v));
-            if (g.out8) {
-              const float q = fminf(fmaxf(v * oscale, -448.f), 448.f);
-              g.out8[(int64_t)row * g.N + col] = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(q, 0.f, 0, false) & 0xff);
-            } else {
-              op[(int64_t)row * g.ldo] = v;
-            }
+      for (int it = 0; it < 4; ++it) {
+        const int rl = 8 * it + rl0, row = m0 + wm * 128 + 32 * i + rl;
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(stg + rl * STG_LD + c16 + 4 * q);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = t[e] * inv + bv[4 * q + e];
+            if (g.act == 1) v[e] = fmaxf(v[e], 0.f);
+            if (row < g.M && colw + c16 + 4 * q + e < g.N) amax = fmaxf(amax, fabsf(v[e]));
           }
+          pk[q] = fp8x4(v[0] * oscale, v[1] * oscale, v[2] * oscale, v[3] * oscale);
+        }
+        if (row < g.M) {
+          uint8_t* dst = g.out8 + (int64_t)row * g.N + colw + c16;
+          if (colw + c16 + 15 < g.N && (g.N & 15) == 0) *reinterpret_cast<u32x4*>(dst) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+          else
+            for (int e = 0; e < 16; ++e)
+              if (colw + c16 + e < g.N) dst[e] = (uint8_t)(pk[e >> 2] >> (8 * (e & 3)));
         }
       }
+    }
+  } else {
+    const int c4 = (lane & 31) * 4, rl0 = lane >> 5;     // 4 columns per lane, 2 rows per pass
+    const bool vec = colw + c4 + 3 < g.N && (g.ldo & 3) == 0 && (!g.residual || (g.ldr & 3) == 0);
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (g.bias && colw + c4 + e < g.N) ? g.bias[colw + c4 + e] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * fh) * STG_LD + 32 * j + fr] = acc[i][j][r];
+      // residual rows of the band first (16 independent 16-byte loads in flight), then the arithmetic and the stores
+      f32x4 res[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = min(m0 + wm * 128 + 32 * i + 2 * it + rl0, g.M - 1);
+        res[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (g.residual) {
+          if (vec) res[it] = *reinterpret_cast<const f32x4*>(g.residual + (int64_t)row * g.ldr + colw + c4);
+          else
+            for (int e = 0; e < 4; ++e) res[it][e] = colw + c4 + e < g.N ? g.residual[(int64_t)row * g.ldr + colw + c4 + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int rl = 2 * it + rl0, row = m0 + wm * 128 + 32 * i + rl;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(stg + rl * STG_LD + c4);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = t[e] * inv + bv[e];
+          if (g.act == 1) x = fmaxf(x, 0.f);
+          v[e] = x + res[it][e];
+          if (row < g.M && colw + c4 + e < g.N) amax = fmaxf(amax, fabsf(v[e]));
+        }
+        if (row < g.M) {
+          float* dst = g.out + (int64_t)row * g.ldo + colw + c4;
+          if (vec) *reinterpret_cast<f32x4*>(dst) = v;
+          else
+            for (int e = 0; e < 4; ++e)
+              if (colw + c4 + e < g.N) dst[e] = v[e];
+        }
+      }
+    }
   }
   if (g.out_absmax) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
     if (lane == 0) atomicMax(g.out_absmax, __float_as_uint(amax));
   }
+}
+
+static int launch_fp8(const Fp8Gemm& g, int blocks, int K, hipStream_t stream, const char* name) {
+  // (the 128-byte stage - half the barriers - needs 64 more staging registers than the pipelined k-steps leave: it spills; kept for A/B runs)
+  static const bool bk128 = getenv("PATHS_FP8_BK128") != nullptr && atoi(getenv("PATHS_FP8_BK128")) != 0;
+  if (K % 256 == 0 && bk128) {
+    PATHS_LDS_OPT_IN(gemm_fp8_kernel<128>, 4 * Fp8Tile<128>::TILE_B, name);
+    hipLaunchKernelGGL(gemm_fp8_kernel<128>, dim3(blocks), dim3(256), 4 * Fp8Tile<128>::TILE_B, stream, g);
+  } else {
+    PATHS_LDS_OPT_IN(gemm_fp8_kernel<64>, 4 * Fp8Tile<64>::TILE_B, name);
+    hipLaunchKernelGGL(gemm_fp8_kernel<64>, dim3(blocks), dim3(256), 4 * Fp8Tile<64>::TILE_B, stream, g);
+  }
+  PATHS_LAUNCH_CHECK(name);
+  return PATHS_OK;
 }
 
 }  // namespace
@@ -282,14 +374,13 @@ int paths_fp8_quantize(const float* x, int64_t ld, int M, int K, const float* sc
 int paths_gemm_nt_fp8(const uint8_t* a8, const uint8_t* w8, const float* a_scale, const float* w_scale, const float* bias,
                       float* out, int64_t ldo, int M, int N, int K, int act, const float* residual, int64_t ldr, hipStream_t stream) {
   PATHS_REQUIRE(a8 && w8 && a_scale && w_scale && out && M > 0 && N > 0 && K > 0, "gemm_nt_fp8: bad arguments");
-  PATHS_REQUIRE(K % (2 * BK) == 0 && ((uintptr_t)a8 | (uintptr_t)w8) % 16 == 0, "gemm_nt_fp8: K (%d) must be a multiple of 128, operands 16-byte aligned", K);
+  PATHS_REQUIRE(K % 128 == 0 && ((uintptr_t)a8 | (uintptr_t)w8) % 16 == 0, "gemm_nt_fp8: K (%d) must be a multiple of 128, operands 16-byte aligned", K);
   PATHS_REQUIRE(act == 0 || act == 1, "gemm_nt_fp8: act must be 0 or 1");
-  PATHS_LDS_OPT_IN(gemm_fp8_kernel, 4 * TILE_B, "gemm_nt_fp8");
   const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
   Fp8Gemm g{a8, w8, a_scale, w_scale, bias, residual, ldr, out, ldo, M, N, K, act, MT, NT, nullptr, nullptr, nullptr};
   const int groups = ((MT + 7) / 8 + 3) / 4;            // groups of 4 row panels per XCD
-  hipLaunchKernelGGL(gemm_fp8_kernel, dim3(8 * groups * 4 * NT), dim3(256), 4 * TILE_B, stream, g);
-  PATHS_LAUNCH_CHECK("gemm_nt_fp8");
+  const int rc_ = launch_fp8(g, 8 * groups * 4 * NT, K, stream, "gemm_nt_fp8");
+  if (rc_ != PATHS_OK) return rc_;
   return PATHS_OK;
 }
 
@@ -301,14 +392,13 @@ int paths_gemm_nt_fp8_out8(const uint8_t* a8, const uint8_t* w8, const float* a_
                            uint8_t* out8, const float* out_scale, unsigned int* out_absmax, int M, int N, int K, int act,
                            hipStream_t stream) {
   PATHS_REQUIRE(a8 && w8 && a_scale && w_scale && out8 && out_scale && M > 0 && N > 0 && K > 0, "gemm_nt_fp8_out8: bad arguments");
-  PATHS_REQUIRE(K % (2 * BK) == 0 && ((uintptr_t)a8 | (uintptr_t)w8) % 16 == 0, "gemm_nt_fp8_out8: K (%d) must be a multiple of 128, operands 16-byte aligned", K);
+  PATHS_REQUIRE(K % 128 == 0 && ((uintptr_t)a8 | (uintptr_t)w8) % 16 == 0, "gemm_nt_fp8_out8: K (%d) must be a multiple of 128, operands 16-byte aligned", K);
   PATHS_REQUIRE(act == 0 || act == 1, "gemm_nt_fp8_out8: act must be 0 or 1");
-  PATHS_LDS_OPT_IN(gemm_fp8_kernel, 4 * TILE_B, "gemm_nt_fp8_out8");
   const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
   Fp8Gemm g{a8, w8, a_scale, w_scale, bias, nullptr, 0, nullptr, 0, M, N, K, act, MT, NT, out8, out_scale, out_absmax};
   const int groups = ((MT + 7) / 8 + 3) / 4;
-  hipLaunchKernelGGL(gemm_fp8_kernel, dim3(8 * groups * 4 * NT), dim3(256), 4 * TILE_B, stream, g);
-  PATHS_LAUNCH_CHECK("gemm_nt_fp8_out8");
+  const int rc_ = launch_fp8(g, 8 * groups * 4 * NT, K, stream, "gemm_nt_fp8_out8");
+  if (rc_ != PATHS_OK) return rc_;
   return PATHS_OK;
 }
 
