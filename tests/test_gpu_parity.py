@@ -1605,3 +1605,44 @@ def test_fused_importance_qkv_finish_in_the_recursion(dev, monkeypatch):
             assert torch.equal(ia, ib) and float((la - lb).abs().max()) < 2e-6, (mode, l)
             if ka is not None:
                 assert torch.equal(ka, kb), (mode, l)
+
+
+@pytest.mark.parametrize("pe_mode,d,Hi,N,lens", [(2, 192, 128, 300, [300, 37, 0]), (1, 192, 128, 257, [257, 256]), (2, 64, 36, 96, [96, 5]), (1, 320, 64, 130, [1, 130])])
+def test_importance_tokens_rows_equals_the_two_launches(dev, pe_mode, d, Hi, N, lens):
+    """paths_importance_tokens_rows (generic geometries: importance logits + token rows in one pass, positional encoding from the table)
+    against paths_importance_rows + paths_tokens_assemble on the same [W1 ; Wp] product (reference model/paths.py:95-98,119-124,
+    model/aggregator.py:37-65): importance and the tokens of valid rows bit-identical (same expressions, the table holds the values the
+    sin / cos calls return), padded rows importance 0 and token = bp + PE even when the product's padded rows hold NaN."""
+    import math
+    from paths_amd import _lib
+    B, M, ps = len(lens), len(lens) * N, 256
+    gen = torch.Generator(device=dev); gen.manual_seed(N + d)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=gen) * 2 - 1
+    ldh = Hi + d + 8
+    hid = rnd(M, ldh)
+    num_ims = torch.tensor(lens, device=dev, dtype=torch.int64)
+    valid = (torch.arange(N, device=dev)[None, :] < num_ims[:, None]).reshape(M)
+    hid_nan = hid.clone()
+    hid_nan[~valid] = float("nan")                           # what a skipped all-padding tile may leave behind
+    w2, b2, bp, special = rnd(Hi) * 0.3, rnd(1) * 0.1, rnd(d) * 0.1, rnd(d)
+    locs = (torch.randint(0, 200, (B, N, 2), device=dev, generator=gen) * ps).to(torch.int64)
+    W = d // 2 if pe_mode == 2 else d
+    div = torch.exp(torch.arange(0, W, 2, device=dev).float() * (-math.log(10000.0) / W)).contiguous()
+    rows = 200 if pe_mode == 2 else N
+    tab = torch.empty((rows, W), device=dev)
+    p, st = _lib.ptr, _lib.stream()
+    _lib.call("paths_pe_table", p(div), pe_mode, d, rows, p(tab), st)
+    for imp_mul in (1, 0):
+        imp_a, imp_b = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        tok_a, tok_b = torch.empty(B, N + 1, d, device=dev), torch.empty(B, N + 1, d, device=dev)
+        src = hid_nan if imp_mul else hid                    # (importance not multiplied in: the product's padded rows are zero-filled by the caller)
+        if not imp_mul:
+            src = hid.clone(); src[~valid] = 0.0
+        _lib.call("paths_importance_rows", p(src), ldh, p(w2), p(b2), p(num_ims), N, M, Hi, p(imp_a), 1, st)
+        _lib.call("paths_tokens_assemble", src.data_ptr() + 4 * Hi, ldh, p(imp_a), imp_mul, p(bp), p(special), p(div), p(locs), N, ps, pe_mode, d, B, p(tok_a), st)
+        _lib.call("paths_importance_tokens_rows", p(src), ldh, p(w2), p(b2), p(num_ims), N, M, Hi, p(imp_b), 1, imp_mul, p(bp), p(special), p(tab), rows,
+                  p(locs), ps, pe_mode, d, p(tok_b), st)
+        torch.cuda.synchronize()
+        assert torch.equal(imp_a.view(torch.int32), imp_b.view(torch.int32))
+        assert bool((imp_b[~valid] == 0).all()) and bool(torch.isfinite(tok_b).all())
+        assert torch.equal(tok_a.view(torch.int32), tok_b.view(torch.int32)), (imp_mul, float((tok_a - tok_b).abs().max()))
