@@ -1268,7 +1268,7 @@ def test_attention_h3_any_matches_fp64(dev, hd, H):
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(256, 256, 128, 0, True), (1000, 640, 256, 0, True), (300, 100, 128, 1, False), (4097, 1536, 1536, 0, True),
-                                           (513, 384, 512, 1, False)])
+                                           (513, 384, 512, 1, False), (130, 99, 128, 0, True), (130, 99, 128, 1, False)])
 def test_gemm_fp8_matches_float64_on_the_same_quantised_operands(dev, M, N, K, act, res):
     """csrc/gemm_fp8.hip (v_mfma_scale_f32_32x32x64_f8f6f4, opt-in stress variant): device-side per-tensor scales = 448 / max|.|, and the
     product equals float64 arithmetic on the SAME e4m3-quantised operands to accumulation accuracy (the operand lane map is right,
