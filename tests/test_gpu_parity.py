@@ -860,9 +860,10 @@ def test_weight_stationary_aggregator_path(dev, name):
         assert torch.equal(again["logits"], out_ws["logits"]) and torch.equal(again["ctx_slide"], out_ws["ctx_slide"])
 
 
+@pytest.mark.parametrize("ctx_mode", ["residual", "concat"])
 @pytest.mark.parametrize("d", [128, 192])
 @pytest.mark.parametrize("T,lens", [(2049, [2049, 1844, 700, 1]), (300, [300, 37, 129]), (65, [64, 65]), (8193, [8193, 5000])])
-def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens, d):
+def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens, d, ctx_mode):
     """paths_token_layer_ws (in_proj -> attention image -> post chain) and paths_token0_tail_ws on random weights and ragged slides
     against a float64 torch evaluation of the same decoder layers (reference model/aggregator.py:70-75), at the shipped width (128)
     and at the reference's dataclass default (192, config.py:30: chain kernel and token-0 tail instantiated at 192 / head_dim 48;
@@ -881,14 +882,18 @@ def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens, d):
         for n in ("ln1", "ln2", "ln3"):
             lay[n + "g"], lay[n + "b"] = 1 + rnd(d) * 0.1, rnd(d) * 0.1
         layers.append(lay)
-    lvl = {"layers": layers, "lnfg": 1 + rnd(d) * 0.1, "lnfb": rnd(d) * 0.1, "lnf_eps": 1e-5, "wcls": rnd(4, d) * 0.1, "bcls": rnd(4) * 0.1}
+    if ctx_mode == "concat" and T not in (300, 65):
+        pytest.skip("the concat head (reference model/paths.py:130-139) is checked at the two small shapes")
+    depth = 2 if ctx_mode == "concat" else 0
+    lvl = {"layers": layers, "lnfg": 1 + rnd(d) * 0.1, "lnfb": rnd(d) * 0.1, "lnf_eps": 1e-5, "wcls": rnd(4, (depth + 1) * d) * 0.1, "bcls": rnd(4) * 0.1}
 
     class MC:
-        trans_dim, trans_heads, trans_layers, slide_ctx_mode, importance_mlp_hidden_dim = d, Hh, 2, "residual", 128
+        trans_dim, trans_heads, trans_layers, slide_ctx_mode, importance_mlp_hidden_dim = d, Hh, 2, ctx_mode, 128
     tokens = rnd(B, T, d)
     num_ims = torch.tensor([n - 1 for n in lens], device=dev, dtype=torch.int64)
     ctx_prev = rnd(B, d)
-    out = ops._aggregator_forward(MC, lvl, tokens, num_ims, ctx_prev, None)
+    ctx_all = rnd(B, depth, d) if depth else None
+    out = ops._aggregator_forward(MC, lvl, tokens, num_ims, ctx_prev, ctx_all)
     torch.cuda.synchronize()
     ln = lambda x, g_, b_: torch.nn.functional.layer_norm(x, (d,), g_.double(), b_.double(), 1e-5)
     D = lambda t: t.double()
@@ -905,8 +910,9 @@ def test_token_layer_ws_and_tail_ws_vs_fp64(dev, T, lens, d):
             y = ln(y + D(lay["cab"]), lay["ln2g"], lay["ln2b"])
             y = ln(y + torch.relu(y @ D(lay["w1"]).T + D(lay["b1"])) @ D(lay["w2"]).T + D(lay["b2"]), lay["ln3g"], lay["ln3b"])
             x = y
-        ctx = ln(x[0], lvl["lnfg"], lvl["lnfb"]) + D(ctx_prev[b])
-        logits = ctx @ D(lvl["wcls"]).T + D(lvl["bcls"])
+        ctx = ln(x[0], lvl["lnfg"], lvl["lnfb"]) + (D(ctx_prev[b]) if ctx_mode == "residual" else 0)
+        feat = ctx if ctx_mode == "residual" else torch.cat([D(ctx_all[b]).reshape(-1), ctx])
+        logits = feat @ D(lvl["wcls"]).T + D(lvl["bcls"])
         assert float((D(out["ctx_slide"][b]) - ctx).abs().max()) < 1e-5, (b, n)
         assert float((D(out["logits"][b]) - logits).abs().max()) < 1e-5, (b, n)
 
