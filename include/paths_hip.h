@@ -175,7 +175,8 @@ int paths_gemm_nt_x6(const float* a, int64_t lda, const void* w_x6, int Kpacked,
                      int M, int N, int Npad, int K, int act, const float* residual, int64_t ldr, const float* mask,
                      int64_t ldm, int accumulate, int planes, float w_scale, float a_scale, paths_stream_t stream);
 /* out = act((A + A_add) W^T + b), planes = 2: the GEMM input is summed in fp32 while staged (Y = X + h1, reference model/paths.py:89-91,
- * never materialised); A as a matrix or as row addresses (exactly one of a / a_rows); num_ims (optional) skips whole tiles of padding. */
+ * never materialised); A as a matrix or as row addresses (exactly one of a / a_rows); num_ims (optional) skips whole tiles of padding.
+ * Npad a multiple of 256 (128 x 256 tiles) or of 192 (128 x 192 tiles: a 320-column product pads to 384 instead of 512). */
 int paths_gemm_add_nt_x6(const float* a, int64_t lda, const int64_t* a_rows, const float* a_add, int64_t ld_add, const void* w_x6, int Kpacked,
                          const float* b, float* out, int64_t ldo, int M, int N, int Npad, int K, int act, const int64_t* num_ims,
                          int rows_per_slide, float w_scale, float a_scale, paths_stream_t stream);

@@ -928,9 +928,16 @@ int paths_gemm_add_nt_x6(const float* a, int64_t lda, const int64_t* a_rows, con
                          int rows_per_slide, float w_scale, float a_scale, hipStream_t stream) {
   PATHS_REQUIRE((a != nullptr) != (a_rows != nullptr), "gemm_add_nt_x6: exactly one of a / a_rows");
   PATHS_REQUIRE(a_add != nullptr && ld_add % 4 == 0 && (uintptr_t)a_add % 16 == 0, "gemm_add_nt_x6: a_add must be 16-byte aligned with ld_add %% 4 == 0");
-  PATHS_REQUIRE(pow2(w_scale) && pow2(a_scale) && K == Kpacked && Npad % 256 == 0, "gemm_add_nt_x6: power-of-two scales, whole-K image, Npad %% 256 == 0");
+  PATHS_REQUIRE(pow2(w_scale) && pow2(a_scale) && K == Kpacked && (Npad % 256 == 0 || Npad % 192 == 0),
+                "gemm_add_nt_x6: power-of-two scales, whole-K image, Npad a multiple of 256 or of 192");
   X6Operands g{a, lda, K, a_rows, nullptr, 0, 0, a_add, ld_add, reinterpret_cast<const char*>(w_x6), group_stride(2, Kpacked), M, num_ims, rows_per_slide, a_scale};
   EpiBias e{b, out, ldo, N, act, nullptr, 0, nullptr, 0, 0, 1.0f / (w_scale * a_scale)};
+  if (Npad % 256 != 0) {
+    // 128 x 192 tiles: a width between two multiples of 256 pays for the columns it has (the [W1 ; Wp] product of trans_dim 192 is 320
+    // columns: two tiles of 192 instead of two of 256 - 61 -> 48 us)
+    return a_rows ? launch_x6_np<2, 2, 3, 2, true, true>(g, Npad, e, stream, "gemm_add_nt_x6(rows, 192-wide tiles)")
+                  : launch_x6_np<2, 2, 3, 2, true, false>(g, Npad, e, stream, "gemm_add_nt_x6(192-wide tiles)");
+  }
   return a_rows ? launch_x6_np<2, 2, 4, 2, true, true>(g, Npad, e, stream, "gemm_add_nt_x6(rows)")
                 : launch_x6_np<2, 2, 4, 2, true, false>(g, Npad, e, stream, "gemm_add_nt_x6");
 }

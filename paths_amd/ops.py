@@ -591,7 +591,7 @@ def importance_proj_generic_add(mc, lvl_pack, src, x_rows, add, locs, num_ims, B
     # M / 128 blocks each filled half the chip one after the other (2 x 56 us on the critical path at trans_dim 192), one launch of
     # twice the column tiles fills it once.  The relu of the hidden layer moves into paths_importance_rows (relu = 1).
     n = Hi + d
-    n_pad = (n + 255) // 256 * 256
+    n_pad = min((n + 255) // 256 * 256, (n + 191) // 192 * 192)      # (128 x 256 or 128 x 192 tiles, whichever pads less: 320 -> 384, not 512)
     k6 = f"w1p_x6_{split_planes()}"
     if k6 not in gp:
         gp["w1p"] = torch.cat([gp["w1"][:Hi], gp["wp"][:d]], dim=0).contiguous()
