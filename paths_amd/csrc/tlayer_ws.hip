@@ -352,10 +352,41 @@ tlayer_ws_kernel(WsParams p) {
     }
   };
 
-  // ---- prologue: residual rows, the small vectors, the first activation image, the head of the weight stream
+  // ---- prologue: the first activation image, the head of the weight stream, the small vectors, the residual rows.  Every load is
+  // ISSUED before the first one is waited for, in the order their data is needed (loads return in order): written as "load, store to
+  // LDS" per vector, the prologue was four dependent memory round trips - the bias / LayerNorm vectors drained the queue in front
+  // of the attention-output image - and inside a level every one of them comes from beyond the L2 (5.3 us of a 23-us kernel).
   int tokc[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) tokc[tt] = min(t0 + 16 * tt + ql, p.T - 1);
+  constexpr int NI = G::ACT / (16 * 64 * NW);          // 16-byte pieces of the image per thread
+  constexpr int NB1 = (4 * DM + 64 * NW - 1) / (64 * NW), NBQ = (3 * DM + 64 * NW - 1) / (64 * NW);
+  static_assert(DM <= 64 * NW, "one thread per feature for the small vectors");
+  const bool img_in = POST && p.attn_img != nullptr;
+  u32x4 oi[POST ? NI : 1];
+  if (img_in) {
+    // the attention kernel writes one image per 64-TOKEN GROUP, [kb][4 tiles][plane]; this workgroup takes tiles tt0 .. tt0 + TT - 1
+    constexpr int ACT64 = KB * 4 * 2 * FRAG, ROWB = TT * 2 * FRAG;                 // bytes per group / per k32 block of this workgroup
+    const char* src = p.attn_img + ((int64_t)b * (p.Tp / 64) + (t0 / 64)) * ACT64 + ((t0 >> 4) & 3) * 2 * FRAG;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int piece = tid + i * 64 * NW, kb = piece / (ROWB / 16), r = piece % (ROWB / 16);
+      oi[POST ? i : 0] = ldg_u32x4(src + (int64_t)kb * (4 * 2 * FRAG) + r * 16);
+    }
+  }
+  static_for<0, NPF - 1>([&](auto s) { wload(s); });
+  float v9[POST ? 9 : 1], vb1[POST ? NB1 : 1], vbq[QKV ? NBQ : 1];
+  if constexpr (POST) {
+    const float* const vecs[9] = {p.bo, p.ln1g, p.ln1b, p.cab, p.ln2g, p.ln2b, p.b2, p.ln3g, p.ln3b};
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v9[j] = tid < DM ? vecs[j][tid] : 0.f;
+#pragma unroll
+    for (int q = 0; q < NB1; ++q) vb1[q] = tid + q * 64 * NW < 4 * DM ? p.b1[tid + q * 64 * NW] : 0.f;
+  }
+  if constexpr (QKV) {
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) vbq[q] = tid + q * 64 * NW < 3 * DM ? p.bqkv[tid + q * 64 * NW] : 0.f;
+  }
   f32x4 xr[OT][TT];                 // POST: the residual stream of this lane's (feature, token) set
   if constexpr (POST) {
 #pragma unroll
@@ -363,26 +394,14 @@ tlayer_ws_kernel(WsParams p) {
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) xr[ot][tt] = ldg_f32x4(p.x_in + ((int64_t)b * p.T + tokc[tt]) * DM + fbase + 16 * ot);
   }
-  static_for<0, NPF - 1>([&](auto s) { wload(s); });
-  if constexpr (POST) {
-    const float* const vecs[9] = {p.bo, p.ln1g, p.ln1b, p.cab, p.ln2g, p.ln2b, p.b2, p.ln3g, p.ln3b};
+  // ... and only now the LDS stores, in arrival order
+  if (img_in) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
-      for (int i = tid; i < DM; i += 64 * NW) sVec[j * DM + i] = vecs[j][i];
-    for (int i = tid; i < 4 * DM; i += 64 * NW) sB1[i] = p.b1[i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<u32x4*>(sAct + (tid + i * 64 * NW) * 16) = oi[POST ? i : 0];
   }
-  if constexpr (QKV) for (int i = tid; i < 3 * DM; i += 64 * NW) sBqkv[i] = p.bqkv[i];
 
-  // first B-operand image: the attention output (POST) or the input rows themselves (QKV only)
-  if (POST && p.attn_img != nullptr) {
-    // the attention kernel writes one image per 64-TOKEN GROUP, [kb][4 tiles][plane]; this workgroup takes tiles tt0 .. tt0 + TT - 1
-    constexpr int ACT64 = KB * 4 * 2 * FRAG, ROWB = TT * 2 * FRAG;                 // bytes per group / per k32 block of this workgroup
-    const char* src = p.attn_img + ((int64_t)b * (p.Tp / 64) + (t0 / 64)) * ACT64 + ((t0 >> 4) & 3) * 2 * FRAG;
-#pragma unroll
-    for (int i = 0; i < G::ACT / (16 * 64 * NW); ++i) {
-      const int piece = tid + i * 64 * NW, kb = piece / (ROWB / 16), r = piece % (ROWB / 16);
-      *reinterpret_cast<u32x4*>(sAct + piece * 16) = ldg_u32x4(src + (int64_t)kb * (4 * 2 * FRAG) + r * 16);
-    }
+  // first B-operand image: the attention output as an image (above) or as rows, or the input rows themselves (QKV only)
+  if (img_in) {
   } else if constexpr (FIN) {
     // the input rows are built HERE from the raw result of the importance / projection GEMM (finish_qkv.h); the weight loads and
     // the bias vector issued above land under it
@@ -420,6 +439,21 @@ tlayer_ws_kernel(WsParams p) {
         *reinterpret_cast<u32x4*>(sAct + ((kb * TT + tt) * 2 + 1) * FRAG + lane * 16) = lo;
       }
     }
+  }
+  // the small vectors (first read after the first product / in the in_proj epilogue): behind every other load of the prologue
+  if constexpr (POST) {
+    if (tid < DM) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) sVec[j * DM + tid] = v9[j];
+    }
+#pragma unroll
+    for (int q = 0; q < NB1; ++q)
+      if (tid + q * 64 * NW < 4 * DM) sB1[tid + q * 64 * NW] = vb1[q];
+  }
+  if constexpr (QKV) {
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q)
+      if (tid + q * 64 * NW < 3 * DM) sBqkv[tid + q * 64 * NW] = vbq[q];
   }
   __syncthreads();
   WS_STAMP(1);
