@@ -171,15 +171,48 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
   float bpv[2], spv[2], b1v[2], w2v[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) { const int c = u0 + 32 * j + (lane & 31); bpv[j] = f.bp[c]; spv[j] = f.special[c]; b1v[j] = f.b1[c]; w2v[j] = f.w2[c]; }
-  const float ps_inv = 1.0f / (float)f.patch_size;
-  int tp[16];
+  // Load order (loads return in order; inside a level all of them come from beyond the L2): positions, then the first pair of slab
+  // tiles - ISSUED before the positions are waited for (position -> table row -> table value are two dependent round trips: they run
+  // under the slab stream, not in front of it), then the table rows, then the sums.
+  int64_t lp[16];
   if (f.pe_mode == 2) {
-    int64_t lp[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                     // (clamped indices: always legal)
       const int sl = t0 + 32 * wm + c32_row(r, lane);
       lp[r] = f.locs[2 * ((int64_t)b * f.N + min(sl, f.N - 1)) + wn];
     }
+  }
+  const bool has_rows = t0 < f.N;                      // (the extra tile - slot N, the special token of a full slide - has no GEMM rows behind it)
+  const int64_t trow = (((int64_t)b * f.N + min(t0, f.N - 1)) >> 5) + wm;
+  // hidden-unit tiles (j = 0, 1) only when alpha is computed here; with alpha read back (an importance-only finish ran) only the
+  // projection half of the slabs is touched (64 KB per workgroup instead of 128)
+  f32x4 v[2][4][NZ];
+  auto issue = [&](int j0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j0 + j) * 1024) + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int z = 0; z < NZ; ++z) v[j][q][z] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
+    }
+  };
+  float acc[4][16];
+  auto reduce = [&](auto j0_) __attribute__((always_inline)) {
+    constexpr int j0 = decltype(j0_)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 sum = v[j][q][0] + v[j][q][1];
+        acc[j0 + j][4 * q] = sum[0]; acc[j0 + j][4 * q + 1] = sum[1]; acc[j0 + j][4 * q + 2] = sum[2]; acc[j0 + j][4 * q + 3] = sum[3];
+      }
+  };
+  if (has_rows) issue(f.alpha_from_importance ? 2 : 0);
+  __builtin_amdgcn_sched_barrier(0);
+  const float ps_inv = 1.0f / (float)f.patch_size;
+  int tp[16];
+  if (f.pe_mode == 2) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int px24 = (int)min(max(lp[r], (int64_t)0), (int64_t)((1 << 24) - 1));
@@ -189,45 +222,7 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
 #pragma unroll
     for (int r = 0; r < 16; ++r) tp[r] = min(min(t0 + 32 * wm + c32_row(r, lane), f.N - 1), f.pe_rows - 1);
   }
-  float acc[4][16];
-  if (t0 >= f.N) {                                     // the extra tile (slot N: the special token of a full slide): no GEMM rows behind it
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  } else {
-    const int64_t trow = (((int64_t)b * f.N + t0) >> 5) + wm;
-    // hidden-unit tiles (j = 0, 1) only when alpha is computed here; with alpha read back (an importance-only finish ran) only the
-    // projection half of the slabs is touched (64 KB per workgroup instead of 128)
-    auto load_pair = [&](int j0) __attribute__((always_inline)) {
-      f32x4 v[2][4][NZ];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const f32x4* t = reinterpret_cast<const f32x4*>(f.ws + (trow * 8 + 4 * wn + j0 + j) * 1024) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int z = 0; z < NZ; ++z) v[j][q][z] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(t + 64 * q) + z * f.zstride);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 sum = v[j][q][0] + v[j][q][1];
-          acc[j0 + j][4 * q] = sum[0]; acc[j0 + j][4 * q + 1] = sum[1]; acc[j0 + j][4 * q + 2] = sum[2]; acc[j0 + j][4 * q + 3] = sum[3];
-        }
-    };
-    if (!f.alpha_from_importance) load_pair(0);
-    else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    }
-    load_pair(2);
-  }
-  FIN_STAMP(2);
-  float pev[16][2];                                    // positional-encoding values: in flight while the logits are reduced
+  float pev[16][2];                                    // positional-encoding values: in flight while the slabs land and the logits are reduced
 #pragma unroll
   for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -235,6 +230,24 @@ __device__ __forceinline__ void fin_tokens(const FinQkvParams& f, int b, int t0,
       const int c = u0 + 32 * j + (lane & 31);
       pev[r][j] = f.pe_mode == 2 ? f.pe_table[(int64_t)tp[r] * (d / 2) + (c & (d / 2 - 1))] : f.pe_table[(int64_t)tp[r] * d + c];
     }
+  __builtin_amdgcn_sched_barrier(0);
+  if (!has_rows) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  } else if (f.alpha_from_importance) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    reduce(std::integral_constant<int, 2>{});
+  } else {
+    reduce(std::integral_constant<int, 0>{});
+    issue(2);
+    reduce(std::integral_constant<int, 2>{});
+  }
+  FIN_STAMP(2);
   if (!f.alpha_from_importance) {
     // ---- partial importance logits over this wave's 64 hidden units, summed over the 32 lanes of each half-wave by the halving
     // butterfly of EpiImpProj (gemm_epi.h): afterwards lane l holds the total of row index rho(l) = bits 4..1 of l
