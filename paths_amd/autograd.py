@@ -135,6 +135,24 @@ def fill_dead_grads(model):
         p.grad = zero[:p.numel()].view_as(p)
 
 
+def clear_grads(model, optimizer):
+    """``optimizer.zero_grad(set_to_none=True)`` for one training step of this model - except that the DEAD parameters keep the
+    views of the shared zero buffer :func:`fill_dead_grads` gave them (they are exactly zero and nothing ever writes them: dropping
+    and re-creating 160 views per step was 0.9 ms of host time next to a 13-ms step)."""
+    dead = getattr(model, "_paths_dead_ids", None)
+    if dead is None:
+        dead = frozenset(id(p) for p in dead_params(model))
+        object.__setattr__(model, "_paths_dead_ids", dead)
+    zero = getattr(model, "_paths_dead_zero", None)
+    lo = zero.data_ptr() if zero is not None else 0
+    hi = lo + 4 * zero.numel() if zero is not None else 0
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            g = p.grad
+            if g is not None and not (id(p) in dead and lo <= g.data_ptr() < hi):
+                p.grad = None
+
+
 def next_dropout_seed(device) -> int:
     """A fresh 64-bit seed for one level's dropout masks, taken from the DEVICE's default generator - the stream the reference's
     dropout consumes when it trains on a GPU - by reading (seed, philox offset) on the host and advancing the offset: no device

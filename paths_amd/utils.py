@@ -291,6 +291,7 @@ class PipelinedRecursion:
 
 
 OVERLAP_AGGREGATOR = os.environ.get("PATHS_OVERLAP_AGGREGATOR", "1") != "0"
+ZERO_GRAD_ALL = os.environ.get("PATHS_ZERO_GRAD_ALL", "0") != "0"     # train_step: optimizer.zero_grad(set_to_none=True) over ALL parameters (A/B)
 ROCTX_RANGES = os.environ.get("PATHS_ROCTX", "0") != "0"     # roctx ranges "level i: selection / aggregator / expansion" around the launches
                                                              # of each level (rocprofv3 --marker-trace; torch.cuda.nvtx = roctx on ROCm)
 
@@ -734,7 +735,10 @@ def train_step(model, optimizer, batch, num_levels, keep_patches, task: str = "s
     ``batch`` None = this rank holds no slide of a short global batch: it contributes zeros for exactly the gradient set of
     an active rank.  Returns the (local share of the) loss as a tensor (None for an idle rank)."""
     from . import autograd as pag
-    optimizer.zero_grad(set_to_none=True)
+    if ZERO_GRAD_ALL:
+        optimizer.zero_grad(set_to_none=True)
+    else:
+        pag.clear_grads(model, optimizer)          # (the same for the live parameters; the dead ones keep their shared zero views)
     loss = None
     if batch is None:
         pag.zero_live_grads(model, num_levels)
