@@ -694,9 +694,18 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
   const int64_t gs = group_stride(planes, 2 * D);
   const float sg = 1.0f / (wg_scale * a_scale), sm = 1.0f / (wm_scale * a_scale);
   X6Operands g{x, ldx, D, x_rows, h0, h0 ? ldh0 : 0, h0 ? D : 0, nullptr, 0, wg, gs, M, num_ims, rows_per_slide, a_scale};
+  // Few rows (M <= 8192: K = 1024 x 8 slides, small batches, drop-in calls): 256-row blocks put ceil(M / 256) x 4 <= 128 workgroups on
+  // 256 CUs - half the chip idles through the two biggest launches of a level.  128-row blocks (the parent GEMM's tile family) make it
+  // one full round of workgroups with half the work each; above 8192 rows they would spill into a second round and lose (round 2:
+  // 165 against 280 TFLOP/s per workgroup pair).  Default split (two fp16 planes) only; PATHS_LSTM_SMALL_TILES=0 turns it off.
+  static const bool small_on = getenv("PATHS_LSTM_SMALL_TILES") == nullptr || atoi(getenv("PATHS_LSTM_SMALL_TILES")) != 0;
+  const bool small_m = small_on && planes == 2 && M <= 8192 && (h0 == nullptr);
   if (phases & 1) {   // c-part: N = 3Hc, block 256 x 192
     EpiLstmC e{b_gates, c0, ldc0, state_out + D, ldso, save_frm, (int64_t)3 * Hc, hp, (int64_t)3 * Hc + D, hp_row, sg};
-    int rc = launch_x6<4, 3, 1, false>(planes, g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
+    int rc;
+    if (small_m) rc = x_rows ? launch_x6_np<2, 2, 3, 2, false, true>(g, 3 * Hc, e, stream, "lstm_cell_x6(c, 128-row tiles)")
+                             : launch_x6_np<2, 2, 3, 2, false, false>(g, 3 * Hc, e, stream, "lstm_cell_x6(c, 128-row tiles)");
+    else rc = launch_x6<4, 3, 1, false>(planes, g, 3 * Hc, e, stream, "lstm_cell_x6(c)");
     if (rc) return rc;
   }
   // inference (no Y, no training saves): the gate travels to phase 4 as raw pre-activations in the accumulator layout (EpiLstmORaw)
@@ -707,7 +716,9 @@ int paths_lstm_cell_x6(const float* x, int64_t ldx, const int64_t* x_rows, const
     int rc;
     if (o_raw) {
       EpiLstmORaw e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc, sg};
-      rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o, raw)");
+      if (small_m) rc = x_rows ? launch_x6_np<2, 2, 4, 2, false, true>(go, D, e, stream, "lstm_cell_x6(o, raw, 128-row tiles)")
+                               : launch_x6_np<2, 2, 4, 2, false, false>(go, D, e, stream, "lstm_cell_x6(o, raw, 128-row tiles)");
+      else rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o, raw)");
     } else {
       EpiLstmO e{b_gates + 3 * Hc, ws_o, D, D, hp, (int64_t)3 * Hc + D, hp_row, 3 * Hc, sg};
       rc = launch_x6<4, 4, 1, false>(planes, go, D, e, stream, "lstm_cell_x6(o)");
