@@ -235,3 +235,34 @@ def test_slide_sharding_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "[0, 1, 2, 3]" in outs[0] and "[4, 5, 6]" in outs[1]
+
+
+def test_clear_grads_keeps_the_dead_parameters_zero_views():
+    """``autograd.clear_grads`` (what ``utils.train_step`` calls instead of ``optimizer.zero_grad(set_to_none=True)``): live parameters'
+    gradients are dropped, the DEAD parameters (nn.Transformer's encoder and cross-attention matrices: reference SURVEY 3.3, zero
+    gradients every step) keep their views of the shared zero buffer - unless somebody gave one of them a real gradient."""
+    from paths_amd import autograd as pag
+    from paths_amd.config import Config
+    cfg = Config.load(SAMPLE, test_mode=True)
+    torch.manual_seed(0)
+    model = cfg.get_model()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    dead = pag.dead_params(model)
+    dead_ids = {id(p) for p in dead}
+    live = [p for p in model.parameters() if id(p) not in dead_ids]
+    assert dead and live
+    for p in live:
+        p.grad = torch.ones_like(p)
+    pag.fill_dead_grads(model)
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in dead)
+    ptrs = [p.grad.data_ptr() for p in dead]
+    pag.clear_grads(model, opt)
+    assert all(p.grad is None for p in live)
+    assert [p.grad.data_ptr() for p in dead] == ptrs                      # the same views, not re-created
+    pag.fill_dead_grads(model)                                            # nothing to do now
+    assert [p.grad.data_ptr() for p in dead] == ptrs
+    dead[0].grad = torch.ones_like(dead[0])                               # a gradient that is NOT the shared zero view is cleared like any other
+    pag.clear_grads(model, opt)
+    assert dead[0].grad is None and dead[1].grad is not None
+    pag.fill_dead_grads(model)
+    assert float(dead[0].grad.abs().max()) == 0.0
