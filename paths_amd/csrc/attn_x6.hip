@@ -942,7 +942,10 @@ attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const
   const int grp = wave >> 2;                            // 1 = the half that runs one segment behind; 2 = the four loader waves
   const int qc = lane & 31, h = lane >> 5, l15 = lane & 15, sub = (lane >> 4) & 1;
   const int64_t ibase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 2 * NP;
-  const int qw = q0 + wave * 32;
+  // A block with at most 32 queries (the ninth block of a completely full slide: 2,049 = 8 x 256 + 1 tokens) takes the SMALL path below:
+  // all its waves share the one query tile and split the KEYS (block-uniform branch)
+  const bool small = len - q0 <= 32;
+  const int qw = small ? q0 : q0 + wave * 32;
   const bool active = qw < len && grp < 2;              // (a wave without queries still meets every barrier)
 
   u32x4 qf[2][NP];
@@ -968,6 +971,143 @@ attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const
 
   const int nkt = (len + KSTEP - 1) / KSTEP;
   constexpr int HALF = 4 * NP * FRAG;                   // one 64-key step of K or of V^T
+  // normalise and store this wave's query tile (both paths end here)
+  auto write_out = [&]() __attribute__((always_inline)) {
+    const float l = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l;
+    if (o_img != nullptr) {
+      const int tq = qw + 16 * sub;
+      if (tq < Tp) {
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int i0 = 4 * gg, i1 = 8 + 4 * gg;
+          const float v[8] = {oacc[i0] * inv, oacc[i0 + 1] * inv, oacc[i0 + 2] * inv, oacc[i0 + 3] * inv,
+                              oacc[i1] * inv, oacc[i1 + 1] * inv, oacc[i1 + 2] * inv, oacc[i1 + 3] * inv};
+          u32x4 hi, lo;
+          split8h(v, hi, lo);
+          char* dst = o_img + ((((int64_t)b * (Tp >> 6) + (tq >> 6)) * H + head) * 4 + ((tq >> 4) & 3)) * (2 * FRAG) + (l15 + 16 * (h + 2 * gg)) * 16;
+          *reinterpret_cast<u32x4*>(dst) = hi;
+          *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
+        }
+      }
+      return;
+    }
+    const int qi = qw + qc;
+    if (qi < T) {
+      float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * h;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        *reinterpret_cast<f32x4*>(op + 8 * m) = f32x4{oacc[4 * m] * inv, oacc[4 * m + 1] * inv, oacc[4 * m + 2] * inv, oacc[4 * m + 3] * inv};
+      if (lse && h == 0) lse[((int64_t)b * H + head) * T + qi] = m_run + log2f(l);
+    }
+  };
+  if (small) {
+    // ---- SMALL path: the block's one query tile against key steps wave, wave + NWS, ... per wave, fragments straight from the
+    // images in global memory (they are stored in operand order), the (m, l, O) states merged through LDS by wave 0.  Run as a
+    // ninth block at the pace of a full one (one active wave meeting every barrier of 33 key steps) this took ~35 us as a SECOND ROUND
+    // of workgroups behind the 256 full blocks of eight full slides: 46 -> 82 us for the launch (tools/attn_full_slides.py).
+    constexpr int NWS = PATHS_M32P_LOADERS ? 12 : 8;    // every wave of the workgroup takes key steps (nothing is staged through LDS here)
+    const char* const kg = k6 + ibase;
+    const char* const vg = v6 + ibase;
+    bool first = true;
+    for (int kt = wave; kt < nkt; kt += NWS) {
+      const char* gK = kg + (int64_t)kt * HALF;
+      const char* gV = vg + (int64_t)kt * HALF;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 kf[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            kf[p] = *reinterpret_cast<const u32x4*>(gK + ((2 * t + sub) * NP + p) * FRAG + (l15 + 16 * (2 * ks + h)) * 16);
+          s[t] = mfma32_split(kf, qf[ks], ks == 0 ? negm : s[t]);
+        }
+      if (kt == nkt - 1) {
+        const int kbase = kt * KSTEP + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kbase + 32 * t + (i & 3) + 8 * (i >> 2) >= len) s[t][i] = -INFINITY;
+      }
+      float psum;
+      auto probs = [&]() __attribute__((always_inline)) {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              pv[j] = __builtin_amdgcn_exp2f(s[t][4 * u + (j & 3) + 8 * (j >> 2)]);
+              ps[j & 3] += pv[j];
+            }
+            split8h(pv, pf[t][u][0], pf[t][u][1]);
+          }
+        psum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      };
+      probs();
+      if (first || __any(!(psum <= 256.0f))) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[t][i]), s[t][i + 1]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float d = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+        m_run += d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[i] *= alpha; negm[i] -= d; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[t][i] -= d;
+        probs();
+      }
+      l_run += psum;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          u32x4 vf[NP];
+#pragma unroll
+          for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const u32x4*>(gV + ((t * 2 + sub) * NP + p) * FRAG + (l15 + 16 * (h + 2 * u)) * 16);
+          oacc = mfma32_split(vf, pf[t][u], oacc);
+        }
+      first = false;
+    }
+    // per-lane states -> LDS [NWS waves][18][64]; a wave without a key step publishes the neutral element
+    float* const st = reinterpret_cast<float*>(smem_raw) + wave * (18 * 64);
+    st[lane] = first ? -1e30f : m_run;
+    st[64 + lane] = first ? 0.f : l_run;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[(2 + i) * 64 + lane] = first ? 0.f : oacc[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    pair_barrier();
+    if (wave != 0) return;
+    const float* const all = reinterpret_cast<const float*>(smem_raw);
+    float M = -1e30f;
+#pragma nounroll
+    for (int w = 0; w < NWS; ++w) M = fmaxf(M, all[w * (18 * 64) + lane]);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[i] = 0.f;
+#pragma nounroll
+    for (int w = 0; w < NWS; ++w) {
+      const float sc = __builtin_amdgcn_exp2f(all[w * (18 * 64) + lane] - M);
+      lsum = fmaf(all[w * (18 * 64) + 64 + lane], sc, lsum);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[i] = fmaf(all[w * (18 * 64) + (2 + i) * 64 + lane], sc, oacc[i]);
+    }
+    m_run = M;
+    l_run = lsum;
+    write_out();
+    return;
+  }
   char* const sKb = smem_raw;                           // [4][HALF]
   char* const sVb = smem_raw + 4 * HALF;                // [4][HALF]
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem_raw);
@@ -1229,33 +1369,7 @@ attn_m32p_kernel(const char* __restrict__ q6, const char* __restrict__ k6, const
   }
 #endif
   if (!active) return;
-  const float l = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l;
-  if (o_img != nullptr) {
-    const int tq = qw + 16 * sub;
-    if (tq < Tp) {
-#pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const int i0 = 4 * gg, i1 = 8 + 4 * gg;
-        const float v[8] = {oacc[i0] * inv, oacc[i0 + 1] * inv, oacc[i0 + 2] * inv, oacc[i0 + 3] * inv,
-                            oacc[i1] * inv, oacc[i1 + 1] * inv, oacc[i1 + 2] * inv, oacc[i1 + 3] * inv};
-        u32x4 hi, lo;
-        split8h(v, hi, lo);
-        char* dst = o_img + ((((int64_t)b * (Tp >> 6) + (tq >> 6)) * H + head) * 4 + ((tq >> 4) & 3)) * (2 * FRAG) + (l15 + 16 * (h + 2 * gg)) * 16;
-        *reinterpret_cast<u32x4*>(dst) = hi;
-        *reinterpret_cast<u32x4*>(dst + FRAG) = lo;
-      }
-    }
-    return;
-  }
-  const int qi = qw + qc;
-  if (qi < T) {
-    float* op = o + ((int64_t)b * T + qi) * (H * HD) + head * HD + 4 * h;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      *reinterpret_cast<f32x4*>(op + 8 * m) = f32x4{oacc[4 * m] * inv, oacc[4 * m + 1] * inv, oacc[4 * m + 2] * inv, oacc[4 * m + 3] * inv};
-    if (lse && h == 0) lse[((int64_t)b * H + head) * T + qi] = m_run + log2f(l);
-  }
+  write_out();
 }
 
 #ifndef PATHS_ATTN_M32
