@@ -38,7 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)" (me
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
 MFMA_PER_PRODUCT = {3: 6, 2: 3}   # 16-bit MFMAs issued per fp32 product block: 3 bf16 planes ("x6") / 2 fp16 planes ("h3")
 BASE_SHAPES = {2048: (32, 64), 1024: (32, 32), 256: (16, 16)}
-PMC_PROFILE_H3 = "r05s_pmc_traffic.json"     # separate --pmc passes of the default build in round 5 (tools/refresh_profiles.sh)
+PMC_PROFILE_H3 = "r05fin_pmc_traffic.json"     # separate --pmc passes of the default build in round 5 (tools/refresh_profiles.sh)
 ROOFLINE_FILE = "roofline.json"               # measured MFMA issue peak / stream bandwidth of the pool's boxes (tools/peaks.hip)
 CPU_DSEED = 1234
 # slide ids of the cpu_baseline / parity sample: screened here with the oracle so that every level's top-K boundary gap
