@@ -127,7 +127,13 @@ attn_h3_any_kernel(const char* __restrict__ qi, const char* __restrict__ ki, con
   const int ql = lane & 15, g4 = lane >> 4;
   const int64_t qkbase = ((int64_t)b * H + head) * (int64_t)Tp * (NK * 32) * 4;
   const int64_t vbase = ((int64_t)b * H + head) * (int64_t)Tp * HD * 4;
-  const int qw = q0 + wave * 16 * QT;
+  // A block with at most one wave's worth of queries (the last block of a completely full slide: 2,049 = 16 x 128 + 1 tokens) takes the
+  // SMALL path below: its four waves share the one query tile pair and split the KEY steps (block-uniform branch).  As an ordinary block
+  // it ran all 33 key steps with four waves of garbage queries - a second round of workgroups as long as the first (trans_dim 192,
+  // level 0 of the bench's slides: 131 us against 82 for the ragged levels).
+  // (head_dim 64 keeps its registers for the main loop: it is at the 256-register cap of two waves per SIMD already)
+  const bool small = HD <= 48 && len - q0 <= 16 * QT;
+  const int qw = small ? q0 : q0 + wave * 16 * QT;
 
   u32x4 qf[QT][NK][2];
 #pragma unroll
@@ -146,8 +152,130 @@ attn_h3_any_kernel(const char* __restrict__ qi, const char* __restrict__ ki, con
 #pragma unroll
   for (int j = 0; j < QT; ++j) { m_run[j] = -INFINITY; l_run[j] = 0.f; }
 
-  // staging: threads 0-127 carry the K fragments of a 64-key step (one step ahead), 128-255 its V^T fragments
   const int nkt = (len + KSTEP - 1) / KSTEP;
+  auto write_out = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const float l = rows_sum(l_run[qt]);
+      const float inv = 1.0f / l;
+      const int qidx = qw + 16 * qt + ql;
+      if (qidx < T) {
+        float* op = o + ((int64_t)b * T + qidx) * (H * HD) + head * HD + 4 * g4;
+#pragma unroll
+        for (int dvt = 0; dvt < NDV; ++dvt) *reinterpret_cast<f32x4*>(op + 16 * dvt) = oacc[dvt][qt] * inv;
+      }
+    }
+  };
+  if constexpr (HD <= 48) if (small) {
+    // ---- SMALL path: key steps wave, wave + 4, ... per wave, fragments straight from the images in global memory (operand order),
+    // the four (m, l, O) states merged through LDS by wave 0
+    for (int kt = wave; kt < nkt; kt += 4) {
+      f32x4 s[QT][4];
+      const char* gK = ki + qkbase + (int64_t)kt * KB + lane * 16;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          u32x4 kf[2];
+          kf[0] = *reinterpret_cast<const u32x4*>(gK + (t * NK + kk) * (2 * FB));
+          kf[1] = *reinterpret_cast<const u32x4*>(gK + (t * NK + kk) * (2 * FB) + FB);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma_split(kf, qf[qt][kk], s[qt][t]);
+        }
+      }
+      if (kt == nkt - 1) {
+        const int kbase = kt * KSTEP + 4 * g4;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kbase + 16 * t + r >= len) s[qt][t][r] = -INFINITY;
+      }
+      u32x4 pf[QT][2][2];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          mx = fmaxf(fmaxf(mx, s[qt][t][0]), s[qt][t][1]);
+          mx = fmaxf(fmaxf(mx, s[qt][t][2]), s[qt][t][3]);
+        }
+        mx = rows_max(mx);
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pv[j] = __builtin_amdgcn_exp2f(s[qt][2 * kg + (j >> 2)][j & 3] - m_new);
+            psum += pv[j];
+          }
+          split8h(pv, pf[qt][kg][0], pf[qt][kg][1]);
+        }
+        l_run[qt] = l_run[qt] * alpha + psum;
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int dvt = 0; dvt < NDV; ++dvt) oacc[dvt][qt] *= alpha;
+      }
+      const char* gV = vi + vbase + (int64_t)kt * VB + lane * 16;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int dvt = 0; dvt < NDV; ++dvt) {
+          u32x4 vf[2];
+          vf[0] = *reinterpret_cast<const u32x4*>(gV + (kg * NDV + dvt) * (2 * FB));
+          vf[1] = *reinterpret_cast<const u32x4*>(gV + (kg * NDV + dvt) * (2 * FB) + FB);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) oacc[dvt][qt] = mfma_split(vf, pf[qt][kg], oacc[dvt][qt]);
+        }
+    }
+    // per-lane states -> LDS [4 waves][2 QT + 4 NDV QT][64]  (a wave without a key step: m = -inf, l = 0, O = 0: weight 0 in the merge)
+    constexpr int NST = 2 * QT + 4 * NDV * QT;
+    static_assert(4 * NST * 64 * 4 <= 2 * (KB + VB), "the merge scratch fits the staging LDS");
+    float* const stf = reinterpret_cast<float*>(smem) + wave * (NST * 64);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      stf[qt * 64 + lane] = m_run[qt];
+      stf[(QT + qt) * 64 + lane] = l_run[qt];
+#pragma unroll
+      for (int dvt = 0; dvt < NDV; ++dvt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stf[(2 * QT + (dvt * QT + qt) * 4 + r) * 64 + lane] = oacc[dvt][qt][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float* const all = reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float M = -INFINITY;
+#pragma nounroll
+      for (int w = 0; w < 4; ++w) M = fmaxf(M, all[w * (NST * 64) + qt * 64 + lane]);
+      float lsum = 0.f;
+#pragma unroll
+      for (int dvt = 0; dvt < NDV; ++dvt) oacc[dvt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+      for (int w = 0; w < 4; ++w) {
+        const float* a = all + w * (NST * 64);
+        const float sc = __builtin_amdgcn_exp2f(a[qt * 64 + lane] - M);
+        lsum = fmaf(a[(QT + qt) * 64 + lane], sc, lsum);
+#pragma unroll
+        for (int dvt = 0; dvt < NDV; ++dvt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[dvt][qt][r] = fmaf(a[(2 * QT + (dvt * QT + qt) * 4 + r) * 64 + lane], sc, oacc[dvt][qt][r]);
+      }
+      l_run[qt] = lsum;
+      m_run[qt] = M;
+    }
+    write_out();
+    return;
+  }
+  // staging: threads 0-127 carry the K fragments of a 64-key step (one step ahead), 128-255 its V^T fragments
   const bool carriesK = tid < 128;
   const int chunk = (tid & 127) * 16;
   u32x4 st[NC];
@@ -251,17 +379,7 @@ attn_h3_any_kernel(const char* __restrict__ qi, const char* __restrict__ ki, con
     if (kt + 1 < nkt) { step(kt, sA, sB, false); step(kt + 1, sB, sA, true); }
     else step(kt, sA, sB, true);
   }
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const float l = rows_sum(l_run[qt]);
-    const float inv = 1.0f / l;
-    const int qidx = qw + 16 * qt + ql;
-    if (qidx < T) {
-      float* op = o + ((int64_t)b * T + qidx) * (H * HD) + head * HD + 4 * g4;
-#pragma unroll
-      for (int dvt = 0; dvt < NDV; ++dvt) *reinterpret_cast<f32x4*>(op + 16 * dvt) = oacc[dvt][qt] * inv;
-    }
-  }
+  write_out();
 }
 
 template <int HD>
