@@ -978,6 +978,15 @@ def main():
             fl2, ms2, n2 = agg_roofline(ser_span["aggregator"])
             roofline_attn["serialized_span_us"] = round(ms2 * 1e3 / n2, 2)
             roofline_attn["serialized_frac"] = round(fl2 / (ms2 * 1e-3) / 1e12 / peak, 4)
+            # the same by level of the recursion (sample i of the pass = level i % num_levels): level 0 of the synthetic slides has no
+            # background cells - 2,048 patches + the special token = 2,049 tokens = 8 x 256 queries + 1, 32 x 64 token rows + 1: the
+            # stray query block / token tile of a completely full slide is a second round of workgroups
+            Lv = cfg.num_levels
+            sp = ser_span["aggregator"]
+            by = [[t for i, (t, _) in enumerate(sp) if i % Lv == l] for l in range(Lv)]
+            roofline_attn["serialized_span_by_level_us"] = [round(sum(v) * 1e3 / len(v), 2) if v else None for v in by]
+            roofline_attn["serialized_frac_by_level"] = [round(f_agg[l] / (sum(v) / len(v) * 1e-3) / 1e12 / peak, 4) if v else None for l, v in enumerate(by)]
+            roofline_attn["valid_patches_by_level"] = [int(v) for v in valid]
             if ev_overhead is not None:
                 # the same span net of the bracket's own cost (the pair around one trivial launch): what the three kernels take back to
                 # back - REPORTED BESIDE serialized_frac, never instead of it
@@ -1080,7 +1089,8 @@ def main():
                                                    "serialized_span_replayed_us", "serialized_frac_replayed", "serialized_note",
                                                    "serialized_frac_of_measured_peak", "algorithmic_gflop_per_level_launch",
                                                    "in_proj_fused_into_finish", "algorithmic_gflop_in_proj0_excluded", "fuse_qkv_mode",
-                                                   "event_bracket_overhead", "serialized_frac_net_of_bracket")}),
+                                                   "event_bracket_overhead", "serialized_frac_net_of_bracket", "serialized_span_by_level_us",
+                                                   "serialized_frac_by_level", "valid_patches_by_level")}),
             "roofline_attn_ffn": roofline_attn,
             "host": {"launch_mode": launch_mode,
                      "t_enqueued_over_elapsed": round(t_enqueued / max(elapsed, 1e-9), 3), "eager_instrumented_pass": eager,
